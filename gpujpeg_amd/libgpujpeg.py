@@ -1,0 +1,226 @@
+"""ctypes binding of the libgpujpeg C ABI (reference: libgpujpeg/gpujpeg_common.h, gpujpeg_encoder.h,
+gpujpeg_decoder.h). Struct layouts mirror the reference headers field by field because they ARE the ABI.
+
+The binding is library-agnostic: `Library(path)` loads any shared object exporting the libgpujpeg symbols.
+The product library is gpujpeg_amd/lib/libgpujpeg.so (HIP kernels for gfx950); there is no CPU fallback --
+loading fails loudly if it has not been built.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+MAX_COMPONENT_COUNT = 4
+
+# enum gpujpeg_color_space (gpujpeg_type.h:85-94)
+NONE, RGB, YCBCR_BT601, YCBCR_BT601_256LVLS, YCBCR_BT709, YUV = 0, 1, 2, 3, 4, 5
+YCBCR_JPEG = YCBCR_BT601_256LVLS
+CS_DEFAULT = -1
+# enum gpujpeg_pixel_format (gpujpeg_type.h:108-134)
+PIXFMT_NONE = -1
+U8, P012_444, P0P1P2_444, P1020_422, P0P1P2_422, P0P1P2_420, P0123_4444 = 0, 1, 2, 3, 4, 5, 6
+PIXFMT_AUTODETECT, PIXFMT_NO_ALPHA, PIXFMT_STD, PIXFMT_NATIVE = -2, -3, -4, -5
+# enum gpujpeg_encoder_input_type / gpujpeg_decoder_output_type
+ENCODER_INPUT_IMAGE, ENCODER_INPUT_OPENGL_TEXTURE, ENCODER_INPUT_GPU_IMAGE = 0, 1, 2
+(DECODER_OUTPUT_INTERNAL_BUFFER, DECODER_OUTPUT_CUSTOM_BUFFER, DECODER_OUTPUT_OPENGL_TEXTURE,
+ DECODER_OUTPUT_CUDA_BUFFER, DECODER_OUTPUT_CUSTOM_CUDA_BUFFER) = range(5)
+RESTART_AUTO, RESTART_NONE = -1, 0
+
+
+def MK_SUBSAMPLING(*f):
+    f = list(f) + [0] * (8 - len(f))
+    v = 0
+    for x in f:
+        v = (v << 4) | x
+    return v
+
+
+SUBSAMPLING_444 = MK_SUBSAMPLING(1, 1, 1, 1, 1, 1)
+SUBSAMPLING_422 = MK_SUBSAMPLING(2, 1, 1, 1, 1, 1)
+SUBSAMPLING_420 = MK_SUBSAMPLING(2, 2, 1, 1, 1, 1)
+SUBSAMPLING_4444 = MK_SUBSAMPLING(1, 1, 1, 1, 1, 1, 1, 1)
+SUBSAMPLING_400 = MK_SUBSAMPLING(1, 1)
+
+
+class SamplingFactor(C.Structure):
+    _fields_ = [("horizontal", C.c_uint8), ("vertical", C.c_uint8)]
+
+
+class Parameters(C.Structure):  # struct gpujpeg_parameters, gpujpeg_common.h:176-215
+    _fields_ = [("verbose", C.c_int), ("perf_stats", C.c_int), ("quality", C.c_int), ("restart_interval", C.c_int),
+                ("interleaved", C.c_int), ("segment_info", C.c_int), ("comp_count", C.c_int),
+                ("sampling_factor", SamplingFactor * MAX_COMPONENT_COUNT), ("color_space_internal", C.c_int)]
+
+
+class ImageParameters(C.Structure):  # struct gpujpeg_image_parameters, gpujpeg_common.h:283-294
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("color_space", C.c_int), ("pixel_format", C.c_int),
+                ("width_padding", C.c_int)]
+
+
+class EncoderInput(C.Structure):  # gpujpeg_encoder.h:57-67
+    _fields_ = [("type", C.c_int), ("image", C.c_void_p), ("texture", C.c_void_p)]
+
+
+class DecoderOutput(C.Structure):  # gpujpeg_decoder.h:66-84
+    _fields_ = [("type", C.c_int), ("data", C.c_void_p), ("data_size", C.c_size_t), ("param_image", ImageParameters),
+                ("texture", C.c_void_p), ("metadata", C.c_void_p)]
+
+
+class DecoderInitParameters(C.Structure):  # gpujpeg_decoder.h:90-97
+    _fields_ = [("stream", C.c_void_p), ("verbose", C.c_int), ("perf_stats", C.c_bool), ("ff_cs_itu601_is_709", C.c_bool)]
+
+
+class DurationStats(C.Structure):  # gpujpeg_common.h:352-362
+    _fields_ = [(n, C.c_double) for n in ("duration_memory_to", "duration_memory_from", "duration_memory_map",
+                                          "duration_memory_unmap", "duration_preprocessor", "duration_dct_quantization",
+                                          "duration_huffman_coder", "duration_stream", "duration_in_gpu")]
+
+
+class _ImageInfoFields(C.Structure):
+    _fields_ = [("param_image", ImageParameters), ("param", Parameters), ("segment_count", C.c_int),
+                ("header_type", C.c_int), ("comment", C.c_char_p), ("metadata", C.c_uint8 * 8)]
+
+
+class ImageInfo(C.Union):  # gpujpeg_decoder.h:270-283 (512-byte union)
+    _anonymous_ = ("f",)
+    _fields_ = [("f", _ImageInfoFields), ("reserved", C.c_char * 512)]
+
+
+PRODUCT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgpujpeg.so")
+
+
+class Library:
+    """Thin typed handle on a libgpujpeg shared object."""
+
+    def __init__(self, path=None):
+        path = path or PRODUCT_LIB
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(the HIP library is mandatory, there is no CPU fallback)")
+        self.path = path
+        L = self.L = C.CDLL(path, mode=C.RTLD_GLOBAL if path == PRODUCT_LIB else C.RTLD_LOCAL)
+        vp = C.c_void_p
+        L.gpujpeg_set_default_parameters.argtypes = [C.POINTER(Parameters)]
+        L.gpujpeg_image_set_default_parameters.argtypes = [C.POINTER(ImageParameters)]
+        L.gpujpeg_parameters_chroma_subsampling.argtypes = [C.POINTER(Parameters), C.c_uint32]
+        L.gpujpeg_image_calculate_size.restype = C.c_size_t
+        L.gpujpeg_image_calculate_size.argtypes = [C.POINTER(ImageParameters)]
+        L.gpujpeg_init_device.argtypes = [C.c_int, C.c_int]
+        L.gpujpeg_encoder_create.restype = vp
+        L.gpujpeg_encoder_create.argtypes = [vp]
+        L.gpujpeg_encoder_destroy.argtypes = [vp]
+        L.gpujpeg_encoder_encode.argtypes = [vp, C.POINTER(Parameters), C.POINTER(ImageParameters), C.POINTER(EncoderInput),
+                                             C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.gpujpeg_encoder_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.gpujpeg_encoder_suggest_restart_interval.argtypes = [C.POINTER(ImageParameters), C.c_uint32, C.c_bool, C.c_int]
+        L.gpujpeg_encoder_get_stats.argtypes = [vp, C.POINTER(DurationStats)]
+        L.gpujpeg_decoder_create.restype = vp
+        L.gpujpeg_decoder_create.argtypes = [vp]
+        L.gpujpeg_decoder_destroy.argtypes = [vp]
+        L.gpujpeg_decoder_decode.argtypes = [vp, vp, C.c_size_t, C.POINTER(DecoderOutput)]
+        L.gpujpeg_decoder_set_output_format.argtypes = [vp, C.c_int, C.c_int]
+        L.gpujpeg_decoder_set_output_format.restype = None
+        L.gpujpeg_decoder_get_stats.argtypes = [vp, C.POINTER(DurationStats)]
+        L.gpujpeg_decoder_get_image_info.argtypes = [vp, C.c_size_t, C.POINTER(ImageParameters), C.POINTER(Parameters), C.POINTER(C.c_int)]
+        L.gpujpeg_decoder_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.gpujpeg_version.restype = C.c_int
+
+    # ---- parameter helpers ----
+    def default_parameters(self):
+        p = Parameters()
+        self.L.gpujpeg_set_default_parameters(C.byref(p))
+        return p
+
+    def default_image_parameters(self):
+        p = ImageParameters()
+        self.L.gpujpeg_image_set_default_parameters(C.byref(p))
+        return p
+
+    def image_size(self, param_image):
+        return self.L.gpujpeg_image_calculate_size(C.byref(param_image))
+
+
+class Encoder:
+    """Mirror of the reference encoder object: gpujpeg_encoder_create/encode/destroy (gpujpeg_encoder.h:118-176)."""
+
+    def __init__(self, lib, stream=None):
+        self.lib = lib
+        self.h = lib.L.gpujpeg_encoder_create(stream)
+        if not self.h:
+            raise RuntimeError("gpujpeg_encoder_create failed")
+
+    def set_option(self, opt, val):
+        return self.lib.L.gpujpeg_encoder_set_option(self.h, opt.encode(), val.encode())
+
+    def encode(self, param, param_image, image, gpu=False):
+        """image: numpy uint8 array (host) or an integer device pointer when gpu=True. Returns numpy uint8 copy."""
+        ptr, n = self.encode_noclone(param, param_image, image, gpu)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+    def encode_noclone(self, param, param_image, image, gpu=False):
+        inp = EncoderInput()
+        if gpu:
+            inp.type, inp.image = ENCODER_INPUT_GPU_IMAGE, int(image)
+        else:
+            image = np.ascontiguousarray(image, np.uint8)
+            self._keep = image
+            inp.type, inp.image = ENCODER_INPUT_IMAGE, image.ctypes.data
+        out, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+        rc = self.lib.L.gpujpeg_encoder_encode(self.h, C.byref(param), C.byref(param_image), C.byref(inp), C.byref(out), C.byref(size))
+        if rc != 0:
+            raise RuntimeError(f"gpujpeg_encoder_encode failed ({rc})")
+        return out, size.value
+
+    def stats(self):
+        s = DurationStats()
+        self.lib.L.gpujpeg_encoder_get_stats(self.h, C.byref(s))
+        return s
+
+    def close(self):
+        if self.h:
+            self.lib.L.gpujpeg_encoder_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class Decoder:
+    """Mirror of the reference decoder object: gpujpeg_decoder_create/decode/destroy (gpujpeg_decoder.h:153-202)."""
+
+    def __init__(self, lib, stream=None):
+        self.lib = lib
+        self.h = lib.L.gpujpeg_decoder_create(stream)
+        if not self.h:
+            raise RuntimeError("gpujpeg_decoder_create failed")
+
+    def set_output_format(self, color_space, pixel_format):
+        self.lib.L.gpujpeg_decoder_set_output_format(self.h, color_space, pixel_format)
+
+    def decode(self, jpeg, device_out=None):
+        """jpeg: numpy uint8 array. Returns (numpy uint8 copy of pixels, ImageParameters); with device_out
+        (integer device pointer) decodes into that buffer and returns (None, ImageParameters)."""
+        jpeg = np.ascontiguousarray(jpeg, np.uint8)
+        out = DecoderOutput()
+        if device_out is not None:
+            out.type, out.data = DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, int(device_out)
+        else:
+            out.type = DECODER_OUTPUT_INTERNAL_BUFFER
+        rc = self.lib.L.gpujpeg_decoder_decode(self.h, jpeg.ctypes.data, jpeg.size, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"gpujpeg_decoder_decode failed ({rc})")
+        if device_out is not None:
+            return None, out.param_image
+        buf = (C.c_uint8 * out.data_size).from_address(out.data)
+        return np.frombuffer(buf, np.uint8).copy(), out.param_image
+
+    def stats(self):
+        s = DurationStats()
+        self.lib.L.gpujpeg_decoder_get_stats(self.h, C.byref(s))
+        return s
+
+    def close(self):
+        if self.h:
+            self.lib.L.gpujpeg_decoder_destroy(self.h)
+            self.h = None
+
+    __del__ = close

@@ -1,0 +1,400 @@
+/*
+ * gj_decoder.c -- the libgpujpeg decoder API on MI355X. Host driver counterpart of
+ * src/gpujpeg_decoder.c: same entry points, output types, ownership and error behaviour. The JPEG
+ * bytes are uploaded once and decoded in place (no per-segment host memcpy as in
+ * src/gpujpeg_reader.c:1115,1128).
+ */
+#define _GNU_SOURCE
+#include <assert.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include "gj_internal.h"
+
+struct gpujpeg_decoder {
+    struct gj_coder coder;
+    enum gpujpeg_pixel_format req_pixel_format;
+    enum gpujpeg_color_space req_color_space;
+    bool ff_cs_itu601_is_709;
+    unsigned req_alignment;
+    struct gpujpeg_image_metadata metadata;
+    /* device */
+    uint8_t* d_jpeg; size_t d_jpeg_cap;
+    uint32_t* d_seg; size_t d_seg_cap; /* pos | len | index */
+    uint16_t* d_huff_tab;
+    uint16_t* d_qtab;
+    /* host */
+    uint8_t* h_raw; size_t h_raw_cap; /* pinned internal output buffer */
+    uint32_t* h_seg; size_t h_seg_cap; /* pinned staging of the segment table */
+    uint16_t* h_tabs;                  /* pinned staging: 8 decode tables + 4 quant tables */
+    struct gj_host_segments segs;
+    int use_fused;
+};
+
+/* ------------------------------------------------------------------ output helpers (gpujpeg_decoder.h:105-143) */
+void gpujpeg_decoder_output_set_default(struct gpujpeg_decoder_output* o) { o->type = GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER; o->data = NULL; o->data_size = 0; o->texture = NULL; }
+void gpujpeg_decoder_output_set_custom(struct gpujpeg_decoder_output* o, uint8_t* buf) { o->type = GPUJPEG_DECODER_OUTPUT_CUSTOM_BUFFER; o->data = buf; o->data_size = 0; o->texture = NULL; }
+void gpujpeg_decoder_output_set_texture(struct gpujpeg_decoder_output* o, struct gpujpeg_opengl_texture* t) { o->type = GPUJPEG_DECODER_OUTPUT_OPENGL_TEXTURE; o->data = NULL; o->data_size = 0; o->texture = t; }
+void gpujpeg_decoder_output_set_cuda_buffer(struct gpujpeg_decoder_output* o) { o->type = GPUJPEG_DECODER_OUTPUT_CUDA_BUFFER; o->data = NULL; o->data_size = 0; o->texture = NULL; }
+void gpujpeg_decoder_output_set_custom_cuda(struct gpujpeg_decoder_output* o, uint8_t* d_buf) { o->type = GPUJPEG_DECODER_OUTPUT_CUSTOM_CUDA_BUFFER; o->data = d_buf; o->data_size = 0; o->texture = NULL; }
+
+/* ------------------------------------------------------------------ create / destroy (src/gpujpeg_decoder.c:97-183, 560-584) */
+#define GJ_TABS_WORDS (8 * GJ_DEC_TAB_WORDS + 4 * 64)
+
+struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
+{
+    gj_init_term_colors();
+    struct gpujpeg_decoder* d = calloc(1, sizeof *d);
+    if (!d) return NULL;
+    d->coder.stream = (gj_stream_t)stream;
+    d->req_pixel_format = GPUJPEG_PIXFMT_AUTODETECT;
+    d->req_color_space = GPUJPEG_CS_DEFAULT;
+    d->use_fused = getenv("GPUJPEG_NO_FUSED") ? 0 : 1;
+    gpujpeg_set_default_parameters(&d->coder.param);
+    gpujpeg_image_set_default_parameters(&d->coder.param_image);
+    d->coder.param.comp_count = 0;
+    d->coder.param.restart_interval = 0;
+    if (gj_hip_get_device(&d->coder.device) != 0) goto fail;
+    if (gj_timers_create(&d->coder.timers) != 0) goto fail;
+    d->d_huff_tab = gj_hip_malloc(GJ_TABS_WORDS * sizeof(uint16_t));
+    d->h_tabs = gj_hip_host_alloc(GJ_TABS_WORDS * sizeof(uint16_t));
+    if (!d->d_huff_tab || !d->h_tabs) goto fail;
+    d->d_qtab = d->d_huff_tab + 8 * GJ_DEC_TAB_WORDS;
+    return d;
+fail:
+    GJ_ERROR("Decoder initialisation failed: %s\n", gj_hip_last_error());
+    gpujpeg_decoder_destroy(d);
+    return NULL;
+}
+
+struct gpujpeg_decoder_init_parameters gpujpeg_decoder_default_init_parameters(void)
+{
+    return (struct gpujpeg_decoder_init_parameters){(cudaStream_t)0, 0, false, false};
+}
+
+struct gpujpeg_decoder* gpujpeg_decoder_create_with_params(const struct gpujpeg_decoder_init_parameters* params)
+{
+    struct gpujpeg_decoder* d = gpujpeg_decoder_create(params->stream);
+    if (!d) return NULL;
+    d->coder.param.verbose = params->verbose;
+    d->coder.param.perf_stats = params->perf_stats;
+    d->ff_cs_itu601_is_709 = params->ff_cs_itu601_is_709;
+    return d;
+}
+
+int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
+{
+    if (!d) return -1;
+    gj_coder_process_stats_overall(&d->coder);
+    gj_timers_destroy(&d->coder.timers);
+    gj_hip_free(d->d_jpeg); gj_hip_free(d->d_seg); gj_hip_free(d->d_huff_tab);
+    gj_hip_free(d->coder.d_raw_own); gj_hip_free(d->coder.d_planes); gj_hip_free(d->coder.d_coefs);
+    gj_hip_host_free(d->h_raw); gj_hip_host_free(d->h_seg); gj_hip_host_free(d->h_tabs);
+    free(d->segs.pos); free(d->segs.len); free(d->segs.index);
+    free(d);
+    return 0;
+}
+
+void gpujpeg_decoder_set_output_format(struct gpujpeg_decoder* d, enum gpujpeg_color_space cs, enum gpujpeg_pixel_format pf)
+{
+    d->req_color_space = cs;
+    d->req_pixel_format = pf;
+}
+
+/* ------------------------------------------------------------------ configuration (src/gpujpeg_decoder.c:185-233) */
+static int decoder_configure(struct gpujpeg_decoder* d, const struct gpujpeg_parameters* p, const struct gpujpeg_image_parameters* pi)
+{
+    struct gj_coder* c = &d->coder;
+    const int verbose = c->param.verbose, perf = c->param.perf_stats;
+    if (c->configured && gj_parameters_equal(&c->param, p) && gj_image_parameters_equal(&c->param_image, pi)) return 0;
+    if (c->configured && verbose >= GPUJPEG_LL_INFO) fprintf(stderr, "[GPUJPEG] [Info] Reinitializing decoder.\n");
+    c->configured = false;
+    c->param = *p;
+    c->param.verbose = verbose;
+    c->param.perf_stats = perf;
+    c->param_image = *pi;
+    gj_geom* g = &c->geom;
+    if (gj_geom_init(g, p, pi, false) != 0) {
+        GJ_ERROR("Failed to init coder image!\n");
+        return -1;
+    }
+    if (gj_ensure_device_buffer((void**)&c->d_coefs, &c->d_coefs_cap, g->data_size * sizeof(int16_t)) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&c->d_planes, &c->d_planes_cap, g->data_size) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, ((size_t)g->segment_count * 3 + 4) * sizeof(uint32_t)) != 0) return -1;
+    if ((size_t)g->segment_count * 3 * sizeof(uint32_t) > d->h_seg_cap) {
+        gj_hip_host_free(d->h_seg);
+        d->h_seg_cap = (size_t)g->segment_count * 3 * sizeof(uint32_t);
+        d->h_seg = gj_hip_host_alloc(d->h_seg_cap);
+        if (!d->h_seg) { d->h_seg_cap = 0; return -1; }
+    }
+    c->configured = true;
+    return 0;
+}
+
+int gpujpeg_decoder_init(struct gpujpeg_decoder* d, const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi)
+{
+    d->coder.param.verbose = param->verbose;
+    d->coder.param.perf_stats = param->perf_stats || param->verbose >= GPUJPEG_LL_STATUS;
+    if ((size_t)pi->width * pi->height * param->comp_count == 0) return 0;
+    if (decoder_configure(d, param, pi) != 0) return -1;
+    gpujpeg_decoder_set_output_format(d, pi->color_space, pi->pixel_format);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ decode (src/gpujpeg_decoder.c:235-465) */
+int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t image_size, struct gpujpeg_decoder_output* output)
+{
+    struct gj_coder* c = &d->coder;
+    const bool stats = c->param.perf_stats != 0 || c->param.verbose >= GPUJPEG_LL_STATUS;
+    c->start_time = stats ? gpujpeg_get_time() : 0;
+    memset(&c->stats, 0, sizeof c->stats);
+    const double t_read0 = stats ? gpujpeg_get_time() : 0;
+
+    /* a device-resident stream is fetched once for parsing (MI355X extension, see gpujpeg_decoder.h) */
+    const bool jpeg_on_device = gj_hip_is_device_ptr(image) != 0;
+    uint8_t* host_copy = NULL;
+    const uint8_t* himage = image;
+    if (jpeg_on_device) {
+        host_copy = malloc(image_size);
+        if (!host_copy || gj_hip_memcpy_d2h(host_copy, image, image_size, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) {
+            free(host_copy);
+            return -1;
+        }
+        himage = host_copy;
+    }
+    struct gj_reader_result r;
+    int rc = gj_reader_parse(himage, image_size, c->param.verbose, d->ff_cs_itu601_is_709, d->req_pixel_format, d->req_color_space,
+                             d->req_alignment, &r, false);
+    if (rc != 0) {
+        GJ_ERROR("Decoder failed when decoding image data!\n");
+        free(host_copy);
+        return rc;
+    }
+    for (int i = 0; i < GPUJPEG_METADATA_COUNT; i++) d->metadata.vals[i] = r.metadata.vals[i];
+    if (decoder_configure(d, &r.param, &r.param_image) != 0) { free(host_copy); return -1; }
+    c->init_end_time = stats ? gpujpeg_get_time() : 0;
+    gj_geom* g = &c->geom;
+    for (int i = 0; i < g->comp_count; i++) {
+        g->comp[i].q_table = r.quant_map[i];
+        g->comp[i].dc_table = r.huff_map[i][0];
+        g->comp[i].ac_table = r.huff_map[i][1];
+    }
+    if (gj_reader_split_scans(himage, &r, g, &d->segs, c->param.verbose) != 0) { free(host_copy); return -1; }
+    if (d->segs.count > g->segment_count) {
+        GJ_ERROR("Decoder can't decode image that has segment count %d (maximum segment count for specified parameters is %d)!\n", d->segs.count, g->segment_count);
+        free(host_copy);
+        return -1;
+    }
+    if (d->segs.count != g->segment_count && c->param.verbose >= 0) GJ_WARN("%d segments read, expected %d. Broken JPEG?\n", d->segs.count, g->segment_count);
+    c->stats.duration_stream = stats ? (gpujpeg_get_time() - t_read0) * 1000.0 : 0;
+
+    /* tables: decode tables for every DHT slot present, natural-order quantisation tables */
+    memset(d->h_tabs, 0, GJ_TABS_WORDS * sizeof(uint16_t));
+    for (int th = 0; th < 4; th++)
+        for (int tc = 0; tc < 2; tc++)
+            if (r.h_present[th][tc] && gj_huffman_decoder_table(r.hbits[th][tc], r.hvals[th][tc], d->h_tabs + (th * 2 + tc) * GJ_DEC_TAB_WORDS) != 0) {
+                GJ_ERROR("Invalid Huffman table %d/%d!\n", th, tc);
+                free(host_copy);
+                return -1;
+            }
+    for (int t = 0; t < 4; t++)
+        if (r.q_present[t]) gj_quant_table_inverse(r.qraw[t], d->h_tabs + 8 * GJ_DEC_TAB_WORDS + t * 64);
+    for (int i = 0; i < g->comp_count; i++) {
+        if (!r.q_present[g->comp[i].q_table] || !r.h_present[g->comp[i].dc_table][0] || !r.h_present[g->comp[i].ac_table][1]) {
+            GJ_ERROR("Component %d refers to a table that was not defined!\n", i);
+            free(host_copy);
+            return -1;
+        }
+    }
+
+    if (stats) gj_hip_event_record(c->timers.copy_in[0], c->stream);
+    const uint8_t* d_jpeg;
+    if (jpeg_on_device) {
+        d_jpeg = image;
+    } else {
+        if (gj_ensure_device_buffer((void**)&d->d_jpeg, &d->d_jpeg_cap, image_size + 16) != 0) { free(host_copy); return -1; }
+        if (gj_hip_memcpy_h2d(d->d_jpeg, image, image_size, c->stream) != 0) { free(host_copy); return -1; }
+        d_jpeg = d->d_jpeg;
+    }
+    const size_t ns = (size_t)d->segs.count;
+    memcpy(d->h_seg, d->segs.pos, ns * sizeof(uint32_t));
+    memcpy(d->h_seg + ns, d->segs.len, ns * sizeof(uint32_t));
+    memcpy(d->h_seg + 2 * ns, d->segs.index, ns * sizeof(uint32_t));
+    if (gj_hip_memcpy_h2d(d->d_seg, d->h_seg, 3 * ns * sizeof(uint32_t), c->stream) != 0 ||
+        gj_hip_memcpy_h2d(d->d_huff_tab, d->h_tabs, GJ_TABS_WORDS * sizeof(uint16_t), c->stream) != 0) {
+        GJ_ERROR("Decoder copy compressed data failed: %s\n", gj_hip_last_error());
+        free(host_copy);
+        return -1;
+    }
+    if (stats) gj_hip_event_record(c->timers.copy_in[1], c->stream);
+
+    /* destination (:336-375) */
+    uint8_t* d_raw;
+    if (output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_CUDA_BUFFER) {
+        d_raw = output->data;
+    } else if (output->type == GPUJPEG_DECODER_OUTPUT_OPENGL_TEXTURE) {
+        GJ_ERROR("OpenGL texture output is not supported by the MI355X build.\n");
+        free(host_copy);
+        return -1;
+    } else {
+        if (gj_ensure_device_buffer((void**)&c->d_raw_own, &c->d_raw_cap, g->raw_size) != 0) { free(host_copy); return -1; }
+        d_raw = c->d_raw_own;
+    }
+
+    gj_dec_job job;
+    memset(&job, 0, sizeof job);
+    job.g = *g;
+    job.d_jpeg = d_jpeg;
+    job.jpeg_size = image_size;
+    job.d_seg_pos = d->d_seg;
+    job.d_seg_len = d->d_seg + ns;
+    job.d_seg_index = d->d_seg + 2 * ns;
+    job.seg_count = d->segs.count;
+    job.d_huff_tab = d->d_huff_tab;
+    job.d_qtab = d->d_qtab;
+    job.d_coefs = c->d_coefs;
+    job.d_planes = c->d_planes;
+    job.d_raw = d_raw;
+    job.use_fused = d->use_fused;
+    if (gj_hip_decode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
+        GJ_ERROR("Decoder kernels failed: %s\n", gj_hip_last_error());
+        free(host_copy);
+        return -1;
+    }
+
+    output->data_size = g->raw_size;
+    output->param_image = c->param_image;
+    if (output->param_image.color_space == GPUJPEG_NONE) output->param_image.color_space = c->param.color_space_internal;
+    if (output->type == GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER || output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_BUFFER) {
+        uint8_t* dst;
+        if (output->type == GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER) {
+            if (g->raw_size > d->h_raw_cap) {
+                gj_hip_host_free(d->h_raw);
+                d->h_raw = gj_hip_host_alloc(g->raw_size);
+                d->h_raw_cap = d->h_raw ? g->raw_size : 0;
+                if (!d->h_raw) { free(host_copy); return -1; }
+            }
+            dst = d->h_raw;
+            output->data = d->h_raw;
+        } else {
+            assert(output->data != NULL);
+            dst = output->data;
+        }
+        if (stats) gj_hip_event_record(c->timers.copy_out[0], c->stream);
+        if (gj_hip_memcpy_d2h(dst, d_raw, g->raw_size, c->stream) != 0) { free(host_copy); return -1; }
+        if (stats) gj_hip_event_record(c->timers.copy_out[1], c->stream);
+    } else {
+        output->data = d_raw;
+    }
+    if (gj_hip_stream_sync(c->stream) != 0) {
+        GJ_ERROR("Decoder failed: %s\n", gj_hip_last_error());
+        free(host_copy);
+        return -1;
+    }
+    free(host_copy);
+
+    if (stats) {
+        struct gpujpeg_duration_stats* s = &c->stats;
+        s->duration_huffman_coder = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[1]);
+        s->duration_dct_quantization = gj_hip_event_elapsed_ms(c->timers.ev[1], c->timers.ev[2]);
+        s->duration_preprocessor = gj_hip_event_elapsed_ms(c->timers.ev[2], c->timers.ev[3]);
+        s->duration_in_gpu = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[3]);
+        s->duration_memory_to = gj_hip_event_elapsed_ms(c->timers.copy_in[0], c->timers.copy_in[1]);
+        if (output->type == GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER || output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_BUFFER)
+            s->duration_memory_from = gj_hip_event_elapsed_ms(c->timers.copy_out[0], c->timers.copy_out[1]);
+    }
+    gj_coder_process_stats(c, stats);
+    if (c->param.verbose >= GPUJPEG_LL_STATUS)
+        fprintf(stderr, "Decompressed Size:%13zu bytes %dx%d %s %s\n", output->data_size, output->param_image.width, output->param_image.height,
+                gpujpeg_pixel_format_get_name(output->param_image.pixel_format), gpujpeg_color_space_get_name(output->param_image.color_space));
+    output->metadata = &d->metadata;
+    return 0;
+}
+
+int gpujpeg_decoder_get_stats(struct gpujpeg_decoder* d, struct gpujpeg_duration_stats* stats)
+{
+    if (!d || !stats) return -1;
+    *stats = d->coder.stats;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ image info (src/gpujpeg_reader.c:1739-1872) */
+int gpujpeg_decoder_get_image_info2(uint8_t* image, size_t image_size, struct gpujpeg_image_info* info, int verbose, unsigned flags)
+{
+    struct gj_reader_result r;
+    const bool count_segments = (flags & GPUJPEG_COUNT_SEG_COUNT_REQ) != 0;
+    const int rc = gj_reader_parse(image, image_size, verbose, false, GPUJPEG_PIXFMT_NATIVE, GPUJPEG_NONE, 0, &r, !count_segments);
+    if (rc != 0) return rc;
+    memset(info, 0, sizeof *info);
+    info->param_image = r.param_image;
+    info->param = r.param;
+    info->header_type = r.header_type;
+    info->comment = r.comment;
+    info->metadata = r.metadata;
+    if (info->param_image.color_space == GPUJPEG_NONE) info->param_image.color_space = r.param.color_space_internal;
+    if (count_segments) {
+        gj_geom g;
+        struct gj_host_segments segs = {0};
+        if (gj_geom_init(&g, &r.param, &r.param_image, false) == 0 && gj_reader_split_scans(image, &r, &g, &segs, verbose) == 0)
+            info->segment_count = segs.count;
+        free(segs.pos); free(segs.len); free(segs.index);
+    }
+    return 0;
+}
+
+int gpujpeg_decoder_get_image_info(uint8_t* image, size_t image_size, struct gpujpeg_image_parameters* pi, struct gpujpeg_parameters* param, int* segment_count)
+{
+    struct gpujpeg_image_info info;
+    const int rc = gpujpeg_decoder_get_image_info2(image, image_size, &info, param ? param->verbose : 0, segment_count ? GPUJPEG_COUNT_SEG_COUNT_REQ : 0);
+    if (rc != 0) return rc;
+    if (pi) *pi = info.param_image;
+    if (param) { const int v = param->verbose, ps = param->perf_stats; *param = info.param; param->verbose = v; param->perf_stats = ps; }
+    if (segment_count) *segment_count = info.segment_count;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ options (src/gpujpeg_decoder.c:486-558) */
+int gpujpeg_decoder_set_option(struct gpujpeg_decoder* d, const char* opt, const char* val)
+{
+    if (d == NULL || opt == NULL || val == NULL) return GPUJPEG_ERROR;
+    if (strcmp(opt, GPUJPEG_DEC_OPT_ALIGNMENT_BYTES_INT) == 0) {
+        const int a = atoi(val);
+        if (a < 0) { GJ_ERROR("Wrong alignment: %s\n", val); return GPUJPEG_ERROR; }
+        d->req_alignment = (unsigned)a;
+        return GPUJPEG_NOERR;
+    }
+    if (strcmp(opt, GPUJPEG_DEC_OPT_TGA_RLE_BOOL) == 0) return GPUJPEG_NOERR; /* only affects file output */
+    if (strcmp(opt, GPUJPEG_DEC_OPT_FLIPPED_BOOL) == 0 || strcmp(opt, GPUJPEG_DEC_OPT_CHANNEL_REMAP) == 0) {
+        GJ_ERROR("Option %s is not implemented in the MI355X build yet.\n", opt);
+        return GPUJPEG_ERROR;
+    }
+    GJ_ERROR("Invalid decoder option: %s!\n", opt);
+    return GPUJPEG_ERROR;
+}
+
+void gpujpeg_decoder_print_options(void)
+{
+    printf("\t" GPUJPEG_DEC_OPT_ALIGNMENT_BYTES_INT "=<n> - required line alignment of the decoded image in bytes\n");
+}
+
+/* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
+#include "gpujpeg_amd_ext.h"
+
+size_t gpujpeg_amd_decoder_read_coefficients(struct gpujpeg_decoder* d, int16_t* dst, size_t capacity)
+{
+    const size_t n = d->coder.geom.data_size;
+    if (!d->coder.configured || capacity < n) return 0;
+    if (gj_hip_memcpy_d2h(dst, d->coder.d_coefs, n * sizeof(int16_t), d->coder.stream) != 0 || gj_hip_stream_sync(d->coder.stream) != 0) return 0;
+    return n;
+}
+
+size_t gpujpeg_amd_decoder_read_planes(struct gpujpeg_decoder* d, uint8_t* dst, size_t capacity)
+{
+    const size_t n = d->coder.geom.data_size;
+    if (!d->coder.configured || capacity < n) return 0;
+    if (gj_hip_memcpy_d2h(dst, d->coder.d_planes, n, d->coder.stream) != 0 || gj_hip_stream_sync(d->coder.stream) != 0) return 0;
+    return n;
+}
+
+void gpujpeg_amd_decoder_set_fused(struct gpujpeg_decoder* d, int enabled) { d->use_fused = enabled != 0; }

@@ -1,0 +1,422 @@
+/*
+ * gj_encoder.c -- the libgpujpeg encoder API on MI355X. Host driver counterpart of
+ * src/gpujpeg_encoder.c: same entry points, argument meaning, ownership and error behaviour; the
+ * work itself is one call into the HIP layer (gj_hip_encode) which leaves a finished JPEG in HBM.
+ */
+#define _GNU_SOURCE
+#include <assert.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include "gj_internal.h"
+
+enum { GJ_OUT_PAGEABLE = 0, GJ_OUT_PINNED = 1, GJ_OUT_DEVICE = 2 };
+
+struct gpujpeg_encoder {
+    struct gj_coder coder;
+    enum gpujpeg_header_type header_type;
+    struct gpujpeg_image_metadata metadata;
+    int out_location;
+    bool flipped;
+    /* tables */
+    int table_quality; /* quality the uploaded tables were computed for, -1 = none */
+    uint8_t qraw[2][64];
+    float* d_fwd_q[2];
+    uint32_t* d_huff_lut;
+    /* device work buffers */
+    uint8_t* d_temp; size_t d_temp_cap;
+    uint32_t* d_seg; size_t d_seg_cap; /* bytes | ff | out(+1) */
+    uint8_t* d_jpeg; size_t d_jpeg_cap;
+    uint32_t* d_result;
+    uint8_t* d_scan_hdr; size_t d_scan_hdr_cap;
+    struct gj_scan_headers scan_hdrs;
+    /* host side */
+    uint32_t* h_result; /* pinned */
+    uint8_t* h_header;  /* pinned staging for the main header */
+    uint8_t* out_buf; size_t out_cap; bool out_buf_pinned;
+    int use_fused;
+};
+
+/* ------------------------------------------------------------------ input helpers (gpujpeg_encoder.h:77-110) */
+void gpujpeg_encoder_input_set_image(struct gpujpeg_encoder_input* in, uint8_t* image) { in->type = GPUJPEG_ENCODER_INPUT_IMAGE; in->image = image; in->texture = NULL; }
+void gpujpeg_encoder_input_set_gpu_image(struct gpujpeg_encoder_input* in, uint8_t* image) { in->type = GPUJPEG_ENCODER_INPUT_GPU_IMAGE; in->image = image; in->texture = NULL; }
+void gpujpeg_encoder_input_set_texture(struct gpujpeg_encoder_input* in, struct gpujpeg_opengl_texture* t) { in->type = GPUJPEG_ENCODER_INPUT_OPENGL_TEXTURE; in->image = NULL; in->texture = t; }
+struct gpujpeg_encoder_input gpujpeg_encoder_input_image(uint8_t* image) { struct gpujpeg_encoder_input i; gpujpeg_encoder_input_set_image(&i, image); return i; }
+struct gpujpeg_encoder_input gpujpeg_encoder_input_gpu_image(uint8_t* image) { struct gpujpeg_encoder_input i; gpujpeg_encoder_input_set_gpu_image(&i, image); return i; }
+struct gpujpeg_encoder_input gpujpeg_encoder_input_texture(struct gpujpeg_opengl_texture* t) { struct gpujpeg_encoder_input i; gpujpeg_encoder_input_set_texture(&i, t); return i; }
+
+/* ------------------------------------------------------------------ create / destroy (src/gpujpeg_encoder.c:105-163, 797-823) */
+struct gpujpeg_encoder* gpujpeg_encoder_create(cudaStream_t stream)
+{
+    gj_init_term_colors();
+    struct gpujpeg_encoder* e = calloc(1, sizeof *e);
+    if (!e) return NULL;
+    e->coder.encoder = true;
+    e->coder.stream = (gj_stream_t)stream;
+    e->table_quality = -1;
+    e->use_fused = getenv("GPUJPEG_NO_FUSED") ? 0 : 1;
+    gpujpeg_set_default_parameters(&e->coder.param);
+    gpujpeg_image_set_default_parameters(&e->coder.param_image);
+    e->coder.param.comp_count = 0;
+    if (gj_hip_get_device(&e->coder.device) != 0) goto fail;
+    if (gj_timers_create(&e->coder.timers) != 0) goto fail;
+    e->d_fwd_q[0] = gj_hip_malloc(64 * sizeof(float));
+    e->d_fwd_q[1] = gj_hip_malloc(64 * sizeof(float));
+    e->d_huff_lut = gj_hip_malloc(4 * 256 * sizeof(uint32_t));
+    e->d_result = gj_hip_malloc(4 * sizeof(uint32_t));
+    e->h_result = gj_hip_host_alloc(4 * sizeof(uint32_t));
+    e->h_header = gj_hip_host_alloc(4096);
+    if (!e->d_fwd_q[0] || !e->d_fwd_q[1] || !e->d_huff_lut || !e->d_result || !e->h_result || !e->h_header) goto fail;
+    uint32_t lut[4 * 256];
+    gj_huffman_encoder_lut(lut);
+    if (gj_hip_memcpy_h2d(e->d_huff_lut, lut, sizeof lut, e->coder.stream) != 0 || gj_hip_stream_sync(e->coder.stream) != 0) goto fail;
+    return e;
+fail:
+    GJ_ERROR("Encoder initialisation failed: %s\n", gj_hip_last_error());
+    gpujpeg_encoder_destroy(e);
+    return NULL;
+}
+
+int gpujpeg_encoder_destroy(struct gpujpeg_encoder* e)
+{
+    if (!e) return -1;
+    gj_coder_process_stats_overall(&e->coder);
+    gj_timers_destroy(&e->coder.timers);
+    gj_hip_free(e->d_fwd_q[0]); gj_hip_free(e->d_fwd_q[1]); gj_hip_free(e->d_huff_lut); gj_hip_free(e->d_result);
+    gj_hip_free(e->d_temp); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
+    gj_hip_free(e->coder.d_raw_own); gj_hip_free(e->coder.d_planes); gj_hip_free(e->coder.d_coefs);
+    gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header);
+    if (e->out_buf_pinned) gj_hip_host_free(e->out_buf); else free(e->out_buf);
+    free(e->scan_hdrs.bytes);
+    free(e);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ parameter adjustment (src/gpujpeg_encoder.c:291-346) */
+int gpujpeg_encoder_suggest_restart_interval(const struct gpujpeg_image_parameters* pi, gpujpeg_sampling_factor_t subsampling, bool interleaved, int verbose)
+{
+    const int comps = gpujpeg_pixel_format_get_comp_count(pi->pixel_format);
+    const double mpix3 = ((double)pi->width * pi->height * comps) / (1000000.0 * 3.0);
+    int ri = mpix3 < 1.0 ? 4 : mpix3 < 3.0 ? 8 : mpix3 < 9.0 ? 10 : 12;
+    if (subsampling != GPUJPEG_SUBSAMPLING_444 && interleaved) ri /= 2; /* bigger MCUs */
+    if (!interleaved) ri *= comps;                                       /* one scan per component */
+    GJ_VERBOSE(verbose, "Auto-adjusting restart interval to %d for better performance.\n", ri);
+    return ri;
+}
+
+static struct gpujpeg_parameters adjust_params(const struct gj_coder* c, const struct gpujpeg_parameters* param,
+                                               const struct gpujpeg_image_parameters* pi, bool img_changed)
+{
+    struct gpujpeg_parameters p = *param;
+    if (param->comp_count == 0) {
+        if (img_changed) {
+            const int n = gpujpeg_pixel_format_get_comp_count(pi->pixel_format);
+            p.comp_count = n < 3 ? n : 3;
+            memcpy(p.sampling_factor, gj_pixfmt_sampling(pi->pixel_format), sizeof p.sampling_factor);
+        } else {
+            p.comp_count = c->param.comp_count;
+            memcpy(p.sampling_factor, c->param.sampling_factor, sizeof p.sampling_factor);
+        }
+    }
+    if (param->restart_interval == RESTART_AUTO) {
+        if (img_changed || p.interleaved != c->param.interleaved)
+            p.restart_interval = gpujpeg_encoder_suggest_restart_interval(pi, gj_make_sampling_factor(p.comp_count, p.sampling_factor), p.interleaved, p.verbose);
+        else
+            p.restart_interval = c->param.restart_interval;
+    }
+    return p;
+}
+
+/* ------------------------------------------------------------------ (re)configuration */
+static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_parameters* p, const struct gpujpeg_image_parameters* pi)
+{
+    struct gj_coder* c = &e->coder;
+    if (c->configured && gj_parameters_equal(&c->param, p) && gj_image_parameters_equal(&c->param_image, pi)) {
+        c->param = *p; /* verbose / perf_stats / quality may change without reconfiguration (common.c:632-637) */
+        c->param_image = *pi;
+        return 0;
+    }
+    GJ_DEBUG(p->verbose, "coder image reconfiguration\n");
+    c->configured = false;
+    c->param = *p;
+    c->param_image = *pi;
+    gj_geom* g = &c->geom;
+    if (gj_geom_init(g, p, pi, true) != 0) {
+        GJ_ERROR("Failed to init image encoding!\n");
+        return -1;
+    }
+    if (gj_ensure_device_buffer((void**)&c->d_coefs, &c->d_coefs_cap, g->data_size * sizeof(int16_t)) != 0) return -1;
+    /* planes are needed by the generic path only; zero filled once, padding is never written (common.c:941-944) */
+    if (gj_ensure_device_buffer((void**)&c->d_planes, &c->d_planes_cap, g->data_size) != 0) return -1;
+    if (gj_hip_memset(c->d_planes, 0, g->data_size, c->stream) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_TEMP_BYTES_PER_BLOCK + 256) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&e->d_seg, &e->d_seg_cap, ((size_t)g->segment_count * 3 + 4) * sizeof(uint32_t)) != 0) return -1;
+    if (gj_write_scan_headers(&e->scan_hdrs, g, p) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&e->d_scan_hdr, &e->d_scan_hdr_cap, e->scan_hdrs.size + 16) != 0) return -1;
+    if (gj_hip_memcpy_h2d(e->d_scan_hdr, e->scan_hdrs.bytes, e->scan_hdrs.size, c->stream) != 0) return -1;
+    if (gj_hip_stream_sync(c->stream) != 0) return -1; /* scan_hdrs.bytes is pageable: finish before it can change */
+    /* same sizing rule as the reference writer (writer.c:66-69) plus the scan headers */
+    const size_t jpeg_cap = 1000 + e->scan_hdrs.size + (size_t)pi->width * pi->height * p->comp_count * 2 + 4096;
+    if (gj_ensure_device_buffer((void**)&e->d_jpeg, &e->d_jpeg_cap, jpeg_cap) != 0) return -1;
+    c->configured = true;
+    return 0;
+}
+
+static int ensure_out_buffer(struct gpujpeg_encoder* e, size_t need)
+{
+    const bool want_pinned = e->out_location == GJ_OUT_PINNED;
+    if (need <= e->out_cap && want_pinned == e->out_buf_pinned) return 0;
+    if (e->out_buf_pinned) gj_hip_host_free(e->out_buf); else free(e->out_buf);
+    e->out_buf = want_pinned ? gj_hip_host_alloc(need) : malloc(need);
+    e->out_buf_pinned = want_pinned;
+    e->out_cap = e->out_buf ? need : 0;
+    return e->out_buf ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------ encode (src/gpujpeg_encoder.c:352-644) */
+int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi,
+                           const struct gpujpeg_encoder_input* input, uint8_t** image_compressed, size_t* image_compressed_size)
+{
+    assert(param->comp_count <= GPUJPEG_MAX_COMPONENT_COUNT);
+    assert(param->quality >= 0 && param->quality <= 100);
+    assert(param->restart_interval >= RESTART_AUTO);
+    assert(param->interleaved == 0 || param->interleaved == 1);
+    struct gj_coder* c = &e->coder;
+    const bool img_changed = !c->configured || !gj_image_parameters_equal(&c->param_image, pi);
+    struct gpujpeg_parameters p = adjust_params(c, param, pi, img_changed);
+    p.perf_stats = param->perf_stats || param->verbose >= GPUJPEG_LL_STATUS;
+    const bool stats = p.perf_stats != 0;
+    c->start_time = stats ? gpujpeg_get_time() : 0;
+
+    if (e->table_quality != param->quality) { /* :369-380 */
+        for (int t = 0; t < 2; t++) {
+            float fwd[64];
+            gj_quant_table_raw(t, param->quality, e->qraw[t]);
+            gj_quant_table_forward(e->qraw[t], fwd);
+            if (gj_hip_memcpy_h2d(e->d_fwd_q[t], fwd, sizeof fwd, c->stream) != 0) return -1;
+        }
+        if (gj_hip_stream_sync(c->stream) != 0) return -1; /* stack source */
+        e->table_quality = param->quality;
+    }
+    if (encoder_configure(e, &p, pi) != 0) return -1;
+    const gj_geom* g = &c->geom;
+    c->init_end_time = stats ? gpujpeg_get_time() : 0;
+    memset(&c->stats, 0, sizeof c->stats);
+
+    /* input (:397-475) */
+    const uint8_t* d_raw = NULL;
+    if (input->type == GPUJPEG_ENCODER_INPUT_GPU_IMAGE || (input->type == GPUJPEG_ENCODER_INPUT_IMAGE && gj_hip_is_device_ptr(input->image))) {
+        d_raw = input->image;
+    } else if (input->type == GPUJPEG_ENCODER_INPUT_IMAGE) {
+        if (gj_ensure_device_buffer((void**)&c->d_raw_own, &c->d_raw_cap, g->raw_size) != 0) return -1;
+        if (stats) gj_hip_event_record(c->timers.copy_in[0], c->stream);
+        if (gj_hip_memcpy_h2d(c->d_raw_own, input->image, g->raw_size, c->stream) != 0) {
+            GJ_ERROR("Encoder raw data copy failed: %s\n", gj_hip_last_error());
+            return -1;
+        }
+        if (stats) gj_hip_event_record(c->timers.copy_in[1], c->stream);
+        d_raw = c->d_raw_own;
+    } else {
+        GJ_ERROR("OpenGL texture input is not supported by the MI355X build.\n");
+        return -1;
+    }
+
+    /* main header: host bytes, placed at the start of the device stream */
+    const size_t hdr = gj_write_main_header(e->h_header, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata);
+    if (gj_hip_memcpy_h2d(e->d_jpeg, e->h_header, hdr, c->stream) != 0) return -1;
+
+    gj_enc_job job;
+    memset(&job, 0, sizeof job);
+    job.g = *g;
+    job.d_raw = d_raw;
+    job.d_planes = c->d_planes;
+    job.d_coefs = c->d_coefs;
+    job.d_fwd_q[0] = e->d_fwd_q[0];
+    job.d_fwd_q[1] = e->d_fwd_q[1];
+    job.d_huff_lut = e->d_huff_lut;
+    job.d_temp = e->d_temp;
+    job.d_seg_bytes = e->d_seg;
+    job.d_seg_ff = e->d_seg + g->segment_count;
+    job.d_seg_out = e->d_seg + 2 * (size_t)g->segment_count;
+    job.d_jpeg = e->d_jpeg;
+    job.jpeg_capacity = e->d_jpeg_cap;
+    job.d_result = e->d_result;
+    job.d_scan_hdr = e->d_scan_hdr;
+    memcpy(job.scan_hdr_offset, e->scan_hdrs.offset, sizeof job.scan_hdr_offset);
+    memcpy(job.scan_info_payload, e->scan_hdrs.info_payload, sizeof job.scan_info_payload);
+    job.main_hdr_size = (uint32_t)hdr;
+    job.segment_info = p.segment_info;
+    job.use_fused = e->use_fused && !e->flipped;
+    if (gj_hip_encode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
+        GJ_ERROR("Encoder kernels failed: %s\n", gj_hip_last_error());
+        return -1;
+    }
+    /* size first, then the bytes (:550-563) */
+    if (gj_hip_memcpy_d2h(e->h_result, e->d_result, 2 * sizeof(uint32_t), c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) {
+        GJ_ERROR("Encoder failed: %s\n", gj_hip_last_error());
+        return -1;
+    }
+    const size_t size = e->h_result[0];
+    if (e->h_result[1]) {
+        GJ_ERROR("Compressed stream (%zu B) does not fit the output buffer (%zu B)!\n", size, e->d_jpeg_cap);
+        return -1;
+    }
+    if (e->out_location == GJ_OUT_DEVICE) {
+        *image_compressed = e->d_jpeg;
+    } else {
+        if (ensure_out_buffer(e, e->d_jpeg_cap) != 0) return -1;
+        if (stats) gj_hip_event_record(c->timers.copy_out[0], c->stream);
+        if (gj_hip_memcpy_d2h(e->out_buf, e->d_jpeg, size, c->stream) != 0) return -1;
+        if (stats) gj_hip_event_record(c->timers.copy_out[1], c->stream);
+        if (gj_hip_stream_sync(c->stream) != 0) return -1;
+        *image_compressed = e->out_buf;
+    }
+    *image_compressed_size = size;
+
+    if (stats) {
+        struct gpujpeg_duration_stats* s = &c->stats;
+        s->duration_preprocessor = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[1]);
+        s->duration_dct_quantization = gj_hip_event_elapsed_ms(c->timers.ev[1], c->timers.ev[2]);
+        s->duration_huffman_coder = gj_hip_event_elapsed_ms(c->timers.ev[2], c->timers.ev[3]);
+        s->duration_in_gpu = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[3]);
+        if (d_raw == c->d_raw_own) s->duration_memory_to = gj_hip_event_elapsed_ms(c->timers.copy_in[0], c->timers.copy_in[1]);
+        if (e->out_location != GJ_OUT_DEVICE) s->duration_memory_from = gj_hip_event_elapsed_ms(c->timers.copy_out[0], c->timers.copy_out[1]);
+        c->timers.valid = true;
+    }
+    gj_coder_process_stats(c, stats);
+    if (c->param.verbose >= GPUJPEG_LL_STATUS) {
+        const char* il = p.comp_count == 1 ? "" : (p.interleaved ? " interleaved" : " non-interleaved");
+        fprintf(stderr, "Compressed Size:%15zu bytes %dx%d %s %s%s\n", size, pi->width, pi->height,
+                gpujpeg_color_space_get_name(p.color_space_internal), gpujpeg_subsampling_get_name(p.comp_count, p.sampling_factor), il);
+    }
+    return 0;
+}
+
+int gpujpeg_encoder_get_stats(struct gpujpeg_encoder* e, struct gpujpeg_duration_stats* stats)
+{
+    if (!e || !stats) return -1;
+    *stats = e->coder.stats;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ memory planning (src/gpujpeg_encoder.c:165-288) */
+size_t gpujpeg_encoder_max_memory(struct gpujpeg_parameters* param, struct gpujpeg_image_parameters* pi, enum gpujpeg_encoder_input_type type, int max_pixels)
+{
+    struct gpujpeg_image_parameters t = *pi;
+    t.width = (int)(max_pixels > 0 ? (max_pixels < 65535 ? max_pixels : 65535) : 1);
+    t.height = (max_pixels + t.width - 1) / t.width;
+    if (t.height < 1) t.height = 1;
+    struct gpujpeg_parameters p = *param;
+    if (p.comp_count == 0) {
+        const int n = gpujpeg_pixel_format_get_comp_count(pi->pixel_format);
+        p.comp_count = n < 3 ? n : 3;
+        memcpy(p.sampling_factor, gj_pixfmt_sampling(pi->pixel_format), sizeof p.sampling_factor);
+    }
+    if (p.restart_interval == RESTART_AUTO) p.restart_interval = gpujpeg_encoder_suggest_restart_interval(&t, gj_make_sampling_factor(p.comp_count, p.sampling_factor), p.interleaved, -1);
+    gj_geom g;
+    if (gj_geom_init(&g, &p, &t, true) != 0) return 0;
+    size_t total = g.data_size * 3 + (size_t)g.block_count * GJ_TEMP_BYTES_PER_BLOCK + (size_t)g.segment_count * 12 +
+                   1000 + (size_t)t.width * t.height * p.comp_count * 2;
+    if (type == GPUJPEG_ENCODER_INPUT_IMAGE) total += g.raw_size;
+    return total;
+}
+
+size_t gpujpeg_encoder_max_pixels(struct gpujpeg_parameters* param, struct gpujpeg_image_parameters* pi, enum gpujpeg_encoder_input_type type,
+                                  size_t memory_size, int* max_pixels)
+{
+    int lo = 0, hi = 1 << 30;
+    while (hi - lo > 1024) { /* bisection over the monotone memory model */
+        const int mid = lo + (hi - lo) / 2;
+        const size_t need = gpujpeg_encoder_max_memory(param, pi, type, mid);
+        if (need != 0 && need <= memory_size) lo = mid; else hi = mid;
+    }
+    if (max_pixels) *max_pixels = lo;
+    return lo ? gpujpeg_encoder_max_memory(param, pi, type, lo) : 0;
+}
+
+int gpujpeg_encoder_allocate(struct gpujpeg_encoder* e, const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi,
+                             enum gpujpeg_encoder_input_type type)
+{
+    struct gpujpeg_parameters p = adjust_params(&e->coder, param, pi, true);
+    if (encoder_configure(e, &p, pi) != 0) return -1;
+    if (type == GPUJPEG_ENCODER_INPUT_IMAGE && gj_ensure_device_buffer((void**)&e->coder.d_raw_own, &e->coder.d_raw_cap, e->coder.geom.raw_size) != 0)
+        return -1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ options (src/gpujpeg_encoder.c:648-795) */
+void gpujpeg_encoder_set_jpeg_header(struct gpujpeg_encoder* e, enum gpujpeg_header_type t) { e->header_type = t; }
+
+static int parse_bool(bool* out, const char* val, const char* opt)
+{
+    if (strcasecmp(val, GPUJPEG_VAL_TRUE) == 0) { *out = true; return GPUJPEG_NOERR; }
+    if (strcasecmp(val, GPUJPEG_VAL_FALSE) == 0) { *out = false; return GPUJPEG_NOERR; }
+    GJ_ERROR("Unknown option %s for %s\n", val, opt);
+    return GPUJPEG_ERROR;
+}
+
+int gpujpeg_encoder_set_option(struct gpujpeg_encoder* e, const char* opt, const char* val)
+{
+    if (e == NULL || opt == NULL || val == NULL) return GPUJPEG_ERROR;
+    if (strcmp(opt, GPUJPEG_ENCODER_OPT_OUT_PINNED) == 0) {
+        bool b;
+        if (parse_bool(&b, val, opt) != GPUJPEG_NOERR) return GPUJPEG_ERROR;
+        e->out_location = b ? GJ_OUT_PINNED : GJ_OUT_PAGEABLE;
+        return GPUJPEG_NOERR;
+    }
+    if (strcmp(opt, GPUJPEG_ENC_OPT_OUT) == 0) {
+        if (strcmp(val, GPUJPEG_ENC_OUT_VAL_PAGEABLE) == 0) e->out_location = GJ_OUT_PAGEABLE;
+        else if (strcmp(val, GPUJPEG_ENC_OUT_VAL_PINNED) == 0) e->out_location = GJ_OUT_PINNED;
+        else if (strcmp(val, GPUJPEG_ENC_OUT_VAL_DEVICE) == 0) e->out_location = GJ_OUT_DEVICE;
+        else {
+            GJ_ERROR("Unknown encoder output type: %s\n", val);
+            return GPUJPEG_ERROR;
+        }
+        return GPUJPEG_NOERR;
+    }
+    if (strcmp(opt, GPUJPEG_ENC_OPT_HDR) == 0) {
+        const enum gpujpeg_header_type t = gpujpeg_header_type_by_name(val);
+        if (t == GPUJPEG_HEADER_DEFAULT) {
+            GJ_ERROR("Unknown encoder header type: %s\n", val);
+            return GPUJPEG_ERROR;
+        }
+        e->header_type = t;
+        return GPUJPEG_NOERR;
+    }
+    if (strcmp(opt, GPUJPEG_ENC_OPT_FLIPPED_BOOL) == 0 || strcmp(opt, GPUJPEG_ENC_OPT_CHANNEL_REMAP) == 0 ||
+        strcmp(opt, GPUJPEG_ENC_OPT_EXIF_TAG) == 0 || strcmp(opt, GPUJPEG_ENC_OPT_METADATA) == 0) {
+        GJ_ERROR("Option %s is not implemented in the MI355X build yet.\n", opt);
+        return GPUJPEG_ERROR;
+    }
+    GJ_ERROR("Invalid encoder option: %s!\n", opt);
+    return GPUJPEG_ERROR;
+}
+
+void gpujpeg_encoder_print_options(void)
+{
+    printf("\t" GPUJPEG_ENC_OPT_OUT "=[" GPUJPEG_ENC_OUT_VAL_PAGEABLE "|" GPUJPEG_ENC_OUT_VAL_PINNED "|" GPUJPEG_ENC_OUT_VAL_DEVICE
+           "] - location of the buffer returned by the encoder\n");
+    printf("\t" GPUJPEG_ENC_OPT_HDR "=[" GPUJPEG_ENC_HDR_VAL_JFIF "|" GPUJPEG_ENC_HDR_VAL_ADOBE "|" GPUJPEG_ENC_HDR_VAL_SPIFF "] - JPEG header to emit\n");
+}
+
+/* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
+#include "gpujpeg_amd_ext.h"
+
+size_t gpujpeg_amd_encoder_read_coefficients(struct gpujpeg_encoder* e, int16_t* dst, size_t capacity)
+{
+    const size_t n = e->coder.geom.data_size;
+    if (!e->coder.configured || capacity < n) return 0;
+    if (gj_hip_memcpy_d2h(dst, e->coder.d_coefs, n * sizeof(int16_t), e->coder.stream) != 0 || gj_hip_stream_sync(e->coder.stream) != 0) return 0;
+    return n;
+}
+
+size_t gpujpeg_amd_encoder_read_planes(struct gpujpeg_encoder* e, uint8_t* dst, size_t capacity)
+{
+    const size_t n = e->coder.geom.data_size;
+    if (!e->coder.configured || capacity < n) return 0;
+    if (gj_hip_memcpy_d2h(dst, e->coder.d_planes, n, e->coder.stream) != 0 || gj_hip_stream_sync(e->coder.stream) != 0) return 0;
+    return n;
+}
+
+void gpujpeg_amd_encoder_set_fused(struct gpujpeg_encoder* e, int enabled) { e->use_fused = enabled != 0; }

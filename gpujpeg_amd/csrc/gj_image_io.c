@@ -1,0 +1,426 @@
+/*
+ * gj_image_io.c -- image file front-end of the API: gpujpeg_image_load_from_file / save_to_file /
+ * get_properties / get_file_format (reference: src/gpujpeg_common.c:380-470,1208-1376 and the delegates
+ * in src/utils/image_delegate.c, pam.c, y4m.c).
+ *
+ * Implemented natively: headerless raw files (.rgb .rgba .yuv .yuva .uyvy .i420 .r .raw), PNM (P5/P6),
+ * PAM (P7), Y4M (8-bit 4:4:4 / 4:2:2 / 4:2:0 / mono) and the synthetic ".tst" images. BMP/GIF/PNG/TGA go
+ * through vendored third-party decoders in the reference and are reported as unsupported here.
+ */
+#define _GNU_SOURCE
+#include <ctype.h>
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include "gj_internal.h"
+
+enum gpujpeg_image_file_format gpujpeg_image_get_file_format(const char* filename) /* common.c:380-444 */
+{
+    static const struct { const char* ext; enum gpujpeg_image_file_format f; } exts[] = {
+        {"raw", GPUJPEG_IMAGE_FILE_RAW}, {"rgb", GPUJPEG_IMAGE_FILE_RGB}, {"rgba", GPUJPEG_IMAGE_FILE_RGBA}, {"yuv", GPUJPEG_IMAGE_FILE_YUV},
+        {"yuva", GPUJPEG_IMAGE_FILE_YUVA}, {"uyvy", GPUJPEG_IMAGE_FILE_UYVY}, {"i420", GPUJPEG_IMAGE_FILE_I420}, {"r", GPUJPEG_IMAGE_FILE_GRAY},
+        {"jpg", GPUJPEG_IMAGE_FILE_JPEG}, {"jpeg", GPUJPEG_IMAGE_FILE_JPEG}, {"jfif", GPUJPEG_IMAGE_FILE_JPEG}, {"bmp", GPUJPEG_IMAGE_FILE_BMP},
+        {"gif", GPUJPEG_IMAGE_FILE_GIF}, {"png", GPUJPEG_IMAGE_FILE_PNG}, {"tga", GPUJPEG_IMAGE_FILE_TGA}, {"pnm", GPUJPEG_IMAGE_FILE_PNM},
+        {"pgm", GPUJPEG_IMAGE_FILE_PGM}, {"ppm", GPUJPEG_IMAGE_FILE_PPM}, {"pam", GPUJPEG_IMAGE_FILE_PAM}, {"y4m", GPUJPEG_IMAGE_FILE_Y4M},
+        {"tst", GPUJPEG_IMAGE_FILE_TST}, {"XXX", GPUJPEG_IMAGE_FILE_RAW}};
+    const size_t n = sizeof exts / sizeof exts[0];
+    if (strcmp(filename, "help") == 0) {
+        fprintf(stderr, "Recognized extensions:\n");
+        for (size_t i = 0; i < n; i++)
+            if (exts[i].f != GPUJPEG_IMAGE_FILE_RAW) fprintf(stderr, "\t- %s\n", exts[i].ext);
+        fprintf(stderr, "\nUse \"help.tst\" (eg. `gpujpegtool help.tst null.jpg`) for test image usage).\n");
+        return GPUJPEG_IMAGE_FILE_UNKNOWN;
+    }
+    if (strcmp(filename, "rawhelp") == 0) {
+        fprintf(stderr, "Recognized raw extensions:");
+        for (size_t i = 0; i < n; i++)
+            if (exts[i].f > GPUJPEG_IMAGE_FILE_RAW) fprintf(stderr, " %s", exts[i].ext);
+        fprintf(stderr, "\n");
+        return GPUJPEG_IMAGE_FILE_UNKNOWN;
+    }
+    const char* dot = strrchr(filename, '.');
+    if (!dot) return GPUJPEG_IMAGE_FILE_UNKNOWN;
+    for (size_t i = 0; i < n; i++)
+        if (strcasecmp(dot + 1, exts[i].ext) == 0) return exts[i].f;
+    return GPUJPEG_IMAGE_FILE_UNKNOWN;
+}
+
+/* ------------------------------------------------------------------ .tst synthetic images (image_delegate.c:383-632) */
+enum tst_pattern { TST_GRADIENT, TST_NOISE, TST_RANDOM, TST_BLANK };
+
+static void tst_usage(void)
+{
+    fprintf(stderr, "Test image usage:\n\t<W>x<H>[.c_<cs>][.p_<pixfmt>][.gradient|.noise|.random[_<seed>]|.blank[_<val>]].tst\n");
+}
+
+static int tst_parse(const char* filename, struct gpujpeg_image_parameters* pi, enum tst_pattern* pattern, int* seed, long* blank)
+{
+    char name[4096];
+    snprintf(name, sizeof name, "%s", filename);
+    const char* base = strrchr(name, '/');
+    char* s = base ? (char*)base + 1 : name;
+    char* dot = strrchr(s, '.');
+    if (!dot) return -1;
+    *dot = '\0';
+    char* endp = s;
+    pi->width = (int)strtoul(s, &endp, 10);
+    if (*endp != 'x') { tst_usage(); return -1; }
+    pi->height = (int)strtoul(endp + 1, &endp, 10);
+    if (pi->height == 0) { tst_usage(); return -1; }
+    pi->color_space = GPUJPEG_RGB;
+    pi->pixel_format = GPUJPEG_444_U8_P012;
+    pi->width_padding = 0;
+    *pattern = TST_GRADIENT;
+    *seed = 12345;
+    *blank = 0;
+    char* save = NULL;
+    for (char* item = strtok_r(endp, ".", &save); item; item = strtok_r(NULL, ".", &save)) {
+        const char* us = strchr(item, '_');
+        if (strncmp(item, "c_", 2) == 0) {
+            pi->color_space = gpujpeg_color_space_by_name(us + 1);
+            if (pi->color_space == GPUJPEG_NONE) { GJ_ERROR("[tst] Unknown color space: %s\n", us + 1); return -1; }
+        } else if (strncmp(item, "p_", 2) == 0) {
+            pi->pixel_format = gpujpeg_pixel_format_by_name(us + 1);
+            if (pi->pixel_format == GPUJPEG_PIXFMT_NONE) { GJ_ERROR("[tst] Unknown pixel format: %s\n", us + 1); return -1; }
+        } else if (strcmp(item, "noise") == 0) *pattern = TST_NOISE;
+        else if (strncmp(item, "random", 6) == 0) { *pattern = TST_RANDOM; if (us) *seed = atoi(us + 1); }
+        else if (strncmp(item, "blank", 5) == 0) { *pattern = TST_BLANK; if (us) *blank = strtol(us + 1, NULL, 0); }
+        else if (strcmp(item, "gradient") == 0) *pattern = TST_GRADIENT;
+        else { GJ_ERROR("[tst] unknown test image option: %s!\n", item); return -1; }
+    }
+    return 0;
+}
+
+static int tst_load(const char* filename, uint8_t** image, size_t* size)
+{
+    struct gpujpeg_image_parameters pi;
+    enum tst_pattern pattern;
+    int seed;
+    long blank;
+    if (tst_parse(filename, &pi, &pattern, &seed, &blank) != 0) return -1;
+    *size = gpujpeg_image_calculate_size(&pi);
+    uint8_t* data = gj_hip_host_alloc(*size);
+    if (!data) return -1;
+    switch (pattern) {
+    case TST_GRADIENT: {
+        struct gpujpeg_image_parameters line = pi;
+        line.height = 1;
+        const size_t linesize = gpujpeg_image_calculate_size(&line);
+        for (int i = 0; i < pi.height; i++) memset(data + (size_t)i * linesize, i * 255 / pi.height, linesize);
+        break; }
+    case TST_NOISE:
+        for (size_t i = 0; i < *size; i++) data[i] = (uint8_t)(rand() % 256);
+        break;
+    case TST_RANDOM: { /* LCG of image_delegate.c:562-582 */
+        uint32_t state = (uint32_t)seed;
+        for (size_t i = 0; i < *size; i++) {
+            state = (1664525u * state + 1013904223u) % 2147483647u;
+            data[i] = (uint8_t)(state % 256);
+        }
+        break; }
+    case TST_BLANK: memset(data, (int)blank, *size); break;
+    }
+    *image = data;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ PNM / PAM */
+static int pnm_token(FILE* f, char* buf, size_t n)
+{
+    int c;
+    do {
+        c = fgetc(f);
+        if (c == '#') while ((c = fgetc(f)) != '\n' && c != EOF) {}
+    } while (c != EOF && isspace(c));
+    size_t i = 0;
+    while (c != EOF && !isspace(c) && i + 1 < n) { buf[i++] = (char)c; c = fgetc(f); }
+    buf[i] = '\0';
+    return i > 0 ? 0 : -1;
+}
+
+static int pnm_read_header(FILE* f, int* w, int* h, int* depth, int* maxval)
+{
+    char tok[64];
+    if (pnm_token(f, tok, sizeof tok) != 0) return -1;
+    if (strcmp(tok, "P5") == 0 || strcmp(tok, "P6") == 0) {
+        *depth = tok[1] == '5' ? 1 : 3;
+        if (pnm_token(f, tok, sizeof tok) != 0) return -1;
+        *w = atoi(tok);
+        if (pnm_token(f, tok, sizeof tok) != 0) return -1;
+        *h = atoi(tok);
+        if (pnm_token(f, tok, sizeof tok) != 0) return -1;
+        *maxval = atoi(tok);
+        return 0; /* exactly one whitespace byte was consumed after maxval */
+    }
+    if (strcmp(tok, "P7") == 0) {
+        *w = *h = *depth = *maxval = 0;
+        char line[256];
+        (void)fgets(line, sizeof line, f);
+        while (fgets(line, sizeof line, f)) {
+            if (strncmp(line, "ENDHDR", 6) == 0) return (*w > 0 && *h > 0 && *depth > 0) ? 0 : -1;
+            if (sscanf(line, "WIDTH %d", w) == 1 || sscanf(line, "HEIGHT %d", h) == 1 || sscanf(line, "DEPTH %d", depth) == 1 ||
+                sscanf(line, "MAXVAL %d", maxval) == 1)
+                continue;
+        }
+    }
+    return -1;
+}
+
+static enum gpujpeg_pixel_format depth_pixfmt(int depth)
+{
+    return depth == 1 ? GPUJPEG_U8 : depth == 3 ? GPUJPEG_444_U8_P012 : depth == 4 ? GPUJPEG_4444_U8_P0123 : GPUJPEG_PIXFMT_NONE;
+}
+
+static int pnm_probe(const char* filename, struct gpujpeg_image_parameters* pi, int file_exists)
+{
+    if (!file_exists) { /* output file: keep what the caller chose except the colour space */
+        pi->color_space = GPUJPEG_RGB;
+        if (pi->pixel_format != GPUJPEG_U8 && pi->pixel_format != GPUJPEG_4444_U8_P0123) pi->pixel_format = GPUJPEG_PIXFMT_NO_ALPHA;
+        return 1;
+    }
+    FILE* f = fopen(filename, "rb");
+    if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
+    int w, h, depth, maxval;
+    const int rc = pnm_read_header(f, &w, &h, &depth, &maxval);
+    fclose(f);
+    if (rc != 0 || maxval != 255 || depth_pixfmt(depth) == GPUJPEG_PIXFMT_NONE) { GJ_ERROR("Unsupported PNM/PAM file %s (8-bit, 1/3/4 channels expected)\n", filename); return -1; }
+    pi->width = w;
+    pi->height = h;
+    pi->color_space = depth == 1 ? GPUJPEG_YCBCR_JPEG : GPUJPEG_RGB;
+    pi->pixel_format = depth_pixfmt(depth);
+    return 0;
+}
+
+static int pnm_load(const char* filename, uint8_t** image, size_t* size)
+{
+    FILE* f = fopen(filename, "rb");
+    if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
+    int w, h, depth, maxval;
+    if (pnm_read_header(f, &w, &h, &depth, &maxval) != 0 || maxval != 255) { fclose(f); GJ_ERROR("Unsupported PNM/PAM file %s\n", filename); return -1; }
+    const size_t n = (size_t)w * h * depth;
+    if (*size != 0 && *size != n) GJ_WARN("Image size mismatch: expected %zu, file has %zu bytes\n", *size, n);
+    uint8_t* data = gj_hip_host_alloc(n);
+    if (!data || fread(data, 1, n, f) != n) { fclose(f); gj_hip_host_free(data); GJ_ERROR("Failed to load image data [%zu bytes] from file %s!\n", n, filename); return -1; }
+    fclose(f);
+    *image = data;
+    *size = n;
+    return 0;
+}
+
+static int pnm_save(const char* filename, enum gpujpeg_image_file_format fmt, const uint8_t* image, const struct gpujpeg_image_parameters* pi)
+{
+    const int depth = pi->pixel_format == GPUJPEG_U8 ? 1 : pi->pixel_format == GPUJPEG_444_U8_P012 ? 3 : pi->pixel_format == GPUJPEG_4444_U8_P0123 ? 4 : 0;
+    if (depth == 0 || (depth == 4 && fmt != GPUJPEG_IMAGE_FILE_PAM)) { GJ_ERROR("Pixel format %s cannot be stored in this file type\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1; }
+    FILE* f = fopen(filename, "wb");
+    if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
+    if (fmt == GPUJPEG_IMAGE_FILE_PAM)
+        fprintf(f, "P7\nWIDTH %d\nHEIGHT %d\nDEPTH %d\nMAXVAL 255\nTUPLTYPE %s\nENDHDR\n", pi->width, pi->height, depth,
+                depth == 1 ? "GRAYSCALE" : depth == 3 ? "RGB" : "RGB_ALPHA");
+    else
+        fprintf(f, "P%d\n%d %d\n255\n", depth == 1 ? 5 : 6, pi->width, pi->height);
+    const size_t line = (size_t)pi->width * depth;
+    for (int y = 0; y < pi->height; y++) fwrite(image + (size_t)y * (line + pi->width_padding), 1, line, f);
+    fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ Y4M (8-bit planar) */
+static int y4m_read_header(FILE* f, int* w, int* h, enum gpujpeg_pixel_format* pf, bool* limited)
+{
+    char line[512];
+    if (!fgets(line, sizeof line, f) || strncmp(line, "YUV4MPEG2", 9) != 0) return -1;
+    *pf = GPUJPEG_420_U8_P0P1P2;
+    *limited = true;
+    for (char* t = strtok(line + 9, " \n"); t; t = strtok(NULL, " \n")) {
+        if (t[0] == 'W') *w = atoi(t + 1);
+        else if (t[0] == 'H') *h = atoi(t + 1);
+        else if (t[0] == 'C') {
+            if (strncmp(t + 1, "444", 3) == 0) *pf = GPUJPEG_444_U8_P0P1P2;
+            else if (strncmp(t + 1, "422", 3) == 0) *pf = GPUJPEG_422_U8_P0P1P2;
+            else if (strncmp(t + 1, "420", 3) == 0) *pf = GPUJPEG_420_U8_P0P1P2;
+            else if (strncmp(t + 1, "mono", 4) == 0) *pf = GPUJPEG_U8;
+            else return -1;
+            if (strstr(t, "p1") || strstr(t, "p9") == t + 4) return -1; /* high bit depth */
+        } else if (strncmp(t, "XCOLORRANGE=FULL", 16) == 0) *limited = false;
+    }
+    return (*w > 0 && *h > 0) ? 0 : -1;
+}
+
+static int y4m_probe(const char* filename, struct gpujpeg_image_parameters* pi, int file_exists)
+{
+    if (!file_exists) {
+        if (pi->color_space == GPUJPEG_RGB || pi->color_space == GPUJPEG_NONE) pi->color_space = GPUJPEG_YCBCR_BT709;
+        pi->pixel_format = GPUJPEG_PIXFMT_STD;
+        return 1;
+    }
+    FILE* f = fopen(filename, "rb");
+    if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
+    bool limited;
+    const int rc = y4m_read_header(f, &pi->width, &pi->height, &pi->pixel_format, &limited);
+    fclose(f);
+    if (rc != 0) { GJ_ERROR("Unsupported Y4M file %s\n", filename); return -1; }
+    pi->color_space = limited ? GPUJPEG_YCBCR_BT709 : GPUJPEG_YCBCR_JPEG;
+    return 0;
+}
+
+static int y4m_load(const char* filename, uint8_t** image, size_t* size)
+{
+    FILE* f = fopen(filename, "rb");
+    if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
+    struct gpujpeg_image_parameters pi = gpujpeg_default_image_parameters();
+    bool limited;
+    char line[64];
+    if (y4m_read_header(f, &pi.width, &pi.height, &pi.pixel_format, &limited) != 0 || !fgets(line, sizeof line, f) || strncmp(line, "FRAME", 5) != 0) {
+        fclose(f);
+        GJ_ERROR("Unsupported Y4M file %s\n", filename);
+        return -1;
+    }
+    const size_t n = gpujpeg_image_calculate_size(&pi);
+    uint8_t* data = gj_hip_host_alloc(n);
+    if (!data || fread(data, 1, n, f) != n) { fclose(f); gj_hip_host_free(data); GJ_ERROR("Failed to load image data [%zu bytes] from file %s!\n", n, filename); return -1; }
+    fclose(f);
+    *image = data;
+    *size = n;
+    return 0;
+}
+
+static int y4m_save(const char* filename, const uint8_t* image, size_t size, const struct gpujpeg_image_parameters* pi)
+{
+    const char* c;
+    switch (pi->pixel_format) {
+    case GPUJPEG_444_U8_P0P1P2: c = "444"; break;
+    case GPUJPEG_422_U8_P0P1P2: c = "422"; break;
+    case GPUJPEG_420_U8_P0P1P2: c = "420"; break;
+    case GPUJPEG_U8: c = "mono"; break;
+    default: GJ_ERROR("Y4M needs a planar pixel format, not %s\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1;
+    }
+    FILE* f = fopen(filename, "wb");
+    if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
+    fprintf(f, "YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C%s XCOLORRANGE=%s\nFRAME\n", pi->width, pi->height, c,
+            pi->color_space == GPUJPEG_YCBCR_JPEG ? "FULL" : "LIMITED");
+    fwrite(image, 1, size, f);
+    fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ API front-end */
+int gpujpeg_image_load_from_file(const char* filename, uint8_t** image, size_t* image_size) /* common.c:1217-1253 */
+{
+    const enum gpujpeg_image_file_format fmt = gpujpeg_image_get_file_format(filename);
+    switch (fmt) {
+    case GPUJPEG_IMAGE_FILE_TST: return tst_load(filename, image, image_size);
+    case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
+        return pnm_load(filename, image, image_size);
+    case GPUJPEG_IMAGE_FILE_Y4M: return y4m_load(filename, image, image_size);
+    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG: case GPUJPEG_IMAGE_FILE_TGA:
+        GJ_ERROR("Reading %s needs a third-party decoder that is not part of the MI355X build; convert to PNM/PAM/Y4M.\n", filename);
+        return -1;
+    default: break;
+    }
+    FILE* f = fopen(filename, "rb");
+    if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
+    if (*image_size == 0) {
+        fseek(f, 0, SEEK_END);
+        *image_size = (size_t)ftell(f);
+        rewind(f);
+    }
+    uint8_t* data = gj_hip_host_alloc(*image_size);
+    if (!data) { fclose(f); GJ_ERROR("Initialize host buffer failed: %s\n", gj_hip_last_error()); return -1; }
+    if (fread(data, 1, *image_size, f) != *image_size) {
+        GJ_ERROR("Failed to load image data [%zu bytes] from file %s!\n", *image_size, filename);
+        fclose(f);
+        gj_hip_host_free(data);
+        return -1;
+    }
+    fclose(f);
+    *image = data;
+    return 0;
+}
+
+int gpujpeg_image_save_to_file(const char* filename, const uint8_t* image, size_t image_size, const struct gpujpeg_image_parameters* pi)
+{ /* common.c:1275-1310 */
+    char* dot = strrchr(filename, '.');
+    if (dot && strcmp(dot, ".XXX") == 0 && pi) { /* the caller guarantees a writable string in this case */
+        const char* ext = (pi->pixel_format != GPUJPEG_U8 && pi->color_space != GPUJPEG_RGB) ? "y4m" : pi->pixel_format == GPUJPEG_4444_U8_P0123 ? "pam" : "pnm";
+        strcpy(dot + 1, ext);
+    }
+    const enum gpujpeg_image_file_format fmt = gpujpeg_image_get_file_format(filename);
+    if (pi) {
+        switch (fmt) {
+        case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
+            return pnm_save(filename, fmt, image, pi);
+        case GPUJPEG_IMAGE_FILE_Y4M: return y4m_save(filename, image, image_size, pi);
+        case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG: case GPUJPEG_IMAGE_FILE_TGA:
+            GJ_ERROR("Writing %s needs a third-party encoder that is not part of the MI355X build; use PNM/PAM/Y4M.\n", filename);
+            return -1;
+        default: break;
+        }
+    }
+    FILE* f = fopen(filename, "wb");
+    if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
+    if (fwrite(image, 1, image_size, f) != image_size) {
+        GJ_ERROR("Failed to write image data [%zu bytes] to file %s!\n", image_size, filename);
+        fclose(f);
+        return -1;
+    }
+    fclose(f);
+    return 0;
+}
+
+int gpujpeg_image_get_properties(const char* filename, struct gpujpeg_image_parameters* pi, int file_exists) /* common.c:1312-1370 */
+{
+    const enum gpujpeg_image_file_format fmt = gpujpeg_image_get_file_format(filename);
+    switch (fmt) {
+    case GPUJPEG_IMAGE_FILE_UNKNOWN: GJ_ERROR("GPUJPEG_IMAGE_FILE_UNKNOWN should not be passed!\n"); return -1;
+    case GPUJPEG_IMAGE_FILE_JPEG: GJ_ERROR("GPUJPEG_IMAGE_FILE_JPEG should not be passed!\n"); return -1;
+    case GPUJPEG_IMAGE_FILE_TST: {
+        enum tst_pattern p; int seed; long blank;
+        return tst_parse(filename, pi, &p, &seed, &blank);
+    }
+    case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
+        return pnm_probe(filename, pi, file_exists);
+    case GPUJPEG_IMAGE_FILE_Y4M: return y4m_probe(filename, pi, file_exists);
+    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG: case GPUJPEG_IMAGE_FILE_TGA:
+        pi->color_space = GPUJPEG_RGB;
+        return file_exists ? -1 : 1;
+    case GPUJPEG_IMAGE_FILE_RAW: pi->pixel_format = GPUJPEG_PIXFMT_STD; break;
+    case GPUJPEG_IMAGE_FILE_GRAY: pi->color_space = GPUJPEG_YCBCR_JPEG; pi->pixel_format = GPUJPEG_U8; break;
+    case GPUJPEG_IMAGE_FILE_RGBA: pi->color_space = GPUJPEG_RGB; pi->pixel_format = GPUJPEG_4444_U8_P0123; break;
+    case GPUJPEG_IMAGE_FILE_YUVA: pi->color_space = GPUJPEG_YCBCR_JPEG; pi->pixel_format = GPUJPEG_4444_U8_P0123; break;
+    case GPUJPEG_IMAGE_FILE_UYVY: pi->color_space = GPUJPEG_YCBCR_JPEG; pi->pixel_format = GPUJPEG_422_U8_P1020; break;
+    case GPUJPEG_IMAGE_FILE_I420: pi->color_space = GPUJPEG_YCBCR_JPEG; pi->pixel_format = GPUJPEG_420_U8_P0P1P2; break;
+    case GPUJPEG_IMAGE_FILE_RGB: pi->color_space = GPUJPEG_RGB; pi->pixel_format = GPUJPEG_444_U8_P012; break;
+    case GPUJPEG_IMAGE_FILE_YUV: pi->color_space = GPUJPEG_YCBCR_JPEG; pi->pixel_format = GPUJPEG_444_U8_P012; break;
+    }
+    return 1;
+}
+
+int gpujpeg_image_destroy(uint8_t* image) /* common.c:1372-1378 */
+{
+    gj_hip_host_free(image);
+    return 0;
+}
+
+void gpujpeg_image_range_info(const char* filename, int width, int height, enum gpujpeg_pixel_format pf) /* common.c:1380-1470 */
+{
+    struct gpujpeg_image_parameters pi = gpujpeg_default_image_parameters();
+    pi.width = width;
+    pi.height = height;
+    pi.pixel_format = pf;
+    size_t size = gpujpeg_image_calculate_size(&pi);
+    uint8_t* data = NULL;
+    if (gpujpeg_image_load_from_file(filename, &data, &size) != 0) return;
+    int lo = 255, hi = 0;
+    for (size_t i = 0; i < size; i++) { if (data[i] < lo) lo = data[i]; if (data[i] > hi) hi = data[i]; }
+    printf("Image Samples Range:\n  all components: %d - %d\n", lo, hi);
+    gpujpeg_image_destroy(data);
+}
+
+int gpujpeg_image_convert(const char* input, const char* output, struct gpujpeg_image_parameters from, struct gpujpeg_image_parameters to)
+{
+    (void)input; (void)output; (void)from; (void)to;
+    GJ_ERROR("gpujpeg_image_convert() is defunct (as in the reference).\n");
+    return -1;
+}

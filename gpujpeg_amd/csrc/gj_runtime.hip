@@ -1,0 +1,120 @@
+// gj_runtime.hip -- HIP runtime subset behind the C-ABI of include/gj_hip.h.
+// Replaces the ~25 CUDA runtime entry points the reference's host C calls directly
+// (cudaMalloc, cudaMallocHost, cudaMemcpyAsync, cudaEvent*, ... enumerated over /root/reference/src/*.c).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "gj_hip.h"
+
+static thread_local hipError_t g_last = hipSuccess;
+
+static int chk(hipError_t e)
+{
+    if (e != hipSuccess) {
+        g_last = e;
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int gj_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gj_hip_get_device(int* device) { return chk(hipGetDevice(device)); }
+int gj_hip_set_device(int device) { return chk(hipSetDevice(device)); }
+int gj_hip_device_reset(void) { return chk(hipDeviceReset()); }
+
+int gj_hip_device_props(int device, char name[256], int* major, int* minor, size_t* global_mem, size_t* shared_mem,
+                        int* regs_per_block, int* cu_count)
+{
+    hipDeviceProp_t p;
+    if (chk(hipGetDeviceProperties(&p, device))) return -1;
+    std::snprintf(name, 256, "%s", p.name);
+    *major = p.major;
+    *minor = p.minor;
+    *global_mem = p.totalGlobalMem;
+    *shared_mem = p.sharedMemPerBlock;
+    *regs_per_block = p.regsPerBlock;
+    *cu_count = p.multiProcessorCount;
+    return 0;
+}
+
+int gj_hip_runtime_version(int* driver, int* runtime)
+{
+    if (chk(hipDriverGetVersion(driver))) return -1;
+    return chk(hipRuntimeGetVersion(runtime));
+}
+
+const char* gj_hip_last_error(void)
+{
+    hipError_t e = g_last != hipSuccess ? g_last : hipGetLastError();
+    g_last = hipSuccess;
+    return hipGetErrorString(e);
+}
+
+void* gj_hip_malloc(size_t size)
+{
+    void* p = nullptr;
+    if (chk(hipMalloc(&p, size ? size : 1))) return nullptr;
+    return p;
+}
+void gj_hip_free(void* p)
+{
+    if (p) (void)hipFree(p);
+}
+void* gj_hip_host_alloc(size_t size)
+{
+    void* p = nullptr;
+    if (chk(hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault))) return nullptr;
+    return p;
+}
+void gj_hip_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+int gj_hip_memcpy_h2d(void* d, const void* s, size_t n, gj_stream_t st) { return chk(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); }
+int gj_hip_memcpy_d2h(void* d, const void* s, size_t n, gj_stream_t st) { return chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); }
+int gj_hip_memcpy_d2d(void* d, const void* s, size_t n, gj_stream_t st) { return chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st)); }
+int gj_hip_memset(void* d, int v, size_t n, gj_stream_t st) { return chk(hipMemsetAsync(d, v, n, (hipStream_t)st)); }
+int gj_hip_stream_sync(gj_stream_t st) { return chk(hipStreamSynchronize((hipStream_t)st)); }
+
+int gj_hip_is_device_ptr(const void* p)
+{
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc'd memory reports an error: that is "host"
+        return 0;
+    }
+    return a.type == hipMemoryTypeDevice ? 1 : 0;
+}
+
+gj_event_t gj_hip_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (chk(hipEventCreate(&e))) return nullptr;
+    return (gj_event_t)e;
+}
+void gj_hip_event_destroy(gj_event_t e)
+{
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+int gj_hip_event_record(gj_event_t e, gj_stream_t s) { return chk(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); }
+float gj_hip_event_elapsed_ms(gj_event_t a, gj_event_t b)
+{
+    float ms = 0.0f;
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return 0.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return 0.0f;
+    return ms;
+}
+
+} // extern "C"

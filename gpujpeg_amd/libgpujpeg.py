@@ -124,6 +124,16 @@ class Library:
         L.gpujpeg_decoder_get_image_info.argtypes = [vp, C.c_size_t, C.POINTER(ImageParameters), C.POINTER(Parameters), C.POINTER(C.c_int)]
         L.gpujpeg_decoder_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.gpujpeg_version.restype = C.c_int
+        if hasattr(L, "gpujpeg_amd_encoder_read_coefficients"):  # MI355X extensions (include/gpujpeg_amd_ext.h)
+            for n in ("gpujpeg_amd_encoder_read_coefficients", "gpujpeg_amd_decoder_read_coefficients"):
+                getattr(L, n).restype = C.c_size_t
+                getattr(L, n).argtypes = [vp, C.POINTER(C.c_int16), C.c_size_t]
+            for n in ("gpujpeg_amd_encoder_read_planes", "gpujpeg_amd_decoder_read_planes"):
+                getattr(L, n).restype = C.c_size_t
+                getattr(L, n).argtypes = [vp, C.POINTER(C.c_uint8), C.c_size_t]
+            for n in ("gpujpeg_amd_encoder_set_fused", "gpujpeg_amd_decoder_set_fused"):
+                getattr(L, n).restype = None
+                getattr(L, n).argtypes = [vp, C.c_int]
 
     # ---- parameter helpers ----
     def default_parameters(self):
@@ -176,6 +186,19 @@ class Encoder:
         self.lib.L.gpujpeg_encoder_get_stats(self.h, C.byref(s))
         return s
 
+    def set_fused(self, enabled):
+        self.lib.L.gpujpeg_amd_encoder_set_fused(self.h, int(enabled))
+
+    def coefficients(self, count):
+        a = np.empty(count, np.int16)
+        n = self.lib.L.gpujpeg_amd_encoder_read_coefficients(self.h, a.ctypes.data_as(C.POINTER(C.c_int16)), count)
+        return a[:n]
+
+    def planes(self, count):
+        a = np.empty(count, np.uint8)
+        n = self.lib.L.gpujpeg_amd_encoder_read_planes(self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), count)
+        return a[:n]
+
     def close(self):
         if self.h:
             self.lib.L.gpujpeg_encoder_destroy(self.h)
@@ -217,6 +240,19 @@ class Decoder:
         s = DurationStats()
         self.lib.L.gpujpeg_decoder_get_stats(self.h, C.byref(s))
         return s
+
+    def set_fused(self, enabled):
+        self.lib.L.gpujpeg_amd_decoder_set_fused(self.h, int(enabled))
+
+    def coefficients(self, count):
+        a = np.empty(count, np.int16)
+        n = self.lib.L.gpujpeg_amd_decoder_read_coefficients(self.h, a.ctypes.data_as(C.POINTER(C.c_int16)), count)
+        return a[:n]
+
+    def planes(self, count):
+        a = np.empty(count, np.uint8)
+        n = self.lib.L.gpujpeg_amd_decoder_read_planes(self.h, a.ctypes.data_as(C.POINTER(C.c_uint8)), count)
+        return a[:n]
 
     def close(self):
         if self.h:

@@ -1,0 +1,163 @@
+/*
+ * gj_hip.h -- the thin C-ABI seam between the host C library (encoder/decoder drivers, JFIF writer and
+ * reader, tables) and the hand-written gfx950 HIP code. Plain pointers and sizes only; the host side
+ * never includes a HIP header.
+ *
+ * It replaces the reference's internal seam: the CUDA runtime subset the host C uses
+ * (cudaMalloc/cudaMemcpyAsync/cudaEvent*, enumerated over the files of src/) and the five CUDA module groups
+ *   gpujpeg_preprocessor_encode      src/gpujpeg_preprocessor.h:84-98
+ *   gpujpeg_dct_gpu / gpujpeg_idct_gpu  src/gpujpeg_dct_gpu.h:46-55
+ *   gpujpeg_huffman_gpu_encoder_*    src/gpujpeg_huffman_gpu_encoder.h:48-68
+ *   gpujpeg_huffman_gpu_decoder_*    src/gpujpeg_huffman_gpu_decoder.h:47-60
+ *   gpujpeg_postprocessor_decode     src/gpujpeg_postprocessor.h:46-59
+ * coarsened into one launcher per direction (gj_hip_encode / gj_hip_decode), because on MI355X the
+ * stages are fused and the stream is assembled on the device.
+ */
+#ifndef GJ_HIP_H
+#define GJ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GJ_HIP_API __attribute__((visibility("default")))
+
+typedef void* gj_stream_t; /* hipStream_t */
+typedef void* gj_event_t;  /* hipEvent_t */
+
+/* ------------------------------------------------------------------ runtime subset */
+GJ_HIP_API int gj_hip_device_count(void);
+GJ_HIP_API int gj_hip_get_device(int* device);
+GJ_HIP_API int gj_hip_set_device(int device);
+GJ_HIP_API int gj_hip_device_reset(void);
+GJ_HIP_API int gj_hip_device_props(int device, char name[256], int* major, int* minor, size_t* global_mem, size_t* shared_mem,
+                        int* regs_per_block, int* cu_count);
+GJ_HIP_API int gj_hip_runtime_version(int* driver, int* runtime);
+GJ_HIP_API const char* gj_hip_last_error(void);
+
+GJ_HIP_API void* gj_hip_malloc(size_t size);
+GJ_HIP_API void gj_hip_free(void* p);
+GJ_HIP_API void* gj_hip_host_alloc(size_t size); /* pinned */
+GJ_HIP_API void gj_hip_host_free(void* p);
+GJ_HIP_API int gj_hip_memcpy_h2d(void* dst, const void* src, size_t n, gj_stream_t s); /* async on s */
+GJ_HIP_API int gj_hip_memcpy_d2h(void* dst, const void* src, size_t n, gj_stream_t s);
+GJ_HIP_API int gj_hip_memcpy_d2d(void* dst, const void* src, size_t n, gj_stream_t s);
+GJ_HIP_API int gj_hip_memset(void* dst, int value, size_t n, gj_stream_t s);
+GJ_HIP_API int gj_hip_stream_sync(gj_stream_t s);
+/* 1 if p points to device (HBM) memory, 0 for host memory (reference: test/unit/run_tests.c:40-78) */
+GJ_HIP_API int gj_hip_is_device_ptr(const void* p);
+
+GJ_HIP_API gj_event_t gj_hip_event_create(void);
+GJ_HIP_API void gj_hip_event_destroy(gj_event_t e);
+GJ_HIP_API int gj_hip_event_record(gj_event_t e, gj_stream_t s);
+GJ_HIP_API float gj_hip_event_elapsed_ms(gj_event_t start, gj_event_t stop); /* synchronises on stop */
+
+/* ------------------------------------------------------------------ geometry shared by host and kernels */
+#define GJ_MAX_COMP 4
+#define GJ_MAX_MCU_BLOCKS 16     /* blocks per interleaved MCU we accept (JPEG itself allows 10) */
+#define GJ_TEMP_BYTES_PER_BLOCK 208 /* >= worst case 1658 bits of an 8x8 block before byte stuffing, 16 B multiple */
+
+enum { GJ_PF_U8 = 0, GJ_PF_444_P012 = 1, GJ_PF_444_P0P1P2 = 2, GJ_PF_422_P1020 = 3, GJ_PF_422_P0P1P2 = 4,
+       GJ_PF_420_P0P1P2 = 5, GJ_PF_4444_P0123 = 6 };
+
+typedef struct gj_comp_geom {
+    int type;                  /* 0 luminance tables, 1 chrominance tables (encoder) */
+    int samp_h, samp_v;
+    int sub_h, sub_v;          /* max_h / samp_h, max_v / samp_v */
+    int width, height;         /* real size */
+    int data_width, data_height;
+    int blocks_x, blocks_y;
+    int mcu_count_x, mcu_count;
+    int segment_count;         /* non-interleaved: segments of this component's scan */
+    int first_segment;         /* non-interleaved: global index of its first segment */
+    int q_table, dc_table, ac_table; /* decoder: table slots */
+    int reserved;
+    uint64_t data_offset;      /* offset in samples of the plane / coefficient plane */
+} gj_comp_geom;
+
+typedef struct gj_geom {
+    int width, height, width_padding;
+    int pixel_format, color_space, color_space_internal;
+    int comp_count, interleaved, restart_interval;
+    int max_h, max_v;
+    int mcu_count;             /* interleaved: MCUs in the scan */
+    int mcu_count_x;           /* interleaved */
+    int segment_count;         /* all scans */
+    int scan_count;
+    int blocks_per_mcu;        /* 1 when not interleaved */
+    int seg_blocks;            /* blocks in a full segment (restart_interval * blocks_per_mcu; whole scan if 0) */
+    int block_count;
+    int raw_width;             /* width used by the pixel kernels (even for 4:2:2 packed) */
+    int no_transform;          /* planar copy path: raw layout equals component layout */
+    uint64_t data_size;        /* samples in all planes */
+    uint64_t raw_size;
+    gj_comp_geom comp[GJ_MAX_COMP];
+    uint8_t mcu_comp[GJ_MAX_MCU_BLOCKS]; /* interleaved MCU layout: component of block p */
+    uint8_t mcu_bx[GJ_MAX_MCU_BLOCKS];   /* block x inside the MCU */
+    uint8_t mcu_by[GJ_MAX_MCU_BLOCKS];
+    uint8_t mcu_prev[GJ_MAX_MCU_BLOCKS]; /* distance (in scan order) to the previous block of the same component */
+} gj_geom;
+
+/* ------------------------------------------------------------------ encoder */
+typedef struct gj_enc_job {
+    gj_geom g;
+    const uint8_t* d_raw;          /* input pixels in HBM */
+    uint8_t* d_planes;             /* padded planar components (generic path only) */
+    int16_t* d_coefs;              /* quantised coefficients, 64 per block */
+    const float* d_fwd_q[2];       /* forward tables, luminance / chrominance (src/gpujpeg_table.c:103-123 layout) */
+    const uint32_t* d_huff_lut;    /* [4][256]: (code << 8) | size ; order lumaDC, lumaAC, chromaDC, chromaAC */
+    uint8_t* d_temp;               /* per-segment unstuffed bitstreams */
+    uint32_t* d_seg_bytes;         /* [segment_count] unstuffed byte count */
+    uint32_t* d_seg_ff;            /* [segment_count] number of 0xFF bytes */
+    uint32_t* d_seg_out;           /* [segment_count + 1] final byte offset of each segment in the JPEG */
+    uint8_t* d_jpeg;               /* finished stream */
+    uint64_t jpeg_capacity;
+    uint32_t* d_result;            /* [0] total JPEG size, [1] overflow flag */
+    const uint8_t* d_scan_hdr;     /* scan headers back to back (APP13 placeholders zeroed + SOS) */
+    uint32_t scan_hdr_offset[GJ_MAX_COMP + 1];
+    uint32_t scan_info_payload[GJ_MAX_COMP]; /* offset inside scan header of the first APP13 payload, 0 = none */
+    uint32_t main_hdr_size;        /* bytes already placed at d_jpeg[0..) by the host */
+    int segment_info;
+    int use_fused;                 /* 1: raw -> coefficients in one kernel when the format allows */
+} gj_enc_job;
+
+/* events: 0 start, 1 after preprocess, 2 after DCT, 3 after Huffman+assembly (may be NULL) */
+GJ_HIP_API int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[4]);
+
+/* ------------------------------------------------------------------ decoder */
+typedef struct gj_dec_job {
+    gj_geom g;                     /* pixel_format / color_space describe the requested output */
+    const uint8_t* d_jpeg;         /* whole file in HBM */
+    uint64_t jpeg_size;
+    const uint32_t* d_seg_pos;     /* [seg_count] byte offset of each segment's entropy data */
+    const uint32_t* d_seg_len;     /* [seg_count] */
+    const uint32_t* d_seg_index;   /* [seg_count] geometric segment index */
+    int seg_count;
+    const uint16_t* d_huff_tab;    /* [4 slots][2 classes][GJ_DEC_TAB_WORDS] decode tables */
+    const uint16_t* d_qtab;        /* [4][64] natural order */
+    int16_t* d_coefs;
+    uint8_t* d_planes;
+    uint8_t* d_raw;                /* output pixels */
+    int use_fused;
+} gj_dec_job;
+
+/* decode table layout per (slot, class): 1024 fast entries (len << 8 | symbol, 0 = miss) followed by
+ * maxcode[18] (as u16 pairs lo/hi), valptr[17], mincode[17] and the 256 symbol values */
+#define GJ_DEC_FAST_BITS 10
+#define GJ_DEC_TAB_WORDS (1024 + 36 + 17 + 34 + 256 + 1)
+
+/* events: 0 start, 1 after Huffman, 2 after IDCT, 3 after postprocess (may be NULL) */
+GJ_HIP_API int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4]);
+
+/* GPU marker scan: finds RSTn inside [begin,end) of a device-resident stream and writes segment
+ * offsets/lengths in order; returns the number of segments through d_count (N1 in SURVEY 8f) */
+GJ_HIP_API int gj_hip_scan_markers(const uint8_t* d_jpeg, uint64_t begin, uint64_t end, uint32_t* d_seg_pos, uint32_t* d_seg_len,
+                        uint32_t max_segments, uint32_t* d_count, gj_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X JPEG hot path.
+
+metric: Mpix/s encode+decode (8K RGB q75), BASELINE.json. One step = one pass of the hot path over one
+synthetic 7680x4320 RGB frame that is already resident in HBM: gpujpeg_encoder_encode (GPU_IMAGE input,
+JPEG left in HBM) followed by gpujpeg_decoder_decode of that JPEG (device-resident stream, pixels written to
+HBM), both through the libgpujpeg C ABI. `value` = pixels of all ranks / max-over-ranks time of K steps.
+
+Multi-GPU: frames are independent, so ranks shard the frame batch with no data-path collective (weak scaling,
+one frame per rank and step). N > 1 is launched by torch.distributed.run; RCCL is used only for the barrier
+and the max-over-ranks reduction of the timing.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel of the step (largest average hipEvent duration), algorithmic bytes
+                (raw RGB in + JPEG out for encoder kernels, JPEG in + raw RGB out for decoder kernels;
+                SURVEY.md 8d) divided by that duration, against 8 TB/s HBM3E
+  cpu_baseline  the reference's own host C code + the restated CUDA-only stages (oracle/_ref, kind
+                "reference"; falls back to the pure restatement, kind "port") timed on one host core on a
+                bounded sample of the same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from gpujpeg_amd import libgpujpeg as G  # noqa: E402
+
+WORKLOADS = {
+    "hd": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320), "16k": (15360, 8640),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def synth_frame(width, height, pattern, seed, device):
+    """Deterministic synthetic RGB frame generated on the device.
+    natural: smooth structure + texture + mild sensor noise (compresses like a photograph at q75)
+    noise:   the reference's `.tst` LCG noise semantics, worst case for the entropy coder
+    gradient: the reference's `.tst` default, best case"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if pattern == "noise":
+        return torch.randint(0, 256, (height, width, 3), dtype=torch.uint8, device=device, generator=g)
+    yy = torch.arange(height, device=device, dtype=torch.float32).view(-1, 1)
+    xx = torch.arange(width, device=device, dtype=torch.float32).view(1, -1)
+    if pattern == "gradient":
+        row = (torch.arange(height, device=device) * 255 // height).to(torch.uint8).view(-1, 1, 1)
+        return row.expand(height, width, 3).contiguous()
+    chans = []
+    for k, (fx, fy, ph) in enumerate([(1 / 97.0, 1 / 61.0, 0.3), (1 / 53.0, 1 / 131.0, 1.1), (1 / 211.0, 1 / 89.0, 2.0)]):
+        base = 128 + 70 * torch.sin(xx * fx + ph) * torch.cos(yy * fy) + 30 * torch.sin((xx + yy) * fx * 3.1 + k)
+        tex = 12 * torch.sin(xx * 0.9 + yy * 0.35 + k) * torch.sin(yy * 0.7 - xx * 0.11)
+        nz = 3.0 * torch.randn((height, width), device=device, generator=g)
+        chans.append(base + tex + nz)
+    return torch.stack(chans, -1).clamp(0, 255).to(torch.uint8).contiguous()
+
+
+def cpu_baseline(width, height, frame_host, seconds_budget=20.0):
+    """Reference CPU path on the host cores (1 thread): encode + decode of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    kind = "reference" if O.have_ref() else "port"
+    t_start = time.time()
+    frames = 0
+    if kind == "reference":
+        ref = G.Library(O.REF_PATH)
+        enc, dec = G.Encoder(ref), G.Decoder(ref)
+        p = ref.default_parameters()
+        p.restart_interval, p.verbose = G.RESTART_AUTO, -1
+        pi = ref.default_image_parameters()
+        pi.width, pi.height = width, height
+        while True:
+            jpeg = enc.encode(p, pi, frame_host)
+            dec.decode(jpeg)
+            frames += 1
+            if time.time() - t_start > seconds_budget * 0.5 or frames >= 4:
+                break
+    else:
+        img = O.make_image(width, height)
+        while True:
+            jpeg = O.encode(img, frame_host)
+            O.decode(jpeg)
+            frames += 1
+            if time.time() - t_start > seconds_budget * 0.5 or frames >= 4:
+                break
+    dt = time.time() - t_start
+    return {"value": round(width * height * frames / dt / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": kind,
+            "sample": f"{frames} x encode+decode of the {width}x{height} RGB q75 frame, single thread, "
+                      f"reference host C (writer/reader/CPU Huffman) + restated colour/DCT/IDCT stages, gcc -O2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
+    ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient"])
+    ap.add_argument("--quality", type=int, default=75)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check the round trip of the last frame against the oracle (slow)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    lib = G.Library()  # raises if the HIP library has not been built: there is no fallback
+    assert lib.L.gpujpeg_init_device(local_rank, 0) == 0
+    width, height = WORKLOADS[args.workload]
+    frame = synth_frame(width, height, args.pattern, 12345 + rank, device)
+    out = torch.empty_like(frame)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    enc, dec = G.Encoder(lib, stream), G.Decoder(lib, stream)
+    assert enc.set_option("enc_opt_out", "enc_out_val_device") == 0
+    p = lib.default_parameters()
+    p.quality, p.restart_interval, p.verbose, p.perf_stats = args.quality, G.RESTART_AUTO, -1, 1
+    pi = lib.default_image_parameters()
+    pi.width, pi.height = width, height
+    dec.init(p, lib.default_image_parameters())  # turns perf_stats on for the decoder (same API as the reference)
+
+    def step():
+        jptr, jsize = enc.encode_noclone(p, pi, frame.data_ptr(), gpu=True)
+        o = G.DecoderOutput()
+        o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, out.data_ptr()
+        rc = lib.L.gpujpeg_decoder_decode(dec.h, C.cast(jptr, C.c_void_p), jsize, C.byref(o))
+        assert rc == 0
+        return jsize
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        jsize = step()
+    enc_ms = np.zeros(5)
+    dec_ms = np.zeros(3)
+    enc_wall = dec_wall = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a = time.perf_counter()
+        jptr, jsize = enc.encode_noclone(p, pi, frame.data_ptr(), gpu=True)
+        b = time.perf_counter()
+        o = G.DecoderOutput()
+        o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, out.data_ptr()
+        assert lib.L.gpujpeg_decoder_decode(dec.h, C.cast(jptr, C.c_void_p), jsize, C.byref(o)) == 0
+        c = time.perf_counter()
+        enc_wall += b - a
+        dec_wall += c - b
+        enc_ms += np.array(enc.kernel_times())
+        dec_ms += np.array(dec.kernel_times())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    enc_ms /= args.steps
+    dec_ms /= args.steps
+
+    result = None
+    if rank == 0:
+        pixels = width * height
+        raw_bytes = pixels * 3
+        names = ["enc:k_preprocess", "enc:k_fused_rgb444(pre+dct+quant)", "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
+                 "dec:k_huffman_decode", "dec:k_idct_fused_rgb444(idct+post)", "dec:k_postprocess"]
+        durs = list(enc_ms) + list(dec_ms)
+        dom = int(np.argmax(durs))
+        alg = raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (same sum)
+        achieved = alg / (durs[dom] * 1e-3) / 1e9
+        result = {
+            "metric": "Mpix/s encode+decode (8K RGB q75)", "value": round(pixels * world * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / f32 DCT / i16 coefficients",
+            "data": f"synthetic ({args.pattern}), one {width}x{height} RGB frame per rank resident in HBM",
+            "config": {"workload": f"{width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto ({width}x{height} -> "
+                                   f"{'36' if args.workload in ('8k', '16k') else 'auto'}), encode then decode per step",
+                       "frames_per_step_per_gpu": 1, "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective"},
+            "encode_mpix_s": round(pixels * args.steps / enc_wall / 1e6, 2), "decode_mpix_s": round(pixels * args.steps / dec_wall / 1e6, 2),
+            "kernel_ms": {n: round(float(d), 4) for n, d in zip(names, durs)},
+            "gpu_only_ms": {"encode": round(float(enc_ms.sum()), 4), "decode": round(float(dec_ms.sum()), 4)},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg)},
+        }
+        if args.verify:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as O
+            host = frame.cpu().numpy().reshape(-1)
+            want = O.encode(O.make_image(width, height, quality=args.quality), host)
+            got = np.ctypeslib.as_array(C.cast(jptr, C.POINTER(C.c_uint8)), shape=(1,))  # device pointer: copy through torch
+            jt = torch.empty(jsize, dtype=torch.uint8, device=device)
+            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(jt.data_ptr()), C.cast(jptr, C.c_void_p), C.c_size_t(jsize), 3)
+            torch.cuda.synchronize()
+            result["verified_bit_exact_encode"] = bool(np.array_equal(jt.cpu().numpy(), want))
+            result["verified_bit_exact_decode"] = bool(np.array_equal(out.cpu().numpy().reshape(-1), O.decode(want)[0]))
+            del got
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(width, height, frame.cpu().numpy().reshape(-1))
+        print(json.dumps(result), flush=True)
+    enc.close()
+    dec.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

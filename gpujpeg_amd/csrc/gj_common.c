@@ -512,7 +512,7 @@ int gj_ensure_device_buffer(void** p, size_t* cap, size_t need)
 int gj_timers_create(struct gj_timers* t)
 {
     memset(t, 0, sizeof *t);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < GJ_ENC_EVENTS; i++)
         if ((t->ev[i] = gj_hip_event_create()) == NULL) return -1;
     for (int i = 0; i < 2; i++)
         if ((t->copy_in[i] = gj_hip_event_create()) == NULL || (t->copy_out[i] = gj_hip_event_create()) == NULL) return -1;
@@ -521,7 +521,7 @@ int gj_timers_create(struct gj_timers* t)
 
 void gj_timers_destroy(struct gj_timers* t)
 {
-    for (int i = 0; i < 4; i++) gj_hip_event_destroy(t->ev[i]);
+    for (int i = 0; i < GJ_ENC_EVENTS; i++) gj_hip_event_destroy(t->ev[i]);
     for (int i = 0; i < 2; i++) {
         gj_hip_event_destroy(t->copy_in[i]);
         gj_hip_event_destroy(t->copy_out[i]);

@@ -300,6 +300,8 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         s->duration_dct_quantization = gj_hip_event_elapsed_ms(c->timers.ev[1], c->timers.ev[2]);
         s->duration_preprocessor = gj_hip_event_elapsed_ms(c->timers.ev[2], c->timers.ev[3]);
         s->duration_in_gpu = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[3]);
+        for (int k = 0; k < GJ_DEC_EVENTS - 1; k++) c->kernel_ms[k] = gj_hip_event_elapsed_ms(c->timers.ev[k], c->timers.ev[k + 1]);
+        c->timers.valid = true;
         s->duration_memory_to = gj_hip_event_elapsed_ms(c->timers.copy_in[0], c->timers.copy_in[1]);
         if (output->type == GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER || output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_BUFFER)
             s->duration_memory_from = gj_hip_event_elapsed_ms(c->timers.copy_out[0], c->timers.copy_out[1]);
@@ -398,3 +400,11 @@ size_t gpujpeg_amd_decoder_read_planes(struct gpujpeg_decoder* d, uint8_t* dst, 
 }
 
 void gpujpeg_amd_decoder_set_fused(struct gpujpeg_decoder* d, int enabled) { d->use_fused = enabled != 0; }
+
+/* durations of the kernels of the last decode: [0] k_huffman_decode, [1] IDCT (fused: incl. postprocess), [2] postprocess */
+int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* d, float ms[8])
+{
+    if (!d->coder.timers.valid) return -1;
+    memcpy(ms, d->coder.kernel_ms, 8 * sizeof(float));
+    return 0;
+}

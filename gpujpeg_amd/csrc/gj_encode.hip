@@ -661,7 +661,7 @@ static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
     return nullptr;
 }
 
-extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[4])
+extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS])
 {
     hipStream_t st = (hipStream_t)stream;
     const gj_geom& g = job->g;
@@ -690,10 +690,12 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     const unsigned tiles = ((unsigned)g.segment_count + spt - 1) / spt;
     hipLaunchKernelGGL(k_huffman, dim3(tiles), dim3(256), 0, st, g, job->d_coefs, job->d_huff_lut, job->d_temp, job->d_seg_bytes,
                        job->d_seg_ff);
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
     hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, st, *job);
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[4], st);
     hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 3) / 4), dim3(256), 0, st, *job);
     if (job->segment_info && g.restart_interval > 0)
         hipLaunchKernelGGL(k_segment_info, dim3(((unsigned)g.segment_count + 255) / 256), dim3(256), 0, st, *job);
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
+    if (ev) (void)hipEventRecord((hipEvent_t)ev[5], st);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -278,8 +278,9 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
         struct gpujpeg_duration_stats* s = &c->stats;
         s->duration_preprocessor = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[1]);
         s->duration_dct_quantization = gj_hip_event_elapsed_ms(c->timers.ev[1], c->timers.ev[2]);
-        s->duration_huffman_coder = gj_hip_event_elapsed_ms(c->timers.ev[2], c->timers.ev[3]);
-        s->duration_in_gpu = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[3]);
+        s->duration_huffman_coder = gj_hip_event_elapsed_ms(c->timers.ev[2], c->timers.ev[5]);
+        s->duration_in_gpu = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[5]);
+        for (int k = 0; k < GJ_ENC_EVENTS - 1; k++) c->kernel_ms[k] = gj_hip_event_elapsed_ms(c->timers.ev[k], c->timers.ev[k + 1]);
         if (d_raw == c->d_raw_own) s->duration_memory_to = gj_hip_event_elapsed_ms(c->timers.copy_in[0], c->timers.copy_in[1]);
         if (e->out_location != GJ_OUT_DEVICE) s->duration_memory_from = gj_hip_event_elapsed_ms(c->timers.copy_out[0], c->timers.copy_out[1]);
         c->timers.valid = true;
@@ -420,3 +421,12 @@ size_t gpujpeg_amd_encoder_read_planes(struct gpujpeg_encoder* e, uint8_t* dst, 
 }
 
 void gpujpeg_amd_encoder_set_fused(struct gpujpeg_encoder* e, int enabled) { e->use_fused = enabled != 0; }
+
+/* durations of the kernels of the last encode: [0] preprocess (generic path), [1] DCT+quant (fused: incl. preprocess),
+ * [2] k_huffman, [3] k_scan_segments, [4] k_assemble; needs perf_stats or verbose >= 1 */
+int gpujpeg_amd_encoder_get_kernel_times(struct gpujpeg_encoder* e, float ms[8])
+{
+    if (!e->coder.timers.valid) return -1;
+    memcpy(ms, e->coder.kernel_ms, 8 * sizeof(float));
+    return 0;
+}

@@ -51,7 +51,7 @@ int gj_huffman_decoder_table(const uint8_t bits17[17], const uint8_t* vals, uint
 
 /* ---- timers: hipEvents around the stages (src/gpujpeg_common_internal.h:156-205) ---- */
 struct gj_timers {
-    gj_event_t ev[4];
+    gj_event_t ev[GJ_ENC_EVENTS];
     gj_event_t copy_in[2], copy_out[2];
     bool valid;
 };
@@ -71,6 +71,7 @@ struct gj_coder {
     /* statistics (src/gpujpeg_common.c:2170-2254) */
     struct gj_timers timers;
     struct gpujpeg_duration_stats stats;
+    float kernel_ms[8]; /* per-kernel durations of the last call (include/gpujpeg_amd_ext.h) */
     double start_time, init_end_time, stop_time;
     double first_frame_duration, aggregate_duration;
     long frames;

@@ -117,6 +117,7 @@ class Library:
         L.gpujpeg_decoder_create.restype = vp
         L.gpujpeg_decoder_create.argtypes = [vp]
         L.gpujpeg_decoder_destroy.argtypes = [vp]
+        L.gpujpeg_decoder_init.argtypes = [vp, C.POINTER(Parameters), C.POINTER(ImageParameters)]
         L.gpujpeg_decoder_decode.argtypes = [vp, vp, C.c_size_t, C.POINTER(DecoderOutput)]
         L.gpujpeg_decoder_set_output_format.argtypes = [vp, C.c_int, C.c_int]
         L.gpujpeg_decoder_set_output_format.restype = None
@@ -131,6 +132,8 @@ class Library:
             for n in ("gpujpeg_amd_encoder_read_planes", "gpujpeg_amd_decoder_read_planes"):
                 getattr(L, n).restype = C.c_size_t
                 getattr(L, n).argtypes = [vp, C.POINTER(C.c_uint8), C.c_size_t]
+            for n in ("gpujpeg_amd_encoder_get_kernel_times", "gpujpeg_amd_decoder_get_kernel_times"):
+                getattr(L, n).argtypes = [vp, C.POINTER(C.c_float)]
             for n in ("gpujpeg_amd_encoder_set_fused", "gpujpeg_amd_decoder_set_fused"):
                 getattr(L, n).restype = None
                 getattr(L, n).argtypes = [vp, C.c_int]
@@ -189,6 +192,12 @@ class Encoder:
     def set_fused(self, enabled):
         self.lib.L.gpujpeg_amd_encoder_set_fused(self.h, int(enabled))
 
+    def kernel_times(self):
+        ms = (C.c_float * 8)()
+        if self.lib.L.gpujpeg_amd_encoder_get_kernel_times(self.h, ms) != 0:
+            return None
+        return list(ms)[:5]
+
     def coefficients(self, count):
         a = np.empty(count, np.int16)
         n = self.lib.L.gpujpeg_amd_encoder_read_coefficients(self.h, a.ctypes.data_as(C.POINTER(C.c_int16)), count)
@@ -219,6 +228,9 @@ class Decoder:
     def set_output_format(self, color_space, pixel_format):
         self.lib.L.gpujpeg_decoder_set_output_format(self.h, color_space, pixel_format)
 
+    def init(self, param, param_image):
+        return self.lib.L.gpujpeg_decoder_init(self.h, C.byref(param), C.byref(param_image))
+
     def decode(self, jpeg, device_out=None):
         """jpeg: numpy uint8 array. Returns (numpy uint8 copy of pixels, ImageParameters); with device_out
         (integer device pointer) decodes into that buffer and returns (None, ImageParameters)."""
@@ -243,6 +255,12 @@ class Decoder:
 
     def set_fused(self, enabled):
         self.lib.L.gpujpeg_amd_decoder_set_fused(self.h, int(enabled))
+
+    def kernel_times(self):
+        ms = (C.c_float * 8)()
+        if self.lib.L.gpujpeg_amd_decoder_get_kernel_times(self.h, ms) != 0:
+            return None
+        return list(ms)[:3]
 
     def coefficients(self, count):
         a = np.empty(count, np.int16)

@@ -124,8 +124,10 @@ typedef struct gj_enc_job {
     int use_fused;                 /* 1: raw -> coefficients in one kernel when the format allows */
 } gj_enc_job;
 
-/* events: 0 start, 1 after preprocess, 2 after DCT, 3 after Huffman+assembly (may be NULL) */
-GJ_HIP_API int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[4]);
+/* events (may be NULL): 0 start, 1 after preprocess, 2 after DCT/quant, 3 after k_huffman, 4 after k_scan_segments,
+ * 5 after k_assemble (+ segment info) */
+#define GJ_ENC_EVENTS 6
+GJ_HIP_API int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS]);
 
 /* ------------------------------------------------------------------ decoder */
 typedef struct gj_dec_job {
@@ -149,8 +151,9 @@ typedef struct gj_dec_job {
 #define GJ_DEC_FAST_BITS 10
 #define GJ_DEC_TAB_WORDS (1024 + 36 + 17 + 34 + 256 + 1)
 
-/* events: 0 start, 1 after Huffman, 2 after IDCT, 3 after postprocess (may be NULL) */
-GJ_HIP_API int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4]);
+/* events (may be NULL): 0 start, 1 after Huffman, 2 after IDCT, 3 after postprocess */
+#define GJ_DEC_EVENTS 4
+GJ_HIP_API int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[GJ_DEC_EVENTS]);
 
 /* GPU marker scan: finds RSTn inside [begin,end) of a device-resident stream and writes segment
  * offsets/lengths in order; returns the number of segments through d_count (N1 in SURVEY 8f) */

@@ -30,6 +30,12 @@ GPUJPEG_API size_t gpujpeg_amd_decoder_read_planes(struct gpujpeg_decoder* decod
 GPUJPEG_API void gpujpeg_amd_encoder_set_fused(struct gpujpeg_encoder* encoder, int enabled);
 GPUJPEG_API void gpujpeg_amd_decoder_set_fused(struct gpujpeg_decoder* decoder, int enabled);
 
+/* per-kernel durations (ms, hipEvents on the coder's stream) of the last call made with perf_stats != 0:
+ * encoder: [0] preprocess, [1] DCT+quant (fused path: preprocess included), [2] k_huffman, [3] k_scan_segments, [4] k_assemble
+ * decoder: [0] k_huffman_decode, [1] IDCT (fused path: postprocess included), [2] postprocess */
+GPUJPEG_API int gpujpeg_amd_encoder_get_kernel_times(struct gpujpeg_encoder* encoder, float ms[8]);
+GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* decoder, float ms[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -430,3 +430,50 @@ int gpujpeg_amd_encoder_get_kernel_times(struct gpujpeg_encoder* e, float ms[8])
     memcpy(ms, e->coder.kernel_ms, 8 * sizeof(float));
     return 0;
 }
+
+static int host_adjusted(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi, struct gpujpeg_parameters* p, gj_geom* g)
+{
+    struct gj_coder fresh;
+    memset(&fresh, 0, sizeof fresh);
+    *p = adjust_params(&fresh, param, pi, true);
+    return gj_geom_init(g, p, pi, true);
+}
+
+size_t gpujpeg_amd_host_headers(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi, int header_type,
+                                uint8_t* dst, size_t capacity, size_t* main_header_size)
+{
+    struct gpujpeg_parameters p;
+    gj_geom g;
+    if (host_adjusted(param, pi, &p, &g) != 0) return 0;
+    uint8_t qraw[2][64];
+    gj_quant_table_raw(0, p.quality, qraw[0]);
+    gj_quant_table_raw(1, p.quality, qraw[1]);
+    uint8_t hdr[4096];
+    const size_t n = gj_write_main_header(hdr, &g, &p, (enum gpujpeg_header_type)header_type, (const uint8_t(*)[64])qraw, NULL);
+    struct gj_scan_headers sh;
+    memset(&sh, 0, sizeof sh);
+    if (gj_write_scan_headers(&sh, &g, &p) != 0) return 0;
+    size_t total = 0;
+    if (n + sh.size <= capacity) {
+        memcpy(dst, hdr, n);
+        memcpy(dst + n, sh.bytes, sh.size);
+        total = n + sh.size;
+        if (main_header_size) *main_header_size = n;
+    }
+    free(sh.bytes);
+    return total;
+}
+
+int gpujpeg_amd_host_geometry(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi, int out[20])
+{
+    struct gpujpeg_parameters p;
+    gj_geom g;
+    if (host_adjusted(param, pi, &p, &g) != 0) return -1;
+    memset(out, 0, 20 * sizeof(int));
+    out[0] = g.segment_count; out[1] = g.block_count; out[2] = p.restart_interval; out[3] = g.blocks_per_mcu;
+    for (int c = 0; c < g.comp_count; c++) {
+        out[4 + 4 * c] = g.comp[c].data_width; out[5 + 4 * c] = g.comp[c].data_height;
+        out[6 + 4 * c] = g.interleaved ? g.segment_count : g.comp[c].segment_count; out[7 + 4 * c] = g.comp[c].type;
+    }
+    return 0;
+}

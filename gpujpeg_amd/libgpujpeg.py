@@ -98,7 +98,7 @@ class Library:
             raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(the HIP library is mandatory, there is no CPU fallback)")
         self.path = path
-        L = self.L = C.CDLL(path, mode=C.RTLD_GLOBAL if path == PRODUCT_LIB else C.RTLD_LOCAL)
+        L = self.L = C.CDLL(path, mode=C.RTLD_LOCAL)
         vp = C.c_void_p
         L.gpujpeg_set_default_parameters.argtypes = [C.POINTER(Parameters)]
         L.gpujpeg_image_set_default_parameters.argtypes = [C.POINTER(ImageParameters)]

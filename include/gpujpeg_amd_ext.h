@@ -30,6 +30,17 @@ GPUJPEG_API size_t gpujpeg_amd_decoder_read_planes(struct gpujpeg_decoder* decod
 GPUJPEG_API void gpujpeg_amd_encoder_set_fused(struct gpujpeg_encoder* encoder, int enabled);
 GPUJPEG_API void gpujpeg_amd_decoder_set_fused(struct gpujpeg_decoder* decoder, int enabled);
 
+/* Host-only helper (no device access): the marker segments the encoder would emit for these parameters --
+ * everything up to the first scan (SOI .. COM), followed by the scan headers back to back. Parameters are
+ * adjusted exactly like gpujpeg_encoder_encode() does on a fresh encoder (comp_count 0, RESTART_AUTO).
+ * Returns the number of bytes written, 0 on error. Used by the CPU test-suite to check tables, geometry
+ * and the writer against the oracle without a GPU. */
+GPUJPEG_API size_t gpujpeg_amd_host_headers(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image,
+                                            int header_type, uint8_t* dst, size_t capacity, size_t* main_header_size);
+/* Host-only: geometry summary for the adjusted parameters: out[0] segment_count, [1] block_count, [2] restart interval,
+ * [3] blocks per MCU, [4 + 4*c ..] per component data_width, data_height, segment_count, type */
+GPUJPEG_API int gpujpeg_amd_host_geometry(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image, int out[20]);
+
 /* per-kernel durations (ms, hipEvents on the coder's stream) of the last call made with perf_stats != 0:
  * encoder: [0] preprocess, [1] DCT+quant (fused path: preprocess included), [2] k_huffman, [3] k_scan_segments, [4] k_assemble
  * decoder: [0] k_huffman_decode, [1] IDCT (fused path: postprocess included), [2] postprocess */

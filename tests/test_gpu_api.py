@@ -1,0 +1,99 @@
+"""-m gpu: API behaviour of the drop-in library (ownership, device pointers, statistics, errors)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import api_params, natural_image, oracle_image
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_pointer_inputs_and_outputs(O, G, gpu_lib):
+    """A device pointer passed as ENCODER_INPUT_IMAGE is detected and used in place (test/unit/run_tests.c:40-78);
+    GPU_IMAGE input, CUSTOM_CUDA_BUFFER output and a device-resident JPEG for the decoder."""
+    import torch
+    w, h = 640, 360
+    raw = natural_image(w, h)
+    case = ("x", w, h, 1, 1, 75, -1, 0, None, 3)
+    want = O.encode(oracle_image(O, case), raw)
+    p, pi = api_params(gpu_lib, G, case)
+    d_raw = torch.from_numpy(raw).cuda()
+    enc = G.Encoder(gpu_lib)
+    assert np.array_equal(enc.encode(p, pi, d_raw.data_ptr(), gpu=True), want)
+    inp = G.EncoderInput()
+    inp.type, inp.image = G.ENCODER_INPUT_IMAGE, d_raw.data_ptr()  # device pointer disguised as host image
+    out, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+    assert gpu_lib.L.gpujpeg_encoder_encode(enc.h, C.byref(p), C.byref(pi), C.byref(inp), C.byref(out), C.byref(size)) == 0
+    assert np.array_equal(np.ctypeslib.as_array(out, shape=(size.value,)), want)
+    # device output of the encoder feeds the decoder directly
+    assert enc.set_option("enc_opt_out", "enc_out_val_device") == 0
+    jptr, jsize = enc.encode_noclone(p, pi, d_raw.data_ptr(), gpu=True)
+    assert jsize == want.size
+    d_out = torch.empty(w * h * 3, dtype=torch.uint8, device="cuda")
+    o = G.DecoderOutput()
+    o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, d_out.data_ptr()
+    dec = G.Decoder(gpu_lib)
+    assert gpu_lib.L.gpujpeg_decoder_decode(dec.h, C.cast(jptr, C.c_void_p), jsize, C.byref(o)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), O.decode(want)[0])
+    assert o.data_size == w * h * 3 and o.param_image.width == w
+
+
+def test_output_buffer_ownership_and_pinned_option(O, G, gpu_lib):
+    w, h = 128, 64
+    p, pi = api_params(gpu_lib, G, ("x", w, h, 1, 1, 75, 4, 0, None, 3))
+    enc = G.Encoder(gpu_lib)
+    a = O.noise(w * h * 3, seed=1)
+    b = O.noise(w * h * 3, seed=2)
+    pa, na = enc.encode_noclone(p, pi, a)
+    first = np.ctypeslib.as_array(pa, shape=(na,)).copy()
+    pb, nb = enc.encode_noclone(p, pi, b)
+    assert C.addressof(pa.contents) == C.addressof(pb.contents), "the encoder owns one output buffer that is reused"
+    assert enc.set_option("enc_opt_out", "enc_out_val_pinned") == 0
+    assert np.array_equal(enc.encode(p, pi, a), first)
+    assert enc.set_option("enc_opt_out", "bogus") != 0
+    assert enc.set_option("no_such_option", "1") != 0
+
+
+def test_stats_and_kernel_times(O, G, gpu_lib):
+    w, h = 1920, 1080
+    raw = natural_image(w, h)
+    p, pi = api_params(gpu_lib, G, ("x", w, h, 1, 1, 75, -1, 0, None, 3))
+    p.perf_stats = 1
+    enc = G.Encoder(gpu_lib)
+    jpeg = enc.encode(p, pi, raw)
+    s = enc.stats()
+    assert s.duration_in_gpu > 0 and s.duration_dct_quantization > 0 and s.duration_huffman_coder > 0 and s.duration_memory_to > 0
+    kt = enc.kernel_times()
+    assert kt is not None and abs(sum(kt) - s.duration_in_gpu) < 0.05
+    dec = G.Decoder(gpu_lib)
+    dec.init(p, gpu_lib.default_image_parameters())
+    dec.decode(jpeg)
+    assert dec.stats().duration_in_gpu > 0
+
+
+def test_error_paths(G, gpu_lib):
+    dec = G.Decoder(gpu_lib)
+    bad = np.frombuffer(b"this is not a jpeg", np.uint8).copy()
+    with pytest.raises(RuntimeError):
+        dec.decode(bad)
+    img, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+    gpu_lib.L.gpujpeg_image_load_from_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    assert gpu_lib.L.gpujpeg_image_load_from_file(b"/nonexistent/file.rgb", C.byref(img), C.byref(size)) != 0
+
+
+def test_cli_round_trip(O, G, gpu_lib, tmp_path):
+    """gpujpegtool: synthetic .tst input -> JPEG -> PNM, same files as the reference CLI would produce."""
+    import os
+    import subprocess
+    tool = os.path.join(os.path.dirname(G.PRODUCT_LIB), "gpujpegtool")
+    jpg, pnm = tmp_path / "o.jpg", tmp_path / "o.pnm"
+    subprocess.check_call([tool, "-q", "80", "-r", "16", "640x360.random.tst", str(jpg)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+    raw = O.noise(640 * 360 * 3, seed=12345)
+    want = O.encode(O.make_image(640, 360, quality=80, restart_interval=16), raw)
+    assert np.array_equal(np.fromfile(jpg, np.uint8), want)
+    subprocess.check_call([tool, str(jpg), str(pnm)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+    data = open(pnm, "rb").read()
+    assert data.startswith(b"P6\n640 360\n255\n")
+    assert np.array_equal(np.frombuffer(data[len(b"P6\n640 360\n255\n"):], np.uint8), O.decode(want)[0])

@@ -1,0 +1,154 @@
+"""Host-side logic of the product library that needs no GPU: parameters, names, restart heuristics, geometry,
+tables + JFIF writer (through the host-only helper of include/gpujpeg_amd_ext.h), the reader."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import CASES, api_params, make_raw, oracle_image
+
+
+def test_default_parameters(lib, G):
+    p = lib.default_parameters()
+    assert (p.verbose, p.perf_stats, p.quality, p.restart_interval, p.interleaved, p.segment_info, p.comp_count) == (0, 0, 75, 8, 0, 0, 0)
+    assert p.color_space_internal == G.YCBCR_BT601_256LVLS
+    assert all((p.sampling_factor[i].horizontal, p.sampling_factor[i].vertical) == (1, 1) for i in range(4))
+    pi = lib.default_image_parameters()
+    assert (pi.width, pi.height, pi.color_space, pi.pixel_format, pi.width_padding) == (0, 0, G.RGB, G.P012_444, 0)
+
+
+@pytest.mark.parametrize("w,h,pf,il,sub,want", [
+    (1920, 1080, 1, False, "444", 24), (3840, 2160, 1, False, "444", 30), (7680, 4320, 1, False, "444", 36),
+    (15360, 8640, 3, True, "422", 6), (640, 480, 1, True, "444", 4), (640, 480, 0, False, "400", 4), (1920, 1080, 1, True, "420", 4)])
+def test_suggest_restart_interval(lib, G, w, h, pf, il, sub, want):
+    pi = lib.default_image_parameters()
+    pi.width, pi.height, pi.pixel_format = w, h, pf
+    s = {"444": G.SUBSAMPLING_444, "422": G.SUBSAMPLING_422, "420": G.SUBSAMPLING_420, "400": G.SUBSAMPLING_400}[sub]
+    assert lib.L.gpujpeg_encoder_suggest_restart_interval(C.byref(pi), s, il, -1) == want
+
+
+def test_names(lib, G):
+    L = lib.L
+    L.gpujpeg_subsampling_get_name.restype = C.c_char_p
+    L.gpujpeg_subsampling_get_name.argtypes = [C.c_int, C.POINTER(G.SamplingFactor)]
+    L.gpujpeg_subsampling_from_name.restype = C.c_uint32
+    L.gpujpeg_subsampling_from_name.argtypes = [C.c_char_p]
+    L.gpujpeg_pixel_format_get_name.restype = C.c_char_p
+    L.gpujpeg_color_space_get_name.restype = C.c_char_p
+    L.gpujpeg_pixel_format_by_name.argtypes = [C.c_char_p]
+    L.gpujpeg_color_space_by_name.argtypes = [C.c_char_p]
+    L.gpujpeg_version_to_string.restype = C.c_char_p
+    for text, packed in [("4:4:4", G.SUBSAMPLING_444), ("4:2:2", G.SUBSAMPLING_422), ("4:2:0", G.SUBSAMPLING_420), ("420", G.SUBSAMPLING_420),
+                         ("4:4:4:4", G.SUBSAMPLING_4444), ("4:0:0", G.SUBSAMPLING_400)]:
+        assert L.gpujpeg_subsampling_from_name(text.encode()) == packed
+        p = lib.default_parameters()
+        L.gpujpeg_parameters_chroma_subsampling(C.byref(p), packed)
+        if ":" in text:
+            assert L.gpujpeg_subsampling_get_name(p.comp_count, p.sampling_factor).decode() == text
+    assert L.gpujpeg_subsampling_from_name(b"5:1:1") == 0
+    for name, pf in [("u8", 0), ("444-u8-p012", 1), ("444-u8-p0p1p2", 2), ("422-u8-p1020", 3), ("422-u8-p0p1p2", 4), ("420-u8-p0p1p2", 5), ("4444-u8-p0123", 6)]:
+        assert L.gpujpeg_pixel_format_by_name(name.encode()) == pf
+        assert L.gpujpeg_pixel_format_get_name(pf).decode() == name
+    assert L.gpujpeg_pixel_format_by_name(b"nope") == -1
+    assert [L.gpujpeg_pixel_format_get_comp_count(i) for i in range(7)] == [1, 3, 3, 3, 3, 3, 4]
+    assert [L.gpujpeg_pixel_format_is_planar(i) for i in range(7)] == [0, 0, 1, 0, 1, 1, 0]
+    for name, cs in [("rgb", 1), ("ycbcr-jpeg", 3), ("ycbcr-bt601", 2), ("ycbcr-bt709", 4), ("ycbcr", 4), ("yuv", 5)]:
+        assert L.gpujpeg_color_space_by_name(name.encode()) == cs
+    assert L.gpujpeg_color_space_get_name(3).decode() == "YCbCr BT.601 256 Levels (YCbCr JPEG)"
+    assert L.gpujpeg_version_to_string(L.gpujpeg_version()).decode() == "0.27.13"
+
+
+@pytest.mark.parametrize("pf,w,h,pad,want", [(1, 1920, 1080, 0, 6220800), (3, 15360, 8640, 0, 265420800), (5, 5, 5, 0, 43), (4, 5, 5, 0, 55),
+                                              (2, 7, 3, 0, 63), (6, 10, 10, 2, 480), (0, 9, 9, 0, 81)])
+def test_image_size(lib, pf, w, h, pad, want):
+    pi = lib.default_image_parameters()
+    pi.width, pi.height, pi.pixel_format, pi.width_padding = w, h, pf, pad
+    assert lib.image_size(pi) == want
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_headers_and_geometry_match_oracle(O, G, lib, case):
+    """Tables, JFIF/Adobe/SPIFF writer and geometry of the PRODUCT host code vs the oracle (which is itself pinned
+    against the reference writer): the marker segments must be byte-identical."""
+    L = lib.L
+    L.gpujpeg_amd_host_headers.restype = C.c_size_t
+    L.gpujpeg_amd_host_headers.argtypes = [C.POINTER(G.Parameters), C.POINTER(G.ImageParameters), C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.gpujpeg_amd_host_geometry.argtypes = [C.POINTER(G.Parameters), C.POINTER(G.ImageParameters), C.POINTER(C.c_int)]
+    for seginfo in (0, 1):
+        p, pi = api_params(lib, G, case, segment_info=seginfo)
+        img = oracle_image(O, case, segment_info=seginfo)
+        geo = (C.c_int * 20)()
+        assert L.gpujpeg_amd_host_geometry(C.byref(p), C.byref(pi), geo) == 0
+        assert (geo[0], geo[1], geo[2]) == (img.segment_count, img.block_count, img.restart_interval)
+        for c in range(img.comp_count):
+            assert (geo[4 + 4 * c], geo[5 + 4 * c], geo[7 + 4 * c]) == (img.comp[c].data_width, img.comp[c].data_height, img.comp[c].type)
+        buf = (C.c_uint8 * (1 << 20))()
+        main = C.c_size_t()
+        n = L.gpujpeg_amd_host_headers(C.byref(p), C.byref(pi), 0, buf, len(buf), C.byref(main))
+        assert n > 0
+        ours = np.frombuffer(buf, np.uint8, n)
+        # oracle: header bytes; scan headers are found in a complete oracle stream
+        raw = make_raw(O, case)
+        jpeg = O.encode(img, raw)
+        assert np.array_equal(ours[:main.value], jpeg[:main.value]), "main header differs"
+        s = O.parse(jpeg)
+        scan_hdr = ours[main.value:]
+        pos = 0
+        first_of_scan = [i for i in range(s.seg_count) if s.seg_index_in_scan[i] == 0]
+        for i, seg in enumerate(first_of_scan):
+            start = s.seg_offset[seg]
+            # SOS is 10 or 6+2n bytes; with segment info APP13 precedes it
+            sos_len = 2 + (6 + 2 * img.comp_count if img.interleaved else 8)
+            info_len = 0
+            if seginfo and img.restart_interval > 0:
+                segs = img.segment_count if img.interleaved else img.comp[i].segment_count
+                data = (segs + 1) * 4
+                info_len = data + 5 * ((data + 65435) // 65436)
+            hdr_len = sos_len + info_len
+            theirs = jpeg[start - hdr_len:start]
+            mine = scan_hdr[pos:pos + hdr_len]
+            if info_len:  # placeholders are zero on the host, the device fills them in
+                assert np.array_equal(mine[:5], theirs[:5])
+                assert np.array_equal(mine[info_len:], theirs[info_len:])
+            else:
+                assert np.array_equal(mine, theirs)
+            pos += hdr_len
+        assert pos == scan_hdr.size
+        O.lib().gjo_stream_free(C.byref(s))
+
+
+@pytest.mark.parametrize("case", CASES[:12], ids=[c[0] for c in CASES[:12]])
+def test_reader_image_info(O, G, lib, case):
+    """gpujpeg_decoder_get_image_info (host only) on oracle streams."""
+    raw = make_raw(O, case)
+    img = oracle_image(O, case)
+    jpeg = O.encode(img, raw)
+    pi, p, segs = G.ImageParameters(), G.Parameters(), C.c_int()
+    assert lib.L.gpujpeg_decoder_get_image_info(jpeg.ctypes.data, jpeg.size, C.byref(pi), C.byref(p), C.byref(segs)) == 0
+    assert (pi.width, pi.height) == (case[1], case[2])
+    assert p.comp_count == img.comp_count and p.interleaved == (img.interleaved if img.comp_count > 1 else 0)
+    assert p.restart_interval == img.restart_interval
+    assert segs.value == img.segment_count
+    assert p.color_space_internal == img.color_space_internal
+
+
+def test_reader_rejects_garbage(lib, G):
+    bad = np.frombuffer(b"\x00\x01\x02\x03not a jpeg at all", np.uint8).copy()
+    pi, p, segs = G.ImageParameters(), G.Parameters(), C.c_int()
+    assert lib.L.gpujpeg_decoder_get_image_info(bad.ctypes.data, bad.size, C.byref(pi), C.byref(p), C.byref(segs)) != 0
+    trunc = np.array([0xFF, 0xD8, 0xFF, 0xDB, 0x00, 0x43, 0x00], np.uint8)
+    assert lib.L.gpujpeg_decoder_get_image_info(trunc.ctypes.data, trunc.size, C.byref(pi), C.byref(p), C.byref(segs)) != 0
+
+
+def test_file_format_detection(lib, G):
+    L = lib.L
+    L.gpujpeg_image_get_file_format.argtypes = [C.c_char_p]
+    for name, fmt in [("a.rgb", 4), ("a.jpg", 1), ("b.JPEG", 1), ("c.yuv", 15), ("d.uyvy", 17), ("e.i420", 18), ("f.pnm", 12), ("g.pam", 13),
+                      ("h.y4m", 14), ("1920x1080.tst", 19), ("noext", 0), ("x.r", 3), ("x.rgba", 5)]:
+        assert L.gpujpeg_image_get_file_format(name.encode()) == fmt, name
+    pi = lib.default_image_parameters()
+    L.gpujpeg_image_get_properties.argtypes = [C.c_char_p, C.POINTER(G.ImageParameters), C.c_int]
+    assert L.gpujpeg_image_get_properties(b"1119x561.p_u8.random.tst", C.byref(pi), 1) == 0
+    assert (pi.width, pi.height, pi.pixel_format) == (1119, 561, 0)
+    assert L.gpujpeg_image_get_properties(b"64x32.c_ycbcr-jpeg.p_422-u8-p1020.tst", C.byref(pi), 1) == 0
+    assert (pi.width, pi.height, pi.pixel_format, pi.color_space) == (64, 32, 3, 3)

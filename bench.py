@@ -177,7 +177,7 @@ def main():
     if rank == 0:
         pixels = width * height
         raw_bytes = pixels * 3
-        names = ["enc:k_preprocess", "enc:k_fused_rgb444(pre+dct+quant)", "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
+        names = ["enc:k_preprocess", "enc:k_fused_rgb444(pre+dct+quant)", "enc:k_huffman", "enc:k_scan_partial+k_scan_final", "enc:k_assemble",
                  "dec:k_huffman_decode", "dec:k_idct_fused_rgb444(idct+post)", "dec:k_postprocess"]
         durs = list(enc_ms) + list(dec_ms)
         dom = int(np.argmax(durs))

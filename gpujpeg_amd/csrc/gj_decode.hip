@@ -14,138 +14,238 @@
 #include "gj_hip.h"
 
 // ================================================================================================
-// Entropy decoder
+// Entropy decoder: one lane per restart segment (the code is serial inside a segment).
+//
+// The hot loop touches no global memory on its input side: every lane owns a 256-byte window of its segment in LDS
+// (rows of 65 dwords, so both the cooperative fill and the per-lane reads are bank-conflict free). The wave fills
+// the windows together -- for lane j, all 64 lanes fetch 256 contiguous bytes -- first for everybody, later only for
+// the lanes that have used three quarters of their window (rare: an average q75 segment is ~170 bytes). With no loads
+// in the loop, the 2-byte coefficient stores are never waited for (on gfx9 loads and stores share vmcnt).
+// Byte stuffing is removed on the fly: a dword without 0xFF (98.5 % of them) is appended with one shift.
+// Lanes do not wait for each other at block boundaries: one symbol per iteration, every lane moves on to its next
+// block on its own, so a wave needs max-over-lanes(symbols of a segment) iterations.
 // ================================================================================================
+#define GJ_WIN_DW 64
+#define GJ_WIN_STRIDE 65
+
 struct GjBits {
-    const uint8_t* p;
-    const uint8_t* end;
-    uint64_t acc; // valid bits are left aligned
+    const uint32_t* src; // global address of window dword 0
+    int rd;              // next window dword to consume
+    int remaining;       // bytes of the segment not yet moved into the accumulator
+    int prev_ff;         // last consumed byte was 0xFF (a following 0x00 is stuffing)
+    uint64_t acc;        // valid bits are left aligned
     int n;
 };
 
-__device__ __forceinline__ void gj_refill(GjBits& b)
+// (re)fill the windows of the lanes in `mask` from their `src`; all 64 lanes must call this
+__device__ __forceinline__ void gj_fill_windows(unsigned long long mask, const uint32_t* src, const uint32_t* end, uint32_t* s_win, int lane)
 {
-    while (b.n <= 56) {
-        uint32_t byte = 0; // past the end of the segment: zero bits (src/gpujpeg_huffman_cpu_decoder.c:80-118)
-        if (b.p < b.end) {
-            byte = *b.p++;
-            if (byte == 0xFFu && b.p < b.end && *b.p == 0) b.p++; // stuffed zero
+    const unsigned lo = (unsigned)(uintptr_t)src, hi = (unsigned)((uintptr_t)src >> 32);
+    while (mask) {
+        uint32_t v[4];
+        int js[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            js[u] = -1;
+            v[u] = 0;
+            if (mask) {
+                const int j = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                js[u] = j;
+                const uint32_t* a = reinterpret_cast<const uint32_t*>(((uintptr_t)(unsigned)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                                                      (unsigned)__builtin_amdgcn_readlane((int)lo, j)) + lane;
+                if (a < end) v[u] = *a;
+            }
         }
-        b.acc |= (uint64_t)byte << (56 - b.n);
-        b.n += 8;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (js[u] >= 0) s_win[js[u] * GJ_WIN_STRIDE + lane] = v[u];
     }
 }
 
-__device__ __forceinline__ uint32_t gj_get_bits(GjBits& b, int n)
+// canonical search for codes longer than the fast table (ITU T.81 F.2.2.3); rare
+__device__ __forceinline__ uint32_t gj_decode_slow(uint32_t hi, const uint16_t* t)
 {
-    const uint32_t v = (uint32_t)(b.acc >> (64 - n));
-    b.acc <<= n;
-    b.n -= n;
-    return v;
-}
-
-// table words: see GJ_DEC_TAB_WORDS in gj_hip.h
-__device__ __forceinline__ int gj_decode_symbol(GjBits& b, const uint16_t* t)
-{
-    const uint32_t peek = (uint32_t)(b.acc >> 48); // 16 bits
-    const uint32_t fast = t[peek >> (16 - GJ_DEC_FAST_BITS)];
-    if (fast) {
-        const int len = fast >> 8;
-        b.acc <<= len;
-        b.n -= len;
-        return (int)(fast & 0xFFu);
-    }
-    // codes longer than 10 bits: canonical search (ITU T.81 F.2.2.3)
-    const uint16_t* maxcode = t + 1024;       // [18] as (lo, hi)
-    const uint16_t* valptr = t + 1024 + 36;   // [17]
+    const uint16_t* maxcode = t + 1024;           // [18] as (lo, hi)
+    const uint16_t* valptr = t + 1024 + 36;       // [17]
     const uint16_t* mincode = t + 1024 + 36 + 17; // [17] as (lo, hi)
     const uint16_t* vals = t + 1024 + 36 + 17 + 34;
     for (int l = GJ_DEC_FAST_BITS + 1; l <= 16; l++) {
-        const int code = (int)(peek >> (16 - l));
+        const int code = (int)(hi >> (32 - l));
         const int mx = (int)((uint32_t)maxcode[2 * l] | ((uint32_t)maxcode[2 * l + 1] << 16));
         if (mx >= 0 && code <= mx) {
             const int mn = (int)((uint32_t)mincode[2 * l] | ((uint32_t)mincode[2 * l + 1] << 16));
-            b.acc <<= l;
-            b.n -= l;
-            return vals[(valptr[l] + code - mn) & 0xFF];
+            return ((uint32_t)l << 8) | vals[(valptr[l] + code - mn) & 0xFF];
         }
     }
-    b.acc <<= 16; // corrupt stream: consume and continue (output is undefined but in bounds)
-    b.n -= 16;
-    return 0;
+    return (16u << 8); // corrupt stream: consume 16 bits, symbol 0 (output is undefined but in bounds)
 }
 
-__device__ __forceinline__ int gj_extend(uint32_t v, int n) // ITU T.81 F.2.2.1
-{
-    return v < (1u << (n - 1)) ? (int)v - (int)((1u << n) - 1u) : (int)v;
-}
-
-__global__ __launch_bounds__(64) void k_huffman_decode(const gj_geom g, const uint8_t* __restrict__ jpeg,
-                                                       const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
-                                                       const uint32_t* __restrict__ seg_index, const int seg_count,
-                                                       const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs)
+// The loop body is written to compile to (almost) straight-line predicated code: a lone wave per SIMD pays for every
+// divergent branch with exec-mask round trips, which dominated the first versions of this kernel.
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+                                                        const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
+                                                        const uint32_t* __restrict__ seg_index, const uint32_t* __restrict__ seg_count_ptr,
+                                                        const int seg_count_max, const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs)
 {
     __shared__ uint16_t s_tab[8 * GJ_DEC_TAB_WORDS];
-    // [dword][lane]: one 8x8 block per lane, every lane in its own bank. Written as int16, zeroed and read back
-    // as dwords: the dword view must be may_alias or the zero stores get forwarded into the final loads.
-    typedef uint32_t __attribute__((may_alias)) u32a;
-    __shared__ __attribute__((aligned(16))) int16_t s_blk16[64 * 64];
-    u32a* s_blk = reinterpret_cast<u32a*>(s_blk16);
-    const int lane = threadIdx.x;
-    for (int t = lane; t < 8 * GJ_DEC_TAB_WORDS / 2; t += 64)
+    __shared__ uint32_t s_win_all[4 * 64 * GJ_WIN_STRIDE];
+    __shared__ uint8_t s_zz[64 + 32];
+    for (int t = threadIdx.x; t < 8 * GJ_DEC_TAB_WORDS / 2; t += 256)
         reinterpret_cast<uint32_t*>(s_tab)[t] = reinterpret_cast<const uint32_t*>(tabs)[t];
+    if (threadIdx.x < 96) s_zz[threadIdx.x] = threadIdx.x < 64 ? GJ_ZZ[threadIdx.x] : 63;
     __syncthreads();
-    const int si = blockIdx.x * 64 + lane;
-    if (si >= seg_count) return;
-    const int s = (int)seg_index[si];
-    if (s >= g.segment_count) return;
-    const GjSeg sg = gj_segment(g, s);
-    GjBits b;
-    b.p = jpeg + seg_pos[si];
-    b.end = b.p + seg_len[si];
-    b.acc = 0;
-    b.n = 0;
-    int dc[GJ_MAX_COMP] = {0, 0, 0, 0};
-    for (int k = 0; k < sg.nblocks; k++) {
-        int comp, mcu_pos;
-        const uint64_t off = gj_segment_block(g, sg, k, &comp, &mcu_pos);
-        const uint16_t* tdc = s_tab + (g.comp[comp].dc_table * 2 + 0) * GJ_DEC_TAB_WORDS;
-        const uint16_t* tac = s_tab + (g.comp[comp].ac_table * 2 + 1) * GJ_DEC_TAB_WORDS;
-#pragma unroll
-        for (int q = 0; q < 32; q++) s_blk[q * 64 + lane] = 0;
-        gj_refill(b);
-        {
-            const int sz = gj_decode_symbol(b, tdc) & 15;
-            int diff = 0;
-            if (sz) diff = gj_extend(gj_get_bits(b, sz), sz);
-            int d = (comp == 0 ? dc[0] : comp == 1 ? dc[1] : comp == 2 ? dc[2] : dc[3]) + diff;
-            if (comp == 0) dc[0] = d; else if (comp == 1) dc[1] = d; else if (comp == 2) dc[2] = d; else dc[3] = d;
-            s_blk16[(0 * 64 + lane) * 2] = (int16_t)d;
+    const int lane = threadIdx.x & 63;
+    uint32_t* s_win = s_win_all + (threadIdx.x >> 6) * 64 * GJ_WIN_STRIDE; // this wave's 64 rows
+    const uint32_t* s_row = s_win + lane * GJ_WIN_STRIDE;
+    const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
+
+    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
+    const int si = blockIdx.x * 256 + threadIdx.x;
+    uint32_t s = 0xFFFFFFFFu;
+    if (si < seg_count) s = seg_index[si];
+    GjSeg sg;
+    sg.nblocks = 0;
+    sg.mcu_first = 0;
+    sg.comp = 0;
+    if (s < (uint32_t)g.segment_count) sg = gj_segment(g, (int)s);
+    int left = sg.nblocks > 0 ? sg.nblocks : 0;
+
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(jpeg); // global address of window dword 0
+    int rd = 0;          // next window dword
+    int remaining = 0;   // bytes of the segment not yet moved into the accumulator
+    int prev_ff = 0;     // last byte moved was 0xFF (a following 0x00 is stuffing)
+    uint64_t acc = 0;    // valid bits are left aligned
+    int n = 0;
+    int lead = 0;
+    if (left > 0) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + seg_pos[si];
+        src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+        remaining = (int)seg_len[si];
+        lead = (int)(a & 3);
+    }
+    gj_fill_windows(__ballot(left > 0), src, end, s_win, lane);
+    if (lead) { // drop the bytes in front of the segment inside its first dword
+        const uint32_t w = s_row[0];
+        rd = 1;
+        for (int i = lead; i < 4 && remaining > 0; i++) {
+            const uint32_t byte = (w >> (8 * i)) & 0xFFu;
+            remaining--;
+            if (prev_ff && byte == 0) { prev_ff = 0; continue; }
+            prev_ff = byte == 0xFFu;
+            acc |= (uint64_t)byte << (56 - n);
+            n += 8;
         }
-        for (int kk = 1; kk < 64;) {
-            gj_refill(b);
-            const int rs = gj_decode_symbol(b, tac);
-            const int run = rs >> 4, sz = rs & 15;
-            if (sz == 0) {
-                if (run == 15) { kk += 16; continue; }
-                break; // EOB
+    }
+
+    // block cursor
+    const int P = g.blocks_per_mcu;
+    int p = 0;
+    unsigned mx = 0, my = 0;
+    int comp = sg.comp;
+    uint64_t off;
+    if (INTERLEAVED) {
+        my = (unsigned)sg.mcu_first / (unsigned)g.mcu_count_x;
+        mx = (unsigned)sg.mcu_first - my * (unsigned)g.mcu_count_x;
+        comp = g.mcu_comp[0];
+        const gj_comp_geom& kc = g.comp[comp];
+        off = kc.data_offset + ((uint64_t)(my * kc.samp_v + g.mcu_by[0]) * kc.blocks_x + mx * kc.samp_h + g.mcu_bx[0]) * 64;
+    } else {
+        off = g.comp[comp].data_offset + (uint64_t)sg.mcu_first * 64;
+    }
+    const uint16_t* tdc = s_tab + (g.comp[comp].dc_table * 2 + 0) * GJ_DEC_TAB_WORDS;
+    const uint16_t* tac = s_tab + (g.comp[comp].ac_table * 2 + 1) * GJ_DEC_TAB_WORDS;
+    int dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
+    int kk = 0; // 0: DC expected, 1..63: next AC position
+    while (__any(left > 0)) {
+        // lanes that have used 3/4 of their window get a fresh one starting at their current dword (wave-uniform branch)
+        const unsigned long long need = __ballot(left > 0 && rd >= GJ_WIN_DW - 16);
+        if (need) {
+            if ((need >> lane) & 1) { src += rd; rd = 0; }
+            gj_fill_windows(need, src, end, s_win, lane);
+        }
+        // ---- refill: one dword when fewer than 33 bits are left
+        const bool want = left > 0 && n <= 32;
+        const uint32_t w = s_row[rd];
+        const uint32_t inv = ~w;
+        const bool plain = !(((inv - 0x01010101u) & ~inv & 0x80808080u) != 0) && !prev_ff && remaining >= 4;
+        if (__any(want && !plain)) { // some lane meets 0xFF, a stuffed zero or the tail of its segment: byte-wise for those lanes
+            if (want && !plain) {
+                if (remaining <= 0) {
+                    n = 64; // zero bits past the end (src/gpujpeg_huffman_cpu_decoder.c:80-118)
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (remaining > 0) {
+                            const uint32_t byte = (w >> (8 * i)) & 0xFFu;
+                            remaining--;
+                            if (prev_ff && byte == 0) {
+                                prev_ff = 0;
+                            } else {
+                                prev_ff = byte == 0xFFu;
+                                acc |= (uint64_t)byte << (56 - n);
+                                n += 8;
+                            }
+                        }
+                    }
+                    rd++;
+                }
             }
-            kk += run;
-            if (kk > 63) break;
-            const int v = gj_extend(gj_get_bits(b, sz), sz);
-            const int nat = GJ_ZZ[kk];
-            s_blk16[((nat >> 1) * 64 + lane) * 2 + (nat & 1)] = (int16_t)v;
-            kk++;
         }
-        uint4* dst = reinterpret_cast<uint4*>(coefs + off);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint4 w;
-            w.x = s_blk[(r * 4 + 0) * 64 + lane];
-            w.y = s_blk[(r * 4 + 1) * 64 + lane];
-            w.z = s_blk[(r * 4 + 2) * 64 + lane];
-            w.w = s_blk[(r * 4 + 3) * 64 + lane];
-            dst[r] = w;
+        if (want && plain) {
+            acc |= (uint64_t)__builtin_bswap32(w) << (32 - n);
+            n += 32;
+            remaining -= 4;
+            rd++;
+        }
+        // ---- one symbol (needs up to 16 + 11 bits)
+        const bool go = left > 0 && n >= 27;
+        const uint32_t hi = (uint32_t)(acc >> 32);
+        const uint16_t* t = kk == 0 ? tdc : tac;
+        uint32_t ent = t[hi >> (32 - GJ_DEC_FAST_BITS)];
+        if (__any(go && ent == 0)) {
+            if (go && ent == 0) ent = gj_decode_slow(hi, t);
+        }
+        if (go) {
+            const int used = (int)(ent >> 8);
+            const int sym = (int)(ent & 0xFFu);
+            const int run = sym >> 4, sz = sym & 15;
+            const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
+            int v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+            acc <<= (used + sz);
+            n -= used + sz;
+            const bool is_dc = kk == 0;
+            if (is_dc) {
+                if (INTERLEAVED) {
+                    v += (comp == 0 ? dc0 : comp == 1 ? dc1 : comp == 2 ? dc2 : dc3);
+                    if (comp == 0) dc0 = v; else if (comp == 1) dc1 = v; else if (comp == 2) dc2 = v; else dc3 = v;
+                } else {
+                    v += dc0;
+                    dc0 = v;
+                }
+            }
+            const int pos = kk + run; // DC symbols have run 0
+            const bool store = (is_dc || sz != 0) && pos < 64;
+            if (store) coefs[off + s_zz[pos]] = (int16_t)v;
+            kk = (!is_dc && sz == 0) ? (run == 15 ? kk + 16 : 64) : pos + 1;
+            if (kk >= 64) { // next block of this segment
+                kk = 0;
+                left--;
+                if (!INTERLEAVED) {
+                    off += 64;
+                } else {
+                    if (++p == P) {
+                        p = 0;
+                        if (++mx == (unsigned)g.mcu_count_x) { mx = 0; my++; }
+                    }
+                    comp = g.mcu_comp[p];
+                    const gj_comp_geom& kc = g.comp[comp];
+                    off = kc.data_offset + ((uint64_t)(my * kc.samp_v + g.mcu_by[p]) * kc.blocks_x + mx * kc.samp_h + g.mcu_bx[p]) * 64;
+                    tdc = s_tab + (kc.dc_table * 2 + 0) * GJ_DEC_TAB_WORDS;
+                    tac = s_tab + (kc.ac_table * 2 + 1) * GJ_DEC_TAB_WORDS;
+                }
+            }
         }
     }
 }
@@ -360,11 +460,14 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
-    // blocks of segments that are missing from a damaged stream must still be defined
-    if (job->seg_count < g.segment_count) (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
+    // the entropy decoder stores only non-zero coefficients
+    (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
     if (job->seg_count > 0)
-        hipLaunchKernelGGL(k_huffman_decode, dim3(((unsigned)job->seg_count + 63) / 64), dim3(64), 0, st, g, job->d_jpeg, job->d_seg_pos,
-                           job->d_seg_len, job->d_seg_index, job->seg_count, job->d_huff_tab, job->d_coefs);
+    {
+        auto kernel = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;
+        hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + 255) / 256), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size,
+                           job->d_seg_pos, job->d_seg_len, job->d_seg_index, job->d_seg_count, job->seg_count, job->d_huff_tab, job->d_coefs);
+    }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
     if (fused) {
@@ -387,30 +490,53 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
 }
 
 // ================================================================================================
-// Device-side marker scan: the entropy-coded data of a scan contains 0xFF only as
-// "FF 00" (stuffing) or "FF Dn" (restart marker), so every FF Dn pair is a segment boundary.
-// Pass 1 counts boundaries per 1 KiB chunk, a single-workgroup scan turns the counts into ranks,
-// pass 2 writes the segment table in stream order.
+// Device-side segment discovery. Inside entropy-coded data 0xFF is followed by 0x00 (stuffing),
+// by 0xD0..0xD7 (restart marker = segment boundary) or by the marker that ends the scan. Three small launches turn
+// the bytes [begin, size) into the (offset, length, geometric index) table k_huffman_decode consumes, without the host
+// touching the stream (the reference walks it with memchr and copies every segment, src/gpujpeg_reader.c:1039-1155):
+//   k_marker_count   per 2 KiB chunk: number of RSTn; every other marker is appended (rare) to a small list
+//   k_marker_rank    exclusive scan of the chunk counts
+//   k_marker_emit    ordered list of RSTn positions
+//   k_build_segments segment table for every scan + the summary the host validates (gj_scan_summary)
 // ================================================================================================
-#define GJ_SCAN_CHUNK 1024
+#define GJ_SCAN_CHUNK 2048
 
-__global__ __launch_bounds__(256) void k_rst_count(const uint8_t* __restrict__ jpeg, uint64_t begin, uint64_t end, uint32_t* __restrict__ chunk_count)
+__device__ __forceinline__ int gj_marker_at(const uint8_t* __restrict__ jpeg, uint64_t p, uint64_t size)
+{
+    // 0: none, 1: RSTn, 2: other marker
+    if (p + 1 >= size || jpeg[p] != 0xFF) return 0;
+    const int m = jpeg[p + 1];
+    if (m == 0x00 || m == 0xFF) return 0;
+    return (m & 0xF8) == 0xD0 ? 1 : 2;
+}
+
+__global__ __launch_bounds__(256) void k_marker_count(const uint8_t* __restrict__ jpeg, uint64_t begin, uint64_t size,
+                                                      uint32_t* __restrict__ chunk_count, gj_scan_summary* __restrict__ sum)
 {
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint64_t base = begin + (uint64_t)blockIdx.x * GJ_SCAN_CHUNK;
+    const uint64_t base = begin + (uint64_t)blockIdx.x * GJ_SCAN_CHUNK + threadIdx.x * 8u;
     uint32_t n = 0;
-    for (int t = threadIdx.x; t < GJ_SCAN_CHUNK; t += 256) {
-        const uint64_t p = base + t;
-        if (p + 1 < end && jpeg[p] == 0xFF && (jpeg[p + 1] & 0xF8) == 0xD0) n++;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = gj_marker_at(jpeg, base + i, size);
+        if (k == 1) n++;
+        if (k == 2) { // scan boundary material: keep position, code and the 16 bytes that follow
+            const uint32_t slot = atomicAdd(&sum->other_count, 1u);
+            if (slot < GJ_SCAN_MAX_OTHER) {
+                sum->other_pos[slot] = (uint32_t)(base + i);
+                sum->other_code[slot] = jpeg[base + i + 1];
+                for (int b = 0; b < 16; b++) sum->other_bytes[slot][b] = base + i + 2 + b < size ? jpeg[base + i + 2 + b] : 0;
+            }
+        }
     }
     if (n) atomicAdd(&s_n, n);
     __syncthreads();
     if (threadIdx.x == 0) chunk_count[blockIdx.x] = s_n;
 }
 
-__global__ __launch_bounds__(1024) void k_rst_rank(uint32_t* __restrict__ chunk_count, uint32_t chunks, uint32_t* __restrict__ total)
+__global__ __launch_bounds__(1024) void k_marker_rank(uint32_t* __restrict__ chunk_count, uint32_t chunks, gj_scan_summary* __restrict__ sum)
 {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
@@ -430,66 +556,120 @@ __global__ __launch_bounds__(1024) void k_rst_rank(uint32_t* __restrict__ chunk_
         if (t == 1023) s_carry = off + inc;
         __syncthreads();
     }
-    if (t == 0) *total = s_carry;
+    if (t == 0) sum->rst_count = s_carry;
 }
 
-__global__ __launch_bounds__(64) void k_rst_emit(const uint8_t* __restrict__ jpeg, uint64_t begin, uint64_t end,
-                                                 const uint32_t* __restrict__ chunk_rank, uint32_t* __restrict__ marker_pos, uint32_t max_markers)
+__global__ __launch_bounds__(256) void k_marker_emit(const uint8_t* __restrict__ jpeg, uint64_t begin, uint64_t size,
+                                                     const uint32_t* __restrict__ chunk_rank, uint32_t* __restrict__ rst_pos, uint32_t max_rst)
 {
-    // one wave per chunk keeps the order: ballot + popcount of the lower lanes
-    const uint64_t base = begin + (uint64_t)blockIdx.x * GJ_SCAN_CHUNK;
-    uint32_t rank = chunk_rank[blockIdx.x];
-    const int lane = threadIdx.x;
-    for (int t0 = 0; t0 < GJ_SCAN_CHUNK; t0 += 64) {
-        const uint64_t p = base + t0 + lane;
-        const bool hit = p + 1 < end && jpeg[p] == 0xFF && (jpeg[p + 1] & 0xF8) == 0xD0;
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const uint32_t r = rank + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (r < max_markers) marker_pos[r] = (uint32_t)p;
+    __shared__ uint32_t s_tmp[4];
+    const uint64_t base = begin + (uint64_t)blockIdx.x * GJ_SCAN_CHUNK + threadIdx.x * 8u;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (gj_marker_at(jpeg, base + i, size) == 1) mask |= 1u << i;
+    const uint32_t n = (uint32_t)__popc(mask);
+    uint32_t total;
+    uint32_t r = chunk_rank[blockIdx.x] + gj_wg256_incl_scan(n, s_tmp, &total) - n;
+    while (mask) {
+        const int i = __builtin_ctz(mask);
+        mask &= mask - 1;
+        if (r < max_rst) rst_pos[r] = (uint32_t)(base + i);
+        r++;
+    }
+}
+
+// One thread per segment of the table. Scan s is bounded by the "other" markers: it starts after an SOS header and
+// ends at the next other marker. Scan 0 starts at `begin` (the host parsed its SOS).
+__global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const uint32_t* __restrict__ rst_pos, uint64_t begin, uint64_t size,
+                                                        gj_scan_summary* __restrict__ sum, uint32_t* __restrict__ seg_pos,
+                                                        uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, uint32_t max_segments)
+{
+    __shared__ uint32_t s_start[GJ_MAX_COMP + 1], s_end[GJ_MAX_COMP + 1], s_first[GJ_MAX_COMP + 2];
+    __shared__ int s_scans;
+    __shared__ uint32_t s_opos[GJ_SCAN_MAX_OTHER];
+    __shared__ uint8_t s_order[GJ_SCAN_MAX_OTHER];
+    const uint32_t n_rst = min(sum->rst_count, max_segments);
+    const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
+    if (threadIdx.x == 0) {
+        // order the few other markers by position (insertion sort)
+        for (uint32_t i = 0; i < n_other; i++) {
+            uint32_t j = i;
+            const uint32_t p = sum->other_pos[i];
+            while (j > 0 && s_opos[j - 1] > p) { s_opos[j] = s_opos[j - 1]; s_order[j] = s_order[j - 1]; j--; }
+            s_opos[j] = p;
+            s_order[j] = (uint8_t)i;
         }
-        rank += (uint32_t)__popcll(m);
+        int scans = 0;
+        uint32_t start = (uint32_t)begin;
+        int status = 0;
+        for (uint32_t i = 0; i < n_other && scans < GJ_MAX_COMP; i++) {
+            const uint32_t p = s_opos[i];
+                        if (p < start) continue; // lies inside a header we already skipped
+            s_start[scans] = start;
+            s_end[scans] = p;
+            scans++;
+            const uint8_t* hb = sum->other_bytes[s_order[i]];
+            const uint32_t mlen = ((uint32_t)hb[0] << 8) | hb[1];
+            const int m = sum->other_code[s_order[i]];
+            if (m == 0xDA) { start = p + 2 + mlen; continue; } // next scan
+            if (m == 0xD9) { status = 1; break; }              // EOI: done
+            status = 2;                                          // something else between scans: let the host walk it
+            break;
+        }
+        if (status == 0) status = 3; // no EOI seen
+        // rank of the first RSTn of every scan: binary search in the ordered list
+        for (int sc = 0; sc <= scans; sc++) {
+            const uint32_t key = sc < scans ? s_start[sc] : 0xFFFFFFFFu;
+            uint32_t lo = 0, hi = n_rst;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rst_pos[mid] < key) lo = mid + 1; else hi = mid; }
+            s_first[sc] = lo;
+        }
+        s_scans = scans;
+        if (blockIdx.x == 0) {
+            sum->scan_count = (uint32_t)scans;
+            sum->status = (uint32_t)status;
+            sum->segment_count = n_rst + (uint32_t)scans;
+            for (int sc = 0; sc < scans; sc++) { sum->scan_start[sc] = s_start[sc]; sum->scan_end[sc] = s_end[sc]; }
+        }
     }
+    __syncthreads();
+    const int scans = s_scans;
+    const uint32_t gidx = blockIdx.x * 256u + threadIdx.x;
+    if (gidx >= n_rst + (uint32_t)scans || gidx >= max_segments) return;
+    int sc = 0;
+    while (sc + 1 < scans && gidx >= s_first[sc + 1] + (uint32_t)(sc + 1)) sc++;
+    const uint32_t k = gidx - s_first[sc] - (uint32_t)sc;       // index of the segment inside its scan
+    const uint32_t c_s = s_first[sc + 1] - s_first[sc];         // RSTn inside this scan
+    const uint32_t from = k == 0 ? s_start[sc] : rst_pos[s_first[sc] + k - 1] + 2;
+    const uint32_t to = k == c_s ? s_end[sc] : rst_pos[s_first[sc] + k];
+    seg_pos[gidx] = from;
+    seg_len[gidx] = to > from ? to - from : 0;
+    // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
+    const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
+    const uint32_t limit = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].segment_count;
+    seg_index[gidx] = k < limit ? first + k : 0xFFFFFFFFu;
 }
 
-// marker positions -> (segment start, segment length); segment i lies between marker i-1 and marker i
-__global__ __launch_bounds__(256) void k_rst_segments(const uint32_t* __restrict__ marker_pos, const uint32_t* __restrict__ total,
-                                                      uint64_t begin, uint64_t end, uint32_t* __restrict__ seg_pos,
-                                                      uint32_t* __restrict__ seg_len, uint32_t max_segments, uint32_t* __restrict__ count)
+extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                    uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                    gj_scan_summary* d_summary, gj_stream_t stream)
 {
-    const uint32_t n = *total;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0) *count = n + 1;
-    if (i > n || i >= max_segments) return;
-    const uint32_t start = i == 0 ? (uint32_t)begin : marker_pos[i - 1] + 2;
-    const uint32_t stop = i == n ? (uint32_t)end : marker_pos[i];
-    seg_pos[i] = start;
-    seg_len[i] = stop - start;
-}
-
-extern "C" int gj_hip_scan_markers(const uint8_t* d_jpeg, uint64_t begin, uint64_t end, uint32_t* d_seg_pos, uint32_t* d_seg_len,
-                                   uint32_t max_segments, uint32_t* d_count, gj_stream_t stream)
-{
-    // scratch: chunk counters and marker positions live behind the caller's seg_len array is not possible in general,
-    // so a small cached allocation per thread is used
-    static thread_local uint32_t* d_scratch = nullptr;
-    static thread_local size_t scratch_words = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (end <= begin) return -1;
-    const uint32_t chunks = (uint32_t)((end - begin + GJ_SCAN_CHUNK - 1) / GJ_SCAN_CHUNK);
-    const size_t need = (size_t)chunks + max_segments + 4;
-    if (need > scratch_words) {
-        if (d_scratch) (void)hipFree(d_scratch);
-        if (hipMalloc((void**)&d_scratch, need * sizeof(uint32_t)) != hipSuccess) { d_scratch = nullptr; scratch_words = 0; return -1; }
-        scratch_words = need;
-    }
-    uint32_t* d_chunk = d_scratch;
-    uint32_t* d_total = d_scratch + chunks;
-    uint32_t* d_marker = d_scratch + chunks + 4;
-    hipLaunchKernelGGL(k_rst_count, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, end, d_chunk);
-    hipLaunchKernelGGL(k_rst_rank, dim3(1), dim3(1024), 0, st, d_chunk, chunks, d_total);
-    hipLaunchKernelGGL(k_rst_emit, dim3(chunks), dim3(64), 0, st, d_jpeg, begin, end, d_chunk, d_marker, max_segments);
-    hipLaunchKernelGGL(k_rst_segments, dim3((max_segments + 255) / 256), dim3(256), 0, st, d_marker, d_total, begin, end, d_seg_pos,
-                       d_seg_len, max_segments, d_count);
+    if (size <= begin) return -1;
+    const uint32_t chunks = (uint32_t)((size - begin + GJ_SCAN_CHUNK - 1) / GJ_SCAN_CHUNK);
+    uint32_t* d_chunk = d_scratch;          // [chunks]
+    uint32_t* d_rst = d_scratch + chunks;   // [max_segments]
+    (void)hipMemsetAsync(d_summary, 0, sizeof(gj_scan_summary), st);
+    hipLaunchKernelGGL(k_marker_count, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary);
+    hipLaunchKernelGGL(k_marker_rank, dim3(1), dim3(1024), 0, st, d_chunk, chunks, d_summary);
+    hipLaunchKernelGGL(k_marker_emit, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_rst, max_segments);
+    hipLaunchKernelGGL(k_build_segments, dim3((max_segments + GJ_MAX_COMP + 255) / 256), dim3(256), 0, st, *g, d_rst, begin, size, d_summary,
+                       d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments)
+{
+    return (size_t)((size - begin + GJ_SCAN_CHUNK - 1) / GJ_SCAN_CHUNK) + max_segments + 16;
 }

@@ -30,7 +30,15 @@ struct gpujpeg_decoder {
     uint16_t* h_tabs;                  /* pinned staging: 8 decode tables + 4 quant tables */
     struct gj_host_segments segs;
     int use_fused;
+    /* device-side segment discovery */
+    uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
+    uint32_t* d_scan_scratch; size_t d_scan_scratch_cap;
+    gj_scan_summary* d_summary;
+    gj_scan_summary* h_summary;   /* pinned */
+    int host_scan;                /* 1: always walk the stream on the host (reference behaviour) */
 };
+
+#define GJ_HDR_WINDOW 65536
 
 /* ------------------------------------------------------------------ output helpers (gpujpeg_decoder.h:105-143) */
 void gpujpeg_decoder_output_set_default(struct gpujpeg_decoder_output* o) { o->type = GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER; o->data = NULL; o->data_size = 0; o->texture = NULL; }
@@ -61,6 +69,11 @@ struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
     d->h_tabs = gj_hip_host_alloc(GJ_TABS_WORDS * sizeof(uint16_t));
     if (!d->d_huff_tab || !d->h_tabs) goto fail;
     d->d_qtab = d->d_huff_tab + 8 * GJ_DEC_TAB_WORDS;
+    d->h_hdr = gj_hip_host_alloc(GJ_HDR_WINDOW);
+    d->d_summary = gj_hip_malloc(sizeof(gj_scan_summary));
+    d->h_summary = gj_hip_host_alloc(sizeof(gj_scan_summary));
+    if (!d->h_hdr || !d->d_summary || !d->h_summary) goto fail;
+    d->host_scan = getenv("GPUJPEG_HOST_SCAN") ? 1 : 0;
     return d;
 fail:
     GJ_ERROR("Decoder initialisation failed: %s\n", gj_hip_last_error());
@@ -91,6 +104,7 @@ int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
     gj_hip_free(d->d_jpeg); gj_hip_free(d->d_seg); gj_hip_free(d->d_huff_tab);
     gj_hip_free(d->coder.d_raw_own); gj_hip_free(d->coder.d_planes); gj_hip_free(d->coder.d_coefs);
     gj_hip_host_free(d->h_raw); gj_hip_host_free(d->h_seg); gj_hip_host_free(d->h_tabs);
+    gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
     free(d->segs.pos); free(d->segs.len); free(d->segs.index);
     free(d);
     return 0;
@@ -143,6 +157,38 @@ int gpujpeg_decoder_init(struct gpujpeg_decoder* d, const struct gpujpeg_paramet
 }
 
 /* ------------------------------------------------------------------ decode (src/gpujpeg_decoder.c:235-465) */
+
+/* Validate what the device found: scans in component order, each introduced by a well-formed SOS, EOI at the end.
+ * Fills the Huffman table selectors of the later scans. Returns 0 when the device table can be used. */
+static int accept_device_scan(const gj_scan_summary* su, struct gj_reader_result* r, const gj_geom* g)
+{
+    if (su->status != 1 || su->other_count > GJ_SCAN_MAX_OTHER) return -1;
+    const int expect_scans = g->interleaved ? 1 : g->comp_count;
+    if ((int)su->scan_count != expect_scans) return -1;
+    if (su->segment_count > (uint32_t)g->segment_count) return -1;
+    /* order the markers by position and check them one by one */
+    int order[GJ_SCAN_MAX_OTHER];
+    const int n = (int)su->other_count;
+    for (int i = 0; i < n; i++) {
+        int j = i;
+        while (j > 0 && su->other_pos[order[j - 1]] > su->other_pos[i]) { order[j] = order[j - 1]; j--; }
+        order[j] = i;
+    }
+    int scan = 1;
+    for (int i = 0; i < n; i++) {
+        const int k = order[i];
+        const uint8_t* b = su->other_bytes[k];
+        if (su->other_code[k] == 0xD9) return (scan == expect_scans) ? 0 : -1;
+        if (su->other_code[k] != 0xDA || scan >= expect_scans) return -1;
+        /* SOS of a non-interleaved scan: length 8, one component, id of component `scan`, tables, 0, 63, 0 */
+        if (b[0] != 0 || b[1] != 8 || b[2] != 1 || b[3] != r->comp_id[scan] || b[5] != 0 || b[6] != 63 || b[7] != 0) return -1;
+        r->huff_map[scan][0] = (b[4] >> 4) & 15;
+        r->huff_map[scan][1] = b[4] & 15;
+        scan++;
+    }
+    return -1; /* no EOI */
+}
+
 int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t image_size, struct gpujpeg_decoder_output* output)
 {
     struct gj_coder* c = &d->coder;
@@ -150,95 +196,154 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     c->start_time = stats ? gpujpeg_get_time() : 0;
     memset(&c->stats, 0, sizeof c->stats);
     const double t_read0 = stats ? gpujpeg_get_time() : 0;
-
-    /* a device-resident stream is fetched once for parsing (MI355X extension, see gpujpeg_decoder.h) */
-    const bool jpeg_on_device = gj_hip_is_device_ptr(image) != 0;
     uint8_t* host_copy = NULL;
-    const uint8_t* himage = image;
+    int rc = -1;
+
+    /* ---- 1. headers. A device-resident stream (MI355X extension) is parsed from a 64 KiB window. ---- */
+    const bool jpeg_on_device = gj_hip_is_device_ptr(image) != 0;
+    const uint8_t* himage = image; /* host view of (at least the headers of) the stream */
+    size_t hsize = image_size;
     if (jpeg_on_device) {
-        host_copy = malloc(image_size);
-        if (!host_copy || gj_hip_memcpy_d2h(host_copy, image, image_size, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) {
-            free(host_copy);
-            return -1;
-        }
-        himage = host_copy;
+        hsize = image_size < GJ_HDR_WINDOW ? image_size : GJ_HDR_WINDOW;
+        if (gj_hip_memcpy_d2h(d->h_hdr, image, hsize, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) return -1;
+        himage = d->h_hdr;
     }
     struct gj_reader_result r;
-    int rc = gj_reader_parse(himage, image_size, c->param.verbose, d->ff_cs_itu601_is_709, d->req_pixel_format, d->req_color_space,
+    bool device_scan = !d->host_scan;
+    rc = device_scan ? gj_reader_parse(himage, hsize, hsize < image_size ? GPUJPEG_LL_QUIET - 1 : c->param.verbose, d->ff_cs_itu601_is_709,
+                                       d->req_pixel_format, d->req_color_space, d->req_alignment, &r, true)
+                     : -1;
+    if (rc != 0 || r.seg_info_count[0] > 0) device_scan = false; /* odd header, or an APP13 index that makes scanning unnecessary */
+    if (!device_scan) {
+        if (jpeg_on_device) { /* the host walk needs the whole stream */
+            host_copy = malloc(image_size);
+            if (!host_copy || gj_hip_memcpy_d2h(host_copy, image, image_size, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) goto out;
+            himage = host_copy;
+            hsize = image_size;
+        }
+        rc = gj_reader_parse(himage, image_size, c->param.verbose, d->ff_cs_itu601_is_709, d->req_pixel_format, d->req_color_space,
                              d->req_alignment, &r, false);
-    if (rc != 0) {
-        GJ_ERROR("Decoder failed when decoding image data!\n");
-        free(host_copy);
-        return rc;
-    }
-    for (int i = 0; i < GPUJPEG_METADATA_COUNT; i++) d->metadata.vals[i] = r.metadata.vals[i];
-    if (decoder_configure(d, &r.param, &r.param_image) != 0) { free(host_copy); return -1; }
-    c->init_end_time = stats ? gpujpeg_get_time() : 0;
-    gj_geom* g = &c->geom;
-    for (int i = 0; i < g->comp_count; i++) {
-        g->comp[i].q_table = r.quant_map[i];
-        g->comp[i].dc_table = r.huff_map[i][0];
-        g->comp[i].ac_table = r.huff_map[i][1];
-    }
-    if (gj_reader_split_scans(himage, &r, g, &d->segs, c->param.verbose) != 0) { free(host_copy); return -1; }
-    if (d->segs.count > g->segment_count) {
-        GJ_ERROR("Decoder can't decode image that has segment count %d (maximum segment count for specified parameters is %d)!\n", d->segs.count, g->segment_count);
-        free(host_copy);
-        return -1;
-    }
-    if (d->segs.count != g->segment_count && c->param.verbose >= 0) GJ_WARN("%d segments read, expected %d. Broken JPEG?\n", d->segs.count, g->segment_count);
-    c->stats.duration_stream = stats ? (gpujpeg_get_time() - t_read0) * 1000.0 : 0;
-
-    /* tables: decode tables for every DHT slot present, natural-order quantisation tables */
-    memset(d->h_tabs, 0, GJ_TABS_WORDS * sizeof(uint16_t));
-    for (int th = 0; th < 4; th++)
-        for (int tc = 0; tc < 2; tc++)
-            if (r.h_present[th][tc] && gj_huffman_decoder_table(r.hbits[th][tc], r.hvals[th][tc], d->h_tabs + (th * 2 + tc) * GJ_DEC_TAB_WORDS) != 0) {
-                GJ_ERROR("Invalid Huffman table %d/%d!\n", th, tc);
-                free(host_copy);
-                return -1;
-            }
-    for (int t = 0; t < 4; t++)
-        if (r.q_present[t]) gj_quant_table_inverse(r.qraw[t], d->h_tabs + 8 * GJ_DEC_TAB_WORDS + t * 64);
-    for (int i = 0; i < g->comp_count; i++) {
-        if (!r.q_present[g->comp[i].q_table] || !r.h_present[g->comp[i].dc_table][0] || !r.h_present[g->comp[i].ac_table][1]) {
-            GJ_ERROR("Component %d refers to a table that was not defined!\n", i);
-            free(host_copy);
-            return -1;
+        if (rc != 0) {
+            GJ_ERROR("Decoder failed when decoding image data!\n");
+            goto out;
         }
     }
+    rc = -1;
+    for (int i = 0; i < GPUJPEG_METADATA_COUNT; i++) d->metadata.vals[i] = r.metadata.vals[i];
+    if (decoder_configure(d, &r.param, &r.param_image) != 0) goto out;
+    c->init_end_time = stats ? gpujpeg_get_time() : 0;
+    gj_geom* g = &c->geom;
 
+    /* ---- 2. stream to HBM ---- */
     if (stats) gj_hip_event_record(c->timers.copy_in[0], c->stream);
     const uint8_t* d_jpeg;
     if (jpeg_on_device) {
         d_jpeg = image;
     } else {
-        if (gj_ensure_device_buffer((void**)&d->d_jpeg, &d->d_jpeg_cap, image_size + 16) != 0) { free(host_copy); return -1; }
-        if (gj_hip_memcpy_h2d(d->d_jpeg, image, image_size, c->stream) != 0) { free(host_copy); return -1; }
+        if (gj_ensure_device_buffer((void**)&d->d_jpeg, &d->d_jpeg_cap, image_size + 64) != 0) goto out;
+        if (gj_hip_memcpy_h2d(d->d_jpeg, image, image_size, c->stream) != 0) goto out;
         d_jpeg = d->d_jpeg;
     }
-    const size_t ns = (size_t)d->segs.count;
-    memcpy(d->h_seg, d->segs.pos, ns * sizeof(uint32_t));
-    memcpy(d->h_seg + ns, d->segs.len, ns * sizeof(uint32_t));
-    memcpy(d->h_seg + 2 * ns, d->segs.index, ns * sizeof(uint32_t));
-    if (gj_hip_memcpy_h2d(d->d_seg, d->h_seg, 3 * ns * sizeof(uint32_t), c->stream) != 0 ||
-        gj_hip_memcpy_h2d(d->d_huff_tab, d->h_tabs, GJ_TABS_WORDS * sizeof(uint16_t), c->stream) != 0) {
+
+    /* ---- 3. segment table ---- */
+    int seg_count = 0;
+    const uint32_t* d_seg_count = NULL;
+    const size_t S = (size_t)g->segment_count + GJ_MAX_COMP;
+    if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 3 + 4) * sizeof(uint32_t)) != 0) goto out;
+    if (device_scan) {
+        const size_t words = gj_hip_find_segments_scratch_words(r.scan_begin[0], image_size, (uint32_t)g->segment_count);
+        if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
+        if (gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
+                                 d->d_scan_scratch, d->d_summary, c->stream) != 0 ||
+            gj_hip_memcpy_d2h(d->h_summary, d->d_summary, sizeof(gj_scan_summary), c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) {
+            GJ_ERROR("Marker scan failed: %s\n", gj_hip_last_error());
+            goto out;
+        }
+        if (accept_device_scan(d->h_summary, &r, g) == 0) {
+            seg_count = (int)d->h_summary->segment_count;
+            d_seg_count = NULL;
+        } else {
+            /* unusual stream (markers between scans, damaged data...): the host walk decides */
+            GJ_DEBUG(c->param.verbose, "device marker scan not applicable (status %u), walking the stream on the host\n", d->h_summary->status);
+            device_scan = false;
+            if (jpeg_on_device && !host_copy) {
+                host_copy = malloc(image_size);
+                if (!host_copy || gj_hip_memcpy_d2h(host_copy, image, image_size, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) goto out;
+                himage = host_copy;
+            } else if (!jpeg_on_device) {
+                himage = image;
+            }
+            rc = gj_reader_parse(himage, image_size, c->param.verbose, d->ff_cs_itu601_is_709, d->req_pixel_format, d->req_color_space,
+                                 d->req_alignment, &r, false);
+            if (rc != 0) {
+                GJ_ERROR("Decoder failed when decoding image data!\n");
+                goto out;
+            }
+            rc = -1;
+        }
+    }
+    if (!device_scan) {
+        if (gj_reader_split_scans(himage, &r, g, &d->segs, c->param.verbose) != 0) goto out;
+        if (d->segs.count > g->segment_count) {
+            GJ_ERROR("Decoder can't decode image that has segment count %d (maximum segment count for specified parameters is %d)!\n", d->segs.count, g->segment_count);
+            goto out;
+        }
+        seg_count = d->segs.count;
+        const size_t ns = (size_t)seg_count;
+        if (ns * 3 * sizeof(uint32_t) > d->h_seg_cap) {
+            gj_hip_host_free(d->h_seg);
+            d->h_seg_cap = ns * 3 * sizeof(uint32_t);
+            d->h_seg = gj_hip_host_alloc(d->h_seg_cap);
+            if (!d->h_seg) { d->h_seg_cap = 0; goto out; }
+        }
+        memcpy(d->h_seg, d->segs.pos, ns * sizeof(uint32_t));
+        memcpy(d->h_seg + ns, d->segs.len, ns * sizeof(uint32_t));
+        memcpy(d->h_seg + 2 * ns, d->segs.index, ns * sizeof(uint32_t));
+        if (gj_hip_memcpy_h2d(d->d_seg, d->h_seg, ns * sizeof(uint32_t), c->stream) != 0 ||
+            gj_hip_memcpy_h2d(d->d_seg + S, d->h_seg + ns, ns * sizeof(uint32_t), c->stream) != 0 ||
+            gj_hip_memcpy_h2d(d->d_seg + 2 * S, d->h_seg + 2 * ns, ns * sizeof(uint32_t), c->stream) != 0)
+            goto out;
+    }
+    if (seg_count != g->segment_count && c->param.verbose >= 0) GJ_WARN("%d segments read, expected %d. Broken JPEG?\n", seg_count, g->segment_count);
+    c->stats.duration_stream = stats ? (gpujpeg_get_time() - t_read0) * 1000.0 : 0;
+
+    /* ---- 4. tables: decode tables for every DHT slot present, natural-order quantisation tables ---- */
+    for (int i = 0; i < g->comp_count; i++) {
+        g->comp[i].q_table = r.quant_map[i];
+        g->comp[i].dc_table = r.huff_map[i][0];
+        g->comp[i].ac_table = r.huff_map[i][1];
+    }
+    memset(d->h_tabs, 0, GJ_TABS_WORDS * sizeof(uint16_t));
+    for (int th = 0; th < 4; th++)
+        for (int tc = 0; tc < 2; tc++)
+            if (r.h_present[th][tc] && gj_huffman_decoder_table(r.hbits[th][tc], r.hvals[th][tc], d->h_tabs + (th * 2 + tc) * GJ_DEC_TAB_WORDS) != 0) {
+                GJ_ERROR("Invalid Huffman table %d/%d!\n", th, tc);
+                goto out;
+            }
+    for (int t = 0; t < 4; t++)
+        if (r.q_present[t]) gj_quant_table_inverse(r.qraw[t], d->h_tabs + 8 * GJ_DEC_TAB_WORDS + t * 64);
+    for (int i = 0; i < g->comp_count; i++) {
+        if (g->comp[i].q_table > 3 || g->comp[i].dc_table > 3 || g->comp[i].ac_table > 3 || !r.q_present[g->comp[i].q_table] ||
+            !r.h_present[g->comp[i].dc_table][0] || !r.h_present[g->comp[i].ac_table][1]) {
+            GJ_ERROR("Component %d refers to a table that was not defined!\n", i);
+            goto out;
+        }
+    }
+    if (gj_hip_memcpy_h2d(d->d_huff_tab, d->h_tabs, GJ_TABS_WORDS * sizeof(uint16_t), c->stream) != 0) {
         GJ_ERROR("Decoder copy compressed data failed: %s\n", gj_hip_last_error());
-        free(host_copy);
-        return -1;
+        goto out;
     }
     if (stats) gj_hip_event_record(c->timers.copy_in[1], c->stream);
 
-    /* destination (:336-375) */
+    /* ---- 5. destination (:336-375) ---- */
     uint8_t* d_raw;
     if (output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_CUDA_BUFFER) {
         d_raw = output->data;
     } else if (output->type == GPUJPEG_DECODER_OUTPUT_OPENGL_TEXTURE) {
         GJ_ERROR("OpenGL texture output is not supported by the MI355X build.\n");
-        free(host_copy);
-        return -1;
+        goto out;
     } else {
-        if (gj_ensure_device_buffer((void**)&c->d_raw_own, &c->d_raw_cap, g->raw_size) != 0) { free(host_copy); return -1; }
+        if (gj_ensure_device_buffer((void**)&c->d_raw_own, &c->d_raw_cap, g->raw_size) != 0) goto out;
         d_raw = c->d_raw_own;
     }
 
@@ -248,9 +353,10 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.d_jpeg = d_jpeg;
     job.jpeg_size = image_size;
     job.d_seg_pos = d->d_seg;
-    job.d_seg_len = d->d_seg + ns;
-    job.d_seg_index = d->d_seg + 2 * ns;
-    job.seg_count = d->segs.count;
+    job.d_seg_len = d->d_seg + S;
+    job.d_seg_index = d->d_seg + 2 * S;
+    job.seg_count = seg_count;
+    job.d_seg_count = d_seg_count;
     job.d_huff_tab = d->d_huff_tab;
     job.d_qtab = d->d_qtab;
     job.d_coefs = c->d_coefs;
@@ -259,8 +365,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.use_fused = d->use_fused;
     if (gj_hip_decode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Decoder kernels failed: %s\n", gj_hip_last_error());
-        free(host_copy);
-        return -1;
+        goto out;
     }
 
     output->data_size = g->raw_size;
@@ -273,7 +378,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
                 gj_hip_host_free(d->h_raw);
                 d->h_raw = gj_hip_host_alloc(g->raw_size);
                 d->h_raw_cap = d->h_raw ? g->raw_size : 0;
-                if (!d->h_raw) { free(host_copy); return -1; }
+                if (!d->h_raw) goto out;
             }
             dst = d->h_raw;
             output->data = d->h_raw;
@@ -282,17 +387,15 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
             dst = output->data;
         }
         if (stats) gj_hip_event_record(c->timers.copy_out[0], c->stream);
-        if (gj_hip_memcpy_d2h(dst, d_raw, g->raw_size, c->stream) != 0) { free(host_copy); return -1; }
+        if (gj_hip_memcpy_d2h(dst, d_raw, g->raw_size, c->stream) != 0) goto out;
         if (stats) gj_hip_event_record(c->timers.copy_out[1], c->stream);
     } else {
         output->data = d_raw;
     }
     if (gj_hip_stream_sync(c->stream) != 0) {
         GJ_ERROR("Decoder failed: %s\n", gj_hip_last_error());
-        free(host_copy);
-        return -1;
+        goto out;
     }
-    free(host_copy);
 
     if (stats) {
         struct gpujpeg_duration_stats* s = &c->stats;
@@ -311,7 +414,10 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         fprintf(stderr, "Decompressed Size:%13zu bytes %dx%d %s %s\n", output->data_size, output->param_image.width, output->param_image.height,
                 gpujpeg_pixel_format_get_name(output->param_image.pixel_format), gpujpeg_color_space_get_name(output->param_image.color_space));
     output->metadata = &d->metadata;
-    return 0;
+    rc = 0;
+out:
+    free(host_copy);
+    return rc;
 }
 
 int gpujpeg_decoder_get_stats(struct gpujpeg_decoder* d, struct gpujpeg_duration_stats* stats)

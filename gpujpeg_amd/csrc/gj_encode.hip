@@ -513,46 +513,73 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
 }
 
 // ================================================================================================
-// Final offsets: exclusive prefix sum over stuffed segment sizes (+2 for RSTn except at the end of a scan)
-// and over the scan headers that precede each scan. One workgroup; S is at most a few hundred thousand.
+// Final offsets: exclusive prefix sum over stuffed segment sizes (+2 for RSTn except at the end of a scan) and over
+// the scan headers that precede each scan. Two launches of ceil(S/1024) workgroups: per-workgroup totals, then every
+// workgroup adds the totals of its predecessors (at most a few hundred values) to its local scan.
 // ================================================================================================
-__global__ __launch_bounds__(1024) void k_scan_segments(const gj_enc_job J)
+__device__ __forceinline__ uint32_t gj_segment_out_size(const gj_enc_job& J, int s, uint32_t* hdr)
+{
+    const GjSeg sg = gj_segment(J.g, s);
+    *hdr = 0;
+    if (sg.first_in_scan) {
+        const int scan = J.g.interleaved ? 0 : sg.comp;
+        *hdr = J.scan_hdr_offset[scan + 1] - J.scan_hdr_offset[scan];
+    }
+    return J.d_seg_bytes[s] + J.d_seg_ff[s] + (sg.last_in_scan ? 0u : 2u);
+}
+
+// inclusive scan over a 1024-thread workgroup; s_w needs 16 words
+__device__ __forceinline__ uint32_t gj_wg1024_incl_scan(uint32_t v, uint32_t* s_w, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = gj_wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint32_t x = s_w[w];
+        if (w < wave) off += x;
+        all += x;
+    }
+    if (total) *total = all;
+    return inc + off;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_partial(const gj_enc_job J, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const gj_geom& g = J.g;
-    const int S = g.segment_count;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_carry = J.main_hdr_size;
+    const int s = blockIdx.x * 1024 + threadIdx.x;
+    uint32_t hdr = 0, v = 0;
+    if (s < J.g.segment_count) v = gj_segment_out_size(J, s, &hdr);
+    uint32_t total;
+    gj_wg1024_incl_scan(v + hdr, s_w, &total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_final(const gj_enc_job J, const uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t s_w[16];
+    const int S = J.g.segment_count;
+    // totals of the preceding workgroups (gridDim.x <= 1024 for every image the API accepts: 65535^2 pixels, r >= 1 ... checked on the host)
+    uint32_t pre = ((int)threadIdx.x < (int)blockIdx.x) ? partial[threadIdx.x] : 0;
+    uint32_t base;
+    gj_wg1024_incl_scan(pre, s_w, &base);
+    base += J.main_hdr_size;
     __syncthreads();
-    for (int base = 0; base < S; base += 1024) {
-        const int s = base + t;
-        uint32_t v = 0;
-        uint32_t hdr = 0;
-        if (s < S) {
-            const GjSeg sg = gj_segment(g, s);
-            v = J.d_seg_bytes[s] + J.d_seg_ff[s] + (sg.last_in_scan ? 0u : 2u);
-            if (sg.first_in_scan) {
-                const int scan = g.interleaved ? 0 : sg.comp;
-                hdr = J.scan_hdr_offset[scan + 1] - J.scan_hdr_offset[scan];
-            }
-        }
-        const uint32_t mine = v + hdr;
-        uint32_t inc = gj_wave_incl_scan(mine);
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        uint32_t off = s_carry;
-        for (int w = 0; w < wave; w++) off += s_w[w];
-        if (s < S) J.d_seg_out[s] = off + inc - mine + hdr; // segment data start (its scan header sits right before)
-        __syncthreads();
-        if (t == 1023) s_carry = off + inc;
-        __syncthreads();
-    }
-    if (t == 0) {
-        const uint32_t total = s_carry + 2; // EOI
-        J.d_seg_out[S] = s_carry;
-        J.d_result[0] = total;
-        J.d_result[1] = (uint64_t)total > J.jpeg_capacity ? 1u : 0u;
+    const int s = blockIdx.x * 1024 + threadIdx.x;
+    uint32_t hdr = 0, v = 0;
+    if (s < S) v = gj_segment_out_size(J, s, &hdr);
+    uint32_t total;
+    const uint32_t inc = gj_wg1024_incl_scan(v + hdr, s_w, &total);
+    if (s < S) J.d_seg_out[s] = base + inc - v; // segment data start (its scan header sits right before)
+    if (s == S - 1) {
+        const uint32_t end = base + inc;
+        const uint32_t size = end + 2; // EOI
+        J.d_seg_out[S] = end;
+        J.d_result[0] = size;
+        J.d_result[1] = (uint64_t)size > J.jpeg_capacity ? 1u : 0u;
     }
 }
 
@@ -691,7 +718,10 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     hipLaunchKernelGGL(k_huffman, dim3(tiles), dim3(256), 0, st, g, job->d_coefs, job->d_huff_lut, job->d_temp, job->d_seg_bytes,
                        job->d_seg_ff);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
-    hipLaunchKernelGGL(k_scan_segments, dim3(1), dim3(1024), 0, st, *job);
+    const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;
+    if (scan_wgs > 1024) return -1; // more than 1M segments: not reachable through the API limits (65535^2 pixels) with sane restart intervals
+    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(1024), 0, st, *job, job->d_seg_out + g.segment_count + 8);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(1024), 0, st, *job, job->d_seg_out + g.segment_count + 8);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[4], st);
     hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 3) / 4), dim3(256), 0, st, *job);
     if (job->segment_info && g.restart_interval > 0)

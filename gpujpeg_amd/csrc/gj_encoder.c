@@ -151,7 +151,7 @@ static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_par
     if (gj_ensure_device_buffer((void**)&c->d_planes, &c->d_planes_cap, g->data_size) != 0) return -1;
     if (gj_hip_memset(c->d_planes, 0, g->data_size, c->stream) != 0) return -1;
     if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_TEMP_BYTES_PER_BLOCK + 256) != 0) return -1;
-    if (gj_ensure_device_buffer((void**)&e->d_seg, &e->d_seg_cap, ((size_t)g->segment_count * 3 + 4) * sizeof(uint32_t)) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&e->d_seg, &e->d_seg_cap, ((size_t)g->segment_count * 3 + 16 + ((size_t)g->segment_count + 1023) / 1024) * sizeof(uint32_t)) != 0) return -1;
     if (gj_write_scan_headers(&e->scan_hdrs, g, p) != 0) return -1;
     if (gj_ensure_device_buffer((void**)&e->d_scan_hdr, &e->d_scan_hdr_cap, e->scan_hdrs.size + 16) != 0) return -1;
     if (gj_hip_memcpy_h2d(e->d_scan_hdr, e->scan_hdrs.bytes, e->scan_hdrs.size, c->stream) != 0) return -1;

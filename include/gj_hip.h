@@ -137,7 +137,8 @@ typedef struct gj_dec_job {
     const uint32_t* d_seg_pos;     /* [seg_count] byte offset of each segment's entropy data */
     const uint32_t* d_seg_len;     /* [seg_count] */
     const uint32_t* d_seg_index;   /* [seg_count] geometric segment index */
-    int seg_count;
+    int seg_count;                 /* number of table entries (upper bound when d_seg_count is set) */
+    const uint32_t* d_seg_count;   /* optional: actual count in device memory (written by gj_hip_find_segments) */
     const uint16_t* d_huff_tab;    /* [4 slots][2 classes][GJ_DEC_TAB_WORDS] decode tables */
     const uint16_t* d_qtab;        /* [4][64] natural order */
     int16_t* d_coefs;
@@ -155,10 +156,26 @@ typedef struct gj_dec_job {
 #define GJ_DEC_EVENTS 4
 GJ_HIP_API int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[GJ_DEC_EVENTS]);
 
-/* GPU marker scan: finds RSTn inside [begin,end) of a device-resident stream and writes segment
- * offsets/lengths in order; returns the number of segments through d_count (N1 in SURVEY 8f) */
-GJ_HIP_API int gj_hip_scan_markers(const uint8_t* d_jpeg, uint64_t begin, uint64_t end, uint32_t* d_seg_pos, uint32_t* d_seg_len,
-                        uint32_t max_segments, uint32_t* d_count, gj_stream_t stream);
+/* Device-side segment discovery: finds RSTn and scan boundaries in the device-resident stream [begin, size) and
+ * writes the segment table (offset, length, geometric index) in stream order. The small summary is what the host
+ * reads back to validate the structure (and to learn the segment count). Replaces the host memchr walk of
+ * src/gpujpeg_reader.c:1039-1155. */
+#define GJ_SCAN_MAX_OTHER 16
+typedef struct gj_scan_summary {
+    uint32_t rst_count;                       /* RSTn markers found */
+    uint32_t other_count;                     /* every other marker (SOS of later scans, EOI, ...) */
+    uint32_t other_pos[GJ_SCAN_MAX_OTHER];
+    uint8_t other_code[GJ_SCAN_MAX_OTHER];
+    uint8_t other_bytes[GJ_SCAN_MAX_OTHER][16]; /* the 16 bytes after each of them (length + start of the payload) */
+    uint32_t scan_count, segment_count;
+    uint32_t status;                          /* 1 = clean (scans ... EOI), 2 = unexpected marker between scans, 3 = no EOI */
+    uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];
+} gj_scan_summary;
+
+GJ_HIP_API size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments);
+GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                    uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                    gj_scan_summary* d_summary, gj_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 // src/gpujpeg_huffman_cpu_decoder.c:245-372), src/gpujpeg_dct_gpu.cu:312-366,472-618 and
 // src/gpujpeg_postprocessor.cu:49-217.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "gj_device.h"
 #include "gj_hip.h"
@@ -87,8 +88,12 @@ template <bool INTERLEAVED>
 __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                         const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                         const uint32_t* __restrict__ seg_index, const uint32_t* __restrict__ seg_count_ptr,
-                                                        const int seg_count_max, const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs)
+                                                        const int seg_count_max, const uint32_t* __restrict__ sel,
+                                                        const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs)
 {
+    // `sel` (optional) lists the table entries to decode: the segments the sub-sequence kernel passed on
+    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
+    if ((int)(blockIdx.x * 256u) >= seg_count) return;
     __shared__ uint16_t s_tab[8 * GJ_DEC_TAB_WORDS];
     __shared__ uint32_t s_win_all[4 * 64 * GJ_WIN_STRIDE];
     __shared__ uint8_t s_zz[64 + 32];
@@ -101,10 +106,10 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
     const uint32_t* s_row = s_win + lane * GJ_WIN_STRIDE;
     const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
 
-    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
-    const int si = blockIdx.x * 256 + threadIdx.x;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int si = slot < seg_count ? (sel ? (int)sel[slot] : slot) : 0;
     uint32_t s = 0xFFFFFFFFu;
-    if (si < seg_count) s = seg_index[si];
+    if (slot < seg_count) s = seg_index[si];
     GjSeg sg;
     sg.nblocks = 0;
     sg.mcu_first = 0;
@@ -251,14 +256,443 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
 }
 
 // ================================================================================================
+// Entropy decoder, second design: SUB-SEQUENCE PARALLEL inside every restart segment.
+//
+// The lane-per-segment kernel above leaves an 8K frame with 675 waves and a serial chain of several hundred symbols per
+// lane. Here a workgroup takes a batch of consecutive segments and
+//   1. copies their bytes into LDS with the stuffed zeros removed (one wave per segment, big-endian dwords),
+//   2. cuts every segment into sub-sequences of SUB_BYTES and decodes ALL of them at once: a lane starts at the first bit
+//      of its sub-sequence in the state "DC of MCU block 0 expected"; Huffman codes self-synchronise, so most lanes leave
+//      their sub-sequence in the right state even though they entered it in a wrong one. Rounds: every sub-sequence whose
+//      predecessor now leaves in another state than the one it was entered with goes on a work list and is decoded
+//      again, densely packed onto the lanes. The first sub-sequence of a segment is always right, so this converges
+//      (most sub-sequences after two rounds; at worst after as many rounds as a segment has sub-sequences),
+//   3. turns the per-sub-sequence block counts into block positions with a workgroup prefix sum,
+//   4. decodes once more, now storing the AC coefficients to the (pre-zeroed) coefficient planes and the DC differences
+//      to an LDS array,
+//   5. resolves the DC prediction there (one wave per segment, prefix sum per component) and stores the DC terms.
+// The counting passes need only code lengths and zig-zag advances: one 16-bit table entry per symbol (two-level lookup,
+// 10 + 6 bits) holds both. (Sub-sequence synchronisation: Klein & Wiseman 2003, Weissenberger & Schmidt 2021; the
+// arrangement for short restart segments, the LDS staging and the work lists are specific to this implementation.)
+// Segments that do not fit the LDS stage (longer than GJ_PAR_CAP_U bytes) are appended to a list for the
+// lane-per-segment kernel. Results are identical to src/gpujpeg_huffman_gpu_decoder.cu:287-495 /
+// src/gpujpeg_huffman_cpu_decoder.c:245-372.
+// ================================================================================================
+#define GJ_PAR_CAP_U 8192     // bytes of unstuffed stream per group (incl. 8 B of zero padding per segment)
+#define GJ_PAR_GMAX 64        // segments per batch
+#define GJ_PAR_MAX_BLOCKS 2048 // blocks per batch (DC array in LDS)
+#ifndef GJ_PAR_SUB
+#define GJ_PAR_SUB 16         // bytes per sub-sequence
+#endif
+
+// table entry (gj_hip.h, GJ_DEC2_*): bits [0,5) code length + magnitude bits (0 = second level), [5,9) magnitude bits,
+// [9,16) zig-zag advance. State between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag
+// index, [11,16) block inside the MCU.
+template <bool WRITE, bool INTERLEAVED>
+__device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U, const uint32_t start_bit, const uint32_t end_bit,
+                                                  const uint32_t entry, const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab,
+                                                  const int P, const uint16_t* tdc, const uint16_t* tac, int& nblk_out,
+                                                  int16_t* __restrict__ coefs, const uint32_t first, const uint32_t* __restrict__ s_blk,
+                                                  int16_t* __restrict__ s_dc, int blk, const int nblocks, const uint8_t* __restrict__ s_zz, const int flags = 0)
+{
+    uint32_t bitpos = start_bit + (entry & 31u);
+    int z = (int)((entry >> 5) & 63u);
+    int p = (int)(entry >> 11);
+    if (INTERLEAVED) {
+        const uint32_t pt = s_ptab[p];
+        tdc = s_tab + (pt & 0xFFFFu);
+        tac = s_tab + (pt >> 16);
+    }
+    uint32_t rd = bitpos >> 5;
+    uint64_t acc = (uint64_t)U[rd] << (32 + (bitpos & 31u));
+    int n = 32 - (int)(bitpos & 31u);
+    rd++;
+    uint32_t nxt = U[rd];
+    int nb = 0;
+    while (bitpos < end_bit) {
+        if (n <= 32) {
+            acc |= (uint64_t)nxt << (32 - n);
+            n += 32;
+            rd++;
+            nxt = U[rd];
+        }
+        const uint32_t hi = (uint32_t)(acc >> 32);
+        const uint16_t* t = z == 0 ? tdc : tac;
+        uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
+        if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
+        const int tot = (int)(e & 31u);
+        const int adv = (int)(e >> 9);
+        if (WRITE) {
+            const int sz = (int)((e >> 5) & 15u);
+            const int used = tot - sz;
+            const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
+            const int v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+            const int pos = z + adv - 1;
+            if (blk + nb < nblocks) {
+                if (z == 0) {
+                    s_dc[blk + nb] = (int16_t)v;
+                } else if (sz != 0 && pos < 64) {
+                    const uint32_t b = INTERLEAVED ? s_blk[blk + nb] : first + (uint32_t)(blk + nb);
+                    if (!(flags & 1)) coefs[(uint64_t)b * 64 + s_zz[pos]] = (int16_t)v;
+                }
+            }
+        }
+        acc <<= tot;
+        n -= tot;
+        bitpos += (uint32_t)tot;
+        z += adv;
+        if (z >= 64) {
+            z = 0;
+            nb++;
+            if (INTERLEAVED) {
+                p = p + 1 == P ? 0 : p + 1;
+                const uint32_t pt = s_ptab[p];
+                tdc = s_tab + (pt & 0xFFFFu);
+                tac = s_tab + (pt >> 16);
+            }
+        }
+    }
+    nblk_out = nb;
+    return (bitpos - end_bit) | ((uint32_t)z << 5) | ((uint32_t)p << 11);
+}
+
+template <bool INTERLEAVED, int SUB_BYTES>
+__global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+                                                            const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
+                                                            const uint32_t* __restrict__ seg_index, const int seg_count, const int G,
+                                                            const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
+                                                            uint32_t* __restrict__ fallback /* [0] count, [1..] table entries */,
+                                                            unsigned long long* __restrict__ prof /* optional phase clocks (GJ_DEC_PROF) */, const int flags /* experiments */)
+{
+    unsigned long long t_prof = prof ? wall_clock64() : 0;
+#define GJ_PROF(slot)                                                                            \
+    if (prof) {                                                                                  \
+        __syncthreads();                                                                         \
+        const unsigned long long now = wall_clock64();                                           \
+        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
+        t_prof = now;                                                                            \
+    }
+    constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX;
+    constexpr uint32_t SUB_BITS = SUB_BYTES * 8;
+    __shared__ uint32_t s_U[GJ_PAR_CAP_U / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
+    __shared__ uint8_t s_zz[64 + 64];
+    __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS];      // per MCU block: LDS word offsets of its DC | AC << 16 tables
+    __shared__ uint32_t s_pblk[GJ_MAX_MCU_BLOCKS][4];   // per MCU block: data_offset/64, blocks_x, samp_h | samp_v << 8 | bx << 16 | by << 24, comp
+    // per segment of the batch
+    __shared__ uint32_t s_pos[GJ_PAR_GMAX], s_len[GJ_PAR_GMAX], s_nblk[GJ_PAR_GMAX], s_first[GJ_PAR_GMAX], s_tabs[GJ_PAR_GMAX];
+    __shared__ uint32_t s_bb[GJ_PAR_GMAX + 1], s_ub[GJ_PAR_GMAX + 1], s_ulen[GJ_PAR_GMAX], s_sub0[GJ_PAR_GMAX + 1];
+    // per block of the batch
+    __shared__ int16_t s_dc[GJ_PAR_MAX_BLOCKS];
+    __shared__ uint32_t s_blk[INTERLEAVED ? GJ_PAR_MAX_BLOCKS : 1]; // interleaved: block index in the coefficient planes
+    // per sub-sequence of the group
+    __shared__ uint16_t s_exit[MAX_SUBS], s_entry[MAX_SUBS], s_work[MAX_SUBS];
+    __shared__ uint8_t s_subseg[MAX_SUBS];
+    __shared__ uint32_t s_scan[MAX_SUBS];
+    __shared__ uint32_t s_tmp[4];
+    __shared__ int s_j1;
+    __shared__ uint32_t s_nwork;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(tabs);
+        uint4* dst = reinterpret_cast<uint4*>(s_tab);
+        for (int t = tid; t < 4 * GJ_DEC2_WORDS / 8; t += 256) dst[t] = src[t];
+    }
+    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    const int P = g.blocks_per_mcu;
+    if (tid < GJ_MAX_MCU_BLOCKS) {
+        const int pp = tid < P ? tid : 0;
+        const int c = INTERLEAVED ? g.mcu_comp[pp] : 0;
+        const gj_comp_geom& kc = g.comp[c];
+        s_ptab[tid] = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+        s_pblk[tid][0] = (uint32_t)(kc.data_offset / 64);
+        s_pblk[tid][1] = (uint32_t)kc.blocks_x;
+        s_pblk[tid][2] = (uint32_t)kc.samp_h | ((uint32_t)kc.samp_v << 8) | ((uint32_t)g.mcu_bx[pp] << 16) | ((uint32_t)g.mcu_by[pp] << 24);
+        s_pblk[tid][3] = (uint32_t)c;
+    }
+    const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
+
+    // ---- batch setup: lane j describes segment j of the batch
+    const int si0 = blockIdx.x * G;
+    const int nseg = min(G, seg_count - si0);
+    uint32_t my_nblk = 0, my_ucap = 0;
+    if (tid < GJ_PAR_GMAX) {
+        uint32_t pos = 0, len = 0, nblk = 0, first = 0, tb = 0;
+        if (tid < nseg) {
+            const uint32_t s = seg_index[si0 + tid];
+            if (s < (uint32_t)g.segment_count) {
+                const GjSeg sg = gj_segment(g, (int)s);
+                nblk = (uint32_t)sg.nblocks;
+                pos = seg_pos[si0 + tid];
+                len = seg_len[si0 + tid];
+                if (INTERLEAVED) {
+                    first = (uint32_t)sg.mcu_first; // first MCU
+                } else {
+                    const gj_comp_geom& kc = g.comp[sg.comp];
+                    first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block in the coefficient plane
+                    tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+                }
+                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U) { // too long for the LDS stage: leave it to the lane-per-segment kernel
+                    const uint32_t slot = atomicAdd(&fallback[0], 1u);
+                    fallback[1 + slot] = (uint32_t)(si0 + tid);
+                    len = 0;
+                    nblk = 0;
+                }
+            }
+        }
+        s_pos[tid] = pos;
+        s_len[tid] = len;
+        s_nblk[tid] = nblk;
+        s_first[tid] = first;
+        s_tabs[tid] = tb;
+        my_nblk = nblk;
+        my_ucap = len ? ((len + 3u) & ~3u) + 8u : 0u;
+    }
+    {
+        uint32_t tot;
+        const uint32_t a = gj_wg256_incl_scan(my_nblk, s_tmp, &tot);
+        if (tid < GJ_PAR_GMAX) s_bb[tid + 1] = a;
+        const uint32_t b = gj_wg256_incl_scan(my_ucap, s_tmp, &tot);
+        if (tid < GJ_PAR_GMAX) s_ub[tid + 1] = b;
+        if (tid == 0) { s_bb[0] = 0; s_ub[0] = 0; }
+    }
+    __syncthreads();
+    const int nblocks_batch = (int)s_bb[nseg];
+    if (INTERLEAVED) { // where every block of the batch lives in the coefficient planes
+        for (int t = tid; t < nblocks_batch; t += 256) {
+            int lo = 0, hi = nseg;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_bb[mid] <= (uint32_t)t) lo = mid; else hi = mid;
+            }
+            const uint32_t kb = (uint32_t)t - s_bb[lo];
+            const uint32_t mi = kb / (uint32_t)P, p = kb - mi * (uint32_t)P;
+            const uint32_t m = s_first[lo] + mi;
+            const uint32_t my = m / (uint32_t)g.mcu_count_x, mx = m - my * (uint32_t)g.mcu_count_x;
+            const uint32_t q = s_pblk[p][2];
+            const uint32_t bx = mx * (q & 0xFFu) + ((q >> 16) & 0xFFu), by = my * ((q >> 8) & 0xFFu) + (q >> 24);
+            s_blk[t] = s_pblk[p][0] + by * s_pblk[p][1] + bx;
+        }
+    }
+    GJ_PROF(0) // setup
+
+    // ---- groups of segments whose unstuffed bytes fit the LDS stage (normally one group)
+    for (int j0 = 0; j0 < nseg;) {
+        if (tid == 0) { s_j1 = j0 + 1; s_nwork = 0; }
+        __syncthreads();
+        if (tid > j0 && tid <= nseg && s_ub[tid] - s_ub[j0] <= GJ_PAR_CAP_U) atomicMax(&s_j1, tid);
+        __syncthreads();
+        const int j1 = s_j1;
+        const uint32_t ub0 = s_ub[j0];
+
+        // -- 1. unstuffed copy, one wave per segment. The first 256 B of all segments of this wave are fetched up front, so
+        //       that the wave waits for HBM once and not once per segment.
+        {
+            uint8_t* U8 = reinterpret_cast<uint8_t*>(s_U);
+            uint32_t wpre[GJ_PAR_GMAX / 4];
+#pragma unroll
+            for (int q = 0; q < GJ_PAR_GMAX / 4; q++) {
+                const int j = j0 + wave + 4 * q;
+                wpre[q] = 0;
+                if (j < j1 && s_len[j]) {
+                    const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + s_pos[j];
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+                    const uint32_t ndw = ((uint32_t)(a & 3) + s_len[j] + 3u) >> 2;
+                    if ((uint32_t)lane < ndw && src + lane < end) wpre[q] = src[lane];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < GJ_PAR_GMAX / 4; q++) {
+                const int j = j0 + wave + 4 * q;
+                if (j >= j1) break;
+                const uint32_t len = s_len[j];
+                const uint32_t ubase = s_ub[j] - ub0;
+                uint32_t out = 0;
+                if (len) {
+                    const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + s_pos[j];
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+                    const int lead = (int)(a & 3);
+                    const uint32_t ndw = ((uint32_t)lead + len + 3u) >> 2;
+                    uint32_t carry = 0;
+                    for (uint32_t c0 = 0; c0 < ndw; c0 += 64) {
+                        const uint32_t idx = c0 + (uint32_t)lane;
+                        uint32_t w = wpre[q];
+                        if (c0) {
+                            w = 0;
+                            if (idx < ndw && src + idx < end) w = src[idx];
+                        }
+                        uint32_t pw = __shfl_up(w, 1, 64);
+                        if (lane == 0) pw = carry;
+                        uint32_t prev = pw >> 24;
+                        uint32_t keep = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t b = (w >> (8 * k)) & 0xFFu;
+                            const int off = (int)(idx * 4u) + k - lead;
+                            const bool valid = off >= 0 && off < (int)len;
+                            const bool stuffed = b == 0 && prev == 0xFFu && off > 0;
+                            if (valid && !stuffed) keep |= 1u << k;
+                            prev = b;
+                        }
+                        const uint32_t cnt = (uint32_t)__popc(keep);
+                        const uint32_t inc = gj_wave_incl_scan(cnt);
+                        uint32_t o = ubase + out + inc - cnt;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (keep & (1u << k)) { U8[o ^ 3u] = (uint8_t)(w >> (8 * k)); o++; }
+                        out += __shfl(inc, 63, 64);
+                        carry = __shfl(w, 63, 64);
+                    }
+                    for (uint32_t b = out + (uint32_t)lane; b < ((out + 3u) & ~3u) + 8u; b += 64) U8[(ubase + b) ^ 3u] = 0;
+                }
+                if (lane == 0) s_ulen[j] = out;
+            }
+        }
+        __syncthreads();
+        GJ_PROF(1) // unstuffed copy
+
+        // -- 2. sub-sequence table
+        uint32_t my_nsub = 0;
+        if (tid >= j0 && tid < j1 && s_nblk[tid]) my_nsub = (s_ulen[tid] + SUB_BYTES - 1) / SUB_BYTES;
+        {
+            uint32_t tot;
+            const uint32_t a = gj_wg256_incl_scan(my_nsub, s_tmp, &tot);
+            if (tid >= j0 && tid < j1) s_sub0[tid + 1] = a;
+            if (tid == 0) s_sub0[j0] = 0;
+        }
+        __syncthreads();
+        const int nsub = (int)s_sub0[j1];
+        for (int k = tid; k < nsub; k += 256) {
+            int lo = j0, hi = j1; // segment j with s_sub0[j] <= k < s_sub0[j + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_sub0[mid] <= (uint32_t)k) lo = mid; else hi = mid;
+            }
+            s_subseg[k] = (uint8_t)lo;
+            s_entry[k] = 0;
+            s_work[k] = (uint16_t)k; // round 0: everybody
+        }
+        __syncthreads();
+        GJ_PROF(2) // sub-sequence table
+
+        // -- 3. rounds
+        int nwork = nsub;
+        for (int round = 0; nwork > 0; round++) {
+            for (int w = tid; w < nwork; w += 256) {
+                const int k = s_work[w];
+                const int j = s_subseg[k];
+                const uint32_t i = (uint32_t)k - s_sub0[j];
+                const uint32_t endb = min((i + 1) * SUB_BITS, s_ulen[j] * 8u);
+                const uint32_t tb = s_tabs[j];
+                int nb;
+                const uint32_t x = gj_decode_sub<false, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_entry[k], s_tab, s_ptab, P,
+                                                                     s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
+                s_exit[k] = (uint16_t)x;
+                s_scan[k] = (uint32_t)nb;
+            }
+            __syncthreads();
+            if (prof && threadIdx.x == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[12], (unsigned long long)nwork); }
+            GJ_PROF(round == 0 ? 3 : 4) // first round / further rounds
+            // next work list: sub-sequences whose predecessor leaves in another state than they were entered with
+            for (int k0 = 0; k0 < nsub; k0 += 256) {
+                const int k = k0 + tid;
+                bool cand = false;
+                uint32_t e = 0;
+                if (k < nsub && (uint32_t)k != s_sub0[s_subseg[k]]) {
+                    e = s_exit[k - 1];
+                    cand = e != s_entry[k];
+                }
+                const unsigned long long m = __ballot(cand);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_nwork, (uint32_t)__popcll(m));
+                base = __shfl(base, 0, 64);
+                if (cand) {
+                    s_entry[k] = (uint16_t)e;
+                    s_work[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+                }
+            }
+            __syncthreads();
+            nwork = (int)s_nwork;
+            __syncthreads();
+            if (tid == 0) s_nwork = 0;
+        }
+
+        // -- 4. block position of every sub-sequence inside its segment (inclusive scan, segment start subtracted below)
+        {
+            uint32_t carry = 0;
+            for (int k0 = 0; k0 < nsub; k0 += 256) {
+                const int k = k0 + tid;
+                const uint32_t v = k < nsub ? s_scan[k] : 0;
+                uint32_t tot;
+                const uint32_t inc = gj_wg256_incl_scan(v, s_tmp, &tot);
+                __syncthreads();
+                if (k < nsub) s_scan[k] = carry + inc;
+                carry += tot;
+            }
+        }
+        __syncthreads();
+        GJ_PROF(5) // block positions
+
+        // -- 5. decode once more, now storing the coefficients
+        for (int k = tid; k < nsub; k += 256) {
+            const int j = s_subseg[k];
+            const uint32_t k_first = s_sub0[j];
+            const uint32_t i = (uint32_t)k - k_first;
+            const uint32_t before = (k > 0 ? s_scan[k - 1] : 0u) - (k_first > 0 ? s_scan[k_first - 1] : 0u);
+            const uint32_t endb = min((i + 1) * SUB_BITS, s_ulen[j] * 8u);
+            const uint32_t tb = s_tabs[j];
+            int nb;
+            gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_entry[k], s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
+                                             s_tab + (tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz, flags);
+        }
+        __syncthreads();
+        GJ_PROF(6) // write pass
+        if (prof && threadIdx.x == 0) { atomicAdd(&prof[9], 1ull); atomicAdd(&prof[10], (unsigned long long)nsub); }
+
+        // -- 6. DC prediction: one wave per segment, prefix sum per component, DC terms to HBM
+        for (int j = j0 + wave; j < j1; j += 4) {
+            const int nblk = (int)s_nblk[j];
+            const uint32_t bb = s_bb[j];
+            int carry[GJ_MAX_COMP] = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < nblk; k0 += 64) {
+                const int kb = k0 + lane;
+                const int d = kb < nblk ? (int)s_dc[bb + kb] : 0;
+                int comp = 0;
+                if (INTERLEAVED) comp = (int)s_pblk[(uint32_t)kb % (uint32_t)P][3];
+                int dc = 0;
+#pragma unroll
+                for (int c = 0; c < GJ_MAX_COMP; c++) {
+                    if (c >= (INTERLEAVED ? g.comp_count : 1)) break;
+                    const uint32_t inc = gj_wave_incl_scan((uint32_t)((!INTERLEAVED || comp == c) ? d : 0));
+                    if (!INTERLEAVED || comp == c) dc = carry[c] + (int)inc;
+                    carry[c] += (int)__shfl(inc, 63, 64);
+                }
+                if (kb < nblk) {
+                    const uint32_t b = INTERLEAVED ? s_blk[bb + kb] : s_first[j] + (uint32_t)kb;
+                    coefs[(uint64_t)b * 64] = (int16_t)dc;
+                }
+            }
+        }
+        __syncthreads();
+        GJ_PROF(7) // DC prediction
+        j0 = j1;
+    }
+#undef GJ_PROF
+}
+
+// ================================================================================================
 // Dequantisation + IDCT, one thread per block
 // ================================================================================================
-__device__ __forceinline__ void gj_load_dequant(const int16_t* __restrict__ src, const uint16_t* __restrict__ q, float (&d)[64])
+// `zero`: the block is overwritten with zeros once it has been read, which leaves the coefficient planes ready for the
+// entropy decoder of the next frame (it stores non-zero coefficients only) without a separate 2 B/sample memset.
+__device__ __forceinline__ void gj_load_dequant(int16_t* __restrict__ src, const uint16_t* __restrict__ q, float (&d)[64], const bool zero)
 {
-    const uint4* p = reinterpret_cast<const uint4*>(src);
+    uint4* p = reinterpret_cast<uint4*>(src);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint4 w = p[r];
+        if (zero) p[r] = make_uint4(0, 0, 0, 0);
         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -270,8 +704,8 @@ __device__ __forceinline__ void gj_load_dequant(const int16_t* __restrict__ src,
     }
 }
 
-__global__ __launch_bounds__(256) void k_idct(const gj_geom g, const int16_t* __restrict__ coefs, const uint16_t* __restrict__ qtab,
-                                              uint8_t* __restrict__ planes)
+__global__ __launch_bounds__(256) void k_idct(const gj_geom g, int16_t* __restrict__ coefs, const uint16_t* __restrict__ qtab,
+                                              uint8_t* __restrict__ planes, const int zero)
 {
     const unsigned gb = blockIdx.x * 256u + threadIdx.x;
     if (gb >= (unsigned)g.block_count) return;
@@ -283,7 +717,7 @@ __global__ __launch_bounds__(256) void k_idct(const gj_geom g, const int16_t* __
     const unsigned lb = gb - (unsigned)(k.data_offset / 64);
     const unsigned by = lb / (unsigned)k.blocks_x, bx = lb - by * (unsigned)k.blocks_x;
     float d[64];
-    gj_load_dequant(coefs + (size_t)gb * 64, qtab + k.q_table * 64, d);
+    gj_load_dequant(coefs + (size_t)gb * 64, qtab + k.q_table * 64, d, zero != 0);
     int o[64];
     gj_idct_block(d, o);
     uint8_t* dst = planes + k.data_offset + (size_t)by * 8 * k.data_width + bx * 8;
@@ -307,26 +741,68 @@ __device__ __forceinline__ void gj_color_static_d(int& a, int& b, int& c)
     else if (CS_TO == GJ_CS_RGB) gj_to_rgb(CS_FROM, a, b, c);
 }
 
+// Coefficients travel HBM -> LDS in fully coalesced 16 B chunks (a thread-per-block read would touch 64 different 128 B
+// lines per load instruction); each thread then takes its own block out of LDS. Blocks are padded to 144 B there, which
+// makes both the linear writes and the per-block 16 B reads bank-conflict free (36 dwords: 9 x 4, 9 coprime to 16).
+#define GJ_TILE_PITCH 144
 template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256) void k_idct_fused_rgb444(const gj_geom g, const int16_t* __restrict__ coefs,
-                                                           const uint16_t* __restrict__ qtab, uint8_t* __restrict__ raw)
+__global__ __launch_bounds__(256) void k_idct_fused_rgb444(const gj_geom g, int16_t* __restrict__ coefs,
+                                                           const uint16_t* __restrict__ qtab, uint8_t* __restrict__ raw, const int zero)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * GJ_TILE_PITCH];
     const gj_comp_geom& k0 = g.comp[0];
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
-    const unsigned lb = blockIdx.x * 256u + threadIdx.x;
-    if (lb >= nb) return;
+    const unsigned lb0 = blockIdx.x * 256u;
+    const unsigned lb = lb0 + threadIdx.x;
+    const unsigned nchunk = min(256u, nb - lb0) * 8u; // 16 B chunks of this tile
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
     uint32_t pk[3][16];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
+        uint4* src = reinterpret_cast<uint4*>(coefs + g.comp[c].data_offset + (size_t)lb0 * 64);
+        uint4 w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const unsigned ch = i * 256u + threadIdx.x;
+            w[i] = ch < nchunk ? src[ch] : make_uint4(0, 0, 0, 0);
+        }
+        if (zero) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned ch = i * 256u + threadIdx.x;
+                if (ch < nchunk) src[ch] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (c) __syncthreads(); // everybody has taken the previous component's block out of LDS
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const unsigned ch = i * 256u + threadIdx.x;
+            *reinterpret_cast<uint4*>(s_blk + (ch >> 3) * GJ_TILE_PITCH + (ch & 7u) * 16u) = w[i];
+        }
+        __syncthreads();
         float d[64];
-        gj_load_dequant(coefs + g.comp[c].data_offset + (size_t)lb * 64, qtab + g.comp[c].q_table * 64, d);
+        {
+            const uint16_t* q = qtab + g.comp[c].q_table * 64;
+            const uint4* p = reinterpret_cast<const uint4*>(s_blk + threadIdx.x * GJ_TILE_PITCH);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint4 v = p[r];
+                const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int lo = (int)(int16_t)(ws[j] & 0xFFFF), hi = (int)ws[j] >> 16;
+                    d[r * 8 + 2 * j] = (float)(lo * (int)q[r * 8 + 2 * j]);
+                    d[r * 8 + 2 * j + 1] = (float)(hi * (int)q[r * 8 + 2 * j + 1]);
+                }
+            }
+        }
         int o[64];
         gj_idct_block(d, o);
 #pragma unroll
         for (int i = 0; i < 16; i++)
             pk[c][i] = (uint32_t)o[i * 4] | ((uint32_t)o[i * 4 + 1] << 8) | ((uint32_t)o[i * 4 + 2] << 16) | ((uint32_t)o[i * 4 + 3] << 24);
     }
+    if (lb >= nb) return;
     const size_t pitch = (size_t)g.width * 3 + g.width_padding;
     const bool interior = (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
@@ -438,7 +914,7 @@ __global__ __launch_bounds__(256) void k_copy_planes_out(const gj_geom g, const 
 // ================================================================================================
 // Launcher
 // ================================================================================================
-typedef void (*gj_idct_fused_t)(const gj_geom, const int16_t*, const uint16_t*, uint8_t*);
+typedef void (*gj_idct_fused_t)(const gj_geom, int16_t*, const uint16_t*, uint8_t*, int);
 
 static gj_idct_fused_t gj_idct_fused_kernel(const gj_geom& g)
 {
@@ -460,23 +936,49 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
-    // the entropy decoder stores only non-zero coefficients
-    (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
-    if (job->seg_count > 0)
+    bool par = job->d_huff_tab2 != nullptr && job->d_fallback != nullptr && job->seg_count > 0 && g.seg_blocks <= GJ_PAR_MAX_BLOCKS;
     {
-        auto kernel = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;
-        hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + 255) / 256), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size,
-                           job->d_seg_pos, job->d_seg_len, job->d_seg_index, job->d_seg_count, job->seg_count, job->d_huff_tab, job->d_coefs);
+        const char* e = getenv("GJ_DEC_ENTROPY"); // "serial" forces the lane-per-segment kernel (A/B measurements, tests)
+        if (e && e[0] == 's') par = false;
+    }
+    // both entropy decoders store only non-zero coefficients; the planes are clean when the previous call's IDCT zeroed them
+    if (job->clear_coefs) (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
+    if (par) {
+        // batch: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks
+        const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
+        const char* eg = getenv("GJ_DEC_G");     // tuning aids: segments per batch, bytes per sub-sequence
+        const char* es = getenv("GJ_DEC_SUB");
+        int G = eg ? atoi(eg) : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
+        G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / g.seg_blocks)));
+        const int sub = es ? atoi(es) : GJ_PAR_SUB;
+        const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
+        (void)hipMemsetAsync(job->d_fallback, 0, sizeof(uint32_t), st);
+        auto kernel = g.interleaved ? (sub == 32 ? k_huffman_decode_par<true, 32> : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)
+                                    : (sub == 32 ? k_huffman_decode_par<false, 32> : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
+        hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
+                           job->d_seg_index, job->seg_count, G, job->d_huff_tab2, job->d_coefs, job->d_fallback, (unsigned long long*)job->d_prof,
+                           getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0);
+        // segments too long for the LDS stage (none in ordinary streams: the workgroups leave at once)
+        auto serial = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;
+        hipLaunchKernelGGL(serial, dim3(((unsigned)job->seg_count + 255) / 256), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos,
+                           job->d_seg_len, job->d_seg_index, job->d_fallback, job->seg_count, job->d_fallback + 1, job->d_huff_tab, job->d_coefs);
+    } else {
+        if (job->seg_count > 0) {
+            auto kernel = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;
+            hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + 255) / 256), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos,
+                               job->d_seg_len, job->d_seg_index, job->d_seg_count, job->seg_count, (const uint32_t*)nullptr, job->d_huff_tab,
+                               job->d_coefs);
+        }
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
     if (fused) {
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
-        hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtab, job->d_raw);
+        hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtab, job->d_raw, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else {
         hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtab,
-                           job->d_planes);
+                           job->d_planes, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         if (g.no_transform) {
             hipLaunchKernelGGL(k_copy_planes_out, dim3(2048), dim3(256), 0, st, g, job->d_planes, job->d_raw);

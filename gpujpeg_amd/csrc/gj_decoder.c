@@ -30,6 +30,8 @@ struct gpujpeg_decoder {
     uint16_t* h_tabs;                  /* pinned staging: 8 decode tables + 4 quant tables */
     struct gj_host_segments segs;
     int use_fused;
+    int keep_coefs;               /* 1: leave the coefficients in HBM after the call (gpujpeg_amd_decoder_keep_coefficients) */
+    bool coefs_clean;             /* d_coefs is all zero: the previous call's IDCT cleared what it read */
     /* device-side segment discovery */
     uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
     uint32_t* d_scan_scratch; size_t d_scan_scratch_cap;
@@ -48,7 +50,7 @@ void gpujpeg_decoder_output_set_cuda_buffer(struct gpujpeg_decoder_output* o) { 
 void gpujpeg_decoder_output_set_custom_cuda(struct gpujpeg_decoder_output* o, uint8_t* d_buf) { o->type = GPUJPEG_DECODER_OUTPUT_CUSTOM_CUDA_BUFFER; o->data = d_buf; o->data_size = 0; o->texture = NULL; }
 
 /* ------------------------------------------------------------------ create / destroy (src/gpujpeg_decoder.c:97-183, 560-584) */
-#define GJ_TABS_WORDS (8 * GJ_DEC_TAB_WORDS + 4 * 64)
+#define GJ_TABS_WORDS (8 * GJ_DEC_TAB_WORDS + 4 * 64 + 4 * GJ_DEC2_WORDS)
 
 struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
 {
@@ -124,6 +126,7 @@ static int decoder_configure(struct gpujpeg_decoder* d, const struct gpujpeg_par
     if (c->configured && gj_parameters_equal(&c->param, p) && gj_image_parameters_equal(&c->param_image, pi)) return 0;
     if (c->configured && verbose >= GPUJPEG_LL_INFO) fprintf(stderr, "[GPUJPEG] [Info] Reinitializing decoder.\n");
     c->configured = false;
+    d->coefs_clean = false;
     c->param = *p;
     c->param.verbose = verbose;
     c->param.perf_stats = perf;
@@ -249,7 +252,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     int seg_count = 0;
     const uint32_t* d_seg_count = NULL;
     const size_t S = (size_t)g->segment_count + GJ_MAX_COMP;
-    if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 3 + 4) * sizeof(uint32_t)) != 0) goto out;
+    if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 4 + 8) * sizeof(uint32_t)) != 0) goto out;
     if (device_scan) {
         const size_t words = gj_hip_find_segments_scratch_words(r.scan_begin[0], image_size, (uint32_t)g->segment_count);
         if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
@@ -322,6 +325,15 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
             }
     for (int t = 0; t < 4; t++)
         if (r.q_present[t]) gj_quant_table_inverse(r.qraw[t], d->h_tabs + 8 * GJ_DEC_TAB_WORDS + t * 64);
+    /* two-level tables of the sub-sequence decoder: slots 0 and 1 only, every table has to fit the layout */
+    bool tab2_ok = true;
+    for (int i = 0; i < g->comp_count; i++)
+        if (g->comp[i].dc_table > 1 || g->comp[i].ac_table > 1) tab2_ok = false;
+    for (int th = 0; th < 2 && tab2_ok; th++)
+        for (int tc = 0; tc < 2; tc++)
+            if (r.h_present[th][tc] && gj_huffman_decoder_table2(r.hbits[th][tc], r.hvals[th][tc], tc,
+                                                                  d->h_tabs + 8 * GJ_DEC_TAB_WORDS + 4 * 64 + (th * 2 + tc) * GJ_DEC2_WORDS) != 0)
+                tab2_ok = false;
     for (int i = 0; i < g->comp_count; i++) {
         if (g->comp[i].q_table > 3 || g->comp[i].dc_table > 3 || g->comp[i].ac_table > 3 || !r.q_present[g->comp[i].q_table] ||
             !r.h_present[g->comp[i].dc_table][0] || !r.h_present[g->comp[i].ac_table][1]) {
@@ -359,10 +371,26 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.d_seg_count = d_seg_count;
     job.d_huff_tab = d->d_huff_tab;
     job.d_qtab = d->d_qtab;
+    job.d_huff_tab2 = tab2_ok ? d->d_qtab + 4 * 64 : NULL;
     job.d_coefs = c->d_coefs;
     job.d_planes = c->d_planes;
     job.d_raw = d_raw;
     job.use_fused = d->use_fused;
+    job.clear_coefs = !d->coefs_clean;
+    job.zero_coefs = !d->keep_coefs;
+    d->coefs_clean = false; /* until the kernels below have run to completion */
+    job.d_fallback = d->d_seg + 3 * S + 4;
+    static int prof_on = -1;
+    static uint64_t* d_prof = NULL;
+    if (prof_on < 0) {
+        const char* e = getenv("GJ_DEC_PROF");
+        prof_on = e && e[0] == '1';
+        if (prof_on) d_prof = gj_hip_malloc(16 * sizeof(uint64_t));
+    }
+    if (prof_on && d_prof) {
+        gj_hip_memset(d_prof, 0, 16 * sizeof(uint64_t), c->stream);
+        job.d_prof = d_prof;
+    }
     if (gj_hip_decode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Decoder kernels failed: %s\n", gj_hip_last_error());
         goto out;
@@ -397,6 +425,15 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         goto out;
     }
 
+    if (job.d_prof) {
+        uint64_t hp[16];
+        static const char* names[13] = {"setup", "unstuff", "subtable", "round0", "rounds1+", "blockpos", "write", "dc", "#rounds", "#groups", "#subs", "-", "#decodes"};
+        if (gj_hip_memcpy_d2h(hp, job.d_prof, sizeof hp, c->stream) == 0 && gj_hip_stream_sync(c->stream) == 0) {
+            fprintf(stderr, "[GPUJPEG] [Prof] entropy decoder, sums over workgroups (ticks of 10 ns):");
+            for (int i = 0; i < 13; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)hp[i]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (stats) {
         struct gpujpeg_duration_stats* s = &c->stats;
         s->duration_huffman_coder = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[1]);
@@ -409,6 +446,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         if (output->type == GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER || output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_BUFFER)
             s->duration_memory_from = gj_hip_event_elapsed_ms(c->timers.copy_out[0], c->timers.copy_out[1]);
     }
+    d->coefs_clean = job.zero_coefs != 0;
     gj_coder_process_stats(c, stats);
     if (c->param.verbose >= GPUJPEG_LL_STATUS)
         fprintf(stderr, "Decompressed Size:%13zu bytes %dx%d %s %s\n", output->data_size, output->param_image.width, output->param_image.height,
@@ -506,6 +544,7 @@ size_t gpujpeg_amd_decoder_read_planes(struct gpujpeg_decoder* d, uint8_t* dst, 
 }
 
 void gpujpeg_amd_decoder_set_fused(struct gpujpeg_decoder* d, int enabled) { d->use_fused = enabled != 0; }
+void gpujpeg_amd_decoder_keep_coefficients(struct gpujpeg_decoder* d, int enabled) { d->keep_coefs = enabled != 0; }
 
 /* durations of the kernels of the last decode: [0] k_huffman_decode, [1] IDCT (fused: incl. postprocess), [2] postprocess */
 int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* d, float ms[8])

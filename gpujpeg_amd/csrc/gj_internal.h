@@ -48,6 +48,7 @@ void gj_quant_table_inverse(const uint8_t raw_zigzag[64], uint16_t inv[64]);    
 void gj_huffman_std_spec(int type, int is_ac, const uint8_t** bits17, const uint8_t** vals, int* count); /* :190-254 */
 void gj_huffman_encoder_lut(uint32_t lut[4 * 256]);                                          /* src/gpujpeg_huffman_gpu_encoder.cu:958-969 */
 int gj_huffman_decoder_table(const uint8_t bits17[17], const uint8_t* vals, uint16_t out[GJ_DEC_TAB_WORDS]); /* src/gpujpeg_table.c:384-449 */
+int gj_huffman_decoder_table2(const uint8_t bits17[17], const uint8_t* vals, int is_ac, uint16_t out[GJ_DEC2_WORDS]);
 
 /* ---- timers: hipEvents around the stages (src/gpujpeg_common_internal.h:156-205) ---- */
 struct gj_timers {

@@ -137,3 +137,46 @@ int gj_huffman_decoder_table(const uint8_t bits[17], const uint8_t* vals, uint16
     for (int i = 0; i < p; i++) symbols[i] = vals[i];
     return 0;
 }
+
+/* two-level decode table of the sub-sequence decoder: see GJ_DEC2_WORDS (gj_hip.h) for the layout.
+ * Returns 0, -1 for an invalid table, 1 when the table needs more second-level tables than the layout holds. */
+int gj_huffman_decoder_table2(const uint8_t bits[17], const uint8_t* vals, int is_ac, uint16_t out[GJ_DEC2_WORDS])
+{
+    /* what a code that is not in the table decodes to: 16 bits consumed, symbol 0 (as the canonical search of the
+     * lane-per-segment kernel does) */
+    const uint16_t invalid = (uint16_t)(16 | (0 << 5) | ((is_ac ? 64 : 1) << 9));
+    for (int i = 0; i < GJ_DEC2_WORDS; i++) out[i] = invalid;
+    int subtables = 0;
+    int sub_of_prefix[1024];
+    for (int i = 0; i < 1024; i++) sub_of_prefix[i] = -1;
+    int code = 0, p = 0;
+    for (int len = 1; len <= 16; len++) {
+        for (int i = 0; i < bits[len]; i++, p++, code++) {
+            if (p >= 256 || code >= (1 << len)) return -1;
+            const int sym = vals[p];
+            const int run = sym >> 4, sz = sym & 15;
+            int adv;
+            if (!is_ac) adv = run + 1;
+            else if (sz != 0) adv = run + 1;
+            else adv = run == 15 ? 16 : 64;
+            const uint16_t e = (uint16_t)((len + sz) | (sz << 5) | (adv << 9));
+            if (len <= GJ_DEC_FAST_BITS) {
+                const int shift = GJ_DEC_FAST_BITS - len;
+                for (int f = 0; f < (1 << shift); f++) out[(code << shift) | f] = e;
+            } else {
+                const int prefix = code >> (len - GJ_DEC_FAST_BITS);
+                if (sub_of_prefix[prefix] < 0) {
+                    if (subtables == GJ_DEC2_SUBTABLES) return 1;
+                    sub_of_prefix[prefix] = subtables++;
+                    out[prefix] = (uint16_t)((1024 + 64 * sub_of_prefix[prefix]) << 5); /* low 5 bits 0: second level */
+                }
+                const int rest = len - GJ_DEC_FAST_BITS; /* 1..6 bits inside the second level */
+                const int low = code & ((1 << rest) - 1);
+                uint16_t* sub = out + 1024 + 64 * sub_of_prefix[prefix];
+                for (int f = 0; f < (1 << (6 - rest)); f++) sub[(low << (6 - rest)) | f] = e;
+            }
+        }
+        code <<= 1;
+    }
+    return 0;
+}

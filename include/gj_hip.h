@@ -140,17 +140,30 @@ typedef struct gj_dec_job {
     int seg_count;                 /* number of table entries (upper bound when d_seg_count is set) */
     const uint32_t* d_seg_count;   /* optional: actual count in device memory (written by gj_hip_find_segments) */
     const uint16_t* d_huff_tab;    /* [4 slots][2 classes][GJ_DEC_TAB_WORDS] decode tables */
+    const uint16_t* d_huff_tab2;   /* [2 slots][2 classes][GJ_DEC2_WORDS] two-level tables of the sub-sequence decoder, or NULL when the
+                                      stream's tables do not fit them (then only the lane-per-segment kernel runs) */
     const uint16_t* d_qtab;        /* [4][64] natural order */
     int16_t* d_coefs;
     uint8_t* d_planes;
     uint8_t* d_raw;                /* output pixels */
     int use_fused;
+    int clear_coefs;               /* 1: d_coefs is not known to be all zero, clear it first */
+    int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
+    uint32_t* d_fallback;          /* [1 + seg_count] scratch: segments handed from the sub-sequence kernel to the serial one */
+    uint64_t* d_prof;              /* optional [16] phase clock accumulators of the entropy decoder (developer aid, GJ_DEC_PROF=1) */
 } gj_dec_job;
 
 /* decode table layout per (slot, class): 1024 fast entries (len << 8 | symbol, 0 = miss) followed by
  * maxcode[18] (as u16 pairs lo/hi), valptr[17], mincode[17] and the 256 symbol values */
 #define GJ_DEC_FAST_BITS 10
 #define GJ_DEC_TAB_WORDS (1024 + 36 + 17 + 34 + 256 + 1)
+
+/* two-level table of the sub-sequence decoder: 1024 first-level entries indexed by the next 10 bits, then up to
+ * GJ_DEC2_SUBTABLES second-level tables of 64 entries indexed by the 6 bits after those. Entry: bits [0,5) code length +
+ * magnitude bits (0 in the first level = go to the second level, whose word offset is entry >> 5), [5,9) magnitude bits,
+ * [9,16) zig-zag advance (DC: 1 + high nibble; AC: run + 1, 16 for ZRL, 64 for EOB). */
+#define GJ_DEC2_SUBTABLES 6
+#define GJ_DEC2_WORDS (1024 + 64 * GJ_DEC2_SUBTABLES)
 
 /* events (may be NULL): 0 start, 1 after Huffman, 2 after IDCT, 3 after postprocess */
 #define GJ_DEC_EVENTS 4

@@ -33,6 +33,7 @@ def test_encode_decode_bit_exact(O, G, gpu_lib, case, fused):
     assert hashlib.sha256(jpeg.tobytes()).hexdigest() == g["jpeg_sha256"], "differs from the reference-produced golden stream"
     dec = G.Decoder(gpu_lib)
     dec.set_fused(fused)
+    dec.keep_coefficients()
     px, info = dec.decode(want)
     s = O.parse(want)
     assert np.array_equal(dec.coefficients(s.img.data_size), O.huffman_decode(s, want)), "entropy decoder differs"
@@ -190,3 +191,54 @@ def test_width_padding(O, G, gpu_lib):
         enc = G.Encoder(gpu_lib)
         enc.set_fused(fused)
         assert np.array_equal(enc.encode(p, pi, raw), O.encode(img, raw))
+
+
+# ---- entropy decoder variants: sub-sequence parallel kernel (default), lane-per-segment kernel, and the hand-over of
+# ---- segments that do not fit the LDS stage
+ENTROPY_CASES = [
+    # name, w, h, quality, restart, interleaved, subsampling, noise?
+    ("long_segments_noise_q100", 256, 256, 100, 200, 0, None, True),      # segments of ~35 KB: every full one goes to the serial kernel
+    ("mixed_noise_q100_r40", 320, 200, 100, 40, 0, None, True),           # ~7 KB segments next to short ones at the row ends
+    ("interleaved_420_natural", 400, 300, 85, 3, 1, [(2, 2), (1, 1), (1, 1)], False),
+    ("interleaved_444_noise", 200, 120, 90, 7, 1, None, True),
+    ("tiny_segments_r1", 320, 64, 30, 1, 0, None, False),                  # one block per segment
+    ("wide_natural_auto", 1920, 136, 75, -1, 0, None, False),
+]
+
+
+@pytest.mark.parametrize("mode", ["par", "serial"])
+@pytest.mark.parametrize("ec", ENTROPY_CASES, ids=[c[0] for c in ENTROPY_CASES])
+def test_entropy_decoder_variants(O, G, gpu_lib, ec, mode, monkeypatch):
+    name, w, h, q, ri, il, ss, noisy = ec
+    case = (name, w, h, 1, 1, q, ri, il, ss, 3)
+    raw = O.noise(w * h * 3, seed=w + h) if noisy else natural_image(w, h, 3, seed=q)
+    want = O.encode(oracle_image(O, case), raw)
+    if mode == "serial":
+        monkeypatch.setenv("GJ_DEC_ENTROPY", "serial")
+    else:
+        monkeypatch.delenv("GJ_DEC_ENTROPY", raising=False)
+    dec = G.Decoder(gpu_lib)
+    dec.keep_coefficients()
+    px, _ = dec.decode(want)
+    s = O.parse(want)
+    assert np.array_equal(dec.coefficients(s.img.data_size), O.huffman_decode(s, want)), "entropy decoder differs"
+    O.lib().gjo_stream_free(C.byref(s))
+    assert np.array_equal(px, O.decode(want)[0])
+    dec.close()
+
+
+def test_decoder_reuse_without_clearing(O, G, gpu_lib):
+    """The IDCT leaves the coefficient planes zeroed for the next call: alternate streams of the same and of different
+    geometry through one decoder and check every result."""
+    streams = []
+    for i, (w, h, q) in enumerate([(320, 240, 75), (320, 240, 20), (320, 240, 95), (160, 96, 75), (320, 240, 75)]):
+        case = ("r", w, h, 1, 1, q, -1, 0, None, 3)
+        jpeg = O.encode(oracle_image(O, case), natural_image(w, h, 3, seed=i))
+        streams.append((jpeg, O.decode(jpeg)[0]))
+    dec = G.Decoder(gpu_lib)
+    for fused in (True, False):
+        dec.set_fused(fused)
+        for jpeg, want_px in streams + streams[::-1]:
+            px, _ = dec.decode(jpeg)
+            assert np.array_equal(px, want_px)
+    dec.close()

@@ -64,6 +64,7 @@ def run(name, w, h, raw, pixfmt=G.P012_444, cs=G.RGB, quality=75, restart=-1, in
         # decode the ORACLE stream so that decoder checks do not depend on the encoder
         dec = G.Decoder(lib)
         dec.set_fused(fused)
+        dec.keep_coefficients()
         if opf is not None:
             dec.set_output_format(ocs if ocs is not None else G.CS_DEFAULT, opf)
         t0 = time.time()

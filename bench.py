@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient"])
     ap.add_argument("--quality", type=int, default=75)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--internal-rgb", action="store_true", help="code RGB without colour transform (tuning aid; not the headline config)")
     ap.add_argument("--keep-coefs", action="store_true", help="decoder keeps its coefficients in HBM (adds the per-frame clear; tuning aid)")
     ap.add_argument("--verify", action="store_true", help="check the round trip of the last frame against the oracle (slow)")
     args = ap.parse_args()
@@ -129,6 +130,8 @@ def main():
     assert enc.set_option("enc_opt_out", "enc_out_val_device") == 0
     p = lib.default_parameters()
     p.quality, p.restart_interval, p.verbose, p.perf_stats = args.quality, G.RESTART_AUTO, -1, 1
+    if args.internal_rgb:
+        p.color_space_internal = 1
     pi = lib.default_image_parameters()
     pi.width, pi.height = width, height
     if args.keep_coefs:

@@ -684,27 +684,9 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
 // ================================================================================================
 // Dequantisation + IDCT, one thread per block
 // ================================================================================================
-// `zero`: the block is overwritten with zeros once it has been read, which leaves the coefficient planes ready for the
+// `zero`: every block is overwritten with zeros once it has been read, which leaves the coefficient planes ready for the
 // entropy decoder of the next frame (it stores non-zero coefficients only) without a separate 2 B/sample memset.
-__device__ __forceinline__ void gj_load_dequant(int16_t* __restrict__ src, const uint16_t* __restrict__ q, float (&d)[64], const bool zero)
-{
-    uint4* p = reinterpret_cast<uint4*>(src);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint4 w = p[r];
-        if (zero) p[r] = make_uint4(0, 0, 0, 0);
-        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int lo = (int)(int16_t)(ws[j] & 0xFFFF), hi = (int)ws[j] >> 16;
-            // integer product first, then one conversion (src/gpujpeg_dct_gpu.cu:497-500)
-            d[r * 8 + 2 * j] = (float)(lo * (int)q[r * 8 + 2 * j]);
-            d[r * 8 + 2 * j + 1] = (float)(hi * (int)q[r * 8 + 2 * j + 1]);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_idct(const gj_geom g, int16_t* __restrict__ coefs, const uint16_t* __restrict__ qtab,
+__global__ __launch_bounds__(256) void k_idct(const gj_geom g, int16_t* __restrict__ coefs, const float* __restrict__ qtab,
                                               uint8_t* __restrict__ planes, const int zero)
 {
     const unsigned gb = blockIdx.x * 256u + threadIdx.x;
@@ -716,18 +698,21 @@ __global__ __launch_bounds__(256) void k_idct(const gj_geom g, int16_t* __restri
     const gj_comp_geom& k = g.comp[c];
     const unsigned lb = gb - (unsigned)(k.data_offset / 64);
     const unsigned by = lb / (unsigned)k.blocks_x, bx = lb - by * (unsigned)k.blocks_x;
-    float d[64];
-    gj_load_dequant(coefs + (size_t)gb * 64, qtab + k.q_table * 64, d, zero != 0);
-    int o[64];
-    gj_idct_block(d, o);
+    uint32_t w[32];
+    {
+        uint4* p = reinterpret_cast<uint4*>(coefs + (size_t)gb * 64);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint4 v = p[r];
+            if (zero) p[r] = make_uint4(0, 0, 0, 0);
+            w[r * 4] = v.x; w[r * 4 + 1] = v.y; w[r * 4 + 2] = v.z; w[r * 4 + 3] = v.w;
+        }
+    }
+    uint32_t px[16];
+    gj_idct_pk(w, qtab + k.q_table * 64, px);
     uint8_t* dst = planes + k.data_offset + (size_t)by * 8 * k.data_width + bx * 8;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint2 w;
-        w.x = (uint32_t)o[r * 8] | ((uint32_t)o[r * 8 + 1] << 8) | ((uint32_t)o[r * 8 + 2] << 16) | ((uint32_t)o[r * 8 + 3] << 24);
-        w.y = (uint32_t)o[r * 8 + 4] | ((uint32_t)o[r * 8 + 5] << 8) | ((uint32_t)o[r * 8 + 6] << 16) | ((uint32_t)o[r * 8 + 7] << 24);
-        *reinterpret_cast<uint2*>(dst + (size_t)r * k.data_width) = w;
-    }
+    for (int r = 0; r < 8; r++) *reinterpret_cast<uint2*>(dst + (size_t)r * k.data_width) = make_uint2(px[2 * r], px[2 * r + 1]);
 }
 
 // ================================================================================================
@@ -746,10 +731,12 @@ __device__ __forceinline__ void gj_color_static_d(int& a, int& b, int& c)
 // makes both the linear writes and the per-block 16 B reads bank-conflict free (36 dwords: 9 x 4, 9 coprime to 16).
 #define GJ_TILE_PITCH 144
 template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256) void k_idct_fused_rgb444(const gj_geom g, int16_t* __restrict__ coefs,
-                                                           const uint16_t* __restrict__ qtab, uint8_t* __restrict__ raw, const int zero)
+__global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, int16_t* __restrict__ coefs,
+                                                              const float* __restrict__ qtab, uint8_t* __restrict__ raw, const int zero)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * GJ_TILE_PITCH];
+    __shared__ __attribute__((aligned(8))) float s_q[3][64]; // dequantisation tables: read as VGPR pairs for v_pk_mul_f32
+    if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
     const gj_comp_geom& k0 = g.comp[0];
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
     const unsigned lb0 = blockIdx.x * 256u;
@@ -780,31 +767,24 @@ __global__ __launch_bounds__(256) void k_idct_fused_rgb444(const gj_geom g, int1
             *reinterpret_cast<uint4*>(s_blk + (ch >> 3) * GJ_TILE_PITCH + (ch & 7u) * 16u) = w[i];
         }
         __syncthreads();
-        float d[64];
+        uint32_t wb[32];
         {
-            const uint16_t* q = qtab + g.comp[c].q_table * 64;
             const uint4* p = reinterpret_cast<const uint4*>(s_blk + threadIdx.x * GJ_TILE_PITCH);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const uint4 v = p[r];
-                const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int lo = (int)(int16_t)(ws[j] & 0xFFFF), hi = (int)ws[j] >> 16;
-                    d[r * 8 + 2 * j] = (float)(lo * (int)q[r * 8 + 2 * j]);
-                    d[r * 8 + 2 * j + 1] = (float)(hi * (int)q[r * 8 + 2 * j + 1]);
-                }
+                wb[r * 4] = v.x; wb[r * 4 + 1] = v.y; wb[r * 4 + 2] = v.z; wb[r * 4 + 3] = v.w;
             }
         }
-        int o[64];
-        gj_idct_block(d, o);
+        gj_idct_pk(wb, s_q[c], pk[c]);
+        // pin the transform here: otherwise LLVM sinks all three below the last barrier and spills the staged coefficients
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            pk[c][i] = (uint32_t)o[i * 4] | ((uint32_t)o[i * 4 + 1] << 8) | ((uint32_t)o[i * 4 + 2] << 16) | ((uint32_t)o[i * 4 + 3] << 24);
+        for (int i = 0; i < 16; i++) asm volatile("" : "+v"(pk[c][i]));
     }
-    if (lb >= nb) return;
+    // (no early return for the threads past the last block: the compiler would sink the three transforms below it and keep
+    // every staged coefficient alive until then)
     const size_t pitch = (size_t)g.width * 3 + g.width_padding;
-    const bool interior = (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
+    const bool interior = lb < nb && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -827,13 +807,14 @@ __global__ __launch_bounds__(256) void k_idct_fused_rgb444(const gj_geom g, int1
             p[0] = make_uint2(px[0], px[1]);
             p[1] = make_uint2(px[2], px[3]);
             p[2] = make_uint2(px[4], px[5]);
-        } else if (y < (unsigned)g.height) {
+        } else if (lb < nb && y < (unsigned)g.height) {
 #pragma unroll
             for (int byte = 0; byte < 24; byte++) {
                 const unsigned x = bx * 8 + byte / 3;
                 if (x < (unsigned)g.width) raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] = (uint8_t)(px[byte >> 2] >> ((byte & 3) * 8));
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -914,7 +895,7 @@ __global__ __launch_bounds__(256) void k_copy_planes_out(const gj_geom g, const 
 // ================================================================================================
 // Launcher
 // ================================================================================================
-typedef void (*gj_idct_fused_t)(const gj_geom, int16_t*, const uint16_t*, uint8_t*, int);
+typedef void (*gj_idct_fused_t)(const gj_geom, int16_t*, const float*, uint8_t*, int);
 
 static gj_idct_fused_t gj_idct_fused_kernel(const gj_geom& g)
 {
@@ -974,10 +955,10 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
     if (fused) {
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
-        hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtab, job->d_raw, job->zero_coefs);
+        hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else {
-        hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtab,
+        hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf,
                            job->d_planes, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         if (g.no_transform) {

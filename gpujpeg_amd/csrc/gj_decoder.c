@@ -50,7 +50,8 @@ void gpujpeg_decoder_output_set_cuda_buffer(struct gpujpeg_decoder_output* o) { 
 void gpujpeg_decoder_output_set_custom_cuda(struct gpujpeg_decoder_output* o, uint8_t* d_buf) { o->type = GPUJPEG_DECODER_OUTPUT_CUSTOM_CUDA_BUFFER; o->data = d_buf; o->data_size = 0; o->texture = NULL; }
 
 /* ------------------------------------------------------------------ create / destroy (src/gpujpeg_decoder.c:97-183, 560-584) */
-#define GJ_TABS_WORDS (8 * GJ_DEC_TAB_WORDS + 4 * 64 + 4 * GJ_DEC2_WORDS)
+#define GJ_TABS_QF_OFFSET (8 * GJ_DEC_TAB_WORDS + 4 * 64 + 4 * GJ_DEC2_WORDS) /* u16 words; 4-byte aligned */
+#define GJ_TABS_WORDS (GJ_TABS_QF_OFFSET + 4 * 64 * 2)
 
 struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
 {
@@ -324,7 +325,12 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
                 goto out;
             }
     for (int t = 0; t < 4; t++)
-        if (r.q_present[t]) gj_quant_table_inverse(r.qraw[t], d->h_tabs + 8 * GJ_DEC_TAB_WORDS + t * 64);
+        if (r.q_present[t]) {
+            uint16_t* qi = d->h_tabs + 8 * GJ_DEC_TAB_WORDS + t * 64;
+            float* qf = (float*)(void*)(d->h_tabs + GJ_TABS_QF_OFFSET) + t * 64;
+            gj_quant_table_inverse(r.qraw[t], qi);
+            for (int i = 0; i < 64; i++) qf[i] = (float)qi[i];
+        }
     /* two-level tables of the sub-sequence decoder: slots 0 and 1 only, every table has to fit the layout */
     bool tab2_ok = true;
     for (int i = 0; i < g->comp_count; i++)
@@ -371,6 +377,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.d_seg_count = d_seg_count;
     job.d_huff_tab = d->d_huff_tab;
     job.d_qtab = d->d_qtab;
+    job.d_qtabf = (const float*)(const void*)(d->d_huff_tab + GJ_TABS_QF_OFFSET);
     job.d_huff_tab2 = tab2_ok ? d->d_qtab + 4 * 64 : NULL;
     job.d_coefs = c->d_coefs;
     job.d_planes = c->d_planes;

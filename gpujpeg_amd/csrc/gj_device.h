@@ -184,110 +184,176 @@ __device__ __forceinline__ void gj_color_transform(int from, int to, int& a, int
 
 // ------------------------------------------------------------------------------------------------
 // 8-point forward DCT (AAN) -- src/gpujpeg_dct_gpu.cu:121-163. Built with -ffp-contract=off: the
-// fused operations are exactly the explicit __builtin_fmaf calls (fusion map: DESIGN.md section 3).
+// fused operations are exactly the explicit fma calls (fusion map: DESIGN.md section 3).
+//
+// The transforms are written once for T = float and T = gj_f2 (two floats in a VGPR pair): with gj_f2 every add, mul
+// and fma becomes one v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, i.e. two IEEE-exact fp32 results per instruction
+// (CDNA3/4 packed fp32). A block is held as pairs of horizontally adjacent samples for the column pass and
+// re-paired (v_pk_mov_b32) into vertically adjacent ones for the row pass; results are bit-identical to the
+// scalar sequence.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gj_fdct8(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5, float& x6, float& x7,
-                                         const float level_shift)
+typedef float gj_f2 __attribute__((ext_vector_type(2)));
+
+template <typename T> __device__ __forceinline__ T gj_fma(T a, T b, T c);
+template <> __device__ __forceinline__ float gj_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ gj_f2 gj_fma<gj_f2>(gj_f2 a, gj_f2 b, gj_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ void gj_fdct8(T& x0, T& x1, T& x2, T& x3, T& x4, T& x5, T& x6, T& x7, const float level_shift)
 {
-    const float diff0 = x0 + x7, diff1 = x1 + x6, diff2 = x2 + x5, diff3 = x3 + x4;
-    const float diff4 = x3 - x4, diff5 = x2 - x5, diff6 = x1 - x6, diff7 = x0 - x7;
-    const float even0 = diff0 + diff3, even1 = diff1 + diff2, even2 = diff1 - diff2, even3 = diff0 - diff3;
-    const float even_diff = even2 + even3;
-    const float odd0 = diff4 + diff5, odd1 = diff5 + diff6, odd2 = diff6 + diff7;
-    const float odd_diff5 = (odd0 - odd2) * 0.382683433f;
-    const float odd_diff4 = __builtin_fmaf(1.306562965f, odd2, odd_diff5);
-    const float odd_diff3 = __builtin_fmaf(-odd1, 0.707106781f, diff7);
-    const float odd_diff2 = __builtin_fmaf(0.541196100f, odd0, odd_diff5);
-    const float odd_diff1 = __builtin_fmaf(odd1, 0.707106781f, diff7);
-    x0 = (even0 + even1) + level_shift;
+    const T diff0 = x0 + x7, diff1 = x1 + x6, diff2 = x2 + x5, diff3 = x3 + x4;
+    const T diff4 = x3 - x4, diff5 = x2 - x5, diff6 = x1 - x6, diff7 = x0 - x7;
+    const T even0 = diff0 + diff3, even1 = diff1 + diff2, even2 = diff1 - diff2, even3 = diff0 - diff3;
+    const T even_diff = even2 + even3;
+    const T odd0 = diff4 + diff5, odd1 = diff5 + diff6, odd2 = diff6 + diff7;
+    const T odd_diff5 = (odd0 - odd2) * (T)0.382683433f;
+    const T odd_diff4 = gj_fma<T>((T)1.306562965f, odd2, odd_diff5);
+    const T odd_diff3 = gj_fma<T>(-odd1, (T)0.707106781f, diff7);
+    const T odd_diff2 = gj_fma<T>((T)0.541196100f, odd0, odd_diff5);
+    const T odd_diff1 = gj_fma<T>(odd1, (T)0.707106781f, diff7);
+    x0 = (even0 + even1) + (T)level_shift;
     x1 = odd_diff1 + odd_diff4;
-    x2 = __builtin_fmaf(even_diff, 0.707106781f, even3);
+    x2 = gj_fma<T>(even_diff, (T)0.707106781f, even3);
     x3 = odd_diff3 - odd_diff2;
     x4 = even0 - even1;
     x5 = odd_diff3 + odd_diff2;
-    x6 = __builtin_fmaf(-even_diff, 0.707106781f, even3);
+    x6 = gj_fma<T>(-even_diff, (T)0.707106781f, even3);
     x7 = odd_diff1 - odd_diff4;
 }
 
-// 2-D forward DCT + quantisation of one block held in registers (v[row*8+col], unsigned samples).
+// 2-D forward DCT + quantisation of one block.
+// px: the 64 unsigned samples, one byte each, row r in px[2r] (columns 0..3) and px[2r + 1] (columns 4..7).
 // q = transposed forward table (src/gpujpeg_table.c:112-120): entry [col*8+row].
-// out[i] = natural-order quantised coefficient (src/gpujpeg_dct_gpu.cu:246-294).
-__device__ __forceinline__ void gj_fdct_quant(float (&v)[64], const float* __restrict__ q, int (&out)[64])
+// out: the quantised coefficients in natural order, two int16 per dword = the layout of the coefficient planes
+// (src/gpujpeg_dct_gpu.cu:246-294). rintf(coef * q) is taken with the 1.5 * 2^23 trick: adding it rounds to nearest even
+// exactly like v_rndne_f32 and leaves the integer in the low mantissa bits.
+__device__ __forceinline__ void gj_fdct_quant_pk(const uint32_t (&px)[16], const float* __restrict__ q, uint32_t (&out)[32])
 {
+    gj_f2 D[8][4];
 #pragma unroll
-    for (int c = 0; c < 8; c++) // columns first, level shift folded into the DC term
-        gj_fdct8(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c], -1024.0f);
+    for (int r = 0; r < 8; r++) {
+        const uint32_t a = px[2 * r], b = px[2 * r + 1];
+        D[r][0] = gj_f2{(float)(a & 0xFF), (float)((a >> 8) & 0xFF)};
+        D[r][1] = gj_f2{(float)((a >> 16) & 0xFF), (float)(a >> 24)};
+        D[r][2] = gj_f2{(float)(b & 0xFF), (float)((b >> 8) & 0xFF)};
+        D[r][3] = gj_f2{(float)((b >> 16) & 0xFF), (float)(b >> 24)};
+    }
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-        gj_fdct8(v[r * 8], v[r * 8 + 1], v[r * 8 + 2], v[r * 8 + 3], v[r * 8 + 4], v[r * 8 + 5], v[r * 8 + 6], v[r * 8 + 7], 0.0f);
+    for (int c = 0; c < 4; c++) // columns first, level shift folded into the DC term
+        gj_fdct8<gj_f2>(D[0][c], D[1][c], D[2][c], D[3][c], D[4][c], D[5][c], D[6][c], D[7][c], -1024.0f);
+    __builtin_amdgcn_sched_barrier(0); // keep the scheduler from interleaving the passes (register pressure)
+    const gj_f2* q2 = reinterpret_cast<const gj_f2*>(q);
 #pragma unroll
-    for (int r = 0; r < 8; r++)
+    for (int rp = 0; rp < 4; rp++) {
+        gj_f2 E[8]; // rows 2rp (x) and 2rp + 1 (y)
 #pragma unroll
-        for (int j = 0; j < 8; j++) out[r * 8 + j] = (int)__builtin_rintf(v[r * 8 + j] * q[j * 8 + r]);
+        for (int cp = 0; cp < 4; cp++) {
+            E[2 * cp] = gj_f2{D[2 * rp][cp].x, D[2 * rp + 1][cp].x};
+            E[2 * cp + 1] = gj_f2{D[2 * rp][cp].y, D[2 * rp + 1][cp].y};
+        }
+        gj_fdct8<gj_f2>(E[0], E[1], E[2], E[3], E[4], E[5], E[6], E[7], 0.0f);
+        uint32_t ux[8], uy[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const gj_f2 u = E[j] * q2[j * 4 + rp] + (gj_f2)12582912.0f;
+            const float fx = u.x, fy = u.y; // (bit_cast straight from a vector element reads element 0 for both)
+            ux[j] = __builtin_bit_cast(uint32_t, fx);
+            uy[j] = __builtin_bit_cast(uint32_t, fy);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            out[(2 * rp) * 4 + m] = __builtin_amdgcn_perm(ux[2 * m + 1], ux[2 * m], 0x05040100u);
+            out[(2 * rp + 1) * 4 + m] = __builtin_amdgcn_perm(uy[2 * m + 1], uy[2 * m], 0x05040100u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // 8-point inverse DCT (lifting scheme) -- src/gpujpeg_dct_gpu.cu:312-366, fusion map DESIGN.md 3.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void gj_idct8(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6, float& v7)
+template <typename T>
+__device__ __forceinline__ void gj_idct8(T& v0, T& v1, T& v2, T& v3, T& v4, T& v5, T& v6, T& v7)
 {
     const float k0 = 0.4142135623f, k1 = 0.3535533905f, k2 = 0.4619397662f, k3 = 0.1989123673f, k4 = 0.7071067811f;
-    const float a2 = v2 * 0.5411961f, a4 = v4 * 0.509795579f, a5 = v5 * 0.601344887f;
-    const float t1 = v0 - v1;
-    const float b1 = t1 * k1;
-    const float b0 = __builtin_fmaf(v0, k4, -b1);
-    const float b3 = __builtin_fmaf(v3, k2, a2 * k1);
-    const float b2 = __builtin_fmaf(b3, k0, -a2);
-    const float b6 = __builtin_fmaf(v6, k0, a5 * k2);
-    const float b5 = __builtin_fmaf(b6, -0.6681786379f, a5);
-    const float b7 = __builtin_fmaf(v7, 0.49039264f, a4 * k3);
-    const float b4 = __builtin_fmaf(b7, k3, -a4);
-    const float c1 = __builtin_fmaf(t1, k1, b2);
-    const float c2 = __builtin_fmaf(-2.0f, b2, c1);
-    const float c4 = b5 + b4;
-    const float c5 = __builtin_fmaf(2.0f, b5, -c4);
-    const float c7 = b6 + b7;
-    const float c6 = __builtin_fmaf(-2.0f, b6, c7);
-    const float c0 = b3 + b0;
-    const float c3 = __builtin_fmaf(-2.0f, b3, c0);
-    const float d5 = __builtin_fmaf(c6, k0, c5);
-    const float d6 = __builtin_fmaf(d5, -k4, c6);
-    const float e5 = __builtin_fmaf(d6, k0, d5);
-    const float d3 = c3 + c4;
-    const float e4 = __builtin_fmaf(-2.0f, c4, d3);
-    const float d2 = c2 + e5;
-    const float f5 = __builtin_fmaf(-2.0f, e5, d2);
-    const float e1 = d6 + c1;
-    const float e6 = __builtin_fmaf(-2.0f, d6, e1);
-    const float e0 = c0 + c7;
-    const float e7 = __builtin_fmaf(-2.0f, c7, e0);
+    const T a2 = v2 * (T)0.5411961f, a4 = v4 * (T)0.509795579f, a5 = v5 * (T)0.601344887f;
+    const T t1 = v0 - v1;
+    const T b1 = t1 * (T)k1;
+    const T b0 = gj_fma<T>(v0, (T)k4, -b1);
+    const T b3 = gj_fma<T>(v3, (T)k2, a2 * (T)k1);
+    const T b2 = gj_fma<T>(b3, (T)k0, -a2);
+    const T b6 = gj_fma<T>(v6, (T)k0, a5 * (T)k2);
+    const T b5 = gj_fma<T>(b6, (T)-0.6681786379f, a5);
+    const T b7 = gj_fma<T>(v7, (T)0.49039264f, a4 * (T)k3);
+    const T b4 = gj_fma<T>(b7, (T)k3, -a4);
+    const T c1 = gj_fma<T>(t1, (T)k1, b2);
+    const T c2 = gj_fma<T>((T)-2.0f, b2, c1);
+    const T c4 = b5 + b4;
+    const T c5 = gj_fma<T>((T)2.0f, b5, -c4);
+    const T c7 = b6 + b7;
+    const T c6 = gj_fma<T>((T)-2.0f, b6, c7);
+    const T c0 = b3 + b0;
+    const T c3 = gj_fma<T>((T)-2.0f, b3, c0);
+    const T d5 = gj_fma<T>(c6, (T)k0, c5);
+    const T d6 = gj_fma<T>(d5, (T)-k4, c6);
+    const T e5 = gj_fma<T>(d6, (T)k0, d5);
+    const T d3 = c3 + c4;
+    const T e4 = gj_fma<T>((T)-2.0f, c4, d3);
+    const T d2 = c2 + e5;
+    const T f5 = gj_fma<T>((T)-2.0f, e5, d2);
+    const T e1 = d6 + c1;
+    const T e6 = gj_fma<T>((T)-2.0f, d6, e1);
+    const T e0 = c0 + c7;
+    const T e7 = gj_fma<T>((T)-2.0f, c7, e0);
     v0 = e0; v1 = e1; v2 = d2; v3 = d3; v4 = e4; v5 = f5; v6 = e6; v7 = e7;
 }
 
-// 2-D inverse DCT of one dequantised block in registers (d[row*8+col]); result = clamped samples.
+// Dequantisation + 2-D inverse DCT of one block.
+// w: the 64 quantised coefficients in natural order, two int16 per dword (row r in w[4r .. 4r + 3]).
+// qf: dequantisation table in natural order as float. coefficient * q is exact in fp32 (|coef| <= 2^15, q <= 255: DQT
+// precision is 8 bit, src/gpujpeg_reader.c:682-727), so float(coef) * float(q) equals the reference's
+// float(int(coef) * int(q)) (src/gpujpeg_dct_gpu.cu:497-500).
+// px: clamped samples, one byte each, laid out like gj_fdct_quant_pk's input. clamp(rintf(x + 128)) is one
+// v_cvt_pk_u8_f32 (round to nearest even, saturating; checked against the formula on the device, tools/exp/cvt_u8.hip).
 // The permuted operand order {0,4,6,2,7,5,3,1} is src/gpujpeg_dct_gpu.cu:532-539,:583-590.
-__device__ __forceinline__ void gj_idct_block(float (&d)[64], int (&out)[64])
+__device__ __forceinline__ void gj_idct_pk(const uint32_t (&w)[32], const float* __restrict__ qf, uint32_t (&px)[16])
 {
+    const gj_f2* q2 = reinterpret_cast<const gj_f2*>(qf);
+    gj_f2 D[8][4];
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        float x0 = d[0 * 8 + c], x1 = d[4 * 8 + c], x2 = d[6 * 8 + c], x3 = d[2 * 8 + c];
-        float x4 = d[7 * 8 + c], x5 = d[5 * 8 + c], x6 = d[3 * 8 + c], x7 = d[1 * 8 + c];
-        gj_idct8(x0, x1, x2, x3, x4, x5, x6, x7);
-        d[0 * 8 + c] = x0; d[1 * 8 + c] = x1; d[2 * 8 + c] = x2; d[3 * 8 + c] = x3;
-        d[4 * 8 + c] = x4; d[5 * 8 + c] = x5; d[6 * 8 + c] = x6; d[7 * 8 + c] = x7;
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int cp = 0; cp < 4; cp++) {
+            const uint32_t v = w[r * 4 + cp];
+            D[r][cp] = gj_f2{(float)(int)(int16_t)(v & 0xFFFF), (float)((int)v >> 16)} * q2[r * 4 + cp];
+        }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        gj_f2 x0 = D[0][c], x1 = D[4][c], x2 = D[6][c], x3 = D[2][c], x4 = D[7][c], x5 = D[5][c], x6 = D[3][c], x7 = D[1][c];
+        gj_idct8<gj_f2>(x0, x1, x2, x3, x4, x5, x6, x7);
+        D[0][c] = x0; D[1][c] = x1; D[2][c] = x2; D[3][c] = x3; D[4][c] = x4; D[5][c] = x5; D[6][c] = x6; D[7][c] = x7;
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        float x0 = d[r * 8 + 0], x1 = d[r * 8 + 4], x2 = d[r * 8 + 6], x3 = d[r * 8 + 2];
-        float x4 = d[r * 8 + 7], x5 = d[r * 8 + 5], x6 = d[r * 8 + 3], x7 = d[r * 8 + 1];
-        gj_idct8(x0, x1, x2, x3, x4, x5, x6, x7);
-        out[r * 8 + 0] = gj_clamp8((int)__builtin_rintf(x0 + 128.0f));
-        out[r * 8 + 1] = gj_clamp8((int)__builtin_rintf(x1 + 128.0f));
-        out[r * 8 + 2] = gj_clamp8((int)__builtin_rintf(x2 + 128.0f));
-        out[r * 8 + 3] = gj_clamp8((int)__builtin_rintf(x3 + 128.0f));
-        out[r * 8 + 4] = gj_clamp8((int)__builtin_rintf(x4 + 128.0f));
-        out[r * 8 + 5] = gj_clamp8((int)__builtin_rintf(x5 + 128.0f));
-        out[r * 8 + 6] = gj_clamp8((int)__builtin_rintf(x6 + 128.0f));
-        out[r * 8 + 7] = gj_clamp8((int)__builtin_rintf(x7 + 128.0f));
+    for (int rp = 0; rp < 4; rp++) {
+        gj_f2 E[8];
+#pragma unroll
+        for (int cp = 0; cp < 4; cp++) {
+            E[2 * cp] = gj_f2{D[2 * rp][cp].x, D[2 * rp + 1][cp].x};
+            E[2 * cp + 1] = gj_f2{D[2 * rp][cp].y, D[2 * rp + 1][cp].y};
+        }
+        gj_f2 X[8] = {E[0], E[4], E[6], E[2], E[7], E[5], E[3], E[1]};
+        gj_idct8<gj_f2>(X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7]);
+        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const gj_f2 lo = X[k] + (gj_f2)128.0f, hi = X[k + 4] + (gj_f2)128.0f;
+            a0 = __builtin_amdgcn_cvt_pk_u8_f32(lo.x, k, a0);
+            a1 = __builtin_amdgcn_cvt_pk_u8_f32(hi.x, k, a1);
+            b0 = __builtin_amdgcn_cvt_pk_u8_f32(lo.y, k, b0);
+            b1 = __builtin_amdgcn_cvt_pk_u8_f32(hi.y, k, b1);
+        }
+        px[4 * rp] = a0; px[4 * rp + 1] = a1; px[4 * rp + 2] = b0; px[4 * rp + 3] = b1;
+        __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -11,6 +11,7 @@
 // kernel and stitches segments on the host (src/gpujpeg_encoder.c:485-629); the arithmetic below restates
 // src/gpujpeg_preprocessor.cu, src/gpujpeg_colorspace.h, src/gpujpeg_dct_gpu.cu and src/gpujpeg_huffman_gpu_encoder.cu.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "gj_device.h"
 #include "gj_hip.h"
@@ -89,18 +90,11 @@ __global__ __launch_bounds__(256) void k_copy_planes_in(const gj_geom g, const u
 // No LDS, no cross-lane traffic: the whole block lives in 64 VGPRs. A wave reads 64 neighbouring
 // blocks, i.e. 512 contiguous bytes per image row.
 // ================================================================================================
-__device__ __forceinline__ void gj_store_block(int16_t* __restrict__ dst, const int (&q)[64])
+__device__ __forceinline__ void gj_store_block(int16_t* __restrict__ dst, const uint32_t (&q)[32])
 {
     uint4* o = reinterpret_cast<uint4*>(dst);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint4 w;
-        w.x = (uint32_t)(q[r * 8 + 0] & 0xFFFF) | ((uint32_t)q[r * 8 + 1] << 16);
-        w.y = (uint32_t)(q[r * 8 + 2] & 0xFFFF) | ((uint32_t)q[r * 8 + 3] << 16);
-        w.z = (uint32_t)(q[r * 8 + 4] & 0xFFFF) | ((uint32_t)q[r * 8 + 5] << 16);
-        w.w = (uint32_t)(q[r * 8 + 6] & 0xFFFF) | ((uint32_t)q[r * 8 + 7] << 16);
-        o[r] = w;
-    }
+    for (int r = 0; r < 8; r++) o[r] = make_uint4(q[r * 4], q[r * 4 + 1], q[r * 4 + 2], q[r * 4 + 3]);
 }
 
 __global__ __launch_bounds__(256) void k_dct(const gj_geom g, const uint8_t* __restrict__ planes, int16_t* __restrict__ coefs,
@@ -116,17 +110,15 @@ __global__ __launch_bounds__(256) void k_dct(const gj_geom g, const uint8_t* __r
     const unsigned lb = gb - (unsigned)(k.data_offset / 64);
     const unsigned by = lb / (unsigned)k.blocks_x, bx = lb - by * (unsigned)k.blocks_x;
     const uint8_t* src = planes + k.data_offset + (size_t)by * 8 * k.data_width + bx * 8;
-    float v[64];
+    uint32_t px[16];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint2 w = *reinterpret_cast<const uint2*>(src + (size_t)r * k.data_width);
-        v[r * 8 + 0] = (float)(w.x & 0xFF); v[r * 8 + 1] = (float)((w.x >> 8) & 0xFF);
-        v[r * 8 + 2] = (float)((w.x >> 16) & 0xFF); v[r * 8 + 3] = (float)(w.x >> 24);
-        v[r * 8 + 4] = (float)(w.y & 0xFF); v[r * 8 + 5] = (float)((w.y >> 8) & 0xFF);
-        v[r * 8 + 6] = (float)((w.y >> 16) & 0xFF); v[r * 8 + 7] = (float)(w.y >> 24);
+        px[2 * r] = w.x;
+        px[2 * r + 1] = w.y;
     }
-    int q[64];
-    gj_fdct_quant(v, k.type ? q_chroma : q_luma, q);
+    uint32_t q[32];
+    gj_fdct_quant_pk(px, k.type ? q_chroma : q_luma, q);
     gj_store_block(coefs + (size_t)gb * 64, q);
 }
 
@@ -147,9 +139,12 @@ __device__ __forceinline__ void gj_color_static(int& a, int& b, int& c)
 }
 
 template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256) void k_fused_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, int16_t* __restrict__ coefs,
-                                                      const float* __restrict__ q_luma, const float* __restrict__ q_chroma)
+__global__ __launch_bounds__(256, 3) void k_fused_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, int16_t* __restrict__ coefs,
+                                                         const float* __restrict__ q_luma, const float* __restrict__ q_chroma, const int flags)
 {
+    __shared__ __attribute__((aligned(8))) float s_q[3][64]; // forward tables: read as VGPR pairs for v_pk_mul_f32
+    if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = (g.comp[threadIdx.x >> 6].type ? q_chroma : q_luma)[threadIdx.x & 63];
+    __syncthreads();
     const gj_comp_geom& k0 = g.comp[0];
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
     const unsigned lb = blockIdx.x * 256u + threadIdx.x;
@@ -197,19 +192,14 @@ __global__ __launch_bounds__(256) void k_fused_rgb444(const gj_geom g, const uin
         pk[0][r * 2] = o0[0]; pk[0][r * 2 + 1] = o0[1];
         pk[1][r * 2] = o1[0]; pk[1][r * 2 + 1] = o1[1];
         pk[2][r * 2] = o2[0]; pk[2][r * 2 + 1] = o2[1];
+        // pin the colour transform of this row here (keeps the raw pixels from staying alive into the transforms)
+        asm volatile("" : "+v"(pk[0][r * 2]), "+v"(pk[0][r * 2 + 1]), "+v"(pk[1][r * 2]), "+v"(pk[1][r * 2 + 1]), "+v"(pk[2][r * 2]), "+v"(pk[2][r * 2 + 1]));
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        float v[64];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t w = pk[c][i];
-            v[i * 4 + 0] = (float)(w & 0xFF); v[i * 4 + 1] = (float)((w >> 8) & 0xFF);
-            v[i * 4 + 2] = (float)((w >> 16) & 0xFF); v[i * 4 + 3] = (float)(w >> 24);
-        }
-        int q[64];
-        gj_fdct_quant(v, g.comp[c].type ? q_chroma : q_luma, q);
-        gj_store_block(coefs + g.comp[c].data_offset + (size_t)lb * 64, q);
+        uint32_t q[32];
+        gj_fdct_quant_pk(pk[c], s_q[c], q);
+        if (!(flags & 1) || q[5] == 0x12345678u) gj_store_block(coefs + g.comp[c].data_offset + (size_t)lb * 64, q);
     }
 }
 
@@ -513,6 +503,210 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
 }
 
 // ================================================================================================
+// Fully fused fast path: packed 4:4:4 pixels -> per-segment (unstuffed) Huffman streams, no coefficient planes.
+//
+// k_fused_rgb444 + k_huffman move 2 x 199 MB of int16 coefficients through HBM for an 8K frame; measured, the store half
+// alone costs as much as all arithmetic of the kernel. Both kernels already give one thread one 8x8 block, so the
+// quantised block can stay in that thread's registers: a workgroup takes spt = 256 / B whole restart segments (B blocks
+// each, e.g. 7 x 36 = 252 block positions) of ALL THREE component scans, colour-converts its pixels once, then for one
+// component after the other transforms the block, parks it in LDS in zig-zag order and runs the two coding passes of
+// k_huffman on it. The per-segment output (unstuffed bytes in d_temp, byte and 0xFF counts) is exactly what
+// k_scan_partial / k_assemble expect. Used for non-interleaved 4:4:4 with 0 < restart interval <= 256 blocks.
+// ================================================================================================
+template <int CS_FROM, int CS_TO>
+__global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
+                                                          const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
+                                                          uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
+                                                          uint32_t* __restrict__ seg_ff)
+{
+    __shared__ __attribute__((aligned(8))) float s_q[3][64];
+    __shared__ uint32_t s_coef[32 * 256];
+    __shared__ uint32_t s_bits[GJ_HUFF_CAP_DW];
+    __shared__ uint32_t s_lut[1024];
+    __shared__ int s_dc[256];
+    __shared__ uint32_t s_segx[256], s_segend[256], s_segbase[257], s_segbits[256], s_segff[256];
+    __shared__ uint32_t s_tmp[4];
+
+    const int i = threadIdx.x;
+    for (int t = i; t < 1024; t += 256) s_lut[t] = lut[t];
+    if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
+
+    const gj_comp_geom& k0 = g.comp[0];
+    const int B = g.seg_blocks;
+    const int spt = 256 / B;       // segments per workgroup (per component)
+    const int tile_blocks = spt * B;
+    const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
+    const int j = (int)(((uint32_t)i * recip) >> 16);
+    const int k = i - j * B;       // block inside its segment
+    const int seg0 = blockIdx.x * spt; // first segment (inside each component's scan)
+    const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
+    const unsigned lb = (unsigned)blockIdx.x * (unsigned)tile_blocks + (unsigned)i;
+    const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
+    const int seg_count_c = k0.segment_count;
+    const bool seg_in_tile = i < spt && seg0 + i < seg_count_c; // lane i keeps the books of local segment i
+    const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
+    const size_t pitch = (size_t)g.width * 3 + g.width_padding;
+    const bool interior = active && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
+    const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
+
+    // ---- pixels -> three byte-packed component blocks (as k_fused_rgb444)
+    uint32_t pk[3][16];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t px[6];
+        if (interior && aligned) {
+            const uint2* p = reinterpret_cast<const uint2*>(raw + (size_t)(by * 8 + r) * pitch + (size_t)bx * 24);
+            const uint2 a = p[0], b = p[1], c = p[2];
+            px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y;
+        } else {
+            const unsigned y = by * 8 + r;
+#pragma unroll
+            for (int w = 0; w < 6; w++) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const unsigned byte = w * 4 + b, x = bx * 8 + byte / 3;
+                    if (active && x < (unsigned)g.width && y < (unsigned)g.height) d |= (uint32_t)raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] << (8 * b);
+                }
+                px[w] = d;
+            }
+        }
+        uint32_t o0[2] = {0, 0}, o1[2] = {0, 0}, o2[2] = {0, 0};
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            const int b0 = x * 3, b1 = x * 3 + 1, b2 = x * 3 + 2;
+            int c0 = (px[b0 >> 2] >> ((b0 & 3) * 8)) & 0xFF;
+            int c1 = (px[b1 >> 2] >> ((b1 & 3) * 8)) & 0xFF;
+            int c2 = (px[b2 >> 2] >> ((b2 & 3) * 8)) & 0xFF;
+            gj_color_static<CS_FROM, CS_TO>(c0, c1, c2);
+            if (!interior && (bx * 8 + x >= (unsigned)g.width || by * 8 + r >= (unsigned)g.height)) c0 = c1 = c2 = 0;
+            o0[x >> 2] |= (uint32_t)c0 << ((x & 3) * 8);
+            o1[x >> 2] |= (uint32_t)c1 << ((x & 3) * 8);
+            o2[x >> 2] |= (uint32_t)c2 << ((x & 3) * 8);
+        }
+        pk[0][r * 2] = o0[0]; pk[0][r * 2 + 1] = o0[1];
+        pk[1][r * 2] = o1[0]; pk[1][r * 2 + 1] = o1[1];
+        pk[2][r * 2] = o2[0]; pk[2][r * 2 + 1] = o2[1];
+        asm volatile("" : "+v"(pk[0][r * 2]), "+v"(pk[0][r * 2 + 1]), "+v"(pk[1][r * 2]), "+v"(pk[1][r * 2 + 1]), "+v"(pk[2][r * 2]), "+v"(pk[2][r * 2 + 1]));
+    }
+    __syncthreads(); // tables are in LDS
+
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const gj_comp_geom& kc = g.comp[c];
+        // ---- transform; zig-zag; park in LDS as [dword][lane]
+        if (c) __syncthreads(); // the previous component's coding passes are done with LDS
+        // (pinned behind the barrier: the transform of component c + 1 would otherwise be hoisted over the coding passes of c)
+#pragma unroll
+        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[c][t]));
+        uint32_t n[32];
+        gj_fdct_quant_pk(pk[c], s_q[c], n);
+        int dc = 0;
+        uint64_t mask = 0;
+        if (active) {
+            dc = (int)(int16_t)(n[0] & 0xFFFF);
+            uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                const int na = GJ_ZZ[2 * q], nbz = GJ_ZZ[2 * q + 1];
+                const uint32_t sel = (uint32_t)((na & 1) * 2) | ((uint32_t)((na & 1) * 2 + 1) << 8) | ((uint32_t)(4 + (nbz & 1) * 2) << 16) |
+                                     ((uint32_t)(5 + (nbz & 1) * 2) << 24);
+                const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
+                s_coef[q * 256 + i] = d;
+                const uint32_t f = ((d & 0xFFFFu) ? 1u : 0u) | ((d >> 16) ? 2u : 0u);
+                if (q < 16) mlo |= f << (2 * q);
+                else mhi |= f << (2 * (q - 16));
+            }
+            mask = ((uint64_t)mhi << 32) | mlo;
+        }
+        s_dc[i] = dc;
+        s_segff[i] = 0;
+        __syncthreads();
+
+        // ---- DC prediction + pass A (lengths)
+        const int table = kc.type;
+        int dc_diff = 0;
+        uint32_t len = 0;
+        GjEmit e = {0, 0, 0};
+        const int nblocks = active ? min(B, (int)nb - (seg0 + j) * B) : 0; // blocks of this lane's segment
+        if (active) {
+            dc_diff = dc - (k == 0 ? 0 : s_dc[i - 1]);
+            len = gj_code_block<false>(s_coef, s_lut, i, dc_diff, mask, table, 0, e, nullptr, 0, 0);
+        }
+        // ---- bit positions
+        uint32_t total_bits;
+        const uint32_t incl = gj_wg256_incl_scan(len, s_tmp, &total_bits);
+        const uint32_t excl = incl - len;
+        if (active && k == 0) s_segx[j] = excl;
+        if (active && k == nblocks - 1) s_segend[j] = incl;
+        __syncthreads();
+        uint32_t my_dw = 0;
+        if (seg_in_tile) {
+            uint32_t bits = s_segend[i] - s_segx[i];
+            bits += (8u - (bits & 7u)) & 7u; // ones-padding to a byte boundary
+            s_segbits[i] = bits;
+            my_dw = (bits + 31u) >> 5;
+        }
+        uint32_t total_dw;
+        const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total_dw);
+        if (i < spt) s_segbase[i] = base_incl - my_dw;
+        if (i == 0) s_segbase[spt] = total_dw;
+        __syncthreads();
+        int pad_bits = 0;
+        uint32_t start_bit = 0, end_bit = 0;
+        if (active) {
+            start_bit = s_segbase[j] * 32u + (excl - s_segx[j]);
+            if (k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
+            end_bit = start_bit + len + (uint32_t)pad_bits;
+        }
+        // first block of every local segment in coding order (addresses d_temp)
+        const uint64_t seg_first_block = kc.data_offset / 64;
+
+        // ---- pass B window by window, then drain each window to HBM
+        for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_HUFF_CAP_DW) {
+            const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_HUFF_CAP_DW);
+            for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
+            __syncthreads();
+            if (active && end_bit > wbase * 32u && start_bit < wend * 32u && end_bit > start_bit) {
+                e.acc = 0;
+                e.accbits = (int)(start_bit & 31u);
+                e.dw = start_bit >> 5;
+                gj_code_block<true>(s_coef, s_lut, i, dc_diff, mask, table, pad_bits, e, s_bits, wbase, wend);
+                if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
+            }
+            __syncthreads();
+            for (uint32_t d = wbase + i; d < wend; d += 256) {
+                int lo = 0, hi = spt; // local segment that owns dword d
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_segbase[mid] <= d) lo = mid; else hi = mid;
+                }
+                const uint32_t bits = s_segbits[lo];
+                const uint32_t el = d - s_segbase[lo];
+                const uint32_t nflush = (bits + 31u) >> 5;
+                const uint32_t v = s_bits[d - wbase];
+                if (el < nflush) {
+                    int vb = 4;
+                    if (el == nflush - 1) vb = (int)((bits - el * 32u + 7u) >> 3);
+                    uint32_t ff = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (b < vb && ((v >> (24 - 8 * b)) & 0xFFu) == 0xFFu) ff++;
+                    if (ff) atomicAdd(&s_segff[lo], ff);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(temp + (seg_first_block + (uint64_t)(seg0 + lo) * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
+                    *dst = __builtin_bswap32(v);
+                }
+            }
+            __syncthreads();
+        }
+        if (seg_in_tile) {
+            seg_bytes[kc.first_segment + seg0 + i] = (s_segbits[i] + 7u) >> 3;
+            seg_ff[kc.first_segment + seg0 + i] = s_segff[i];
+        }
+    }
+}
+
+// ================================================================================================
 // Final offsets: exclusive prefix sum over stuffed segment sizes (+2 for RSTn except at the end of a scan) and over
 // the scan headers that precede each scan. Two launches of ceil(S/1024) workgroups: per-workgroup totals, then every
 // workgroup adds the totals of its predecessors (at most a few hundred values) to its local scan.
@@ -671,7 +865,8 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // ================================================================================================
 // Launcher
 // ================================================================================================
-typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
+typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*, int);
+typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*);
 
 // fused kernel for this configuration, or nullptr when the generic path has to be used
 static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
@@ -688,18 +883,42 @@ static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
     return nullptr;
 }
 
+// fully fused kernel for this configuration, or nullptr
+static gj_encode_kernel_t gj_encode_kernel(const gj_geom& g)
+{
+    if (g.pixel_format != GJ_PF_444_P012 || g.comp_count != 3 || g.interleaved || g.restart_interval <= 0 || g.seg_blocks > 256) return nullptr;
+    for (int c = 0; c < 3; c++)
+        if (g.comp[c].samp_h != 1 || g.comp[c].samp_v != 1) return nullptr;
+    const int from = g.color_space, to = g.color_space_internal;
+    if (from == to || from == GJ_CS_NONE || to == GJ_CS_NONE) return k_encode_rgb444<GJ_CS_NONE, GJ_CS_NONE>;
+    if (from == GJ_CS_RGB && to == GJ_CS_BT601_256) return k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601_256>;
+    if (from == GJ_CS_RGB && to == GJ_CS_BT601) return k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601>;
+    if (from == GJ_CS_RGB && to == GJ_CS_BT709) return k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT709>;
+    if (from == GJ_CS_BT601_256 && to == GJ_CS_RGB) return k_encode_rgb444<GJ_CS_BT601_256, GJ_CS_RGB>;
+    return nullptr;
+}
+
 extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS])
 {
     hipStream_t st = (hipStream_t)stream;
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
+    gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
+    if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+        const int spt = 256 / g.seg_blocks;
+        const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
+        hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
+                           job->d_seg_bytes, job->d_seg_ff);
+    } else {
     if (fused) {
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
         hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->d_coefs, job->d_fwd_q[0],
-                           job->d_fwd_q[1]);
+                           job->d_fwd_q[1], getenv("GJ_ENC_EXP") ? atoi(getenv("GJ_ENC_EXP")) : 0);
     } else {
         if (g.no_transform) {
             hipLaunchKernelGGL(k_copy_planes_in, dim3(2048), dim3(256), 0, st, g, job->d_raw, job->d_planes);
@@ -717,6 +936,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     const unsigned tiles = ((unsigned)g.segment_count + spt - 1) / spt;
     hipLaunchKernelGGL(k_huffman, dim3(tiles), dim3(256), 0, st, g, job->d_coefs, job->d_huff_lut, job->d_temp, job->d_seg_bytes,
                        job->d_seg_ff);
+    }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
     const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;
     if (scan_wgs > 1024) return -1; // more than 1M segments: not reachable through the API limits (65535^2 pixels) with sane restart intervals

@@ -36,6 +36,7 @@ struct gpujpeg_encoder {
     uint8_t* h_header;  /* pinned staging for the main header */
     uint8_t* out_buf; size_t out_cap; bool out_buf_pinned;
     int use_fused;
+    int keep_coefs; /* gpujpeg_amd_encoder_keep_coefficients */
 };
 
 /* ------------------------------------------------------------------ input helpers (gpujpeg_encoder.h:77-110) */
@@ -248,6 +249,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.main_hdr_size = (uint32_t)hdr;
     job.segment_info = p.segment_info;
     job.use_fused = e->use_fused && !e->flipped;
+    job.keep_coefs = e->keep_coefs;
     if (gj_hip_encode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Encoder kernels failed: %s\n", gj_hip_last_error());
         return -1;
@@ -421,6 +423,7 @@ size_t gpujpeg_amd_encoder_read_planes(struct gpujpeg_encoder* e, uint8_t* dst, 
 }
 
 void gpujpeg_amd_encoder_set_fused(struct gpujpeg_encoder* e, int enabled) { e->use_fused = enabled != 0; }
+void gpujpeg_amd_encoder_keep_coefficients(struct gpujpeg_encoder* e, int enabled) { e->keep_coefs = enabled != 0; }
 
 /* durations of the kernels of the last encode: [0] preprocess (generic path), [1] DCT+quant (fused: incl. preprocess),
  * [2] k_huffman, [3] k_scan_segments, [4] k_assemble; needs perf_stats or verbose >= 1 */

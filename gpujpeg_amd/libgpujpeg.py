@@ -134,7 +134,7 @@ class Library:
                 getattr(L, n).argtypes = [vp, C.POINTER(C.c_uint8), C.c_size_t]
             for n in ("gpujpeg_amd_encoder_get_kernel_times", "gpujpeg_amd_decoder_get_kernel_times"):
                 getattr(L, n).argtypes = [vp, C.POINTER(C.c_float)]
-            for n in ("gpujpeg_amd_encoder_set_fused", "gpujpeg_amd_decoder_set_fused", "gpujpeg_amd_decoder_keep_coefficients"):
+            for n in ("gpujpeg_amd_encoder_set_fused", "gpujpeg_amd_decoder_set_fused", "gpujpeg_amd_decoder_keep_coefficients", "gpujpeg_amd_encoder_keep_coefficients"):
                 getattr(L, n).restype = None
                 getattr(L, n).argtypes = [vp, C.c_int]
 
@@ -191,6 +191,10 @@ class Encoder:
 
     def set_fused(self, enabled):
         self.lib.L.gpujpeg_amd_encoder_set_fused(self.h, int(enabled))
+
+    def keep_coefficients(self, enabled=True):
+        """Leave the quantised coefficients of the following encode calls in HBM (for coefficients())."""
+        self.lib.L.gpujpeg_amd_encoder_keep_coefficients(self.h, int(enabled))
 
     def kernel_times(self):
         ms = (C.c_float * 8)()

@@ -121,7 +121,8 @@ typedef struct gj_enc_job {
     uint32_t scan_info_payload[GJ_MAX_COMP]; /* offset inside scan header of the first APP13 payload, 0 = none */
     uint32_t main_hdr_size;        /* bytes already placed at d_jpeg[0..) by the host */
     int segment_info;
-    int use_fused;                 /* 1: raw -> coefficients in one kernel when the format allows */
+    int use_fused;                 /* 1: fused kernels when the format allows (raw -> segment streams, or raw -> coefficients) */
+    int keep_coefs;                /* 1: the caller wants the coefficient planes in d_coefs (tests): do not use the fully fused kernel */
 } gj_enc_job;
 
 /* events (may be NULL): 0 start, 1 after preprocess, 2 after DCT/quant, 3 after k_huffman, 4 after k_scan_segments,
@@ -143,6 +144,7 @@ typedef struct gj_dec_job {
     const uint16_t* d_huff_tab2;   /* [2 slots][2 classes][GJ_DEC2_WORDS] two-level tables of the sub-sequence decoder, or NULL when the
                                       stream's tables do not fit them (then only the lane-per-segment kernel runs) */
     const uint16_t* d_qtab;        /* [4][64] natural order */
+    const float* d_qtabf;          /* the same as float: what the IDCT kernels multiply with */
     int16_t* d_coefs;
     uint8_t* d_planes;
     uint8_t* d_raw;                /* output pixels */

@@ -29,6 +29,9 @@ GPUJPEG_API size_t gpujpeg_amd_decoder_read_planes(struct gpujpeg_decoder* decod
 /* 1 = use the fused fast-path kernels when the format allows (default), 0 = always take the generic path */
 GPUJPEG_API void gpujpeg_amd_encoder_set_fused(struct gpujpeg_encoder* encoder, int enabled);
 GPUJPEG_API void gpujpeg_amd_decoder_set_fused(struct gpujpeg_decoder* decoder, int enabled);
+/* 1 = the following encode calls leave the quantised coefficients in HBM for gpujpeg_amd_encoder_read_coefficients (tests).
+ * Default 0: where the format allows, pixels go to entropy-coded segments in one kernel and no coefficient planes exist. */
+GPUJPEG_API void gpujpeg_amd_encoder_keep_coefficients(struct gpujpeg_encoder* encoder, int enabled);
 /* 1 = leave the coefficients of the following decode calls in HBM for gpujpeg_amd_decoder_read_coefficients (tests).
  * Default 0: the IDCT clears each block once it has read it, which saves the per-frame clear of the coefficient planes. */
 GPUJPEG_API void gpujpeg_amd_decoder_keep_coefficients(struct gpujpeg_decoder* decoder, int enabled);

@@ -26,6 +26,9 @@ def test_encode_decode_bit_exact(O, G, gpu_lib, case, fused):
     p, pi = api_params(gpu_lib, G, case)
     enc = G.Encoder(gpu_lib)
     enc.set_fused(fused)
+    if fused:  # default product path: pixels -> entropy-coded segments in one kernel where the format allows, no coefficient planes
+        assert np.array_equal(enc.encode(p, pi, raw), want), "JPEG bytes differ (fully fused path)"
+    enc.keep_coefficients()
     jpeg = enc.encode(p, pi, raw)
     assert np.array_equal(enc.coefficients(img.data_size), coefs), "quantised coefficients differ"
     assert np.array_equal(jpeg, want), "JPEG bytes differ"

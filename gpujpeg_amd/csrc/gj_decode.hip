@@ -359,7 +359,8 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
 template <bool INTERLEAVED, int SUB_BYTES>
 __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                             const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
-                                                            const uint32_t* __restrict__ seg_index, const int seg_count, const int G,
+                                                            const uint32_t* __restrict__ seg_index, const int seg_count_max,
+                                                            const uint32_t* __restrict__ seg_count_ptr, const int G,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
                                                             uint32_t* __restrict__ fallback /* [0] count, [1..] table entries */,
                                                             unsigned long long* __restrict__ prof /* optional phase clocks (GJ_DEC_PROF) */, const int flags /* experiments */)
@@ -414,7 +415,9 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
 
     // ---- batch setup: lane j describes segment j of the batch
+    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
     const int si0 = blockIdx.x * G;
+    if (si0 >= seg_count) return;
     const int nseg = min(G, seg_count - si0);
     uint32_t my_nblk = 0, my_ucap = 0;
     if (tid < GJ_PAR_GMAX) {
@@ -937,7 +940,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         auto kernel = g.interleaved ? (sub == 32 ? k_huffman_decode_par<true, 32> : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)
                                     : (sub == 32 ? k_huffman_decode_par<false, 32> : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
         hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                           job->d_seg_index, job->seg_count, G, job->d_huff_tab2, job->d_coefs, job->d_fallback, (unsigned long long*)job->d_prof,
+                           job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, job->d_fallback, (unsigned long long*)job->d_prof,
                            getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0);
         // segments too long for the LDS stage (none in ordinary streams: the workgroups leave at once)
         auto serial = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;
@@ -1149,6 +1152,21 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     hipLaunchKernelGGL(k_marker_emit, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_rst, max_segments);
     hipLaunchKernelGGL(k_build_segments, dim3((max_segments + GJ_MAX_COMP + 255) / 256), dim3(256), 0, st, *g, d_rst, begin, size, d_summary,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+__global__ __launch_bounds__(256) void k_compare_header(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t n,
+                                                         gj_scan_summary* __restrict__ sum)
+{
+    int diff = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) diff |= a[i] != b[i];
+    diff = __syncthreads_or(diff);
+    if (threadIdx.x == 0) sum->header_differs = diff ? 1u : 0u;
+}
+
+extern "C" int gj_hip_compare_header(const uint8_t* d_jpeg, const uint8_t* d_ref, uint32_t n, gj_scan_summary* d_summary, gj_stream_t stream)
+{
+    hipLaunchKernelGGL(k_compare_header, dim3(1), dim3(256), 0, (hipStream_t)stream, d_jpeg, d_ref, n, d_summary);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

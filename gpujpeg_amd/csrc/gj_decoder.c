@@ -38,6 +38,11 @@ struct gpujpeg_decoder {
     gj_scan_summary* d_summary;
     gj_scan_summary* h_summary;   /* pinned */
     int host_scan;                /* 1: always walk the stream on the host (reference behaviour) */
+    /* header cache: a stream that starts with the same bytes (SOI .. first SOS header) as the previous one has the same
+     * tables and geometry, so the call goes straight to the kernels and is validated after the fact */
+    uint8_t* hdr_cache; uint8_t* d_hdr_cache; size_t hdr_cache_len; bool hdr_cache_valid;
+    struct gj_reader_result hdr_cache_r;
+    bool tab2_ok;
 };
 
 #define GJ_HDR_WINDOW 65536
@@ -107,6 +112,7 @@ int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
     gj_hip_free(d->d_jpeg); gj_hip_free(d->d_seg); gj_hip_free(d->d_huff_tab);
     gj_hip_free(d->coder.d_raw_own); gj_hip_free(d->coder.d_planes); gj_hip_free(d->coder.d_coefs);
     gj_hip_host_free(d->h_raw); gj_hip_host_free(d->h_seg); gj_hip_host_free(d->h_tabs);
+    free(d->hdr_cache); gj_hip_free(d->d_hdr_cache);
     gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
     free(d->segs.pos); free(d->segs.len); free(d->segs.index);
     free(d);
@@ -117,6 +123,7 @@ void gpujpeg_decoder_set_output_format(struct gpujpeg_decoder* d, enum gpujpeg_c
 {
     d->req_color_space = cs;
     d->req_pixel_format = pf;
+    d->hdr_cache_valid = false; /* the cached parse result embeds the requested output format */
 }
 
 /* ------------------------------------------------------------------ configuration (src/gpujpeg_decoder.c:185-233) */
@@ -207,13 +214,20 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     const bool jpeg_on_device = gj_hip_is_device_ptr(image) != 0;
     const uint8_t* himage = image; /* host view of (at least the headers of) the stream */
     size_t hsize = image_size;
+    struct gj_reader_result r;
+    bool device_scan = !d->host_scan;
+    /* speculative path: same header as last time (compared on the device for a device-resident stream) */
+    bool spec = device_scan && d->hdr_cache_valid && image_size > d->hdr_cache_len && getenv("GJ_DEC_NO_SPEC") == NULL;
+    if (spec && !jpeg_on_device) spec = memcmp(image, d->hdr_cache, d->hdr_cache_len) == 0;
+    if (spec) {
+        r = d->hdr_cache_r;
+        rc = 0;
+    } else {
     if (jpeg_on_device) {
         hsize = image_size < GJ_HDR_WINDOW ? image_size : GJ_HDR_WINDOW;
         if (gj_hip_memcpy_d2h(d->h_hdr, image, hsize, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) return -1;
         himage = d->h_hdr;
     }
-    struct gj_reader_result r;
-    bool device_scan = !d->host_scan;
     rc = device_scan ? gj_reader_parse(himage, hsize, hsize < image_size ? GPUJPEG_LL_QUIET - 1 : c->param.verbose, d->ff_cs_itu601_is_709,
                                        d->req_pixel_format, d->req_color_space, d->req_alignment, &r, true)
                      : -1;
@@ -231,6 +245,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
             GJ_ERROR("Decoder failed when decoding image data!\n");
             goto out;
         }
+    }
     }
     rc = -1;
     for (int i = 0; i < GPUJPEG_METADATA_COUNT; i++) d->metadata.vals[i] = r.metadata.vals[i];
@@ -259,11 +274,15 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
         if (gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
                                  d->d_scan_scratch, d->d_summary, c->stream) != 0 ||
-            gj_hip_memcpy_d2h(d->h_summary, d->d_summary, sizeof(gj_scan_summary), c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) {
+            (spec && jpeg_on_device && gj_hip_compare_header(d_jpeg, d->d_hdr_cache, (uint32_t)d->hdr_cache_len, d->d_summary, c->stream) != 0) ||
+            gj_hip_memcpy_d2h(d->h_summary, d->d_summary, sizeof(gj_scan_summary), c->stream) != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
             GJ_ERROR("Marker scan failed: %s\n", gj_hip_last_error());
             goto out;
         }
-        if (accept_device_scan(d->h_summary, &r, g) == 0) {
+        if (spec) { /* the kernels take the segment count from the device; the summary is checked once everything has run */
+            seg_count = g->segment_count;
+            d_seg_count = &d->d_summary->segment_count;
+        } else if (accept_device_scan(d->h_summary, &r, g) == 0) {
             seg_count = (int)d->h_summary->segment_count;
             d_seg_count = NULL;
         } else {
@@ -317,6 +336,8 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         g->comp[i].dc_table = r.huff_map[i][0];
         g->comp[i].ac_table = r.huff_map[i][1];
     }
+    bool tab2_ok = d->tab2_ok;
+    if (!spec) {
     memset(d->h_tabs, 0, GJ_TABS_WORDS * sizeof(uint16_t));
     for (int th = 0; th < 4; th++)
         for (int tc = 0; tc < 2; tc++)
@@ -332,7 +353,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
             for (int i = 0; i < 64; i++) qf[i] = (float)qi[i];
         }
     /* two-level tables of the sub-sequence decoder: slots 0 and 1 only, every table has to fit the layout */
-    bool tab2_ok = true;
+    tab2_ok = true;
     for (int i = 0; i < g->comp_count; i++)
         if (g->comp[i].dc_table > 1 || g->comp[i].ac_table > 1) tab2_ok = false;
     for (int th = 0; th < 2 && tab2_ok; th++)
@@ -350,6 +371,8 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     if (gj_hip_memcpy_h2d(d->d_huff_tab, d->h_tabs, GJ_TABS_WORDS * sizeof(uint16_t), c->stream) != 0) {
         GJ_ERROR("Decoder copy compressed data failed: %s\n", gj_hip_last_error());
         goto out;
+    }
+    d->tab2_ok = tab2_ok;
     }
     if (stats) gj_hip_event_record(c->timers.copy_in[1], c->stream);
 
@@ -432,6 +455,35 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         goto out;
     }
 
+    if (spec) { /* now the summary of this stream is on the host: was it what we assumed? */
+        struct gj_reader_result chk = r;
+        bool ok = d->h_summary->header_differs == 0 && accept_device_scan(d->h_summary, &chk, g) == 0;
+        for (int i = 0; ok && i < g->comp_count; i++)
+            if (chk.huff_map[i][0] != r.huff_map[i][0] || chk.huff_map[i][1] != r.huff_map[i][1]) ok = false;
+        if (!ok) { /* different header or unusual scan structure: decode again the careful way */
+            d->hdr_cache_valid = false;
+            free(host_copy);
+            return gpujpeg_decoder_decode(d, image, image_size, output);
+        }
+        if ((int)d->h_summary->segment_count != g->segment_count && c->param.verbose >= 0)
+            GJ_WARN("%d segments read, expected %d. Broken JPEG?\n", (int)d->h_summary->segment_count, g->segment_count);
+    } else if (device_scan && r.scan_begin[0] <= GJ_HDR_WINDOW && r.scan_begin[0] < image_size) {
+        /* remember this header (SOI .. first SOS header) for the next call */
+        const size_t n = r.scan_begin[0];
+        if (!d->hdr_cache) d->hdr_cache = malloc(GJ_HDR_WINDOW);
+        if (!d->d_hdr_cache) d->d_hdr_cache = gj_hip_malloc(GJ_HDR_WINDOW);
+        if (d->hdr_cache && d->d_hdr_cache) {
+            memcpy(d->hdr_cache, himage, n);
+            if (gj_hip_memcpy_h2d(d->d_hdr_cache, d->hdr_cache, n, c->stream) == 0 && gj_hip_stream_sync(c->stream) == 0) {
+                d->hdr_cache_len = n;
+                d->hdr_cache_r = r;
+                d->hdr_cache_r.comment = NULL;
+                d->hdr_cache_valid = true;
+            }
+        }
+    } else {
+        d->hdr_cache_valid = false;
+    }
     if (job.d_prof) {
         uint64_t hp[16];
         static const char* names[13] = {"setup", "unstuff", "subtable", "round0", "rounds1+", "blockpos", "write", "dc", "#rounds", "#groups", "#subs", "-", "#decodes"};
@@ -515,6 +567,7 @@ int gpujpeg_decoder_set_option(struct gpujpeg_decoder* d, const char* opt, const
         const int a = atoi(val);
         if (a < 0) { GJ_ERROR("Wrong alignment: %s\n", val); return GPUJPEG_ERROR; }
         d->req_alignment = (unsigned)a;
+        d->hdr_cache_valid = false;
         return GPUJPEG_NOERR;
     }
     if (strcmp(opt, GPUJPEG_DEC_OPT_TGA_RLE_BOOL) == 0) return GPUJPEG_NOERR; /* only affects file output */

@@ -185,8 +185,11 @@ typedef struct gj_scan_summary {
     uint32_t scan_count, segment_count;
     uint32_t status;                          /* 1 = clean (scans ... EOI), 2 = unexpected marker between scans, 3 = no EOI */
     uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];
+    uint32_t header_differs;                  /* gj_hip_compare_header: 1 when the stream does not start with the cached header */
 } gj_scan_summary;
 
+/* sets d_summary->header_differs = (d_jpeg[0..n) != d_ref[0..n)); launch after gj_hip_find_segments (which clears the summary) */
+GJ_HIP_API int gj_hip_compare_header(const uint8_t* d_jpeg, const uint8_t* d_ref, uint32_t n, gj_scan_summary* d_summary, gj_stream_t stream);
 GJ_HIP_API size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments);
 GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,

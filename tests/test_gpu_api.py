@@ -97,3 +97,41 @@ def test_cli_round_trip(O, G, gpu_lib, tmp_path):
     data = open(pnm, "rb").read()
     assert data.startswith(b"P6\n640 360\n255\n")
     assert np.array_equal(np.frombuffer(data[len(b"P6\n640 360\n255\n"):], np.uint8), O.decode(want)[0])
+
+
+def test_decoder_header_cache(O, G, gpu_lib, monkeypatch):
+    """Streams that start with the same header take the speculative path (kernels first, validation after); a stream
+    with another header, another output format or a damaged scan structure must fall back and still decode right."""
+    import torch
+    mk = lambda w, h, q, seed, ri=-1: O.encode(oracle_image(O, ("c", w, h, 1, 1, q, ri, 0, None, 3)), natural_image(w, h, 3, seed=seed))
+    a1, a2, a3 = mk(320, 240, 75, 1), mk(320, 240, 75, 2), mk(320, 240, 75, 3)   # same header, different content
+    b = mk(320, 240, 60, 4)                                                         # other quantisation tables
+    c = mk(336, 240, 75, 5)                                                         # other geometry
+    dec = G.Decoder(gpu_lib)
+    for jpeg in (a1, a2, a3, b, a1, c, c, a2, b, b):
+        px, _ = dec.decode(jpeg)
+        assert np.array_equal(px, O.decode(jpeg)[0])
+    # device-resident streams: the header is compared on the device
+    for jpeg in (a1, a2, b, a3, a3):
+        dj = torch.from_numpy(jpeg).cuda()
+        out = torch.empty(320 * 240 * 3, dtype=torch.uint8, device="cuda")
+        o = G.DecoderOutput()
+        o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, out.data_ptr()
+        assert gpu_lib.L.gpujpeg_decoder_decode(dec.h, C.c_void_p(dj.data_ptr()), jpeg.size, C.byref(o)) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), O.decode(jpeg)[0])
+    # changing the requested output format invalidates the cached parse
+    dec.set_output_format(G.NONE, G.PIXFMT_NATIVE)
+    px, info = dec.decode(a1)
+    assert np.array_equal(px, O.decode(a1, info.pixel_format, info.color_space)[0])
+    # same header, truncated scan data (no EOI): speculative run, validation fails, careful path reports it like before
+    px_full, _ = dec.decode(a2)
+    cut = a2[: a2.size - 40].copy()
+    try:
+        px_cut, _ = dec.decode(cut)
+        assert px_cut.size == px_full.size
+    except Exception:
+        pass  # an error return is acceptable for a damaged stream; it must not crash or hang
+    px, _ = dec.decode(a3)
+    assert np.array_equal(px, O.decode(a3, info.pixel_format, info.color_space)[0])
+    dec.close()

@@ -741,32 +741,31 @@ __device__ __forceinline__ uint32_t gj_wg1024_incl_scan(uint32_t v, uint32_t* s_
     return inc + off;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_partial(const gj_enc_job J, uint32_t* __restrict__ partial)
-{
-    __shared__ uint32_t s_w[16];
-    const int s = blockIdx.x * 1024 + threadIdx.x;
-    uint32_t hdr = 0, v = 0;
-    if (s < J.g.segment_count) v = gj_segment_out_size(J, s, &hdr);
-    uint32_t total;
-    gj_wg1024_incl_scan(v + hdr, s_w, &total);
-    if (threadIdx.x == 0) partial[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_final(const gj_enc_job J, const uint32_t* __restrict__ partial)
+// One launch: every workgroup scans its 1024 segments, publishes its total tagged with the call's epoch, then adds up the
+// totals of its predecessors as soon as they appear (all workgroups of a frame are resident at once and are dispatched
+// in index order, so a predecessor never waits for a successor). The epoch tag makes clearing the slots unnecessary.
+__global__ __launch_bounds__(1024) void k_scan_segments(const gj_enc_job J, unsigned long long* __restrict__ partial, const uint32_t epoch)
 {
     __shared__ uint32_t s_w[16];
     const int S = J.g.segment_count;
-    // totals of the preceding workgroups (gridDim.x <= 1024 for every image the API accepts: 65535^2 pixels, r >= 1 ... checked on the host)
-    uint32_t pre = ((int)threadIdx.x < (int)blockIdx.x) ? partial[threadIdx.x] : 0;
-    uint32_t base;
-    gj_wg1024_incl_scan(pre, s_w, &base);
-    base += J.main_hdr_size;
-    __syncthreads();
     const int s = blockIdx.x * 1024 + threadIdx.x;
     uint32_t hdr = 0, v = 0;
     if (s < S) v = gj_segment_out_size(J, s, &hdr);
     uint32_t total;
     const uint32_t inc = gj_wg1024_incl_scan(v + hdr, s_w, &total);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&partial[blockIdx.x], ((unsigned long long)epoch << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t pre = 0;
+    for (unsigned t = threadIdx.x; t < blockIdx.x; t += 1024) {
+        unsigned long long p;
+        do {
+            p = __hip_atomic_load(&partial[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((uint32_t)(p >> 32) != epoch);
+        pre += (uint32_t)p;
+    }
+    uint32_t base;
+    gj_wg1024_incl_scan(pre, s_w, &base);
+    base += J.main_hdr_size;
     if (s < S) J.d_seg_out[s] = base + inc - v; // segment data start (its scan header sits right before)
     if (s == S - 1) {
         const uint32_t end = base + inc;
@@ -939,9 +938,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
     const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;
-    if (scan_wgs > 1024) return -1; // more than 1M segments: not reachable through the API limits (65535^2 pixels) with sane restart intervals
-    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(1024), 0, st, *job, job->d_seg_out + g.segment_count + 8);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(1024), 0, st, *job, job->d_seg_out + g.segment_count + 8);
+    hipLaunchKernelGGL(k_scan_segments, dim3(scan_wgs), dim3(1024), 0, st, *job, (unsigned long long*)job->d_scan_partial, job->epoch);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[4], st);
     hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 3) / 4), dim3(256), 0, st, *job);
     if (job->segment_info && g.restart_interval > 0)

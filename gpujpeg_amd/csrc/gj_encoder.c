@@ -29,6 +29,8 @@ struct gpujpeg_encoder {
     uint32_t* d_seg; size_t d_seg_cap; /* bytes | ff | out(+1) */
     uint8_t* d_jpeg; size_t d_jpeg_cap;
     uint32_t* d_result;
+    uint64_t* d_scan_partial; size_t d_scan_partial_cap;
+    uint32_t epoch;
     uint8_t* d_scan_hdr; size_t d_scan_hdr_cap;
     struct gj_scan_headers scan_hdrs;
     /* host side */
@@ -85,7 +87,7 @@ int gpujpeg_encoder_destroy(struct gpujpeg_encoder* e)
     gj_coder_process_stats_overall(&e->coder);
     gj_timers_destroy(&e->coder.timers);
     gj_hip_free(e->d_fwd_q[0]); gj_hip_free(e->d_fwd_q[1]); gj_hip_free(e->d_huff_lut); gj_hip_free(e->d_result);
-    gj_hip_free(e->d_temp); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
+    gj_hip_free(e->d_temp); gj_hip_free(e->d_scan_partial); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
     gj_hip_free(e->coder.d_raw_own); gj_hip_free(e->coder.d_planes); gj_hip_free(e->coder.d_coefs);
     gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header);
     if (e->out_buf_pinned) gj_hip_host_free(e->out_buf); else free(e->out_buf);
@@ -152,6 +154,12 @@ static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_par
     if (gj_ensure_device_buffer((void**)&c->d_planes, &c->d_planes_cap, g->data_size) != 0) return -1;
     if (gj_hip_memset(c->d_planes, 0, g->data_size, c->stream) != 0) return -1;
     if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_TEMP_BYTES_PER_BLOCK + 256) != 0) return -1;
+    {
+        const size_t need = (((size_t)g->segment_count + 1023) / 1024 + 1) * sizeof(uint64_t);
+        const size_t had = e->d_scan_partial_cap;
+        if (gj_ensure_device_buffer((void**)&e->d_scan_partial, &e->d_scan_partial_cap, need) != 0) return -1;
+        if (e->d_scan_partial_cap != had && gj_hip_memset(e->d_scan_partial, 0, e->d_scan_partial_cap, c->stream) != 0) return -1;
+    }
     if (gj_ensure_device_buffer((void**)&e->d_seg, &e->d_seg_cap, ((size_t)g->segment_count * 3 + 16 + ((size_t)g->segment_count + 1023) / 1024) * sizeof(uint32_t)) != 0) return -1;
     if (gj_write_scan_headers(&e->scan_hdrs, g, p) != 0) return -1;
     if (gj_ensure_device_buffer((void**)&e->d_scan_hdr, &e->d_scan_hdr_cap, e->scan_hdrs.size + 16) != 0) return -1;
@@ -243,6 +251,9 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.d_jpeg = e->d_jpeg;
     job.jpeg_capacity = e->d_jpeg_cap;
     job.d_result = e->d_result;
+    job.d_scan_partial = e->d_scan_partial;
+    if (++e->epoch == 0) e->epoch = 1;
+    job.epoch = e->epoch;
     job.d_scan_hdr = e->d_scan_hdr;
     memcpy(job.scan_hdr_offset, e->scan_hdrs.offset, sizeof job.scan_hdr_offset);
     memcpy(job.scan_info_payload, e->scan_hdrs.info_payload, sizeof job.scan_info_payload);

@@ -116,6 +116,8 @@ typedef struct gj_enc_job {
     uint8_t* d_jpeg;               /* finished stream */
     uint64_t jpeg_capacity;
     uint32_t* d_result;            /* [0] total JPEG size, [1] overflow flag */
+    uint64_t* d_scan_partial;      /* [ceil(segment_count / 1024)] epoch-tagged workgroup totals of the offset scan; zero at allocation */
+    uint32_t epoch;                /* differs from the previous call's (and is never 0) */
     const uint8_t* d_scan_hdr;     /* scan headers back to back (APP13 placeholders zeroed + SOS) */
     uint32_t scan_hdr_offset[GJ_MAX_COMP + 1];
     uint32_t scan_info_payload[GJ_MAX_COMP]; /* offset inside scan header of the first APP13 payload, 0 = none */

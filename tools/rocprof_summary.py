@@ -1,24 +1,70 @@
 #!/usr/bin/env python3
-"""Turn a rocprofv3 --kernel-trace --stats results database into the short per-kernel table kept under profiles/."""
-import sqlite3
+"""Condense the rocprofv3 CSV output of tools/profile.sh into the short tables kept under profiles/.
+
+usage: rocprof_summary.py <dir with prof_stats/ prof_fetch/ prof_write/> <tag>
+writes <dir>/<tag>_kernel_stats.txt and <dir>/<tag>_hbm_traffic.txt (copy them to profiles/)."""
+import csv
+import glob
+import os
 import sys
+from collections import defaultdict
 
 
-def main(db_path, out_path, note=""):
-    db = sqlite3.connect(db_path)
-    rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    with open(out_path, "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats summary ({db_path.split('/')[-1]})\n")
-        if note:
-            f.write(f"# {note}\n")
-        f.write("# durations in microseconds\n")
-        f.write(f"{'kernel':<72} {'calls':>6} {'total_us':>12} {'avg_us':>10} {'pct':>6}\n")
-        for name, calls, total, avg, pct in rows:
-            short = name.split("(")[0].replace("void ", "")
-            if len(short) > 70:
-                short = short[:67] + "..."
-            f.write(f"{short:<72} {calls:>6} {total:>12.1f} {avg:>10.2f} {pct:>6.2f}\n")
+def find(d, suffix):
+    f = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    return f[0] if f else None
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    return n if len(n) <= 70 else n[:67] + "..."
+
+
+def kernel_stats(d, out, note):
+    f = find(os.path.join(d, "prof_stats"), "kernel_stats.csv")
+    if not f:
+        print("no kernel_stats.csv under", d)
+        return
+    rows = list(csv.DictReader(open(f)))
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats summary\n# " + note + "\n# durations in microseconds\n")
+        o.write(f"{'kernel':<72} {'calls':>6} {'total_us':>12} {'avg_us':>10} {'pct':>6}\n")
+        for r in rows:
+            o.write(f"{short(r['Name']):<72} {int(r['Calls']):>6} {float(r['TotalDurationNs']) / 1e3:>12.1f} "
+                    f"{float(r['AverageNs']) / 1e3:>10.2f} {float(r['Percentage']):>6.2f}\n")
+    print(open(out).read())
+
+
+def counter_table(d, sub, counter):
+    f = find(os.path.join(d, sub), "counter_collection.csv")
+    acc = defaultdict(lambda: [0, 0.0])
+    if not f:
+        return acc
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != counter:
+            continue
+        a = acc[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return acc
+
+
+def traffic(d, out, note):
+    fe = counter_table(d, "prof_fetch", "FETCH_SIZE")
+    wr = counter_table(d, "prof_write", "WRITE_SIZE")
+    with open(out, "w") as o:
+        o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per-dispatch averages, raw counter values in KiB\n")
+        o.write("# " + note + "\n")
+        o.write(f"{'kernel':<72} {'disp':>5} {'FETCH_SIZE_avg':>15} {'WRITE_SIZE_avg':>15}\n")
+        for k in sorted(set(fe) | set(wr), key=lambda k: -(fe[k][1] + wr[k][1])):
+            nf, sf = fe[k]
+            nw, sw = wr[k]
+            o.write(f"{k:<72} {max(nf, nw):>5} {sf / nf if nf else 0:>15.1f} {sw / nw if nw else 0:>15.1f}\n")
+    print(open(out).read())
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], " ".join(sys.argv[3:]))
+    d, tag = sys.argv[1], sys.argv[2]
+    note = " ".join(sys.argv[3:]) or "cmd: see tools/profile.sh (python bench.py, 8K RGB q75 natural pattern)"
+    kernel_stats(d, os.path.join(d, tag + "_kernel_stats.txt"), note)
+    traffic(d, os.path.join(d, tag + "_hbm_traffic.txt"), note)

@@ -183,6 +183,103 @@ __device__ __forceinline__ void gj_color_transform(int from, int to, int& a, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same integer colour transforms evaluated in fp32, two pixels at a time (v_pk_fma_f32), for the fused kernels.
+//
+// Reference arithmetic (src/gpujpeg_colorspace.h:64-102): out_k = clamp(((sum_j m_kj * c'_j + 128) >> 8) + b_k), c' = c*256/255
+// (= c + (c == 255)). Every quantity is an integer below 2^18, so with the matrix pre-divided by 256 all products and
+// partial sums are multiples of 1/512 below 2^11: exact in fp32, in any order. floor(x / 256) equals
+// rint((x - 127.5) / 256) for integer x (the fraction is never a tie), and v_cvt_pk_u8_f32 rounds to nearest even
+// and saturates to 0..255 -- so "shift, add offset, clamp" is the conversion instruction applied to
+//     sum_j (m_kj / 256) * c'_j + b_k + 0.5 / 256 .
+// The functions return that sum; the caller converts. Checked against the integer path for all 2^24 inputs per matrix
+// on the device (tests/test_gpu_parity.py::test_exhaustive_colour_transform_fused).
+// ------------------------------------------------------------------------------------------------
+typedef float gj_f2 __attribute__((ext_vector_type(2)));
+
+// byte k of a dword as float: the AMDGPU back end selects v_cvt_f32_ubyte<k> for this pattern
+template <int K> __device__ __forceinline__ float gj_ubyte_f(uint32_t w) { return (float)((w >> (8 * K)) & 0xFFu); }
+
+// c * 256 / 255 for c in [-254, 255]: c + (c == 255)
+__device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
+{
+    return __builtin_elementwise_max(v, __builtin_elementwise_fma(v, (gj_f2)256.0f, (gj_f2)-65024.0f));
+}
+
+__device__ __forceinline__ void gj_matrix_to_f(gj_f2& c0, gj_f2& c1, gj_f2& c2, const int m0, const int m1, const int m2, const int m3, const int m4,
+                                               const int m5, const int m6, const int m7, const int m8, const int b0, const int b1, const int b2)
+{
+    const float s = 1.0f / 256.0f, h = 0.5f / 256.0f;
+    const gj_f2 r0 = gj_scale256_f(c0), r1 = gj_scale256_f(c1), r2 = gj_scale256_f(c2);
+    c0 = __builtin_elementwise_fma((gj_f2)(m0 * s), r0, __builtin_elementwise_fma((gj_f2)(m1 * s), r1, __builtin_elementwise_fma((gj_f2)(m2 * s), r2, (gj_f2)(b0 + h))));
+    c1 = __builtin_elementwise_fma((gj_f2)(m3 * s), r0, __builtin_elementwise_fma((gj_f2)(m4 * s), r1, __builtin_elementwise_fma((gj_f2)(m5 * s), r2, (gj_f2)(b1 + h))));
+    c2 = __builtin_elementwise_fma((gj_f2)(m6 * s), r0, __builtin_elementwise_fma((gj_f2)(m7 * s), r1, __builtin_elementwise_fma((gj_f2)(m8 * s), r2, (gj_f2)(b2 + h))));
+}
+
+__device__ __forceinline__ void gj_matrix_from_f(gj_f2& c0, gj_f2& c1, gj_f2& c2, const int m0, const int m1, const int m2, const int m3,
+                                                 const int m4, const int m5, const int m6, const int m7, const int m8, const int b0, const int b1,
+                                                 const int b2)
+{
+    const float s = 1.0f / 256.0f, h = 0.5f / 256.0f;
+    const gj_f2 r0 = gj_scale256_f(c0 - (gj_f2)(float)b0), r1 = gj_scale256_f(c1 - (gj_f2)(float)b1), r2 = gj_scale256_f(c2 - (gj_f2)(float)b2);
+    c0 = __builtin_elementwise_fma((gj_f2)(m0 * s), r0, __builtin_elementwise_fma((gj_f2)(m1 * s), r1, __builtin_elementwise_fma((gj_f2)(m2 * s), r2, (gj_f2)h)));
+    c1 = __builtin_elementwise_fma((gj_f2)(m3 * s), r0, __builtin_elementwise_fma((gj_f2)(m4 * s), r1, __builtin_elementwise_fma((gj_f2)(m5 * s), r2, (gj_f2)h)));
+    c2 = __builtin_elementwise_fma((gj_f2)(m6 * s), r0, __builtin_elementwise_fma((gj_f2)(m7 * s), r1, __builtin_elementwise_fma((gj_f2)(m8 * s), r2, (gj_f2)h)));
+}
+
+// compile-time colour transform of the fused kernels (the same matrices as gj_rgb_to / gj_to_rgb)
+template <int CS_FROM, int CS_TO>
+__device__ __forceinline__ void gj_color_f(gj_f2& a, gj_f2& b, gj_f2& c)
+{
+    if (CS_FROM == CS_TO || CS_FROM == GJ_CS_NONE || CS_TO == GJ_CS_NONE) return;
+    if (CS_FROM == GJ_CS_RGB) {
+        if (CS_TO == GJ_CS_BT601) gj_matrix_to_f(a, b, c, 66, 129, 25, -38, -74, 112, 112, -94, -18, 16, 128, 128);
+        if (CS_TO == GJ_CS_BT601_256) gj_matrix_to_f(a, b, c, 77, 150, 29, -43, -85, 128, 128, -107, -21, 0, 128, 128);
+        if (CS_TO == GJ_CS_BT709) gj_matrix_to_f(a, b, c, 47, 157, 16, -26, -87, 112, 112, -102, -10, 16, 128, 128);
+        if (CS_TO == GJ_CS_YUV) gj_matrix_to_f(a, b, c, 77, 150, 29, -38, -74, 112, 157, -132, -26, 0, 128, 128);
+    } else if (CS_TO == GJ_CS_RGB) {
+        if (CS_FROM == GJ_CS_BT601) gj_matrix_from_f(a, b, c, 298, 0, 409, 298, -100, -208, 298, 516, 0, 16, 128, 128);
+        if (CS_FROM == GJ_CS_BT601_256) gj_matrix_from_f(a, b, c, 256, 0, 359, 256, -88, -183, 256, 454, 0, 0, 128, 128);
+        if (CS_FROM == GJ_CS_BT709) gj_matrix_from_f(a, b, c, 298, 0, 459, 298, -55, -136, 298, 541, 0, 16, 128, 128);
+        if (CS_FROM == GJ_CS_YUV) gj_matrix_from_f(a, b, c, 256, 0, 292, 256, -101, -149, 256, 520, 0, 0, 128, 128);
+    }
+}
+
+// byte `i` (compile-time) of a 24-byte row held in six dwords, as float
+template <int I>
+__device__ __forceinline__ float gj_row_byte_f(const uint32_t (&px)[6])
+{
+    const uint32_t w = px[I >> 2];
+    return (I & 3) == 0 ? gj_ubyte_f<0>(w) : (I & 3) == 1 ? gj_ubyte_f<1>(w)
+         : (I & 3) == 2 ? gj_ubyte_f<2>(w) : gj_ubyte_f<3>(w);
+}
+
+// One row of a packed 4:4:4 block: 8 pixels x 3 bytes -> the row of each of the three component blocks (2 dwords each)
+template <int CS_FROM, int CS_TO, int X>
+__device__ __forceinline__ void gj_color_row_pair(const uint32_t (&px)[6], uint32_t (&o0)[2], uint32_t (&o1)[2], uint32_t (&o2)[2])
+{
+    gj_f2 a = gj_f2{gj_row_byte_f<3 * X>(px), gj_row_byte_f<3 * X + 3>(px)};
+    gj_f2 b = gj_f2{gj_row_byte_f<3 * X + 1>(px), gj_row_byte_f<3 * X + 4>(px)};
+    gj_f2 c = gj_f2{gj_row_byte_f<3 * X + 2>(px), gj_row_byte_f<3 * X + 5>(px)};
+    gj_color_f<CS_FROM, CS_TO>(a, b, c);
+    o0[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a.x, X & 3, o0[X >> 2]);
+    o0[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a.y, (X + 1) & 3, o0[X >> 2]);
+    o1[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(b.x, X & 3, o1[X >> 2]);
+    o1[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(b.y, (X + 1) & 3, o1[X >> 2]);
+    o2[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c.x, X & 3, o2[X >> 2]);
+    o2[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c.y, (X + 1) & 3, o2[X >> 2]);
+}
+
+template <int CS_FROM, int CS_TO>
+__device__ __forceinline__ void gj_color_row(const uint32_t (&px)[6], uint32_t (&o0)[2], uint32_t (&o1)[2], uint32_t (&o2)[2])
+{
+    o0[0] = o0[1] = o1[0] = o1[1] = o2[0] = o2[1] = 0;
+    gj_color_row_pair<CS_FROM, CS_TO, 0>(px, o0, o1, o2);
+    gj_color_row_pair<CS_FROM, CS_TO, 2>(px, o0, o1, o2);
+    gj_color_row_pair<CS_FROM, CS_TO, 4>(px, o0, o1, o2);
+    gj_color_row_pair<CS_FROM, CS_TO, 6>(px, o0, o1, o2);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 8-point forward DCT (AAN) -- src/gpujpeg_dct_gpu.cu:121-163. Built with -ffp-contract=off: the
 // fused operations are exactly the explicit fma calls (fusion map: DESIGN.md section 3).
 //
@@ -192,7 +289,6 @@ __device__ __forceinline__ void gj_color_transform(int from, int to, int& a, int
 // re-paired (v_pk_mov_b32) into vertically adjacent ones for the row pass; results are bit-identical to the
 // scalar sequence.
 // ------------------------------------------------------------------------------------------------
-typedef float gj_f2 __attribute__((ext_vector_type(2)));
 
 template <typename T> __device__ __forceinline__ T gj_fma(T a, T b, T c);
 template <> __device__ __forceinline__ float gj_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -233,10 +329,10 @@ __device__ __forceinline__ void gj_fdct_quant_pk(const uint32_t (&px)[16], const
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t a = px[2 * r], b = px[2 * r + 1];
-        D[r][0] = gj_f2{(float)(a & 0xFF), (float)((a >> 8) & 0xFF)};
-        D[r][1] = gj_f2{(float)((a >> 16) & 0xFF), (float)(a >> 24)};
-        D[r][2] = gj_f2{(float)(b & 0xFF), (float)((b >> 8) & 0xFF)};
-        D[r][3] = gj_f2{(float)((b >> 16) & 0xFF), (float)(b >> 24)};
+        D[r][0] = gj_f2{gj_ubyte_f<0>(a), gj_ubyte_f<1>(a)};
+        D[r][1] = gj_f2{gj_ubyte_f<2>(a), gj_ubyte_f<3>(a)};
+        D[r][2] = gj_f2{gj_ubyte_f<0>(b), gj_ubyte_f<1>(b)};
+        D[r][3] = gj_f2{gj_ubyte_f<2>(b), gj_ubyte_f<3>(b)};
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) // columns first, level shift folded into the DC term

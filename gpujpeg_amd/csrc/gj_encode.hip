@@ -138,8 +138,94 @@ __device__ __forceinline__ void gj_color_static(int& a, int& b, int& c)
     else if (CS_TO == GJ_CS_RGB) gj_to_rgb(CS_FROM, a, b, c);
 }
 
+// Pixels of one 8x8 block position (packed 4:4:4, 3 B/pixel) -> the three component blocks, one byte per sample.
+// All 24 loads are issued before the first use (the wave waits for HBM once); the colour transform runs in fp32 on
+// pixel pairs (gj_color_row). Samples outside the image are zero *component* values (src/gpujpeg_common.c:941-944).
 template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256, 3) void k_fused_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, int16_t* __restrict__ coefs,
+__device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by,
+                                                  const bool exists, uint32_t (&pk)[3][16])
+{
+    const size_t pitch = (size_t)g.width * 3 + g.width_padding;
+    const bool interior = exists && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
+    const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
+    uint32_t px[8][6]; // 8 rows x 24 bytes
+    if (interior && aligned) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint2* p = reinterpret_cast<const uint2*>(raw + (size_t)(by * 8 + r) * pitch + (size_t)bx * 24);
+            const uint2 a = p[0], b = p[1], c = p[2];
+            px[r][0] = a.x; px[r][1] = a.y; px[r][2] = b.x; px[r][3] = b.y; px[r][4] = c.x; px[r][5] = c.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned y = by * 8 + r;
+#pragma unroll
+            for (int w = 0; w < 6; w++) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const unsigned byte = w * 4 + b, x = bx * 8 + byte / 3;
+                    if (exists && x < (unsigned)g.width && y < (unsigned)g.height) d |= (uint32_t)raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] << (8 * b);
+                }
+                px[r][w] = d;
+            }
+        }
+    }
+    // byte masks of the samples that lie inside the image (all ones for interior blocks)
+    const int cols = exists ? min(8, max(0, g.width - (int)(bx * 8))) : 0, rows = exists ? min(8, max(0, g.height - (int)(by * 8))) : 0;
+    const uint32_t m_lo = cols >= 4 ? 0xFFFFFFFFu : (1u << (8 * cols)) - 1u;
+    const uint32_t m_hi = cols >= 8 ? 0xFFFFFFFFu : cols > 4 ? (1u << (8 * (cols - 4))) - 1u : 0u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t o0[2], o1[2], o2[2];
+        gj_color_row<CS_FROM, CS_TO>(px[r], o0, o1, o2);
+        if (!interior) {
+            const uint32_t lo = r < rows ? m_lo : 0u, hi = r < rows ? m_hi : 0u;
+            o0[0] &= lo; o0[1] &= hi; o1[0] &= lo; o1[1] &= hi; o2[0] &= lo; o2[1] &= hi;
+        }
+        pk[0][r * 2] = o0[0]; pk[0][r * 2 + 1] = o0[1];
+        pk[1][r * 2] = o1[0]; pk[1][r * 2 + 1] = o1[1];
+        pk[2][r * 2] = o2[0]; pk[2][r * 2 + 1] = o2[1];
+        // pin the colour transform of this row here (keeps the raw pixels from staying alive into the transforms)
+        asm volatile("" : "+v"(pk[0][r * 2]), "+v"(pk[0][r * 2 + 1]), "+v"(pk[1][r * 2]), "+v"(pk[1][r * 2 + 1]), "+v"(pk[2][r * 2]), "+v"(pk[2][r * 2 + 1]));
+    }
+}
+
+// test hook: the colour transform of the fused kernels applied to rows of 8 packed pixels -> three planes
+template <int CS_FROM, int CS_TO>
+__global__ __launch_bounds__(256) void k_test_color444(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const uint32_t nrows)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nrows) return;
+    uint32_t px[6], o0[2], o1[2], o2[2];
+    const uint2* p = reinterpret_cast<const uint2*>(in + (size_t)i * 24);
+    const uint2 a = p[0], b = p[1], c = p[2];
+    px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y;
+    gj_color_row<CS_FROM, CS_TO>(px, o0, o1, o2);
+    const size_t plane = (size_t)nrows * 8;
+    *reinterpret_cast<uint2*>(out + (size_t)i * 8) = make_uint2(o0[0], o0[1]);
+    *reinterpret_cast<uint2*>(out + plane + (size_t)i * 8) = make_uint2(o1[0], o1[1]);
+    *reinterpret_cast<uint2*>(out + 2 * plane + (size_t)i * 8) = make_uint2(o2[0], o2[1]);
+}
+
+extern "C" int gj_hip_test_color444(int cs_from, int cs_to, const uint8_t* d_in, uint8_t* d_out, uint32_t nrows, gj_stream_t stream)
+{
+    void (*k)(const uint8_t*, uint8_t*, uint32_t) = nullptr;
+    if (cs_from == GJ_CS_RGB && cs_to == GJ_CS_BT601_256) k = k_test_color444<GJ_CS_RGB, GJ_CS_BT601_256>;
+    if (cs_from == GJ_CS_RGB && cs_to == GJ_CS_BT601) k = k_test_color444<GJ_CS_RGB, GJ_CS_BT601>;
+    if (cs_from == GJ_CS_RGB && cs_to == GJ_CS_BT709) k = k_test_color444<GJ_CS_RGB, GJ_CS_BT709>;
+    if (cs_from == GJ_CS_BT601_256 && cs_to == GJ_CS_RGB) k = k_test_color444<GJ_CS_BT601_256, GJ_CS_RGB>;
+    if (cs_from == GJ_CS_BT601 && cs_to == GJ_CS_RGB) k = k_test_color444<GJ_CS_BT601, GJ_CS_RGB>;
+    if (cs_from == GJ_CS_BT709 && cs_to == GJ_CS_RGB) k = k_test_color444<GJ_CS_BT709, GJ_CS_RGB>;
+    if (cs_from == cs_to) k = k_test_color444<GJ_CS_NONE, GJ_CS_NONE>;
+    if (!k) return -1;
+    hipLaunchKernelGGL(k, dim3((nrows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, nrows);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int CS_FROM, int CS_TO>
+__global__ __launch_bounds__(256, 2) void k_fused_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, int16_t* __restrict__ coefs,
                                                          const float* __restrict__ q_luma, const float* __restrict__ q_chroma, const int flags)
 {
     __shared__ __attribute__((aligned(8))) float s_q[3][64]; // forward tables: read as VGPR pairs for v_pk_mul_f32
@@ -150,51 +236,8 @@ __global__ __launch_bounds__(256, 3) void k_fused_rgb444(const gj_geom g, const 
     const unsigned lb = blockIdx.x * 256u + threadIdx.x;
     if (lb >= nb) return;
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
-    const size_t pitch = (size_t)g.width * 3 + g.width_padding;
-    const bool interior = (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
-    const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
-
     uint32_t pk[3][16]; // the three component blocks, one byte per sample
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint32_t px[6]; // 24 bytes = 8 pixels of this row
-        if (interior && aligned) {
-            const uint2* p = reinterpret_cast<const uint2*>(raw + (size_t)(by * 8 + r) * pitch + (size_t)bx * 24);
-            const uint2 a = p[0], b = p[1], c = p[2];
-            px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y;
-        } else {
-            const unsigned y = by * 8 + r;
-#pragma unroll
-            for (int w = 0; w < 6; w++) {
-                uint32_t d = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const unsigned byte = w * 4 + b, x = bx * 8 + byte / 3;
-                    if (x < (unsigned)g.width && y < (unsigned)g.height) d |= (uint32_t)raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] << (8 * b);
-                }
-                px[w] = d;
-            }
-        }
-        uint32_t o0[2] = {0, 0}, o1[2] = {0, 0}, o2[2] = {0, 0};
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const int b0 = x * 3, b1 = x * 3 + 1, b2 = x * 3 + 2;
-            int c0 = (px[b0 >> 2] >> ((b0 & 3) * 8)) & 0xFF;
-            int c1 = (px[b1 >> 2] >> ((b1 & 3) * 8)) & 0xFF;
-            int c2 = (px[b2 >> 2] >> ((b2 & 3) * 8)) & 0xFF;
-            gj_color_static<CS_FROM, CS_TO>(c0, c1, c2);
-            // samples outside the image are zero *component* values (src/gpujpeg_common.c:941-944)
-            if (!interior && (bx * 8 + x >= (unsigned)g.width || by * 8 + r >= (unsigned)g.height)) c0 = c1 = c2 = 0;
-            o0[x >> 2] |= (uint32_t)c0 << ((x & 3) * 8);
-            o1[x >> 2] |= (uint32_t)c1 << ((x & 3) * 8);
-            o2[x >> 2] |= (uint32_t)c2 << ((x & 3) * 8);
-        }
-        pk[0][r * 2] = o0[0]; pk[0][r * 2 + 1] = o0[1];
-        pk[1][r * 2] = o1[0]; pk[1][r * 2 + 1] = o1[1];
-        pk[2][r * 2] = o2[0]; pk[2][r * 2 + 1] = o2[1];
-        // pin the colour transform of this row here (keeps the raw pixels from staying alive into the transforms)
-        asm volatile("" : "+v"(pk[0][r * 2]), "+v"(pk[0][r * 2 + 1]), "+v"(pk[1][r * 2]), "+v"(pk[1][r * 2 + 1]), "+v"(pk[2][r * 2]), "+v"(pk[2][r * 2 + 1]));
-    }
+    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, true, pk);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         uint32_t q[32];
@@ -517,8 +560,16 @@ template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                          uint32_t* __restrict__ seg_ff)
+                                                          uint32_t* __restrict__ seg_ff, unsigned long long* __restrict__ prof)
 {
+    unsigned long long t_prof = prof ? wall_clock64() : 0;
+#define GJ_PROF(slot)                                                                            \
+    if (prof) {                                                                                  \
+        __syncthreads();                                                                         \
+        const unsigned long long now = wall_clock64();                                           \
+        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
+        t_prof = now;                                                                            \
+    }
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
     __shared__ uint32_t s_coef[32 * 256];
     __shared__ uint32_t s_bits[GJ_HUFF_CAP_DW];
@@ -545,51 +596,12 @@ __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const
     const int seg_count_c = k0.segment_count;
     const bool seg_in_tile = i < spt && seg0 + i < seg_count_c; // lane i keeps the books of local segment i
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
-    const size_t pitch = (size_t)g.width * 3 + g.width_padding;
-    const bool interior = active && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
-    const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
 
-    // ---- pixels -> three byte-packed component blocks (as k_fused_rgb444)
+    // ---- pixels -> three byte-packed component blocks
     uint32_t pk[3][16];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        uint32_t px[6];
-        if (interior && aligned) {
-            const uint2* p = reinterpret_cast<const uint2*>(raw + (size_t)(by * 8 + r) * pitch + (size_t)bx * 24);
-            const uint2 a = p[0], b = p[1], c = p[2];
-            px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y;
-        } else {
-            const unsigned y = by * 8 + r;
-#pragma unroll
-            for (int w = 0; w < 6; w++) {
-                uint32_t d = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const unsigned byte = w * 4 + b, x = bx * 8 + byte / 3;
-                    if (active && x < (unsigned)g.width && y < (unsigned)g.height) d |= (uint32_t)raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] << (8 * b);
-                }
-                px[w] = d;
-            }
-        }
-        uint32_t o0[2] = {0, 0}, o1[2] = {0, 0}, o2[2] = {0, 0};
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const int b0 = x * 3, b1 = x * 3 + 1, b2 = x * 3 + 2;
-            int c0 = (px[b0 >> 2] >> ((b0 & 3) * 8)) & 0xFF;
-            int c1 = (px[b1 >> 2] >> ((b1 & 3) * 8)) & 0xFF;
-            int c2 = (px[b2 >> 2] >> ((b2 & 3) * 8)) & 0xFF;
-            gj_color_static<CS_FROM, CS_TO>(c0, c1, c2);
-            if (!interior && (bx * 8 + x >= (unsigned)g.width || by * 8 + r >= (unsigned)g.height)) c0 = c1 = c2 = 0;
-            o0[x >> 2] |= (uint32_t)c0 << ((x & 3) * 8);
-            o1[x >> 2] |= (uint32_t)c1 << ((x & 3) * 8);
-            o2[x >> 2] |= (uint32_t)c2 << ((x & 3) * 8);
-        }
-        pk[0][r * 2] = o0[0]; pk[0][r * 2 + 1] = o0[1];
-        pk[1][r * 2] = o1[0]; pk[1][r * 2 + 1] = o1[1];
-        pk[2][r * 2] = o2[0]; pk[2][r * 2 + 1] = o2[1];
-        asm volatile("" : "+v"(pk[0][r * 2]), "+v"(pk[0][r * 2 + 1]), "+v"(pk[1][r * 2]), "+v"(pk[1][r * 2 + 1]), "+v"(pk[2][r * 2]), "+v"(pk[2][r * 2 + 1]));
-    }
+    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, active, pk);
     __syncthreads(); // tables are in LDS
+    GJ_PROF(0) // pixels + colour
 
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -622,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const
         s_dc[i] = dc;
         s_segff[i] = 0;
         __syncthreads();
+        GJ_PROF(1) // transform + zig-zag park
 
         // ---- DC prediction + pass A (lengths)
         const int table = kc.type;
@@ -633,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const
             dc_diff = dc - (k == 0 ? 0 : s_dc[i - 1]);
             len = gj_code_block<false>(s_coef, s_lut, i, dc_diff, mask, table, 0, e, nullptr, 0, 0);
         }
+        GJ_PROF(2) // pass A
         // ---- bit positions
         uint32_t total_bits;
         const uint32_t incl = gj_wg256_incl_scan(len, s_tmp, &total_bits);
@@ -661,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const
         }
         // first block of every local segment in coding order (addresses d_temp)
         const uint64_t seg_first_block = kc.data_offset / 64;
+        GJ_PROF(3) // scans
 
         // ---- pass B window by window, then drain each window to HBM
         for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_HUFF_CAP_DW) {
@@ -675,6 +690,7 @@ __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const
                 if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
             }
             __syncthreads();
+            GJ_PROF(4) // pass B
             for (uint32_t d = wbase + i; d < wend; d += 256) {
                 int lo = 0, hi = spt; // local segment that owns dword d
                 while (hi - lo > 1) {
@@ -703,7 +719,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const
             seg_bytes[kc.first_segment + seg0 + i] = (s_segbits[i] + 7u) >> 3;
             seg_ff[kc.first_segment + seg0 + i] = s_segff[i];
         }
+        GJ_PROF(5) // drain
     }
+#undef GJ_PROF
 }
 
 // ================================================================================================
@@ -865,7 +883,7 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // Launcher
 // ================================================================================================
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*, int);
-typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*);
+typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, unsigned long long*);
 
 // fused kernel for this configuration, or nullptr when the generic path has to be used
 static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
@@ -911,7 +929,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
-                           job->d_seg_bytes, job->d_seg_ff);
+                           job->d_seg_bytes, job->d_seg_ff, (unsigned long long*)job->d_prof);
     } else {
     if (fused) {
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);

@@ -118,6 +118,7 @@ typedef struct gj_enc_job {
     uint32_t* d_result;            /* [0] total JPEG size, [1] overflow flag */
     uint64_t* d_scan_partial;      /* [ceil(segment_count / 1024)] epoch-tagged workgroup totals of the offset scan; zero at allocation */
     uint32_t epoch;                /* differs from the previous call's (and is never 0) */
+    uint64_t* d_prof;              /* optional [8] phase clock accumulators of k_encode_rgb444 (developer aid, GJ_ENC_PROF=1) */
     const uint8_t* d_scan_hdr;     /* scan headers back to back (APP13 placeholders zeroed + SOS) */
     uint32_t scan_hdr_offset[GJ_MAX_COMP + 1];
     uint32_t scan_info_payload[GJ_MAX_COMP]; /* offset inside scan header of the first APP13 payload, 0 = none */
@@ -131,6 +132,10 @@ typedef struct gj_enc_job {
  * 5 after k_assemble (+ segment info) */
 #define GJ_ENC_EVENTS 6
 GJ_HIP_API int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS]);
+
+/* test hook: the fp32 colour transform of the fused kernels on `nrows` rows of 8 packed pixels (24 B) -> three planes of
+ * nrows * 8 bytes in d_out; colour spaces use the kernels' GJ_CS_* numbering (= the public enum). -1: pair not instantiated */
+GJ_HIP_API int gj_hip_test_color444(int cs_from, int cs_to, const uint8_t* d_in, uint8_t* d_out, uint32_t nrows, gj_stream_t stream);
 
 /* ------------------------------------------------------------------ decoder */
 typedef struct gj_dec_job {

@@ -91,10 +91,34 @@ def test_exhaustive_colour_transform(O, G, gpu_lib):
         enc.encode(p, pi, raw)
         assert np.array_equal(enc.planes(img.data_size), O.preprocess(img, raw)), csi
         enc.set_fused(True)
+        enc.keep_coefficients()
         j2 = enc.encode(p, pi, raw)
         assert np.array_equal(enc.coefficients(img.data_size), O.fdct_quant(img, O.preprocess(img, raw))), csi
         enc.close()
         del j2
+
+
+@pytest.mark.parametrize("cs_from,cs_to", [(1, 3), (1, 2), (1, 4), (3, 1), (2, 1), (4, 1), (1, 1)])
+def test_exhaustive_colour_transform_fused(O, G, gpu_lib, cs_from, cs_to):
+    """The fused kernels evaluate the integer colour transforms of src/gpujpeg_colorspace.h in fp32 (v_pk_fma_f32 +
+    v_cvt_pk_u8_f32): all 2^24 input triples of every instantiated matrix must give the oracle's bytes."""
+    import torch
+    n = 1 << 24
+    v = np.arange(n, dtype=np.uint32)
+    triples = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], -1).astype(np.uint8)
+    img = oracle_image(O, ("x", 4096, 4096, 1, cs_from, 90, 36, 0, None, cs_to))  # the oracle's preprocessor = the transform per pixel
+    want = O.preprocess(img, triples.reshape(-1)).reshape(3, n).T
+    d_in = torch.from_numpy(triples.reshape(-1)).cuda()
+    d_out = torch.empty(3 * n, dtype=torch.uint8, device="cuda")
+    fn = gpu_lib.L.gj_hip_test_color444
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    assert fn(cs_from, cs_to, d_in.data_ptr(), d_out.data_ptr(), n // 8, None) == 0
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().reshape(3, n)
+    for c in range(3):
+        bad = np.nonzero(got[c] != want[:, c])[0]
+        assert bad.size == 0, (c, bad[:5], triples[bad[:5]], got[c][bad[:5]], want[bad[:5], c])
 
 
 @pytest.mark.parametrize("name,w,h,restart", [("hd_config1", 1920, 1080, 24), ("4k", 3840, 2160, -1), ("8k", 7680, 4320, -1)])

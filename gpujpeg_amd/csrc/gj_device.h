@@ -323,7 +323,10 @@ __device__ __forceinline__ void gj_fdct8(T& x0, T& x1, T& x2, T& x3, T& x4, T& x
 // out: the quantised coefficients in natural order, two int16 per dword = the layout of the coefficient planes
 // (src/gpujpeg_dct_gpu.cu:246-294). rintf(coef * q) is taken with the 1.5 * 2^23 trick: adding it rounds to nearest even
 // exactly like v_rndne_f32 and leaves the integer in the low mantissa bits.
-__device__ __forceinline__ void gj_fdct_quant_pk(const uint32_t (&px)[16], const float* __restrict__ q, uint32_t (&out)[32])
+// TO_LDS: the rows go to LDS as they are finished (lds_col[dword * 256], the [dword][lane] layout of the coding kernels) instead
+// of accumulating in 32 more VGPRs while the 64 of the block are still alive.
+template <bool TO_LDS = false>
+__device__ __forceinline__ void gj_fdct_quant_pk(const uint32_t (&px)[16], const float* __restrict__ q, uint32_t (&out)[32], uint32_t* lds_col = nullptr)
 {
     gj_f2 D[8][4];
 #pragma unroll
@@ -358,8 +361,15 @@ __device__ __forceinline__ void gj_fdct_quant_pk(const uint32_t (&px)[16], const
         }
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            out[(2 * rp) * 4 + m] = __builtin_amdgcn_perm(ux[2 * m + 1], ux[2 * m], 0x05040100u);
-            out[(2 * rp + 1) * 4 + m] = __builtin_amdgcn_perm(uy[2 * m + 1], uy[2 * m], 0x05040100u);
+            const uint32_t e0 = __builtin_amdgcn_perm(ux[2 * m + 1], ux[2 * m], 0x05040100u);
+            const uint32_t e1 = __builtin_amdgcn_perm(uy[2 * m + 1], uy[2 * m], 0x05040100u);
+            if (TO_LDS) {
+                lds_col[((2 * rp) * 4 + m) * 256] = e0;
+                lds_col[((2 * rp + 1) * 4 + m) * 256] = e1;
+            } else {
+                out[(2 * rp) * 4 + m] = e0;
+                out[(2 * rp + 1) * 4 + m] = e1;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
 // k_scan_partial / k_assemble expect. Used for non-interleaved 4:4:4 with 0 < restart interval <= 256 blocks.
 // ================================================================================================
 template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
+__global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
                                                           uint32_t* __restrict__ seg_ff, unsigned long long* __restrict__ prof)
@@ -612,7 +612,9 @@ __global__ __launch_bounds__(256, 2) void k_encode_rgb444(const gj_geom g, const
 #pragma unroll
         for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[c][t]));
         uint32_t n[32];
-        gj_fdct_quant_pk(pk[c], s_q[c], n);
+        gj_fdct_quant_pk<true>(pk[c], s_q[c], n, s_coef + i); // rows park in this lane's LDS column in natural order ...
+#pragma unroll
+        for (int t = 0; t < 32; t++) n[t] = s_coef[t * 256 + i]; // ... and come back once the transform's registers are free
         int dc = 0;
         uint64_t mask = 0;
         if (active) {

@@ -1104,19 +1104,32 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
             break;
         }
         if (status == 0) status = 3; // no EOI seen
-        // rank of the first RSTn of every scan: binary search in the ordered list
-        for (int sc = 0; sc <= scans; sc++) {
-            const uint32_t key = sc < scans ? s_start[sc] : 0xFFFFFFFFu;
-            uint32_t lo = 0, hi = n_rst;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rst_pos[mid] < key) lo = mid + 1; else hi = mid; }
-            s_first[sc] = lo;
-        }
         s_scans = scans;
         if (blockIdx.x == 0) {
             sum->scan_count = (uint32_t)scans;
             sum->status = (uint32_t)status;
             sum->segment_count = n_rst + (uint32_t)scans;
             for (int sc = 0; sc < scans; sc++) { sum->scan_start[sc] = s_start[sc]; sum->scan_end[sc] = s_end[sc]; }
+        }
+    }
+    __syncthreads();
+    {   // rank of the first RSTn of every scan (lower bound in the ordered list): wave sc searches for scan sc with 64 probes
+        // per round, i.e. three dependent loads instead of sixteen
+        const int sc = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (threadIdx.x == 0) s_first[s_scans] = n_rst; // sentinel: everything lies below the end
+        if (sc < s_scans) {
+            const uint32_t key = s_start[sc];
+            uint32_t lo = 0, hi = n_rst;
+            while (lo < hi) {
+                const uint32_t step = (hi - lo + 63u) / 64u;
+                const uint32_t idx = lo + (uint32_t)lane * step;
+                const bool below = idx < hi && rst_pos[idx] < key;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(below)); // the probes are ordered: the first cnt are below the key
+                if (step == 1) { lo += cnt; break; }
+                if (cnt < 64u) hi = min(hi, lo + cnt * step);
+                if (cnt) lo += (cnt - 1u) * step + 1u;
+            }
+            if (lane == 0) s_first[sc] = lo;
         }
     }
     __syncthreads();

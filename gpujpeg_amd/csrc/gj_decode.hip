@@ -822,6 +822,73 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
 }
 
 // ================================================================================================
+// Fused fast path for packed 4:2:2 (UYVY) output without colour transform (BASELINE config 4): one thread per MCU takes
+// its two luminance blocks (256 contiguous bytes), Cb and Cr, transforms them in registers, interleaves the samples with
+// byte permutes and stores 8 rows x 32 B. Replaces k_idct + k_postprocess (one thread per pixel) and the planar round trip.
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void k_idct_fused_uyvy422(const gj_geom g, int16_t* __restrict__ coefs, const float* __restrict__ qtab,
+                                                               uint8_t* __restrict__ raw, const int zero)
+{
+    __shared__ __attribute__((aligned(8))) float s_q[3][64];
+    if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
+    __syncthreads();
+    const gj_comp_geom& kc = g.comp[1];
+    const unsigned nm = (unsigned)(kc.blocks_x * kc.blocks_y);
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= nm) return;
+    const unsigned my = m / (unsigned)kc.blocks_x, mx = m - my * (unsigned)kc.blocks_x;
+    uint32_t pk[4][16];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int c = b < 2 ? 0 : b - 1;
+        const size_t blk = b < 2 ? (size_t)my * g.comp[0].blocks_x + 2 * mx + b : (size_t)m;
+        uint4* p = reinterpret_cast<uint4*>(coefs + g.comp[c].data_offset + blk * 64);
+        uint32_t w[32];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint4 v = p[r];
+            if (zero) p[r] = make_uint4(0, 0, 0, 0);
+            w[r * 4] = v.x; w[r * 4 + 1] = v.y; w[r * 4 + 2] = v.z; w[r * 4 + 3] = v.w;
+        }
+        gj_idct_pk(w, s_q[c], pk[b]);
+#pragma unroll
+        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[b][t])); // one transform at a time
+    }
+    const size_t pitch = (size_t)g.width * 2 + g.width_padding;
+    const bool interior = (mx * 16 + 16 <= (unsigned)g.width) && (my * 8 + 8 <= (unsigned)g.height);
+    const bool aligned = ((pitch | (size_t)raw) & 15) == 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        // UYVY: dword k = U_k | Y_2k << 8 | V_k << 16 | Y_2k+1 << 24
+        uint32_t d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t yy = pk[k >> 2][2 * r + ((k >> 1) & 1)]; // four luminance samples, two of them ours
+            const uint32_t uu = pk[2][2 * r + (k >> 2)], vv = pk[3][2 * r + (k >> 2)];
+            // bytes: U_k from uu byte (k & 3), Y from yy bytes 2(k&1), 2(k&1)+1, V_k from vv byte (k & 3)
+            const uint32_t uv = __builtin_amdgcn_perm(vv, uu, 0x0C040C00u + (uint32_t)(k & 3) * 0x00010001u); // [U_k, 0, V_k, 0]
+            const uint32_t ys = __builtin_amdgcn_perm(0u, yy, (k & 1) ? 0x030C020Cu : 0x010C000Cu);       // [0, Y_2k, 0, Y_2k+1]
+            d[k] = uv | ys;
+        }
+        const unsigned y = my * 8 + r;
+        if (interior && aligned) {
+            uint4* p = reinterpret_cast<uint4*>(raw + (size_t)y * pitch + (size_t)mx * 32);
+            p[0] = make_uint4(d[0], d[1], d[2], d[3]);
+            p[1] = make_uint4(d[4], d[5], d[6], d[7]);
+        } else if (y < (unsigned)g.height) {
+            // the generic store writes chroma only with the even pixel and whole pixels only (k_postprocess)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned x0 = mx * 16 + 2 * k;
+                uint8_t* q = raw + (size_t)y * pitch + (size_t)x0 * 2;
+                if (x0 < (unsigned)g.raw_width) { q[0] = (uint8_t)d[k]; q[1] = (uint8_t)(d[k] >> 8); }
+                if (x0 + 1 < (unsigned)g.raw_width) { q[2] = (uint8_t)(d[k] >> 16); q[3] = (uint8_t)(d[k] >> 24); }
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // Generic postprocessor: one thread per output pixel (src/gpujpeg_postprocessor.cu:193-217 and the
 // stores of src/gpujpeg_preprocessor_common.cuh:118-203).
 // ================================================================================================
@@ -933,6 +1000,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const char* eg = getenv("GJ_DEC_G");     // tuning aids: segments per batch, bytes per sub-sequence
         const char* es = getenv("GJ_DEC_SUB");
         int G = eg ? atoi(eg) : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
+        if (!eg) G = min(G, job->seg_count / 1024); // small frames: rather more, shorter batches than idle CUs (4 per CU)
         G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / g.seg_blocks)));
         const int sub = es ? atoi(es) : GJ_PAR_SUB;
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
@@ -956,7 +1024,16 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
-    if (fused) {
+    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 &&
+                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
+                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
+                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
+                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
+    if (uyvy) {
+        const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);
+        hipLaunchKernelGGL(k_idct_fused_uyvy422, dim3((nm + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+    } else if (fused) {
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
         hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);

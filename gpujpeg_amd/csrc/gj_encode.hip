@@ -247,6 +247,74 @@ __global__ __launch_bounds__(256, 2) void k_fused_rgb444(const gj_geom g, const 
 }
 
 // ================================================================================================
+// Fused fast path for packed 4:2:2 (UYVY, 2 B/pixel) without colour transform (BASELINE config 4): one thread per MCU
+// (16 x 8 pixels = two luminance blocks + Cb + Cr). A wave reads 2 KiB of contiguous bytes per pixel row (2 x 16 B per
+// lane), the de-interleave is byte permutes (12 v_perm_b32 per row), then four packed-fp32 transforms in registers.
+// Replaces k_preprocess (one thread per pixel, byte loads and stores) + k_dct and their planar round trip.
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void k_fused_uyvy422(const gj_geom g, const uint8_t* __restrict__ raw, int16_t* __restrict__ coefs,
+                                                          const float* __restrict__ q_luma, const float* __restrict__ q_chroma)
+{
+    __shared__ __attribute__((aligned(8))) float s_q[2][64];
+    if (threadIdx.x < 128) s_q[threadIdx.x >> 6][threadIdx.x & 63] = (threadIdx.x < 64 ? q_luma : q_chroma)[threadIdx.x & 63];
+    __syncthreads();
+    const gj_comp_geom& kc = g.comp[1];
+    const unsigned nm = (unsigned)(kc.blocks_x * kc.blocks_y); // MCUs = chroma blocks
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= nm) return;
+    const unsigned my = m / (unsigned)kc.blocks_x, mx = m - my * (unsigned)kc.blocks_x;
+    const size_t pitch = (size_t)g.width * 2 + g.width_padding;
+    const bool interior = (mx * 16 + 16 <= (unsigned)g.width) && (my * 8 + 8 <= (unsigned)g.height);
+    const bool aligned = ((pitch | (size_t)raw) & 15) == 0;
+    uint32_t pk[4][16]; // Y0, Y1, Cb, Cr: one byte per sample, row r in [2r], [2r + 1]
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t d[8];
+        if (interior && aligned) {
+            const uint4* p = reinterpret_cast<const uint4*>(raw + (size_t)(my * 8 + r) * pitch + (size_t)mx * 32);
+            const uint4 a = p[0], b = p[1];
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        } else {
+            // samples outside the image are zero component values (src/gpujpeg_common.c:941-944); the odd last pixel of an
+            // odd-width row shares the chroma of its pair like the generic loader does
+            const unsigned y = my * 8 + r;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                uint32_t v = 0;
+                const unsigned x0 = mx * 16 + w * 2; // pixels x0, x0 + 1
+                if (y < (unsigned)g.height) {
+                    const uint8_t* q = raw + (size_t)y * pitch + (size_t)x0 * 2;
+                    if (x0 < (unsigned)g.width) v |= (uint32_t)q[1] << 8;
+                    if (x0 + 1 < (unsigned)g.width) v |= (uint32_t)q[3] << 24;
+                    if (x0 / 2 < (unsigned)kc.width) v |= (uint32_t)q[0] | ((uint32_t)q[2] << 16);
+                }
+                d[w] = v;
+            }
+        }
+        pk[0][2 * r] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);
+        pk[0][2 * r + 1] = __builtin_amdgcn_perm(d[3], d[2], 0x07050301u);
+        pk[1][2 * r] = __builtin_amdgcn_perm(d[5], d[4], 0x07050301u);
+        pk[1][2 * r + 1] = __builtin_amdgcn_perm(d[7], d[6], 0x07050301u);
+        const uint32_t uv01 = __builtin_amdgcn_perm(d[1], d[0], 0x06020400u), uv23 = __builtin_amdgcn_perm(d[3], d[2], 0x06020400u);
+        const uint32_t uv45 = __builtin_amdgcn_perm(d[5], d[4], 0x06020400u), uv67 = __builtin_amdgcn_perm(d[7], d[6], 0x06020400u);
+        pk[2][2 * r] = __builtin_amdgcn_perm(uv23, uv01, 0x05040100u);
+        pk[2][2 * r + 1] = __builtin_amdgcn_perm(uv67, uv45, 0x05040100u);
+        pk[3][2 * r] = __builtin_amdgcn_perm(uv23, uv01, 0x07060302u);
+        pk[3][2 * r + 1] = __builtin_amdgcn_perm(uv67, uv45, 0x07060302u);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[b][t])); // one transform at a time
+        const int c = b < 2 ? 0 : b - 1;
+        uint32_t q[32];
+        gj_fdct_quant_pk(pk[b], s_q[g.comp[c].type ? 1 : 0], q);
+        const size_t blk = b < 2 ? (size_t)my * g.comp[0].blocks_x + 2 * mx + b : (size_t)m;
+        gj_store_block(coefs + g.comp[c].data_offset + blk * 64, q);
+    }
+}
+
+// ================================================================================================
 // Huffman coder: one LANE per 8x8 block, 256 blocks per workgroup tile.
 //
 //  1. each lane loads its block (8 x 16 B), reorders it to zig-zag order with byte permutes and parks it in LDS
@@ -933,7 +1001,16 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
                            job->d_seg_bytes, job->d_seg_ff, (unsigned long long*)job->d_prof);
     } else {
-    if (fused) {
+    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 && g.no_transform == 0 &&
+                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
+                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
+                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
+                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
+    if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
+        const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);
+        hipLaunchKernelGGL(k_fused_uyvy422, dim3((nm + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->d_coefs, job->d_fwd_q[0], job->d_fwd_q[1]);
+    } else if (fused) {
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
         hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->d_coefs, job->d_fwd_q[0],

@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     __shared__ int16_t s_dc[GJ_PAR_MAX_BLOCKS];
     __shared__ uint32_t s_blk[INTERLEAVED ? GJ_PAR_MAX_BLOCKS : 1]; // interleaved: block index in the coefficient planes
     // per sub-sequence of the group
-    __shared__ uint16_t s_exit[MAX_SUBS], s_entry[MAX_SUBS], s_work[MAX_SUBS];
+    __shared__ __attribute__((aligned(8))) uint2 s_rec[MAX_SUBS];
+    __shared__ uint16_t s_work[MAX_SUBS];
     __shared__ uint8_t s_subseg[MAX_SUBS];
     __shared__ uint32_t s_scan[MAX_SUBS];
     __shared__ uint32_t s_tmp[4];
@@ -573,53 +574,57 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                 if (s_sub0[mid] <= (uint32_t)k) lo = mid; else hi = mid;
             }
             s_subseg[k] = (uint8_t)lo;
-            s_entry[k] = 0;
+            // assumed entry state: the first sub-sequence starts a block; any other one most likely starts in the middle of one (AC table)
+            s_rec[k] = make_uint2(((uint32_t)k == s_sub0[lo] || (flags & 4)) ? 0u : (1u << 5), 0u);
             s_work[k] = (uint16_t)k; // round 0: everybody
         }
         __syncthreads();
         GJ_PROF(2) // sub-sequence table
 
-        // -- 3. rounds
+        // -- 3. rounds. s_rec[k] = (entry state | exit state << 16, blocks completed) is written with one 64-bit LDS store, so a
+        //       record always describes one decoding of sub-sequence k, whoever wrote it last.
         int nwork = nsub;
         for (int round = 0; nwork > 0; round++) {
             for (int w = tid; w < nwork; w += 256) {
                 const int k = s_work[w];
                 const int j = s_subseg[k];
-                const uint32_t i = (uint32_t)k - s_sub0[j];
-                const uint32_t endb = min((i + 1) * SUB_BITS, s_ulen[j] * 8u);
+                const uint32_t k_first = s_sub0[j];
                 const uint32_t tb = s_tabs[j];
+                const uint32_t* U = s_U + ((s_ub[j] - ub0) >> 2);
+                const uint32_t seg_bits = s_ulen[j] * 8u;
+                // round 0: the assumed entry state; later: what the predecessor leaves now
+                const uint32_t e = round == 0 ? (s_rec[k].x & 0xFFFFu) : (s_rec[k - 1].x >> 16);
+                const uint32_t i = (uint32_t)k - k_first;
                 int nb;
-                const uint32_t x = gj_decode_sub<false, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_entry[k], s_tab, s_ptab, P,
+                const uint32_t x = gj_decode_sub<false, INTERLEAVED>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
                                                                      s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
-                s_exit[k] = (uint16_t)x;
-                s_scan[k] = (uint32_t)nb;
+                s_rec[k] = make_uint2(e | (x << 16), (uint32_t)nb);
             }
             __syncthreads();
             if (prof && threadIdx.x == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[12], (unsigned long long)nwork); }
             GJ_PROF(round == 0 ? 3 : 4) // first round / further rounds
-            // next work list: sub-sequences whose predecessor leaves in another state than they were entered with
+            // next work list: sub-sequences whose predecessor leaves in another state than they were entered with (measured: walking
+            // down runs of them with one lane, or seeding interleaved scans with one hypothesis per MCU block, costs more than it saves)
             for (int k0 = 0; k0 < nsub; k0 += 256) {
                 const int k = k0 + tid;
                 bool cand = false;
-                uint32_t e = 0;
-                if (k < nsub && (uint32_t)k != s_sub0[s_subseg[k]]) {
-                    e = s_exit[k - 1];
-                    cand = e != s_entry[k];
+                if (k < nsub) {
+                    const uint32_t first = s_sub0[s_subseg[k]];
+                    cand = (uint32_t)k != first && (s_rec[k - 1].x >> 16) != (s_rec[k].x & 0xFFFFu);
                 }
                 const unsigned long long m = __ballot(cand);
                 uint32_t base = 0;
                 if (lane == 0 && m) base = atomicAdd(&s_nwork, (uint32_t)__popcll(m));
                 base = __shfl(base, 0, 64);
-                if (cand) {
-                    s_entry[k] = (uint16_t)e;
-                    s_work[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
-                }
+                if (cand) s_work[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
             }
             __syncthreads();
             nwork = (int)s_nwork;
             __syncthreads();
             if (tid == 0) s_nwork = 0;
         }
+        for (int k = tid; k < nsub; k += 256) s_scan[k] = s_rec[k].y;
+        __syncthreads();
 
         // -- 4. block position of every sub-sequence inside its segment (inclusive scan, segment start subtracted below)
         {
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             const uint32_t endb = min((i + 1) * SUB_BITS, s_ulen[j] * 8u);
             const uint32_t tb = s_tabs[j];
             int nb;
-            gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_entry[k], s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
+            gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
                                              s_tab + (tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz, flags);
         }
         __syncthreads();

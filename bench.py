@@ -38,6 +38,10 @@ WORKLOADS = {
     "16k422": (15360, 8640), "8k422": (7680, 4320), "hd422": (1920, 1080),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
+# HBM bytes per launch of the dominant kernels from the PMC passes committed under profiles/ (8K RGB q75 natural frame):
+# FETCH_SIZE doubled (gfx950 counts 128 B requests as 64 B, guide section HBM) + WRITE_SIZE
+TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49830.2 * 2 + 8350.0) * 1024), "dec:k_huffman_decode_par": int((4631.7 * 2 + 180453.4) * 1024),
+                 "dec:k_idct_fused_rgb444": int((97447.5 * 2 + 291607.7) * 1024)}
 
 
 def synth_frame(width, height, pattern, seed, device):
@@ -105,6 +109,8 @@ def main():
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient"])
     ap.add_argument("--quality", type=int, default=75)
+    ap.add_argument("--streams", type=int, default=3, help="independent encoder+decoder pairs per GPU, each on its own HIP stream and host thread; "
+                    "one step codes one frame per stream (hides the host side of one call behind the kernels of the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--internal-rgb", action="store_true", help="code RGB without colour transform (tuning aid; not the headline config)")
     ap.add_argument("--calibrate", action="store_true", help="run a 256 MiB device fill + copy first (known byte counts for calibrating PMC traffic counters)")
@@ -137,10 +143,17 @@ def main():
         frame = uyvy.contiguous()
         if args.quality == 75:
             args.quality = 90
-    out = torch.empty_like(frame)
-    stream = torch.cuda.current_stream(device).cuda_stream
-    enc, dec = G.Encoder(lib, stream), G.Decoder(lib, stream)
-    assert enc.set_option("enc_opt_out", "enc_out_val_device") == 0
+    import threading
+    S = max(1, args.streams)
+    lanes = []  # one pipeline per stream: its own frame, output buffer, stream, encoder and decoder
+    for si in range(S):
+        f = frame if si == 0 else frame.clone()
+        ts = torch.cuda.current_stream(device) if S == 1 else torch.cuda.Stream(device)
+        e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
+        assert e.set_option("enc_opt_out", "enc_out_val_device") == 0
+        lanes.append({"frame": f, "out": torch.empty_like(f), "stream": ts, "enc": e, "dec": d})
+    torch.cuda.synchronize()
+    enc, dec, out = lanes[0]["enc"], lanes[0]["dec"], lanes[0]["out"]
     p = lib.default_parameters()
     p.quality, p.restart_interval, p.verbose, p.perf_stats = args.quality, G.RESTART_AUTO, -1, 1
     if args.internal_rgb:
@@ -151,19 +164,20 @@ def main():
         pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG
         p.interleaved = 1
         lib.L.gpujpeg_parameters_chroma_subsampling(C.byref(p), G.SUBSAMPLING_422)
-    if args.keep_coefs:
-        dec.keep_coefficients()
-    dec.init(p, lib.default_image_parameters())  # turns perf_stats on for the decoder (same API as the reference)
-    if is422:
-        dec.set_output_format(G.YCBCR_JPEG, G.P1020_422)
+    for ln in lanes:
+        if args.keep_coefs:
+            ln["dec"].keep_coefficients()
+        ln["dec"].init(p, lib.default_image_parameters())  # turns perf_stats on for the decoder (same API as the reference)
+        if is422:
+            ln["dec"].set_output_format(G.YCBCR_JPEG, G.P1020_422)
 
-    def step():
-        jptr, jsize = enc.encode_noclone(p, pi, frame.data_ptr(), gpu=True)
+    def step(ln):
+        jptr, jsize = ln["enc"].encode_noclone(p, pi, ln["frame"].data_ptr(), gpu=True)
         o = G.DecoderOutput()
-        o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, out.data_ptr()
-        rc = lib.L.gpujpeg_decoder_decode(dec.h, C.cast(jptr, C.c_void_p), jsize, C.byref(o))
+        o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
+        rc = lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jptr, C.c_void_p), jsize, C.byref(o))
         assert rc == 0
-        return jsize
+        return jptr, jsize
 
     def barrier():
         if world > 1:
@@ -175,27 +189,52 @@ def main():
         cal_b = cal_a.clone()
         torch.cuda.synchronize()
         del cal_a, cal_b
+    solo_ms = np.zeros(8)  # kernel durations with the GPU to themselves (untimed warm-up of pipeline 0; reference for the roofline)
     for _ in range(args.warmup):
-        jsize = step()
+        for ln in lanes:
+            jptr, jsize = step(ln)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        jptr, jsize = step(lanes[0])
+        torch.cuda.synchronize()
+        solo_ms += np.array(list(lanes[0]["enc"].kernel_times()) + list(lanes[0]["dec"].kernel_times()))
+    solo_ms /= 3
     enc_ms = np.zeros(5)
     dec_ms = np.zeros(3)
-    enc_wall = dec_wall = 0.0
+    walls = [0.0, 0.0]
+    go = threading.Event()
+
+    def worker(idx):
+        torch.cuda.set_device(local_rank)  # the HIP device is per host thread
+        ln = lanes[idx]
+        go.wait()
+        for _ in range(args.steps):
+            a = time.perf_counter()
+            jp, js = ln["enc"].encode_noclone(p, pi, ln["frame"].data_ptr(), gpu=True)
+            b = time.perf_counter()
+            o = G.DecoderOutput()
+            o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
+            assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
+            c = time.perf_counter()
+            if idx == 0:  # per-kernel hipEvent durations of pipeline 0 (its kernels may share the GPU with the other pipelines')
+                walls[0] += b - a
+                walls[1] += c - b
+                enc_ms[:] += np.array(ln["enc"].kernel_times())
+                dec_ms[:] += np.array(ln["dec"].kernel_times())
+            ln["last"] = (jp, js)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
+    for t in threads:
+        t.start()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        a = time.perf_counter()
-        jptr, jsize = enc.encode_noclone(p, pi, frame.data_ptr(), gpu=True)
-        b = time.perf_counter()
-        o = G.DecoderOutput()
-        o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, out.data_ptr()
-        assert lib.L.gpujpeg_decoder_decode(dec.h, C.cast(jptr, C.c_void_p), jsize, C.byref(o)) == 0
-        c = time.perf_counter()
-        enc_wall += b - a
-        dec_wall += c - b
-        enc_ms += np.array(enc.kernel_times())
-        dec_ms += np.array(dec.kernel_times())
+    go.set()
+    for t in threads:
+        t.join()
     barrier()
     elapsed = time.perf_counter() - t0
+    enc_wall, dec_wall = walls
+    jptr, jsize = lanes[0]["last"]
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,20 +255,26 @@ def main():
         alg = raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (same sum)
         achieved = alg / (durs[dom] * 1e-3) / 1e9
         result = {
-            "metric": "Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})", "value": round(pixels * world * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
+            "metric": "Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})", "value": round(pixels * world * S * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / f32 DCT / i16 coefficients",
-            "data": f"synthetic ({args.pattern}), one {width}x{height} RGB frame per rank resident in HBM",
+            "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per stream",
             "config": {"workload": (f"{width}x{height} YCbCr 4:2:2 (UYVY) q{args.quality} interleaved, restart auto, encode then decode per step" if is422 else
                                     f"{width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto ({width}x{height} -> "
                                     f"{'36' if args.workload in ('8k', '16k') else 'auto'}), encode then decode per step"),
-                       "frames_per_step_per_gpu": 1, "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective"},
+                       "frames_per_step_per_gpu": S, "streams_per_gpu": S, "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective"},
             "encode_mpix_s": round(pixels * args.steps / enc_wall / 1e6, 2), "decode_mpix_s": round(pixels * args.steps / dec_wall / 1e6, 2),
             "kernel_ms": {n: round(float(d), 4) for n, d in zip(names, durs)},
             "gpu_only_ms": {"encode": round(float(enc_ms.sum()), 4), "decode": round(float(dec_ms.sum()), 4)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(alg)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES.get(names[dom].split("(")[0]),
+                         "algorithmic_bytes_per_launch": int(alg), "concurrent_pipelines": S,
+                         "note": "duration = average hipEvent duration of one launch in the timed region, where launches of the other "
+                                 "pipelines share the GPU; traffic = FETCH_SIZE x 2 + WRITE_SIZE per launch from profiles/ (separate PMC passes)"},
+            "roofline_solo": {"kernel": names[int(np.argmax(solo_ms))], "ms": round(float(solo_ms.max()), 4),
+                              "achieved": round(alg / (float(solo_ms.max()) * 1e-3) / 1e9, 2), "unit": "GB/s",
+                              "frac": round(alg / (float(solo_ms.max()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                              "kernel_ms": {n: round(float(d), 4) for n, d in zip(names, solo_ms)}},
         }
         if args.verify:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -246,8 +291,9 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(width, height, frame.cpu().numpy().reshape(-1))
         print(json.dumps(result), flush=True)
-    enc.close()
-    dec.close()
+    for ln in lanes:
+        ln["enc"].close()
+        ln["dec"].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -734,6 +734,30 @@ __device__ __forceinline__ void gj_color_static_d(int& a, int& b, int& c)
     else if (CS_TO == GJ_CS_RGB) gj_to_rgb(CS_FROM, a, b, c);
 }
 
+// byte X (compile-time) of an 8-sample row held in two dwords, as float
+template <int X>
+__device__ __forceinline__ float gj_sample_f(const uint32_t (&c)[2])
+{
+    return gj_ubyte_f<X & 3>(c[X >> 2]);
+}
+
+// pixels X and X + 1 of a row: component samples -> colour transform -> bytes 3X .. 3X + 5 of the packed output row
+template <int CS_FROM, int CS_TO, int X>
+__device__ __forceinline__ void gj_store_pair(const uint32_t (&c0)[2], const uint32_t (&c1)[2], const uint32_t (&c2)[2], uint32_t (&px)[6])
+{
+    gj_f2 a = gj_f2{gj_sample_f<X>(c0), gj_sample_f<X + 1>(c0)};
+    gj_f2 b = gj_f2{gj_sample_f<X>(c1), gj_sample_f<X + 1>(c1)};
+    gj_f2 c = gj_f2{gj_sample_f<X>(c2), gj_sample_f<X + 1>(c2)};
+    gj_color_f<CS_FROM, CS_TO>(a, b, c);
+    constexpr int B = 3 * X;
+    px[(B + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a.x, (B + 0) & 3, px[(B + 0) >> 2]);
+    px[(B + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(b.x, (B + 1) & 3, px[(B + 1) >> 2]);
+    px[(B + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c.x, (B + 2) & 3, px[(B + 2) >> 2]);
+    px[(B + 3) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a.y, (B + 3) & 3, px[(B + 3) >> 2]);
+    px[(B + 4) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(b.y, (B + 4) & 3, px[(B + 4) >> 2]);
+    px[(B + 5) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c.y, (B + 5) & 3, px[(B + 5) >> 2]);
+}
+
 // Coefficients travel HBM -> LDS in fully coalesced 16 B chunks (a thread-per-block read would touch 64 different 128 B
 // lines per load instruction); each thread then takes its own block out of LDS. Blocks are padded to 144 B there, which
 // makes both the linear writes and the per-block 16 B reads bank-conflict free (36 dwords: 9 x 4, 9 coprime to 16).
@@ -796,19 +820,13 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
+        // colour transform in fp32 on pixel pairs (gj_color_f, exact; see gj_device.h), results packed straight into the 24 output bytes
         uint32_t px[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const int i = r * 8 + x;
-            int c0 = (pk[0][i >> 2] >> ((i & 3) * 8)) & 0xFF;
-            int c1 = (pk[1][i >> 2] >> ((i & 3) * 8)) & 0xFF;
-            int c2 = (pk[2][i >> 2] >> ((i & 3) * 8)) & 0xFF;
-            gj_color_static_d<CS_FROM, CS_TO>(c0, c1, c2);
-            const int b0 = x * 3, b1 = x * 3 + 1, b2 = x * 3 + 2;
-            px[b0 >> 2] |= (uint32_t)c0 << ((b0 & 3) * 8);
-            px[b1 >> 2] |= (uint32_t)c1 << ((b1 & 3) * 8);
-            px[b2 >> 2] |= (uint32_t)c2 << ((b2 & 3) * 8);
-        }
+        const uint32_t c0[2] = {pk[0][2 * r], pk[0][2 * r + 1]}, c1[2] = {pk[1][2 * r], pk[1][2 * r + 1]}, c2[2] = {pk[2][2 * r], pk[2][2 * r + 1]};
+        gj_store_pair<CS_FROM, CS_TO, 0>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 2>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 4>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 6>(c0, c1, c2, px);
         const unsigned y = by * 8 + r;
         if (interior && aligned) {
             uint2* p = reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)bx * 24);

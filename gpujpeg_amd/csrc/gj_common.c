@@ -582,3 +582,36 @@ struct gpujpeg_opengl_texture* gpujpeg_opengl_texture_register(int id, enum gpuj
 void gpujpeg_opengl_texture_unregister(struct gpujpeg_opengl_texture* t) { (void)t; }
 uint8_t* gpujpeg_opengl_texture_map(struct gpujpeg_opengl_texture* t, size_t* n) { (void)t; if (n) *n = 0; return NULL; }
 void gpujpeg_opengl_texture_unmap(struct gpujpeg_opengl_texture* t) { (void)t; }
+
+/* "XYZ" / "XYZW" -> packed channel mapping (src/gpujpeg_encoder.c:661-699): nibble i = source channel of output channel i,
+ * 4 = all ones ('F'), 5 = all zeros ('Z'); bits 24.. = number of channels */
+int gj_parse_channel_remap(unsigned* out, const char* val, const char* optname)
+{
+    if (strcmp(val, "help") == 0) {
+        printf("syntax for %s:\n", optname);
+        printf("\t\"XYZ\" or \"XYZW\" where the letters are input channel indices\n");
+        printf("\tplaceholder 'Z' or 'F' can be used to set the channel to all-zeros or all-ones\n");
+        printf("\n");
+        printf("examples:\n");
+        printf("\t\"1230\" or \"123F\" to map ARGB to RGBA\n");
+        return GPUJPEG_ERROR;
+    }
+    const int mapped_count = (int)strlen(val);
+    if (mapped_count > GPUJPEG_MAX_COMPONENT_COUNT) {
+        GJ_ERROR("Mapping for more than %d channels specified!\n", GPUJPEG_MAX_COMPONENT_COUNT);
+        return GPUJPEG_ERROR;
+    }
+    unsigned map = 0;
+    for (const char* ptr = val + mapped_count - 1; ptr >= val; ptr--) {
+        int src_chan = *ptr - '0';
+        if (*ptr == 'F') src_chan = 4;
+        else if (*ptr == 'Z') src_chan = 5;
+        else if (src_chan < 0 || src_chan >= mapped_count) {
+            GJ_ERROR("Invalid channel index %c for %s (mapping %d channels)!\n", *ptr, optname, mapped_count);
+            return GPUJPEG_ERROR;
+        }
+        map = (map << 4) | (unsigned)src_chan;
+    }
+    *out = map | ((unsigned)mapped_count << 24);
+    return GPUJPEG_NOERR;
+}

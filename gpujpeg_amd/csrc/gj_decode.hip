@@ -1063,6 +1063,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     } else {
         hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf,
                            job->d_planes, job->zero_coefs);
+        if (job->flipped) hipLaunchKernelGGL(k_flip_planes, dim3(1024), dim3(256), 0, st, g, job->d_planes); // src/gpujpeg_postprocessor.cu:447
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         if (g.no_transform) {
             hipLaunchKernelGGL(k_copy_planes_out, dim3(2048), dim3(256), 0, st, g, job->d_planes, job->d_raw);
@@ -1070,6 +1071,10 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
             const unsigned n = (unsigned)g.raw_width * (unsigned)g.height;
             hipLaunchKernelGGL(k_postprocess, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_planes, job->d_raw);
         }
+    }
+    if (job->channel_remap) { // src/gpujpeg_postprocessor.cu:450,493: the finished image is permuted in place
+        const unsigned n = (unsigned)g.width * (unsigned)g.height;
+        hipLaunchKernelGGL(k_channel_remap, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->channel_remap & 0xFFFFu);
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -30,6 +30,8 @@ struct gpujpeg_decoder {
     uint16_t* h_tabs;                  /* pinned staging: 8 decode tables + 4 quant tables */
     struct gj_host_segments segs;
     int use_fused;
+    bool flipped;                 /* dec_opt_flipped */
+    unsigned channel_remap;       /* dec_opt_channel_remap, packed; 0 = none */
     int keep_coefs;               /* 1: leave the coefficients in HBM after the call (gpujpeg_amd_decoder_keep_coefficients) */
     bool coefs_clean;             /* d_coefs is all zero: the previous call's IDCT cleared what it read */
     /* device-side segment discovery */
@@ -405,7 +407,20 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.d_coefs = c->d_coefs;
     job.d_planes = c->d_planes;
     job.d_raw = d_raw;
-    job.use_fused = d->use_fused;
+    job.use_fused = d->use_fused && !d->flipped;
+    job.flipped = d->flipped;
+    job.channel_remap = d->channel_remap;
+    if (d->channel_remap) {
+        const enum gpujpeg_pixel_format pf = c->param_image.pixel_format;
+        if ((int)(d->channel_remap >> 24) != gpujpeg_pixel_format_get_comp_count(pf)) {
+            GJ_ERROR("Wrong channel remapping given, given %u channels but pixel format has %d!\n", d->channel_remap >> 24, gpujpeg_pixel_format_get_comp_count(pf));
+            goto out;
+        }
+        if (pf != GPUJPEG_U8 && pf != GPUJPEG_444_U8_P012 && pf != GPUJPEG_4444_U8_P0123 && pf != GPUJPEG_444_U8_P0P1P2) {
+            GJ_ERROR("Channel remapping is implemented for pixel formats whose pixels do not share samples (u8, 444-u8-p012, 4444-u8-p0123, 444-u8-p0p1p2).\n");
+            goto out;
+        }
+    }
     job.clear_coefs = !d->coefs_clean;
     job.zero_coefs = !d->keep_coefs;
     d->coefs_clean = false; /* until the kernels below have run to completion */
@@ -571,10 +586,13 @@ int gpujpeg_decoder_set_option(struct gpujpeg_decoder* d, const char* opt, const
         return GPUJPEG_NOERR;
     }
     if (strcmp(opt, GPUJPEG_DEC_OPT_TGA_RLE_BOOL) == 0) return GPUJPEG_NOERR; /* only affects file output */
-    if (strcmp(opt, GPUJPEG_DEC_OPT_FLIPPED_BOOL) == 0 || strcmp(opt, GPUJPEG_DEC_OPT_CHANNEL_REMAP) == 0) {
-        GJ_ERROR("Option %s is not implemented in the MI355X build yet.\n", opt);
-        return GPUJPEG_ERROR;
+    if (strcmp(opt, GPUJPEG_DEC_OPT_FLIPPED_BOOL) == 0) { /* src/gpujpeg_decoder.c:499-501 */
+        if (strcasecmp(val, GPUJPEG_VAL_TRUE) == 0 || strcmp(val, "1") == 0) d->flipped = true;
+        else if (strcasecmp(val, GPUJPEG_VAL_FALSE) == 0 || strcmp(val, "0") == 0) d->flipped = false;
+        else { GJ_ERROR("Unknown option %s for " GPUJPEG_DEC_OPT_FLIPPED_BOOL "\n", val); return GPUJPEG_ERROR; }
+        return GPUJPEG_NOERR;
     }
+    if (strcmp(opt, GPUJPEG_DEC_OPT_CHANNEL_REMAP) == 0) return gj_parse_channel_remap(&d->channel_remap, val, opt);
     GJ_ERROR("Invalid decoder option: %s!\n", opt);
     return GPUJPEG_ERROR;
 }
@@ -582,6 +600,8 @@ int gpujpeg_decoder_set_option(struct gpujpeg_decoder* d, const char* opt, const
 void gpujpeg_decoder_print_options(void)
 {
     printf("\t" GPUJPEG_DEC_OPT_ALIGNMENT_BYTES_INT "=<n> - required line alignment of the decoded image in bytes\n");
+    printf("\t" GPUJPEG_DEC_OPT_FLIPPED_BOOL "=[" GPUJPEG_VAL_TRUE "|" GPUJPEG_VAL_FALSE "] - whether the output image should be vertically flipped\n");
+    printf("\t" GPUJPEG_DEC_OPT_CHANNEL_REMAP "=XYZ[W] - output channel remapping, 'help' for details\n");
 }
 
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */

@@ -463,3 +463,53 @@ __device__ __forceinline__ void gj_idct_pk(const uint32_t (&w)[32], const float*
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Options that act on the planes / the raw image
+// ------------------------------------------------------------------------------------------------
+// vertical flip of every padded component plane: row y <-> data_height - 1 - y, 4 bytes per thread
+// (src/gpujpeg_preprocessor.cu:455-486; the padding rows take part, as in the reference)
+static __global__ __launch_bounds__(256) void k_flip_planes(const gj_geom g, uint8_t* __restrict__ planes)
+{
+    for (int c = 0; c < g.comp_count; c++) {
+        const gj_comp_geom& k = g.comp[c];
+        const unsigned wd = (unsigned)k.data_width / 4, half = (unsigned)k.data_height / 2;
+        uint32_t* p = reinterpret_cast<uint32_t*>(planes + k.data_offset);
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < wd * half; i += gridDim.x * 256u) {
+            const unsigned y = i / wd, x = i - y * wd;
+            uint32_t* a = p + (size_t)y * wd + x;
+            uint32_t* b = p + (size_t)((unsigned)k.data_height - 1 - y) * wd + x;
+            const uint32_t t = *a;
+            *a = *b;
+            *b = t;
+        }
+    }
+}
+
+// in-place channel permutation of the raw image (src/gpujpeg_preprocessor.cu:488-559): output channel i takes the source channel in
+// nibble i of `map`; 4 = 0xFF, 5 = 0. Formats whose pixels do not share samples: grey, packed 4:4:4 / 4:4:4:4, planar 4:4:4.
+static __global__ __launch_bounds__(256) void k_channel_remap(const gj_geom g, uint8_t* __restrict__ raw, const uint32_t map)
+{
+    const unsigned W = (unsigned)g.width, H = (unsigned)g.height;
+    const unsigned pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos >= W * H) return;
+    const unsigned y = pos / W;
+    uint8_t* ch[4] = {nullptr, nullptr, nullptr, nullptr};
+    switch (g.pixel_format) {
+    case GJ_PF_U8: ch[0] = raw + (size_t)pos + (size_t)g.width_padding * y; break;
+    case GJ_PF_444_P012:
+        for (int c = 0; c < 3; c++) ch[c] = raw + (size_t)pos * 3 + (size_t)g.width_padding * y + c;
+        break;
+    case GJ_PF_4444_P0123:
+        for (int c = 0; c < 4; c++) ch[c] = raw + (size_t)pos * 4 + (size_t)g.width_padding * y + c;
+        break;
+    default: // GJ_PF_444_P0P1P2
+        for (int c = 0; c < 3; c++) ch[c] = raw + (size_t)c * W * H + pos;
+        break;
+    }
+    const uint8_t fill = g.pixel_format == GJ_PF_U8 ? 128 : 0; // what the loaders give a channel the format does not have
+    uint8_t in[8] = {ch[0] ? *ch[0] : (uint8_t)0, ch[1] ? *ch[1] : fill, ch[2] ? *ch[2] : fill, ch[3] ? *ch[3] : (uint8_t)0, 0xFF, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (ch[c]) *ch[c] = in[(map >> (4 * c)) & 7];
+}

@@ -991,6 +991,10 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
+    if (job->channel_remap) { // the reference permutes the channels of the raw image in place first (src/gpujpeg_preprocessor.cu:570-575)
+        const unsigned n = (unsigned)g.width * (unsigned)g.height;
+        hipLaunchKernelGGL(k_channel_remap, dim3((n + 255) / 256), dim3(256), 0, st, g, const_cast<uint8_t*>(job->d_raw), job->channel_remap & 0xFFFFu);
+    }
     gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
     if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
@@ -1022,6 +1026,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
             const unsigned n = (unsigned)g.raw_width * (unsigned)g.height;
             hipLaunchKernelGGL(k_preprocess, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->d_planes);
         }
+        if (job->flipped) hipLaunchKernelGGL(k_flip_planes, dim3(1024), dim3(256), 0, st, g, job->d_planes);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         hipLaunchKernelGGL(k_dct, dim3(((unsigned)g.block_count + 255) / 256), dim3(256), 0, st, g, job->d_planes, job->d_coefs,
                            job->d_fwd_q[0], job->d_fwd_q[1]);

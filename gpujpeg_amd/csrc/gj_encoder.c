@@ -19,6 +19,7 @@ struct gpujpeg_encoder {
     struct gpujpeg_image_metadata metadata;
     int out_location;
     bool flipped;
+    unsigned channel_remap; /* packed like the reference's preprocessor.channel_remap, 0 = none */
     /* tables */
     int table_quality; /* quality the uploaded tables were computed for, -1 = none */
     uint8_t qraw[2][64];
@@ -239,6 +240,19 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     memset(&job, 0, sizeof job);
     job.g = *g;
     job.d_raw = d_raw;
+    job.flipped = e->flipped;
+    job.channel_remap = e->channel_remap;
+    if (e->channel_remap) {
+        const enum gpujpeg_pixel_format pf = c->param_image.pixel_format;
+        if ((int)(e->channel_remap >> 24) != gpujpeg_pixel_format_get_comp_count(pf)) {
+            GJ_ERROR("Wrong channel remapping given, given %u channels but pixel format has %d!\n", e->channel_remap >> 24, gpujpeg_pixel_format_get_comp_count(pf));
+            return -1;
+        }
+        if (pf != GPUJPEG_U8 && pf != GPUJPEG_444_U8_P012 && pf != GPUJPEG_4444_U8_P0123 && pf != GPUJPEG_444_U8_P0P1P2) {
+            GJ_ERROR("Channel remapping is implemented for pixel formats whose pixels do not share samples (u8, 444-u8-p012, 4444-u8-p0123, 444-u8-p0p1p2).\n");
+            return -1;
+        }
+    }
     job.d_planes = c->d_planes;
     job.d_coefs = c->d_coefs;
     job.d_fwd_q[0] = e->d_fwd_q[0];
@@ -418,8 +432,9 @@ int gpujpeg_encoder_set_option(struct gpujpeg_encoder* e, const char* opt, const
         e->header_type = t;
         return GPUJPEG_NOERR;
     }
-    if (strcmp(opt, GPUJPEG_ENC_OPT_FLIPPED_BOOL) == 0 || strcmp(opt, GPUJPEG_ENC_OPT_CHANNEL_REMAP) == 0 ||
-        strcmp(opt, GPUJPEG_ENC_OPT_EXIF_TAG) == 0 || strcmp(opt, GPUJPEG_ENC_OPT_METADATA) == 0) {
+    if (strcmp(opt, GPUJPEG_ENC_OPT_FLIPPED_BOOL) == 0) return parse_bool(&e->flipped, val, opt); /* src/gpujpeg_encoder.c:767-769 */
+    if (strcmp(opt, GPUJPEG_ENC_OPT_CHANNEL_REMAP) == 0) return gj_parse_channel_remap(&e->channel_remap, val, opt);
+    if (strcmp(opt, GPUJPEG_ENC_OPT_EXIF_TAG) == 0 || strcmp(opt, GPUJPEG_ENC_OPT_METADATA) == 0) {
         GJ_ERROR("Option %s is not implemented in the MI355X build yet.\n", opt);
         return GPUJPEG_ERROR;
     }
@@ -431,6 +446,8 @@ void gpujpeg_encoder_print_options(void)
 {
     printf("\t" GPUJPEG_ENC_OPT_OUT "=[" GPUJPEG_ENC_OUT_VAL_PAGEABLE "|" GPUJPEG_ENC_OUT_VAL_PINNED "|" GPUJPEG_ENC_OUT_VAL_DEVICE
            "] - location of the buffer returned by the encoder\n");
+    printf("\t" GPUJPEG_ENC_OPT_FLIPPED_BOOL "=[" GPUJPEG_VAL_TRUE "|" GPUJPEG_VAL_FALSE "] - whether is the input image should be vertically flipped (prior encode)\n");
+    printf("\t" GPUJPEG_ENC_OPT_CHANNEL_REMAP "=XYZ[W] - input channel remapping, 'help' for details\n");
     printf("\t" GPUJPEG_ENC_OPT_HDR "=[" GPUJPEG_ENC_HDR_VAL_JFIF "|" GPUJPEG_ENC_HDR_VAL_ADOBE "|" GPUJPEG_ENC_HDR_VAL_SPIFF "] - JPEG header to emit\n");
 }
 

@@ -34,6 +34,7 @@ int gj_pixfmt_unit_size(enum gpujpeg_pixel_format pf);
 const struct gpujpeg_component_sampling_factor* gj_pixfmt_sampling(enum gpujpeg_pixel_format pf);
 int gj_pixfmt_is_interleaved(enum gpujpeg_pixel_format pf);
 gpujpeg_sampling_factor_t gj_make_sampling_factor(int comp_count, const struct gpujpeg_component_sampling_factor* sf);
+int gj_parse_channel_remap(unsigned* out, const char* val, const char* optname); /* src/gpujpeg_encoder.c:661-699 */
 bool gj_parameters_equal(const struct gpujpeg_parameters* a, const struct gpujpeg_parameters* b);
 bool gj_image_parameters_equal(const struct gpujpeg_image_parameters* a, const struct gpujpeg_image_parameters* b);
 

@@ -126,6 +126,8 @@ typedef struct gj_enc_job {
     int segment_info;
     int use_fused;                 /* 1: fused kernels when the format allows (raw -> segment streams, or raw -> coefficients) */
     int keep_coefs;                /* 1: the caller wants the coefficient planes in d_coefs (tests): do not use the fully fused kernel */
+    int flipped;                   /* enc_opt_flipped: flip the component planes vertically after the colour stage (generic path) */
+    uint32_t channel_remap;        /* enc_opt_channel_remap: packed mapping, 0 = none; applied to d_raw IN PLACE before anything else */
 } gj_enc_job;
 
 /* events (may be NULL): 0 start, 1 after preprocess, 2 after DCT/quant, 3 after k_huffman, 4 after k_scan_segments,
@@ -156,6 +158,8 @@ typedef struct gj_dec_job {
     uint8_t* d_planes;
     uint8_t* d_raw;                /* output pixels */
     int use_fused;
+    int flipped;                   /* dec_opt_flipped: flip the component planes before the colour stage (generic path) */
+    uint32_t channel_remap;        /* dec_opt_channel_remap: applied to the finished image in d_raw */
     int clear_coefs;               /* 1: d_coefs is not known to be all zero, clear it first */
     int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
     uint32_t* d_fallback;          /* [1 + seg_count] scratch: segments handed from the sub-sequence kernel to the serial one */

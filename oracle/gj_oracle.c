@@ -1258,3 +1258,66 @@ void gjo_fill_gradient(uint8_t* dst, int width, int height, int bpp)
     size_t linesize = (size_t)width * bpp;
     for (int i = 0; i < height; i++) memset(dst + (size_t)i * linesize, i * 255 / height, linesize);
 }
+
+/* ---- options that act on the raw image / the planes ---- */
+
+/* vertical flip of every padded component plane, rows 0 .. data_height-1 (src/gpujpeg_preprocessor.cu:455-486:
+ * the kernel swaps row y with data_height-1-y, i.e. padding rows take part) */
+void gjo_flip_planes(const gjo_image* img, uint8_t* planes)
+{
+    for (int c = 0; c < img->comp_count; c++) {
+        const gjo_comp* k = &img->comp[c];
+        uint8_t* p = planes + k->data_offset;
+        for (int y = 0; y < k->data_height / 2; y++) {
+            uint8_t* a = p + (size_t)y * k->data_width;
+            uint8_t* b = p + (size_t)(k->data_height - 1 - y) * k->data_width;
+            for (int x = 0; x < k->data_width; x++) { const uint8_t t = a[x]; a[x] = b[x]; b[x] = t; }
+        }
+    }
+}
+
+/* "XYZ"/"XYZW" -> packed mapping (src/gpujpeg_encoder.c:661-699): nibble i = source channel of output channel i,
+ * 4 = all ones ('F'), 5 = all zeros ('Z'); bits 24.. = number of channels. Returns 0 for an invalid string. */
+unsigned gjo_parse_channel_remap(const char* val)
+{
+    const int n = (int)strlen(val);
+    if (n == 0 || n > GJO_MAX_COMP) return 0;
+    unsigned map = 0;
+    for (int i = n - 1; i >= 0; i--) {
+        int src = val[i] - '0';
+        if (val[i] == 'F') src = 4;
+        else if (val[i] == 'Z') src = 5;
+        else if (src < 0 || src >= n) return 0;
+        map = (map << 4) | (unsigned)src;
+    }
+    return map | ((unsigned)n << 24);
+}
+
+/* in-place channel permutation of the raw image, pixel by pixel in raster order
+ * (src/gpujpeg_preprocessor.cu:488-559; __byte_perm(val, 0xFF, map): selector 0-3 = channel, 4 = 0xFF, 5-7 = 0).
+ * Restated for the formats whose pixels do not share samples (packed 4:4:4 / 4:4:4:4, planar 4:4:4, grey). */
+int gjo_channel_remap(const gjo_image* img, uint8_t* raw, unsigned channel_remap)
+{
+    const int pf = img->pixel_format;
+    if (pf != GJO_PF_444_P012 && pf != GJO_PF_4444_P0123 && pf != GJO_PF_444_P0P1P2 && pf != GJO_PF_U8) return -1;
+    if ((int)(channel_remap >> 24) != gjo_pixfmt_comp_count(pf)) return -1;
+    const unsigned map = channel_remap & 0xFFFF;
+    const int W = img->width, H = img->height;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t pos = (size_t)y * W + x;
+            uint8_t* ch[4] = {0, 0, 0, 0};
+            switch (pf) {
+            case GJO_PF_U8: ch[0] = raw + pos + (size_t)img->width_padding * y; break;
+            case GJO_PF_444_P012: for (int c = 0; c < 3; c++) ch[c] = raw + pos * 3 + (size_t)img->width_padding * y + c; break;
+            case GJO_PF_4444_P0123: for (int c = 0; c < 4; c++) ch[c] = raw + pos * 4 + (size_t)img->width_padding * y + c; break;
+            default: for (int c = 0; c < 3; c++) ch[c] = raw + (size_t)c * W * H + pos; break;
+            }
+            /* the loaders fill missing channels like raw_load does: grey -> (v, 128, 128, 0), three channels -> w = 0 */
+            uint8_t in[8] = {ch[0] ? *ch[0] : 0, ch[1] ? *ch[1] : (uint8_t)(pf == GJO_PF_U8 ? 128 : 0), ch[2] ? *ch[2] : (uint8_t)(pf == GJO_PF_U8 ? 128 : 0),
+                             ch[3] ? *ch[3] : 0, 0xFF, 0, 0, 0};
+            for (int c = 0; c < 4; c++)
+                if (ch[c]) *ch[c] = in[(map >> (4 * c)) & 7];
+        }
+    return 0;
+}

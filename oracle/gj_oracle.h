@@ -135,6 +135,11 @@ void gjo_postprocess(const gjo_image* img, const uint8_t* planes, uint8_t* raw);
 int  gjo_decode(const uint8_t* jpeg, size_t size, int req_pixel_format, int req_color_space,
                 uint8_t* out, size_t cap, gjo_image* info);
 
+/* options acting on the planes / the raw image (src/gpujpeg_preprocessor.cu:455-559, src/gpujpeg_encoder.c:661-699) */
+void gjo_flip_planes(const gjo_image* img, uint8_t* planes);
+unsigned gjo_parse_channel_remap(const char* val);
+int  gjo_channel_remap(const gjo_image* img, uint8_t* raw, unsigned channel_remap);
+
 /* colour transform of one pixel, exposed for exhaustive tests (src/gpujpeg_colorspace.h:64-102,216-430) */
 void gjo_color_transform(int cs_from, int cs_to, uint8_t c[3]);
 

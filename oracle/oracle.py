@@ -82,6 +82,10 @@ def lib():
         L.gjo_postprocess.argtypes = [C.POINTER(Image), u8p, u8p]
         L.gjo_decode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(Image)]
         L.gjo_color_transform.argtypes = [C.c_int, C.c_int, u8p]
+        L.gjo_flip_planes.argtypes = [C.POINTER(Image), u8p]
+        L.gjo_parse_channel_remap.restype = C.c_uint
+        L.gjo_parse_channel_remap.argtypes = [C.c_char_p]
+        L.gjo_channel_remap.argtypes = [C.POINTER(Image), u8p, C.c_uint]
         L.gjo_fill_noise.argtypes = [u8p, C.c_size_t, C.c_uint]
         L.gjo_fill_gradient.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
         L.gjo_quant_table.argtypes = [C.c_int, C.c_int, u8p, C.POINTER(C.c_float), C.POINTER(C.c_uint16)]
@@ -208,6 +212,22 @@ def decode(jpeg, req_pixel_format=-1, req_color_space=-1):
     finally:
         lib().gjo_stream_free(C.byref(s))
     return raw, img
+
+
+def flip_planes(img, planes):
+    """Vertical flip of the padded component planes (encoder option enc_opt_flipped / dec_opt_flipped)."""
+    out = np.ascontiguousarray(planes).copy()
+    lib().gjo_flip_planes(C.byref(img), _u8(out))
+    return out
+
+
+def channel_remap(img, raw, mapping):
+    """Channel permutation of the raw image, e.g. "210" (enc_opt_channel_remap / dec_opt_channel_remap)."""
+    m = lib().gjo_parse_channel_remap(mapping.encode())
+    out = np.ascontiguousarray(raw).copy()
+    if m == 0 or lib().gjo_channel_remap(C.byref(img), _u8(out), m) != 0:
+        raise ValueError("invalid channel mapping for this pixel format")
+    return out
 
 
 def color_transform(cs_from, cs_to, rgb):

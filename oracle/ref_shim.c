@@ -100,18 +100,33 @@ int gpujpeg_preprocessor_encoder_init(struct gpujpeg_coder* coder)
 int gpujpeg_preprocessor_encode(struct gpujpeg_encoder* encoder)
 {
     struct gpujpeg_coder* coder = &encoder->coder;
-    if (coder->preprocessor.channel_remap != 0 || coder->preprocessor.flipped) {
-        fprintf(stderr, "[ref_shim] channel remap / flip are not restated\n");
-        return -1;
-    }
     gjo_image img;
     image_from_coder(coder, &img);
+    /* order as in src/gpujpeg_preprocessor.cu:563-586: remap the raw image in place, convert, flip the planes */
+    if (coder->preprocessor.channel_remap != 0 && gpujpeg_preprocessor_channel_remap(coder) != 0) return -1;
     gjo_preprocess(&img, coder->d_data_raw, coder->d_data);
+    if (coder->preprocessor.flipped) return gpujpeg_preprocessor_flip_lines(coder);
     return 0;
 }
 
-int gpujpeg_preprocessor_channel_remap(struct gpujpeg_coder* coder) { (void)coder; return -1; }
-int gpujpeg_preprocessor_flip_lines(struct gpujpeg_coder* coder) { (void)coder; return -1; }
+int gpujpeg_preprocessor_channel_remap(struct gpujpeg_coder* coder)
+{
+    gjo_image img;
+    image_from_coder(coder, &img);
+    if (gjo_channel_remap(&img, coder->d_data_raw, coder->preprocessor.channel_remap) != 0) {
+        fprintf(stderr, "[ref_shim] channel remap: wrong channel count or a pixel format whose pixels share samples (not restated)\n");
+        return -1;
+    }
+    return 0;
+}
+
+int gpujpeg_preprocessor_flip_lines(struct gpujpeg_coder* coder)
+{
+    gjo_image img;
+    image_from_coder(coder, &img);
+    gjo_flip_planes(&img, coder->d_data);
+    return 0;
+}
 
 /* ---- DCT (reference: src/gpujpeg_dct_gpu.cu:622,682) -- uses the REFERENCE's tables ---- */
 int gpujpeg_dct_gpu(struct gpujpeg_encoder* encoder)
@@ -206,10 +221,12 @@ int gpujpeg_postprocessor_decoder_init(struct gpujpeg_coder* coder)
 int gpujpeg_postprocessor_decode(struct gpujpeg_coder* coder, cudaStream_t stream)
 {
     (void)stream;
-    if (coder->preprocessor.channel_remap != 0 || coder->preprocessor.flipped) return -1;
     gjo_image img;
     image_from_coder(coder, &img);
+    /* order as in src/gpujpeg_postprocessor.cu:445-496: flip the planes, convert, remap the raw image */
+    if (coder->preprocessor.flipped) gpujpeg_preprocessor_flip_lines(coder);
     gjo_postprocess(&img, coder->d_data, coder->d_data_raw);
+    if (coder->preprocessor.channel_remap != 0 && gpujpeg_preprocessor_channel_remap(coder) != 0) return -1;
     return 0;
 }
 

@@ -135,3 +135,44 @@ def test_decoder_header_cache(O, G, gpu_lib, monkeypatch):
     px, _ = dec.decode(a3)
     assert np.array_equal(px, O.decode(a3, info.pixel_format, info.color_space)[0])
     dec.close()
+
+
+@pytest.mark.parametrize("pf,comps,mapping", [(1, 3, "210"), (1, 3, "F0Z"), (6, 4, "1230"), (2, 3, "201"), (0, 1, "0")])
+def test_channel_remap_and_flip(O, G, gpu_lib, pf, comps, mapping):
+    """enc_opt_channel_remap / enc_opt_flipped and their decoder counterparts (src/gpujpeg_preprocessor.cu:455-586,
+    src/gpujpeg_postprocessor.cu:445-496): the raw image is permuted in place, the padded planes are flipped."""
+    w, h = 152, 100  # height not a multiple of 8: the padding rows take part in the flip, as in the reference
+    cs = 1 if pf in (1, 6) else 3
+    raw = O.noise(O.raw_size(w, h, pf), seed=7 * pf + comps)
+    case = ("x", w, h, pf, cs, 85, 5, 1 if pf == 6 else 0, [(1, 1)] * 4 if pf == 6 else None, 3)
+    img = oracle_image(O, case)
+    p, pi = api_params(gpu_lib, G, case)
+    for flip in (False, True):
+        planes = O.preprocess(img, O.channel_remap(img, raw, mapping))
+        if flip:
+            planes = O.flip_planes(img, planes)
+        want = O.encode_from_coefs(img, O.fdct_quant(img, planes))
+        enc = G.Encoder(gpu_lib)
+        assert enc.set_option("enc_opt_channel_remap", mapping) == 0
+        assert enc.set_option("enc_opt_flipped", "1" if flip else "0") == 0
+        assert np.array_equal(enc.encode(p, pi, raw), want), ("encode", flip)
+        enc.close()
+        # decoder: planes flipped before the colour stage, finished image permuted
+        s = O.parse(want)
+        dplanes = O.idct(s, O.huffman_decode(s, want))
+        if flip:
+            dplanes = O.flip_planes(s.img, dplanes)
+        want_px = O.channel_remap(s.img, O.postprocess(s.img, dplanes), mapping)
+        O.lib().gjo_stream_free(C.byref(s))
+        dec = G.Decoder(gpu_lib)
+        assert gpu_lib.L.gpujpeg_decoder_set_option(dec.h, b"dec_opt_channel_remap", mapping.encode()) == 0
+        assert gpu_lib.L.gpujpeg_decoder_set_option(dec.h, b"dec_opt_flipped", b"1" if flip else b"0") == 0
+        px, _ = dec.decode(want)
+        assert np.array_equal(px, want_px), ("decode", flip)
+        dec.close()
+    enc = G.Encoder(gpu_lib)
+    assert enc.set_option("enc_opt_channel_remap", "0123"[: comps + 1] if comps < 4 else "012") == 0  # wrong channel count: rejected at encode time
+    with pytest.raises(Exception):
+        enc.encode(p, pi, raw)
+    assert enc.set_option("enc_opt_channel_remap", "9") != 0
+    enc.close()

@@ -79,3 +79,34 @@ def test_output_format_requests(O, G, ref, pf, w, h):
         px, info = dec.decode(jpeg)
         opx, oinfo = O.decode(jpeg, info.pixel_format, info.color_space)
         assert np.array_equal(px, opx), (opf, ocs)
+
+
+@pytest.mark.parametrize("pf,mapping,flip", [(1, "210", False), (1, "F0Z", True), (6, "1230", True), (2, "201", False), (1, "012", True)])
+def test_channel_remap_and_flip_options(O, G, ref, pf, mapping, flip):
+    """The reference's own option parsing and call order (src/gpujpeg_encoder.c:661-699,767-771, src/gpujpeg_decoder.c:499-503)
+    around the restated in-place channel permutation and plane flip."""
+    w, h = 88, 52
+    cs = 1 if pf in (1, 6) else 3
+    raw = O.noise(O.raw_size(w, h, pf), seed=3 * pf + len(mapping))
+    case = ("x", w, h, pf, cs, 85, 5, 1 if pf == 6 else 0, [(1, 1)] * 4 if pf == 6 else None, 3)
+    img = oracle_image(O, case)
+    planes = O.preprocess(img, O.channel_remap(img, raw, mapping))
+    if flip:
+        planes = O.flip_planes(img, planes)
+    want = O.encode_from_coefs(img, O.fdct_quant(img, planes))
+    p, pi = api_params(ref, G, case)
+    enc = G.Encoder(ref)
+    assert enc.set_option("enc_opt_channel_remap", mapping) == 0
+    assert enc.set_option("enc_opt_flipped", "1" if flip else "0") == 0
+    assert np.array_equal(enc.encode(p, pi, raw), want)
+    s = O.parse(want)
+    dplanes = O.idct(s, O.huffman_decode(s, want))
+    if flip:
+        dplanes = O.flip_planes(s.img, dplanes)
+    want_px = O.channel_remap(s.img, O.postprocess(s.img, dplanes), mapping)
+    O.lib().gjo_stream_free(C.byref(s))
+    dec = G.Decoder(ref)
+    assert ref.L.gpujpeg_decoder_set_option(dec.h, b"dec_opt_channel_remap", mapping.encode()) == 0
+    assert ref.L.gpujpeg_decoder_set_option(dec.h, b"dec_opt_flipped", b"1" if flip else b"0") == 0
+    px, _ = dec.decode(want)
+    assert np.array_equal(px, want_px)

@@ -434,7 +434,32 @@ int gpujpeg_encoder_set_option(struct gpujpeg_encoder* e, const char* opt, const
     }
     if (strcmp(opt, GPUJPEG_ENC_OPT_FLIPPED_BOOL) == 0) return parse_bool(&e->flipped, val, opt); /* src/gpujpeg_encoder.c:767-769 */
     if (strcmp(opt, GPUJPEG_ENC_OPT_CHANNEL_REMAP) == 0) return gj_parse_channel_remap(&e->channel_remap, val, opt);
-    if (strcmp(opt, GPUJPEG_ENC_OPT_EXIF_TAG) == 0 || strcmp(opt, GPUJPEG_ENC_OPT_METADATA) == 0) {
+    if (strcmp(opt, GPUJPEG_ENC_OPT_METADATA) == 0) { /* src/gpujpeg_encoder.c:700-732: orientation=<deg>[-], carried by the SPIFF directory */
+        if (strstr(val, "help") != NULL) {
+            printf(GPUJPEG_ENC_OPT_METADATA " usage:\n");
+            printf("\t" GPUJPEG_ENC_OPT_METADATA "=orientation=<deg>[-]\n");
+            printf("\t\t<deg> - clockwise rotation - 0, 90, 180 or 270 degrees\n");
+            printf("\t\t'-'   - mirror the image horizontally after rotation applied\n");
+            return GPUJPEG_ERROR;
+        }
+        if (strstr(val, "orientation=") != val) {
+            printf("Wrong metadata item: %s\n", val);
+            return GPUJPEG_ERROR;
+        }
+        char* endptr = NULL;
+        const int deg = (int)strtol(strchr(val, '=') + 1, &endptr, 10);
+        bool flip = false;
+        if (*endptr == '-') { flip = true; endptr++; }
+        if (*endptr != '\0' || deg < 0 || deg > 270 || deg % 90 != 0) {
+            printf("Wrong orientation value: %s\n", val);
+            return GPUJPEG_ERROR;
+        }
+        e->metadata.vals[GPUJPEG_METADATA_ORIENTATION].set = 1;
+        e->metadata.vals[GPUJPEG_METADATA_ORIENTATION].orient.rotation = (unsigned)deg / 90;
+        e->metadata.vals[GPUJPEG_METADATA_ORIENTATION].orient.flip = flip;
+        return GPUJPEG_NOERR;
+    }
+    if (strcmp(opt, GPUJPEG_ENC_OPT_EXIF_TAG) == 0) {
         GJ_ERROR("Option %s is not implemented in the MI355X build yet.\n", opt);
         return GPUJPEG_ERROR;
     }

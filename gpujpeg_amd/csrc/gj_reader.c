@@ -146,6 +146,42 @@ static long walk_scan(const uint8_t* image, size_t begin, size_t size, uint32_t 
     }
 }
 
+/* Orientation (tag 0x0112) from the 0th IFD of an Exif APP1 segment -> rotation / flip metadata
+ * (src/gpujpeg_exif.c:159-168,646-764). d points behind the length field, dl = payload bytes. */
+static void exif_orientation(const uint8_t* d, size_t dl, struct gpujpeg_image_metadata* md)
+{
+    static const uint8_t map[8][2] = {{0, 0}, {0, 1}, {2, 0}, {2, 1}, {1, 1}, {1, 0}, {3, 1}, {3, 0}}; /* {rotation, flip} of values 1..8 */
+    if (dl + 2 < 18 || dl < 14) { GJ_WARN("Insufficient Exif header length %zu!\n", dl + 2); return; }
+    const uint8_t* base = d + 6; /* "Exif\0" + padding byte */
+    const size_t n = dl - 6;
+    bool le;
+    if (base[0] == 'I' && base[1] == 'I') le = true;
+    else if (base[0] == 'M' && base[1] == 'M') le = false;
+    else { GJ_WARN("Unexpected endianity!\n"); return; }
+#define XRD2(p) (le ? (unsigned)((p)[0] | (p)[1] << 8) : (unsigned)((p)[0] << 8 | (p)[1]))
+#define XRD4(p) (le ? ((uint32_t)(p)[0] | (uint32_t)(p)[1] << 8 | (uint32_t)(p)[2] << 16 | (uint32_t)(p)[3] << 24) \
+                   : ((uint32_t)(p)[0] << 24 | (uint32_t)(p)[1] << 16 | (uint32_t)(p)[2] << 8 | (uint32_t)(p)[3]))
+    if (XRD2(base + 2) != 0x002A) { GJ_WARN("Wrong TIFF tag, expected 0x%04x!\n", 0x002A); return; }
+    const uint32_t off = XRD4(base + 4);
+    if ((size_t)off + 2 > n) { GJ_WARN("Unexpected end of file!\n"); return; }
+    const unsigned items = XRD2(base + off);
+    if ((size_t)off + 2 + (size_t)items * 12 > n) { GJ_WARN("Insufficient space to hold %u IFD0 items!\n", items); return; }
+    for (unsigned i = 0; i < items; i++) {
+        const uint8_t* e = base + off + 2 + (size_t)i * 12;
+        const unsigned tag = XRD2(e), type = XRD2(e + 2);
+        uint32_t val = XRD4(e + 8);
+        if (!le && (type == 1 || type == 3)) val >>= type == 1 ? 8 : 16; /* :682-686 (short values sit in the upper half) */
+        if (tag == 0x0112) {
+            if (val == 0 || val > 8) { GJ_WARN("Flawed orientation value %u! Should be 1-8...\n", val); continue; }
+            md->vals[GPUJPEG_METADATA_ORIENTATION].orient.rotation = map[val - 1][0];
+            md->vals[GPUJPEG_METADATA_ORIENTATION].orient.flip = map[val - 1][1];
+            md->vals[GPUJPEG_METADATA_ORIENTATION].set = 1;
+        }
+    }
+#undef XRD2
+#undef XRD4
+}
+
 int gj_reader_parse(const uint8_t* image, size_t size, int verbose, bool ff_cs_itu601_is_709, enum gpujpeg_pixel_format req_pixfmt,
                     enum gpujpeg_color_space req_cs, unsigned req_alignment, struct gj_reader_result* r, bool headers_only)
 {
@@ -190,7 +226,11 @@ int gj_reader_parse(const uint8_t* image, size_t size, int verbose, bool ff_cs_i
             if (dl >= 5 && memcmp(d, "JFIF", 5) == 0) { r->header_type = GPUJPEG_HEADER_JFIF; r->header_color_space = GPUJPEG_YCBCR_BT601_256LVLS; }
             break;
         case 0xE1: /* APP1 (reader.c:312-335): Exif implies YCbCr-JPEG; tags themselves are metadata (N4) */
-            if (dl >= 5 && memcmp(d, "Exif", 5) == 0) { r->header_type = GPUJPEG_HEADER_EXIF; r->header_color_space = GPUJPEG_YCBCR_BT601_256LVLS; }
+            if (dl >= 5 && memcmp(d, "Exif", 5) == 0) {
+                r->header_type = GPUJPEG_HEADER_EXIF;
+                r->header_color_space = GPUJPEG_YCBCR_BT601_256LVLS;
+                exif_orientation(d, dl, &r->metadata);
+            }
             else if (verbose >= 0) GJ_WARN("Skipping unsupported APP1 marker!\n");
             break;
         case 0xE8: /* APP8 SPIFF header / directory (reader.c:387-556) */

@@ -176,3 +176,25 @@ def test_channel_remap_and_flip(O, G, gpu_lib, pf, comps, mapping):
         enc.encode(p, pi, raw)
     assert enc.set_option("enc_opt_channel_remap", "9") != 0
     enc.close()
+
+
+def test_encoder_metadata_orientation(O, G, gpu_lib):
+    """enc_opt_metadata=orientation=270- switches the default header to SPIFF and the decoder side reports it
+    (src/gpujpeg_encoder.c:700-732, src/gpujpeg_writer.c:229-235,456-461, src/gpujpeg_reader.c:449-556)."""
+    w, h = 96, 64
+    raw = natural_image(w, h)
+    case = ("m", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    enc = G.Encoder(gpu_lib)
+    assert enc.set_option("enc_opt_metadata", "orientation=45") != 0
+    assert enc.set_option("enc_opt_metadata", "orientation=270-") == 0
+    jpeg = enc.encode(p, pi, raw)
+    assert bytes(jpeg[2:4]) == b"\xff\xe8" and b"SPIFF" in bytes(jpeg[:32])
+    info = G.ImageInfo()
+    assert gpu_lib.L.gpujpeg_decoder_get_image_info2(jpeg.ctypes.data_as(C.POINTER(C.c_uint8)), jpeg.size, C.byref(info), -1, 0) == 0
+    md = bytes(info.metadata)
+    assert md[4] & 1 == 1 and md[0] & 3 == 3 and (md[0] >> 2) & 1 == 1
+    px, _ = G.Decoder(gpu_lib).decode(jpeg)  # pixels are not rotated: the orientation is metadata only
+    plain = G.Encoder(gpu_lib).encode(p, pi, raw)
+    assert np.array_equal(px, G.Decoder(gpu_lib).decode(plain)[0])
+    enc.close()

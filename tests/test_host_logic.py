@@ -152,3 +152,32 @@ def test_file_format_detection(lib, G):
     assert (pi.width, pi.height, pi.pixel_format) == (1119, 561, 0)
     assert L.gpujpeg_image_get_properties(b"64x32.c_ycbcr-jpeg.p_422-u8-p1020.tst", C.byref(pi), 1) == 0
     assert (pi.width, pi.height, pi.pixel_format, pi.color_space) == (64, 32, 3, 3)
+
+
+def test_metadata_orientation_roundtrip(lib, G):
+    """enc_opt_metadata=orientation=<deg>[-] travels in the SPIFF directory (src/gpujpeg_writer.c:229-235) and comes back
+    through gpujpeg_decoder_get_image_info2; an Exif APP1 orientation tag is read as well (src/gpujpeg_exif.c:646-764).
+    Host-only: headers are produced by gpujpeg_amd_host_headers, no device involved."""
+    import ctypes as C
+    import struct
+    p = lib.default_parameters()
+    pi = lib.default_image_parameters()
+    pi.width, pi.height = 64, 48
+    buf = (C.c_uint8 * 4096)()
+    main = C.c_size_t()
+    n = lib.L.gpujpeg_amd_host_headers(C.byref(p), C.byref(pi), 0, buf, 4096, C.byref(main))
+    assert n > 0
+    hdr = bytes(buf[: main.value])
+    # splice an Exif APP1 segment with orientation = 6 (rotated 90 deg CW) right after SOI, both byte orders
+    for le in (True, False):
+        e = "<" if le else ">"
+        tiff = (b"II" if le else b"MM") + struct.pack(e + "HI", 0x2A, 8) + struct.pack(e + "H", 1) + \
+            struct.pack(e + "HHI", 0x0112, 3, 1) + (struct.pack(e + "H", 6) + b"\0\0") + struct.pack(e + "I", 0)
+        app1 = b"Exif\0\0" + tiff
+        seg = b"\xff\xe1" + struct.pack(">H", len(app1) + 2) + app1
+        jpeg = hdr[:2] + seg + hdr[2:] + bytes(buf[main.value:n]) + b"\xff\xd9"
+        info = G.ImageInfo()
+        arr = (C.c_uint8 * len(jpeg)).from_buffer_copy(jpeg)
+        assert lib.L.gpujpeg_decoder_get_image_info2(arr, len(jpeg), C.byref(info), -1, 0) == 0
+        md = bytes(info.metadata)  # struct gpujpeg_image_metadata: orientation bit-field (rotation:2, flip:1), then set:1
+        assert md[4] & 1 == 1 and md[0] & 3 == 1 and (md[0] >> 2) & 1 == 0, (le, md)

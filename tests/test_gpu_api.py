@@ -179,15 +179,15 @@ def test_channel_remap_and_flip(O, G, gpu_lib, pf, comps, mapping):
 
 
 def test_encoder_metadata_orientation(O, G, gpu_lib):
-    """enc_opt_metadata=orientation=270- switches the default header to SPIFF and the decoder side reports it
+    """enc_metadata=orientation=270- switches the default header to SPIFF and the decoder side reports it
     (src/gpujpeg_encoder.c:700-732, src/gpujpeg_writer.c:229-235,456-461, src/gpujpeg_reader.c:449-556)."""
     w, h = 96, 64
     raw = natural_image(w, h)
     case = ("m", w, h, 1, 1, 75, -1, 0, None, 3)
     p, pi = api_params(gpu_lib, G, case)
     enc = G.Encoder(gpu_lib)
-    assert enc.set_option("enc_opt_metadata", "orientation=45") != 0
-    assert enc.set_option("enc_opt_metadata", "orientation=270-") == 0
+    assert enc.set_option("enc_metadata", "orientation=45") != 0
+    assert enc.set_option("enc_metadata", "orientation=270-") == 0
     jpeg = enc.encode(p, pi, raw)
     assert bytes(jpeg[2:4]) == b"\xff\xe8" and b"SPIFF" in bytes(jpeg[:32])
     info = G.ImageInfo()

@@ -356,13 +356,68 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
     return (bitpos - end_bit) | ((uint32_t)z << 5) | ((uint32_t)p << 11);
 }
 
+// A segment that does not fit the LDS stage (more than GJ_PAR_CAP_U bytes: huge restart intervals, noise at q100) is walked by
+// one lane straight from HBM, byte by byte. Slow, rare, and it keeps such streams inside this kernel.
+template <bool INTERLEAVED>
+__device__ void gj_decode_segment_serial(const gj_geom& g, const GjSeg& sg, const uint8_t* __restrict__ p, uint32_t remaining,
+                                         const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab, const uint8_t* __restrict__ s_zz,
+                                         int16_t* __restrict__ coefs)
+{
+    const int P = g.blocks_per_mcu;
+    uint64_t acc = 0;
+    int n = 0, prev_ff = 0;
+    int dc[GJ_MAX_COMP] = {0, 0, 0, 0};
+    for (int k = 0; k < sg.nblocks; k++) {
+        int comp, mcu_pos;
+        const uint64_t off = gj_segment_block(g, sg, k, &comp, &mcu_pos);
+        uint32_t pt;
+        if (INTERLEAVED) {
+            pt = s_ptab[mcu_pos];
+        } else {
+            const gj_comp_geom& kc = g.comp[comp];
+            pt = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+        }
+        const uint16_t* tdc = s_tab + (pt & 0xFFFFu);
+        const uint16_t* tac = s_tab + (pt >> 16);
+        int z = 0;
+        while (z < 64) {
+            while (n <= 56 && remaining > 0) { // refill, dropping the zero stuffed after 0xFF
+                const uint32_t b = *p++;
+                remaining--;
+                if (prev_ff && b == 0) { prev_ff = 0; continue; }
+                prev_ff = b == 0xFFu;
+                acc |= (uint64_t)b << (56 - n);
+                n += 8;
+            }
+            const uint32_t hi = (uint32_t)(acc >> 32);
+            const uint16_t* t = z == 0 ? tdc : tac;
+            uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
+            if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)];
+            const int tot = (int)(e & 31u), adv = (int)(e >> 9), sz = (int)((e >> 5) & 15u);
+            const int used = tot - sz;
+            const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
+            int v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+            const int pos = z + adv - 1;
+            if (z == 0) {
+                v += dc[comp];
+                dc[comp] = v;
+                coefs[off] = (int16_t)v;
+            } else if (sz != 0 && pos < 64) {
+                coefs[off + s_zz[pos]] = (int16_t)v;
+            }
+            acc <<= tot; // past the end of the data the accumulator supplies zero bits, like the reference's reader
+            n = n > tot ? n - tot : 0;
+            z += adv;
+        }
+    }
+}
+
 template <bool INTERLEAVED, int SUB_BYTES>
 __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                             const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const int G,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
-                                                            uint32_t* __restrict__ fallback /* [0] count, [1..] table entries */,
                                                             unsigned long long* __restrict__ prof /* optional phase clocks (GJ_DEC_PROF) */, const int flags /* experiments */)
 {
     unsigned long long t_prof = prof ? wall_clock64() : 0;
@@ -421,6 +476,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     if (si0 >= seg_count) return;
     const int nseg = min(G, seg_count - si0);
     uint32_t my_nblk = 0, my_ucap = 0;
+    bool oversize = false;
     if (tid < GJ_PAR_GMAX) {
         uint32_t pos = 0, len = 0, nblk = 0, first = 0, tb = 0;
         if (tid < nseg) {
@@ -437,9 +493,8 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                     first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block in the coefficient plane
                     tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
                 }
-                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U) { // too long for the LDS stage: leave it to the lane-per-segment kernel
-                    const uint32_t slot = atomicAdd(&fallback[0], 1u);
-                    fallback[1 + slot] = (uint32_t)(si0 + tid);
+                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U) { // too long for the LDS stage: this lane walks it alone at the end
+                    oversize = true;
                     len = 0;
                     nblk = 0;
                 }
@@ -685,6 +740,11 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         __syncthreads();
         GJ_PROF(7) // DC prediction
         j0 = j1;
+    }
+    if (oversize) {
+        const uint32_t s = seg_index[si0 + tid];
+        const GjSeg sg = gj_segment(g, (int)s);
+        gj_decode_segment_serial<INTERLEAVED>(g, sg, jpeg + seg_pos[si0 + tid], seg_len[si0 + tid], s_tab, s_ptab, s_zz, coefs);
     }
 #undef GJ_PROF
 }
@@ -1010,7 +1070,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
-    bool par = job->d_huff_tab2 != nullptr && job->d_fallback != nullptr && job->seg_count > 0 && g.seg_blocks <= GJ_PAR_MAX_BLOCKS;
+    bool par = job->d_huff_tab2 != nullptr && job->seg_count > 0 && g.seg_blocks <= GJ_PAR_MAX_BLOCKS;
     {
         const char* e = getenv("GJ_DEC_ENTROPY"); // "serial" forces the lane-per-segment kernel (A/B measurements, tests)
         if (e && e[0] == 's') par = false;
@@ -1027,16 +1087,11 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / g.seg_blocks)));
         const int sub = es ? atoi(es) : GJ_PAR_SUB;
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
-        (void)hipMemsetAsync(job->d_fallback, 0, sizeof(uint32_t), st);
         auto kernel = g.interleaved ? (sub == 32 ? k_huffman_decode_par<true, 32> : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)
                                     : (sub == 32 ? k_huffman_decode_par<false, 32> : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
         hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                           job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, job->d_fallback, (unsigned long long*)job->d_prof,
+                           job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, (unsigned long long*)job->d_prof,
                            getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0);
-        // segments too long for the LDS stage (none in ordinary streams: the workgroups leave at once)
-        auto serial = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;
-        hipLaunchKernelGGL(serial, dim3(((unsigned)job->seg_count + 255) / 256), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos,
-                           job->d_seg_len, job->d_seg_index, job->d_fallback, job->seg_count, job->d_fallback + 1, job->d_huff_tab, job->d_coefs);
     } else {
         if (job->seg_count > 0) {
             auto kernel = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;

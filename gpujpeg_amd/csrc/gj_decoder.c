@@ -424,7 +424,6 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.clear_coefs = !d->coefs_clean;
     job.zero_coefs = !d->keep_coefs;
     d->coefs_clean = false; /* until the kernels below have run to completion */
-    job.d_fallback = d->d_seg + 3 * S + 4;
     static int prof_on = -1;
     static uint64_t* d_prof = NULL;
     if (prof_on < 0) {

@@ -162,7 +162,6 @@ typedef struct gj_dec_job {
     uint32_t channel_remap;        /* dec_opt_channel_remap: applied to the finished image in d_raw */
     int clear_coefs;               /* 1: d_coefs is not known to be all zero, clear it first */
     int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
-    uint32_t* d_fallback;          /* [1 + seg_count] scratch: segments handed from the sub-sequence kernel to the serial one */
     uint64_t* d_prof;              /* optional [16] phase clock accumulators of the entropy decoder (developer aid, GJ_DEC_PROF=1) */
 } gj_dec_job;
 

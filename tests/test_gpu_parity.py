@@ -228,6 +228,7 @@ ENTROPY_CASES = [
     ("mixed_noise_q100_r40", 320, 200, 100, 40, 0, None, True),           # ~7 KB segments next to short ones at the row ends
     ("interleaved_420_natural", 400, 300, 85, 3, 1, [(2, 2), (1, 1), (1, 1)], False),
     ("interleaved_444_noise", 200, 120, 90, 7, 1, None, True),
+    ("interleaved_long_noise", 128, 128, 100, 60, 1, None, True),         # interleaved segments of ~30 KB: walked by one lane each
     ("tiny_segments_r1", 320, 64, 30, 1, 0, None, False),                  # one block per segment
     ("wide_natural_auto", 1920, 136, 75, -1, 0, None, False),
 ]

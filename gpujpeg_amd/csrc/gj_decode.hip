@@ -418,7 +418,8 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const int G,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
-                                                            unsigned long long* __restrict__ prof /* optional phase clocks (GJ_DEC_PROF) */, const int flags /* experiments */)
+                                                            unsigned long long* __restrict__ prof /* optional phase clocks (GJ_DEC_PROF) */, const int flags /* experiments */,
+                                                            const int zero_fill /* 1: the planes are not known to be zero */)
 {
     unsigned long long t_prof = prof ? wall_clock64() : 0;
 #define GJ_PROF(slot)                                                                            \
@@ -534,7 +535,21 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             s_blk[t] = s_pblk[p][0] + by * s_pblk[p][1] + bx;
         }
     }
-    GJ_PROF(0) // setup
+    // ---- every block of the batch is filled with zeros (fully coalesced 16 B stores, 128 B per block) before its non-zero
+    //      coefficients are scattered into it: the planes need no clearing between frames, and the scattered stores land in
+    //      lines this workgroup has just put into L2 instead of pulling the whole plane through partial-line write-backs
+    if (INTERLEAVED) __syncthreads(); // s_blk is complete
+    if (zero_fill) {
+        for (int j = wave; j < nseg; j += 4) {
+            const uint32_t chunks = s_nblk[j] * 8u;
+            for (uint32_t c = (uint32_t)lane; c < chunks; c += 64) {
+                const uint32_t b = INTERLEAVED ? s_blk[s_bb[j] + (c >> 3)] : s_first[j] + (c >> 3);
+                reinterpret_cast<uint4*>(coefs + (uint64_t)b * 64)[c & 7u] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads(); // (orders the zeros before the coefficient stores of the other lanes)
+    }
+    GJ_PROF(0) // setup + zero fill
 
     // ---- groups of segments whose unstuffed bytes fit the LDS stage (normally one group)
     for (int j0 = 0; j0 < nseg;) {
@@ -744,6 +759,15 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     if (oversize) {
         const uint32_t s = seg_index[si0 + tid];
         const GjSeg sg = gj_segment(g, (int)s);
+        if (zero_fill) {
+            for (int k = 0; k < sg.nblocks; k++) {
+                int comp, mcu_pos;
+                uint4* z = reinterpret_cast<uint4*>(coefs + gj_segment_block(g, sg, k, &comp, &mcu_pos));
+#pragma unroll
+                for (int r = 0; r < 8; r++) z[r] = make_uint4(0, 0, 0, 0);
+            }
+            __threadfence_block();
+        }
         gj_decode_segment_serial<INTERLEAVED>(g, sg, jpeg + seg_pos[si0 + tid], seg_len[si0 + tid], s_tab, s_ptab, s_zz, coefs);
     }
 #undef GJ_PROF
@@ -1075,8 +1099,9 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const char* e = getenv("GJ_DEC_ENTROPY"); // "serial" forces the lane-per-segment kernel (A/B measurements, tests)
         if (e && e[0] == 's') par = false;
     }
-    // both entropy decoders store only non-zero coefficients; the planes are clean when the previous call's IDCT zeroed them
-    if (job->clear_coefs) (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
+    // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
+    // decodes itself; clear_coefs asks for a full clear first (segments missing from the table, lane-per-segment kernel).
+    if (job->clear_coefs || !par) (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
     if (par) {
         // batch: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks
         const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
@@ -1091,7 +1116,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
                                     : (sub == 32 ? k_huffman_decode_par<false, 32> : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
         hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
                            job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, (unsigned long long*)job->d_prof,
-                           getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0);
+                           getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0, job->clear_coefs ? 0 : 1);
     } else {
         if (job->seg_count > 0) {
             auto kernel = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;

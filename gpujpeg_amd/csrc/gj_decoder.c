@@ -421,9 +421,11 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
             goto out;
         }
     }
-    job.clear_coefs = !d->coefs_clean;
-    job.zero_coefs = !d->keep_coefs;
-    d->coefs_clean = false; /* until the kernels below have run to completion */
+    /* the sub-sequence entropy decoder zero-fills every block it decodes; a full clear is needed only when segments are missing
+     * from the table (their blocks would keep the previous frame's coefficients) -- unknown before the end in the speculative path,
+     * which is validated and repeated then */
+    job.clear_coefs = !spec && seg_count != g->segment_count;
+    job.zero_coefs = 0;
     static int prof_on = -1;
     static uint64_t* d_prof = NULL;
     if (prof_on < 0) {
@@ -471,7 +473,8 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
 
     if (spec) { /* now the summary of this stream is on the host: was it what we assumed? */
         struct gj_reader_result chk = r;
-        bool ok = d->h_summary->header_differs == 0 && accept_device_scan(d->h_summary, &chk, g) == 0;
+        bool ok = d->h_summary->header_differs == 0 && accept_device_scan(d->h_summary, &chk, g) == 0 &&
+                  (int)d->h_summary->segment_count == g->segment_count; /* (a stream with missing segments needs the planes cleared first) */
         for (int i = 0; ok && i < g->comp_count; i++)
             if (chk.huff_map[i][0] != r.huff_map[i][0] || chk.huff_map[i][1] != r.huff_map[i][1]) ok = false;
         if (!ok) { /* different header or unusual scan structure: decode again the careful way */
@@ -519,7 +522,6 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         if (output->type == GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER || output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_BUFFER)
             s->duration_memory_from = gj_hip_event_elapsed_ms(c->timers.copy_out[0], c->timers.copy_out[1]);
     }
-    d->coefs_clean = job.zero_coefs != 0;
     gj_coder_process_stats(c, stats);
     if (c->param.verbose >= GPUJPEG_LL_STATUS)
         fprintf(stderr, "Decompressed Size:%13zu bytes %dx%d %s %s\n", output->data_size, output->param_image.width, output->param_image.height,

@@ -91,15 +91,19 @@ __device__ __forceinline__ uint64_t gj_segment_block(const gj_geom& g, const GjS
 // ------------------------------------------------------------------------------------------------
 // Wave / workgroup prefix sums
 // ------------------------------------------------------------------------------------------------
+// Inclusive prefix sum over the 64 lanes of a wave with DPP adds (six VALU operations; the shuffle version goes through
+// ds_bpermute and waits for LDS six times): shifts inside the rows of 16 lanes, then the last lane of row 0/2 is broadcast
+// into row 1/3 and the last lane of the lower half into the upper half (row_bcast:15 / row_bcast:31, gfx9 wave64).
 __device__ __forceinline__ uint32_t gj_wave_incl_scan(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
 }
 
 // inclusive scan over a 256-thread workgroup; s_tmp needs 4 words; all threads must call

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                             w = 0;
                             if (idx < ndw && src + idx < end) w = src[idx];
                         }
-                        uint32_t pw = __shfl_up(w, 1, 64);
+                        uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false); // wave_shr:1
                         if (lane == 0) pw = carry;
                         uint32_t prev = pw >> 24;
                         uint32_t keep = 0;
@@ -615,8 +615,8 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
 #pragma unroll
                         for (int k = 0; k < 4; k++)
                             if (keep & (1u << k)) { U8[o ^ 3u] = (uint8_t)(w >> (8 * k)); o++; }
-                        out += __shfl(inc, 63, 64);
-                        carry = __shfl(w, 63, 64);
+                        out += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
                     }
                     for (uint32_t b = out + (uint32_t)lane; b < ((out + 3u) & ~3u) + 8u; b += 64) U8[(ubase + b) ^ 3u] = 0;
                 }
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                 const unsigned long long m = __ballot(cand);
                 uint32_t base = 0;
                 if (lane == 0 && m) base = atomicAdd(&s_nwork, (uint32_t)__popcll(m));
-                base = __shfl(base, 0, 64);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (cand) s_work[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
             }
             __syncthreads();
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                     if (c >= (INTERLEAVED ? g.comp_count : 1)) break;
                     const uint32_t inc = gj_wave_incl_scan((uint32_t)((!INTERLEAVED || comp == c) ? d : 0));
                     if (!INTERLEAVED || comp == c) dc = carry[c] + (int)inc;
-                    carry[c] += (int)__shfl(inc, 63, 64);
+                    carry[c] += (int)(uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 }
                 if (kb < nblk) {
                     const uint32_t b = INTERLEAVED ? s_blk[bb + kb] : s_first[j] + (uint32_t)kb;

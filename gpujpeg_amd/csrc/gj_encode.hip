@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256) void k_assemble(const gj_enc_job J)
                 if (byte == 0xFFu) out[p++] = 0;
             }
         }
-        o += __shfl(inc, 63, 64);
+        o += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
     if (lane == 0) {
         if (!sg.last_in_scan) {

@@ -288,12 +288,14 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
 // table entry (gj_hip.h, GJ_DEC2_*): bits [0,5) code length + magnitude bits (0 = second level), [5,9) magnitude bits,
 // [9,16) zig-zag advance. State between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag
 // index, [11,16) block inside the MCU.
-template <bool WRITE, bool INTERLEAVED>
+// LONG (pieces of a segment that does not fit the LDS stage): block addresses are computed, DC differences go to the plane.
+template <bool WRITE, bool INTERLEAVED, bool LONG = false>
 __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U, const uint32_t start_bit, const uint32_t end_bit,
                                                   const uint32_t entry, const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab,
                                                   const int P, const uint16_t* tdc, const uint16_t* tac, int& nblk_out,
                                                   int16_t* __restrict__ coefs, const uint32_t first, const uint32_t* __restrict__ s_blk,
-                                                  int16_t* __restrict__ s_dc, int blk, const int nblocks, const uint8_t* __restrict__ s_zz, const int flags = 0)
+                                                  int16_t* __restrict__ s_dc, int blk, const int nblocks, const uint8_t* __restrict__ s_zz, const int flags = 0,
+                                                  const gj_geom* lg = nullptr, const GjSeg* lsg = nullptr)
 {
     uint32_t bitpos = start_bit + (entry & 31u);
     int z = (int)((entry >> 5) & 63u);
@@ -329,7 +331,13 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
             const int v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
             const int pos = z + adv - 1;
             if (blk + nb < nblocks) {
-                if (z == 0) {
+                if (LONG) {
+                    if (z == 0 || (sz != 0 && pos < 64)) {
+                        int c_, m_;
+                        const uint64_t off = INTERLEAVED ? gj_segment_block(*lg, *lsg, blk + nb, &c_, &m_) : (uint64_t)(first + (uint32_t)(blk + nb)) * 64;
+                        coefs[off + (z == 0 ? 0 : s_zz[pos])] = (int16_t)v;
+                    }
+                } else if (z == 0) {
                     s_dc[blk + nb] = (int16_t)v;
                 } else if (sz != 0 && pos < 64) {
                     const uint32_t b = INTERLEAVED ? s_blk[blk + nb] : first + (uint32_t)(blk + nb);
@@ -354,62 +362,6 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
     }
     nblk_out = nb;
     return (bitpos - end_bit) | ((uint32_t)z << 5) | ((uint32_t)p << 11);
-}
-
-// A segment that does not fit the LDS stage (more than GJ_PAR_CAP_U bytes: huge restart intervals, noise at q100) is walked by
-// one lane straight from HBM, byte by byte. Slow, rare, and it keeps such streams inside this kernel.
-template <bool INTERLEAVED>
-__device__ void gj_decode_segment_serial(const gj_geom& g, const GjSeg& sg, const uint8_t* __restrict__ p, uint32_t remaining,
-                                         const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab, const uint8_t* __restrict__ s_zz,
-                                         int16_t* __restrict__ coefs)
-{
-    const int P = g.blocks_per_mcu;
-    uint64_t acc = 0;
-    int n = 0, prev_ff = 0;
-    int dc[GJ_MAX_COMP] = {0, 0, 0, 0};
-    for (int k = 0; k < sg.nblocks; k++) {
-        int comp, mcu_pos;
-        const uint64_t off = gj_segment_block(g, sg, k, &comp, &mcu_pos);
-        uint32_t pt;
-        if (INTERLEAVED) {
-            pt = s_ptab[mcu_pos];
-        } else {
-            const gj_comp_geom& kc = g.comp[comp];
-            pt = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
-        }
-        const uint16_t* tdc = s_tab + (pt & 0xFFFFu);
-        const uint16_t* tac = s_tab + (pt >> 16);
-        int z = 0;
-        while (z < 64) {
-            while (n <= 56 && remaining > 0) { // refill, dropping the zero stuffed after 0xFF
-                const uint32_t b = *p++;
-                remaining--;
-                if (prev_ff && b == 0) { prev_ff = 0; continue; }
-                prev_ff = b == 0xFFu;
-                acc |= (uint64_t)b << (56 - n);
-                n += 8;
-            }
-            const uint32_t hi = (uint32_t)(acc >> 32);
-            const uint16_t* t = z == 0 ? tdc : tac;
-            uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
-            if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)];
-            const int tot = (int)(e & 31u), adv = (int)(e >> 9), sz = (int)((e >> 5) & 15u);
-            const int used = tot - sz;
-            const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
-            int v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
-            const int pos = z + adv - 1;
-            if (z == 0) {
-                v += dc[comp];
-                dc[comp] = v;
-                coefs[off] = (int16_t)v;
-            } else if (sz != 0 && pos < 64) {
-                coefs[off + s_zz[pos]] = (int16_t)v;
-            }
-            acc <<= tot; // past the end of the data the accumulator supplies zero bits, like the reference's reader
-            n = n > tot ? n - tot : 0;
-            z += adv;
-        }
-    }
 }
 
 template <bool INTERLEAVED, int SUB_BYTES>
@@ -450,8 +402,12 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     __shared__ uint32_t s_tmp[4];
     __shared__ int s_j1;
     __shared__ uint32_t s_nwork;
+    __shared__ uint32_t s_long[GJ_PAR_GMAX]; // segments too long for the LDS stage: decoded piece by piece afterwards
+    __shared__ int s_nlong;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_nlong = 0;
+    __syncthreads();
     {
         const uint4* src = reinterpret_cast<const uint4*>(tabs);
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
@@ -477,7 +433,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     if (si0 >= seg_count) return;
     const int nseg = min(G, seg_count - si0);
     uint32_t my_nblk = 0, my_ucap = 0;
-    bool oversize = false;
     if (tid < GJ_PAR_GMAX) {
         uint32_t pos = 0, len = 0, nblk = 0, first = 0, tb = 0;
         if (tid < nseg) {
@@ -494,8 +449,8 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                     first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block in the coefficient plane
                     tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
                 }
-                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U) { // too long for the LDS stage: this lane walks it alone at the end
-                    oversize = true;
+                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U) { // too long for the LDS stage: decoded in pieces at the end
+                    s_long[atomicAdd(&s_nlong, 1)] = (uint32_t)tid;
                     len = 0;
                     nblk = 0;
                 }
@@ -551,6 +506,72 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     }
     GJ_PROF(0) // setup + zero fill
 
+    // (rounds and block positions are shared by the groups of whole segments and by the pieces of long segments)
+    auto run_rounds = [&](const int nsub, const uint32_t ub0) {
+    // rounds. s_rec[k] = (entry state | exit state << 16, blocks completed) is written with one 64-bit LDS store, so a
+    //       record always describes one decoding of sub-sequence k, whoever wrote it last.
+    int nwork = nsub;
+    for (int round = 0; nwork > 0; round++) {
+        for (int w = tid; w < nwork; w += 256) {
+            const int k = s_work[w];
+            const int j = s_subseg[k];
+            const uint32_t k_first = s_sub0[j];
+            const uint32_t tb = s_tabs[j];
+            const uint32_t* U = s_U + ((s_ub[j] - ub0) >> 2);
+            const uint32_t seg_bits = s_ulen[j] * 8u;
+            // round 0: the assumed entry state; later: what the predecessor leaves now
+            const uint32_t e = round == 0 ? (s_rec[k].x & 0xFFFFu) : (s_rec[k - 1].x >> 16);
+            const uint32_t i = (uint32_t)k - k_first;
+            int nb;
+            const uint32_t x = gj_decode_sub<false, INTERLEAVED>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
+                                                                 s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
+            s_rec[k] = make_uint2(e | (x << 16), (uint32_t)nb);
+        }
+        __syncthreads();
+        if (prof && threadIdx.x == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[12], (unsigned long long)nwork); }
+        GJ_PROF(round == 0 ? 3 : 4) // first round / further rounds
+        // next work list: sub-sequences whose predecessor leaves in another state than they were entered with (measured: walking
+        // down runs of them with one lane, or seeding interleaved scans with one hypothesis per MCU block, costs more than it saves)
+        for (int k0 = 0; k0 < nsub; k0 += 256) {
+            const int k = k0 + tid;
+            bool cand = false;
+            if (k < nsub) {
+                const uint32_t first = s_sub0[s_subseg[k]];
+                cand = (uint32_t)k != first && (s_rec[k - 1].x >> 16) != (s_rec[k].x & 0xFFFFu);
+            }
+            const unsigned long long m = __ballot(cand);
+            uint32_t base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_nwork, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (cand) s_work[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+        }
+        __syncthreads();
+        nwork = (int)s_nwork;
+        __syncthreads();
+        if (tid == 0) s_nwork = 0;
+    }
+    for (int k = tid; k < nsub; k += 256) s_scan[k] = s_rec[k].y;
+    __syncthreads();
+
+    };
+    auto block_positions = [&](const int nsub) {
+    //  block position of every sub-sequence inside its segment (inclusive scan, segment start subtracted below)
+    {
+        uint32_t carry = 0;
+        for (int k0 = 0; k0 < nsub; k0 += 256) {
+            const int k = k0 + tid;
+            const uint32_t v = k < nsub ? s_scan[k] : 0;
+            uint32_t tot;
+            const uint32_t inc = gj_wg256_incl_scan(v, s_tmp, &tot);
+            __syncthreads();
+            if (k < nsub) s_scan[k] = carry + inc;
+            carry += tot;
+        }
+    }
+    __syncthreads();
+    GJ_PROF(5) // block positions
+
+    };
     // ---- groups of segments whose unstuffed bytes fit the LDS stage (normally one group)
     for (int j0 = 0; j0 < nseg;) {
         if (tid == 0) { s_j1 = j0 + 1; s_nwork = 0; }
@@ -651,66 +672,9 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         __syncthreads();
         GJ_PROF(2) // sub-sequence table
 
-        // -- 3. rounds. s_rec[k] = (entry state | exit state << 16, blocks completed) is written with one 64-bit LDS store, so a
-        //       record always describes one decoding of sub-sequence k, whoever wrote it last.
-        int nwork = nsub;
-        for (int round = 0; nwork > 0; round++) {
-            for (int w = tid; w < nwork; w += 256) {
-                const int k = s_work[w];
-                const int j = s_subseg[k];
-                const uint32_t k_first = s_sub0[j];
-                const uint32_t tb = s_tabs[j];
-                const uint32_t* U = s_U + ((s_ub[j] - ub0) >> 2);
-                const uint32_t seg_bits = s_ulen[j] * 8u;
-                // round 0: the assumed entry state; later: what the predecessor leaves now
-                const uint32_t e = round == 0 ? (s_rec[k].x & 0xFFFFu) : (s_rec[k - 1].x >> 16);
-                const uint32_t i = (uint32_t)k - k_first;
-                int nb;
-                const uint32_t x = gj_decode_sub<false, INTERLEAVED>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
-                                                                     s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
-                s_rec[k] = make_uint2(e | (x << 16), (uint32_t)nb);
-            }
-            __syncthreads();
-            if (prof && threadIdx.x == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[12], (unsigned long long)nwork); }
-            GJ_PROF(round == 0 ? 3 : 4) // first round / further rounds
-            // next work list: sub-sequences whose predecessor leaves in another state than they were entered with (measured: walking
-            // down runs of them with one lane, or seeding interleaved scans with one hypothesis per MCU block, costs more than it saves)
-            for (int k0 = 0; k0 < nsub; k0 += 256) {
-                const int k = k0 + tid;
-                bool cand = false;
-                if (k < nsub) {
-                    const uint32_t first = s_sub0[s_subseg[k]];
-                    cand = (uint32_t)k != first && (s_rec[k - 1].x >> 16) != (s_rec[k].x & 0xFFFFu);
-                }
-                const unsigned long long m = __ballot(cand);
-                uint32_t base = 0;
-                if (lane == 0 && m) base = atomicAdd(&s_nwork, (uint32_t)__popcll(m));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (cand) s_work[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
-            }
-            __syncthreads();
-            nwork = (int)s_nwork;
-            __syncthreads();
-            if (tid == 0) s_nwork = 0;
-        }
-        for (int k = tid; k < nsub; k += 256) s_scan[k] = s_rec[k].y;
-        __syncthreads();
-
-        // -- 4. block position of every sub-sequence inside its segment (inclusive scan, segment start subtracted below)
-        {
-            uint32_t carry = 0;
-            for (int k0 = 0; k0 < nsub; k0 += 256) {
-                const int k = k0 + tid;
-                const uint32_t v = k < nsub ? s_scan[k] : 0;
-                uint32_t tot;
-                const uint32_t inc = gj_wg256_incl_scan(v, s_tmp, &tot);
-                __syncthreads();
-                if (k < nsub) s_scan[k] = carry + inc;
-                carry += tot;
-            }
-        }
-        __syncthreads();
-        GJ_PROF(5) // block positions
+        // -- 3. rounds, 4. block positions
+        run_rounds(nsub, ub0);
+        block_positions(nsub);
 
         // -- 5. decode once more, now storing the coefficients
         for (int k = tid; k < nsub; k += 256) {
@@ -756,19 +720,113 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         GJ_PROF(7) // DC prediction
         j0 = j1;
     }
-    if (oversize) {
-        const uint32_t s = seg_index[si0 + tid];
-        const GjSeg sg = gj_segment(g, (int)s);
+    // ---- segments longer than the LDS stage (restart interval 0 or very large, noise at q100): piece after piece. A piece is
+    //      GJ_PAR_PIECE stuffed bytes; it is unstuffed by the whole workgroup, cut into sub-sequences and synchronised like a
+    //      segment, except that its first sub-sequence is entered in the state the previous piece was left in. The block count and
+    //      the DC predictors are carried along; the DC differences go to the plane and are summed up there, 256 blocks at a time.
+    constexpr uint32_t GJ_PAR_PIECE = GJ_PAR_CAP_U - 64;
+    const int nlong = s_nlong;
+    for (int li = 0; li < nlong; li++) {
+        const int jl = (int)s_long[li];
+        const GjSeg sg = gj_segment(g, (int)seg_index[si0 + jl]);
+        const uint8_t* base = jpeg + seg_pos[si0 + jl];
+        const uint32_t len = seg_len[si0 + jl];
+        const uint32_t first = s_first[jl];
         if (zero_fill) {
-            for (int k = 0; k < sg.nblocks; k++) {
-                int comp, mcu_pos;
-                uint4* z = reinterpret_cast<uint4*>(coefs + gj_segment_block(g, sg, k, &comp, &mcu_pos));
-#pragma unroll
-                for (int r = 0; r < 8; r++) z[r] = make_uint4(0, 0, 0, 0);
+            for (uint32_t c = (uint32_t)tid; c < (uint32_t)sg.nblocks * 8u; c += 256) {
+                int c_, m_;
+                const uint64_t off = INTERLEAVED ? gj_segment_block(g, sg, (int)(c >> 3), &c_, &m_) : (uint64_t)(first + (c >> 3)) * 64;
+                reinterpret_cast<uint4*>(coefs + off)[c & 7u] = make_uint4(0, 0, 0, 0);
             }
-            __threadfence_block();
         }
-        gj_decode_segment_serial<INTERLEAVED>(g, sg, jpeg + seg_pos[si0 + tid], seg_len[si0 + tid], s_tab, s_ptab, s_zz, coefs);
+        uint32_t src_off = 0, entry = 0, blocks_done = 0;
+        int dc_carry[GJ_MAX_COMP] = {0, 0, 0, 0};
+        while (src_off < len) {
+            __syncthreads();
+            // -- unstuff [src_off, src_off + chunk) plus up to 16 bytes of look-ahead for the symbol that straddles the piece end
+            const uint32_t chunk = min(GJ_PAR_PIECE, len - src_off);
+            const uint32_t look = min(16u, len - src_off - chunk);
+            const uintptr_t a = reinterpret_cast<uintptr_t>(base) + src_off;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+            const int lead = (int)(a & 3);
+            const uint32_t ndw = ((uint32_t)lead + chunk + look + 3u) >> 2;
+            uint8_t* U8 = reinterpret_cast<uint8_t*>(s_U);
+            uint32_t out = 0, ulen = 0; // bytes written so far; those belonging to the piece proper
+            for (uint32_t d0 = 0; d0 < ndw; d0 += 256) {
+                const uint32_t idx = d0 + (uint32_t)tid;
+                uint32_t w = 0;
+                if (idx < ndw && src + idx < end) w = src[idx];
+                uint32_t keep = 0, keep_piece = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int off = (int)(idx * 4u) + k - lead; // offset inside [src_off, ...)
+                    const bool valid = idx < ndw && off >= 0 && off < (int)(chunk + look);
+                    const uint32_t b = (w >> (8 * k)) & 0xFFu;
+                    // the byte before (in the stuffed stream): a zero after 0xFF is stuffing; the first byte of a segment never is
+                    uint32_t prev = 0;
+                    if (valid && src_off + (uint32_t)off > 0) prev = k > 0 ? (w >> (8 * k - 8)) & 0xFFu : base[src_off + (uint32_t)off - 1];
+                    if (valid && !(b == 0 && prev == 0xFFu)) {
+                        keep |= 1u << k;
+                        if (off < (int)chunk) keep_piece |= 1u << k;
+                    }
+                }
+                const uint32_t cnt = (uint32_t)__popc(keep);
+                uint32_t tot;
+                const uint32_t inc = gj_wg256_incl_scan(cnt | ((uint32_t)__popc(keep_piece) << 16), s_tmp, &tot); // two 16-bit sums in one scan
+                uint32_t o = out + (inc & 0xFFFFu) - cnt;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (keep & (1u << k)) { U8[o ^ 3u] = (uint8_t)(w >> (8 * k)); o++; }
+                out += tot & 0xFFFFu;
+                ulen += tot >> 16;
+            }
+            for (uint32_t b = out + (uint32_t)tid; b < ((out + 3u) & ~3u) + 8u; b += 256) U8[b ^ 3u] = 0;
+            // -- the piece as one pseudo segment in slot jl
+            const int nsub = (int)((ulen + SUB_BYTES - 1) / SUB_BYTES);
+            if (tid == 0) { s_sub0[jl] = 0; s_sub0[jl + 1] = (uint32_t)nsub; s_ulen[jl] = ulen; s_ub[jl] = 0; s_nwork = 0; }
+            for (int k = tid; k < nsub; k += 256) {
+                s_subseg[k] = (uint8_t)jl;
+                s_rec[k] = make_uint2(k == 0 ? entry : (1u << 5), 0u);
+                s_work[k] = (uint16_t)k;
+            }
+            __syncthreads();
+            run_rounds(nsub, 0u);
+            block_positions(nsub);
+            // -- coefficients of this piece (DC still as differences)
+            const uint32_t tb = s_tabs[jl];
+            for (int k = tid; k < nsub; k += 256) {
+                const uint32_t before = k > 0 ? s_scan[k - 1] : 0u;
+                const uint32_t endb = min((uint32_t)(k + 1) * SUB_BITS, ulen * 8u);
+                int nb;
+                gj_decode_sub<true, INTERLEAVED, true>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
+                                                       s_tab + (tb >> 16), nb, coefs, first, nullptr, nullptr, (int)(blocks_done + before), sg.nblocks, s_zz, flags,
+                                                       &g, &sg);
+            }
+            __syncthreads(); // (workgroup-scope fence: the differences are visible to the lanes that sum them up)
+            const uint32_t piece_blocks = nsub > 0 ? s_scan[nsub - 1] : 0u;
+            const uint32_t b1 = min(blocks_done + piece_blocks, (uint32_t)sg.nblocks);
+            for (uint32_t k0 = blocks_done; k0 < b1; k0 += 256) {
+                const uint32_t k = k0 + (uint32_t)tid;
+                const bool valid = k < b1;
+                int comp = 0, m_ = 0;
+                uint64_t off = 0;
+                if (valid) off = INTERLEAVED ? gj_segment_block(g, sg, (int)k, &comp, &m_) : (uint64_t)(first + k) * 64;
+                const int d = valid ? (int)coefs[off] : 0;
+#pragma unroll
+                for (int c = 0; c < GJ_MAX_COMP; c++) {
+                    if (c >= (INTERLEAVED ? g.comp_count : 1)) break;
+                    const bool mine = valid && (!INTERLEAVED || comp == c);
+                    uint32_t tot;
+                    const uint32_t inc = gj_wg256_incl_scan((uint32_t)(mine ? d : 0), s_tmp, &tot);
+                    if (mine) coefs[off] = (int16_t)(dc_carry[c] + (int)inc);
+                    dc_carry[c] += (int)tot;
+                }
+            }
+            __syncthreads();
+            if (nsub > 0) entry = s_rec[nsub - 1].x >> 16;
+            blocks_done += piece_blocks;
+            src_off += chunk;
+        }
     }
 #undef GJ_PROF
 }

@@ -229,6 +229,9 @@ ENTROPY_CASES = [
     ("interleaved_420_natural", 400, 300, 85, 3, 1, [(2, 2), (1, 1), (1, 1)], False),
     ("interleaved_444_noise", 200, 120, 90, 7, 1, None, True),
     ("interleaved_long_noise", 128, 128, 100, 60, 1, None, True),         # interleaved segments of ~30 KB: walked by one lane each
+    ("restart0_natural", 512, 384, 85, 0, 0, None, False),                # one segment per scan, tens of KB: decoded piece by piece
+    ("restart0_interleaved_420", 512, 384, 85, 0, 1, [(2, 2), (1, 1), (1, 1)], False),
+    ("restart0_flat", 640, 480, 75, 0, 0, None, None),                     # flat image: thousands of 4-6 bit blocks per piece
     ("tiny_segments_r1", 320, 64, 30, 1, 0, None, False),                  # one block per segment
     ("wide_natural_auto", 1920, 136, 75, -1, 0, None, False),
 ]
@@ -239,7 +242,7 @@ ENTROPY_CASES = [
 def test_entropy_decoder_variants(O, G, gpu_lib, ec, mode, monkeypatch):
     name, w, h, q, ri, il, ss, noisy = ec
     case = (name, w, h, 1, 1, q, ri, il, ss, 3)
-    raw = O.noise(w * h * 3, seed=w + h) if noisy else natural_image(w, h, 3, seed=q)
+    raw = O.noise(w * h * 3, seed=w + h) if noisy else (np.full(w * h * 3, 77, np.uint8) if noisy is None else natural_image(w, h, 3, seed=q))
     want = O.encode(oracle_image(O, case), raw)
     if mode == "serial":
         monkeypatch.setenv("GJ_DEC_ENTROPY", "serial")

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                     first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block in the coefficient plane
                     tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
                 }
-                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U) { // too long for the LDS stage: decoded in pieces at the end
+                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U || nblk > GJ_PAR_MAX_BLOCKS) { // too long for the LDS stage / the per-block arrays: in pieces at the end
                     s_long[atomicAdd(&s_nlong, 1)] = (uint32_t)tid;
                     len = 0;
                     nblk = 0;
@@ -1152,7 +1152,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
-    bool par = job->d_huff_tab2 != nullptr && job->seg_count > 0 && g.seg_blocks <= GJ_PAR_MAX_BLOCKS;
+    bool par = job->d_huff_tab2 != nullptr && job->seg_count > 0;
     {
         const char* e = getenv("GJ_DEC_ENTROPY"); // "serial" forces the lane-per-segment kernel (A/B measurements, tests)
         if (e && e[0] == 's') par = false;
@@ -1167,7 +1167,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const char* es = getenv("GJ_DEC_SUB");
         int G = eg ? atoi(eg) : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
         if (!eg) G = min(G, job->seg_count / 1024); // small frames: rather more, shorter batches than idle CUs (4 per CU)
-        G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / g.seg_blocks)));
+        G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / max(1, g.seg_blocks))));
         const int sub = es ? atoi(es) : GJ_PAR_SUB;
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
         auto kernel = g.interleaved ? (sub == 32 ? k_huffman_decode_par<true, 32> : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)

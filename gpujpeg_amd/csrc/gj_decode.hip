@@ -9,6 +9,7 @@
 // src/gpujpeg_huffman_cpu_decoder.c:245-372), src/gpujpeg_dct_gpu.cu:312-366,472-618 and
 // src/gpujpeg_postprocessor.cu:49-217.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "gj_device.h"
@@ -1127,6 +1128,16 @@ __global__ __launch_bounds__(256) void k_copy_planes_out(const gj_geom g, const 
     }
 }
 
+// developer aid: GJ_DEC_DEBUG_SYNC=1 waits after every launch and names the stage on stderr (which kernel faulted?)
+static void gj_debug_stage(hipStream_t st, const char* what)
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GJ_DEC_DEBUG_SYNC"); on = e && e[0] == '1'; }
+    if (!on) return;
+    const hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, "[GPUJPEG] [Debug] %s: %s\n", what, hipGetErrorString(e));
+}
+
 // ================================================================================================
 // Launcher
 // ================================================================================================
@@ -1183,6 +1194,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
                                job->d_coefs);
         }
     }
+    gj_debug_stage(st, "entropy decoder");
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
     const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 &&
@@ -1210,6 +1222,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
             hipLaunchKernelGGL(k_postprocess, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_planes, job->d_raw);
         }
     }
+    gj_debug_stage(st, "idct / postprocess");
     if (job->channel_remap) { // src/gpujpeg_postprocessor.cu:450,493: the finished image is permuted in place
         const unsigned n = (unsigned)g.width * (unsigned)g.height;
         hipLaunchKernelGGL(k_channel_remap, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->channel_remap & 0xFFFFu);
@@ -1318,7 +1331,9 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
     __shared__ int s_scans;
     __shared__ uint32_t s_opos[GJ_SCAN_MAX_OTHER];
     __shared__ uint8_t s_order[GJ_SCAN_MAX_OTHER];
-    const uint32_t n_rst = min(sum->rst_count, max_segments);
+    // rst_pos holds max_segments - GJ_MAX_COMP valid entries at most (k_marker_emit stops there): a stream with more restart markers
+    // than the geometry allows is damaged; the table is cut and the host, seeing the count, rejects it
+    const uint32_t n_rst = min(sum->rst_count, max_segments - GJ_MAX_COMP);
     const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
     if (threadIdx.x == 0) {
         // order the few other markers by position (insertion sort)
@@ -1351,7 +1366,7 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
         if (blockIdx.x == 0) {
             sum->scan_count = (uint32_t)scans;
             sum->status = (uint32_t)status;
-            sum->segment_count = n_rst + (uint32_t)scans;
+            sum->segment_count = scans ? n_rst + (uint32_t)scans : 0u;
             for (int sc = 0; sc < scans; sc++) { sum->scan_start[sc] = s_start[sc]; sum->scan_end[sc] = s_end[sc]; }
         }
     }
@@ -1378,11 +1393,13 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
     __syncthreads();
     const int scans = s_scans;
     const uint32_t gidx = blockIdx.x * 256u + threadIdx.x;
+    if (scans == 0) return; // no scan ends inside the data (truncated file, no marker at all): the host decides what to do
     if (gidx >= n_rst + (uint32_t)scans || gidx >= max_segments) return;
     int sc = 0;
     while (sc + 1 < scans && gidx >= s_first[sc + 1] + (uint32_t)(sc + 1)) sc++;
     const uint32_t k = gidx - s_first[sc] - (uint32_t)sc;       // index of the segment inside its scan
     const uint32_t c_s = s_first[sc + 1] - s_first[sc];         // RSTn inside this scan
+    if (k > c_s) return;                                        // (inconsistent ranks: damaged stream)
     const uint32_t from = k == 0 ? s_start[sc] : rst_pos[s_first[sc] + k - 1] + 2;
     const uint32_t to = k == c_s ? s_end[sc] : rst_pos[s_first[sc] + k];
     seg_pos[gidx] = from;
@@ -1404,10 +1421,13 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     uint32_t* d_rst = d_scratch + chunks;   // [max_segments]
     (void)hipMemsetAsync(d_summary, 0, sizeof(gj_scan_summary), st);
     hipLaunchKernelGGL(k_marker_count, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary);
+    gj_debug_stage(st, "k_marker_count");
     hipLaunchKernelGGL(k_marker_rank, dim3(1), dim3(1024), 0, st, d_chunk, chunks, d_summary);
     hipLaunchKernelGGL(k_marker_emit, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_rst, max_segments);
+    gj_debug_stage(st, "k_marker_rank + k_marker_emit");
     hipLaunchKernelGGL(k_build_segments, dim3((max_segments + GJ_MAX_COMP + 255) / 256), dim3(256), 0, st, *g, d_rst, begin, size, d_summary,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
+    gj_debug_stage(st, "k_build_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -198,3 +198,39 @@ def test_encoder_metadata_orientation(O, G, gpu_lib):
     plain = G.Encoder(gpu_lib).encode(p, pi, raw)
     assert np.array_equal(px, G.Decoder(gpu_lib).decode(plain)[0])
     enc.close()
+
+
+def test_damaged_streams_do_not_crash(O, G, gpu_lib):
+    """Corrupted entropy data, truncated files and garbage after the headers: the decoder may fail or return garbage pixels, but it
+    must return (no out-of-bounds access, no endless loop in the synchronisation rounds) and keep working afterwards."""
+    rng = np.random.default_rng(5)
+    good = {}
+    for name, w, h, ri, il, ss in [("a", 320, 240, -1, 0, None), ("b", 256, 192, 0, 0, None), ("c", 320, 240, 3, 1, [(2, 2), (1, 1), (1, 1)])]:
+        case = (name, w, h, 1, 1, 80, ri, il, ss, 3)
+        good[name] = O.encode(oracle_image(O, case), natural_image(w, h, 3, seed=w))
+    dec = G.Decoder(gpu_lib)
+    for name, jpeg in good.items():
+        hdr = 700  # leave the headers alone: header damage is the host parser's business (tests/test_host_logic.py)
+        for trial in range(12):
+            bad = jpeg.copy()
+            if trial >= 6:  # many more stray / damaged markers: 0xFF bytes anywhere
+                idx = rng.integers(hdr, bad.size - 2, size=4 * (trial - 5))
+                bad[idx] = 0xFF
+            elif trial < 3:  # random bytes in the entropy-coded part (0xFF avoided: markers would change the segment structure)
+                idx = rng.integers(hdr, bad.size - 2, size=40)
+                bad[idx] = rng.integers(0, 255, size=idx.size, dtype=np.uint8)
+            elif trial == 3:  # stray restart markers
+                idx = rng.integers(hdr, bad.size - 4, size=5)
+                for i in idx:
+                    bad[i], bad[i + 1] = 0xFF, 0xD0 + int(rng.integers(0, 8))
+            elif trial == 4:  # truncated
+                bad = bad[: bad.size // 2].copy()
+            else:  # zeros after the headers
+                bad[hdr + 50:] = 0
+            try:
+                dec.decode(bad)
+            except Exception:
+                pass
+        px, _ = dec.decode(jpeg)  # the decoder object is still usable and correct
+        assert np.array_equal(px, O.decode(jpeg)[0]), name
+    dec.close()

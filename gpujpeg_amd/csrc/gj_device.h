@@ -106,6 +106,14 @@ __device__ __forceinline__ uint32_t gj_wave_incl_scan(uint32_t v)
     return (uint32_t)x;
 }
 
+// per-half minimum of two packed u16 pairs (the compiler scalarises the vector form, hence the instruction itself)
+__device__ __forceinline__ uint32_t gj_pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // inclusive scan over a 256-thread workgroup; s_tmp needs 4 words; all threads must call
 __device__ __forceinline__ uint32_t gj_wg256_incl_scan(uint32_t v, uint32_t* s_tmp, uint32_t* total)
 {

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
                                      ((uint32_t)(5 + (nb & 1) * 2) << 24);
                 const uint32_t d = __builtin_amdgcn_perm(n[nb >> 1], n[na >> 1], sel);
                 s_coef[q * 256 + i] = d;
-                const uint32_t f = ((d & 0xFFFFu) ? 1u : 0u) | ((d >> 16) ? 2u : 0u);
+                const uint32_t m2 = gj_pk_min_u16(d, 0x00010001u); // non-zero flags of the two halves
+                const uint32_t f = (m2 | (m2 >> 15)) & 3u;
                 if (q < 16) mlo |= f << (2 * q);
                 else mhi |= f << (2 * (q - 16));
             }
@@ -695,7 +696,9 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
                                      ((uint32_t)(5 + (nbz & 1) * 2) << 24);
                 const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
                 s_coef[q * 256 + i] = d;
-                const uint32_t f = ((d & 0xFFFFu) ? 1u : 0u) | ((d >> 16) ? 2u : 0u);
+                // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16), fold bit 16 down to bit 1
+                const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
+                const uint32_t f = (m | (m >> 15)) & 3u;
                 if (q < 16) mlo |= f << (2 * q);
                 else mhi |= f << (2 * (q - 16));
             }
@@ -731,11 +734,20 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
             s_segbits[i] = bits;
             my_dw = (bits + 31u) >> 5;
         }
-        uint32_t total_dw;
-        const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total_dw);
-        if (i < spt) s_segbase[i] = base_incl - my_dw;
-        if (i == 0) s_segbase[spt] = total_dw;
+        if (spt <= 64) { // the segment bookkeeping of a tile fits one wave: prefix sum without workgroup barriers
+            if (i < 64) {
+                const uint32_t base_incl = gj_wave_incl_scan(my_dw);
+                if (i < spt) s_segbase[i] = base_incl - my_dw;
+                if (i == 63) s_segbase[spt] = base_incl;
+            }
+        } else {
+            uint32_t total;
+            const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total);
+            if (i < spt) s_segbase[i] = base_incl - my_dw;
+            if (i == 0) s_segbase[spt] = total;
+        }
         __syncthreads();
+        const uint32_t total_dw = s_segbase[spt];
         int pad_bits = 0;
         uint32_t start_bit = 0, end_bit = 0;
         if (active) {

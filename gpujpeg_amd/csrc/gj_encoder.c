@@ -518,6 +518,19 @@ static int host_adjusted(const struct gpujpeg_parameters* param, const struct gp
 size_t gpujpeg_amd_host_headers(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi, int header_type,
                                 uint8_t* dst, size_t capacity, size_t* main_header_size)
 {
+    return gpujpeg_amd_host_headers_md(param, pi, header_type, -1, 0, dst, capacity, main_header_size);
+}
+
+size_t gpujpeg_amd_host_headers_md(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi, int header_type,
+                                   int rotation, int flip, uint8_t* dst, size_t capacity, size_t* main_header_size)
+{
+    struct gpujpeg_image_metadata md;
+    memset(&md, 0, sizeof md);
+    if (rotation >= 0) {
+        md.vals[GPUJPEG_METADATA_ORIENTATION].set = 1;
+        md.vals[GPUJPEG_METADATA_ORIENTATION].orient.rotation = (unsigned)rotation & 3u;
+        md.vals[GPUJPEG_METADATA_ORIENTATION].orient.flip = flip != 0;
+    }
     struct gpujpeg_parameters p;
     gj_geom g;
     if (host_adjusted(param, pi, &p, &g) != 0) return 0;
@@ -525,7 +538,7 @@ size_t gpujpeg_amd_host_headers(const struct gpujpeg_parameters* param, const st
     gj_quant_table_raw(0, p.quality, qraw[0]);
     gj_quant_table_raw(1, p.quality, qraw[1]);
     uint8_t hdr[4096];
-    const size_t n = gj_write_main_header(hdr, &g, &p, (enum gpujpeg_header_type)header_type, (const uint8_t(*)[64])qraw, NULL);
+    const size_t n = gj_write_main_header(hdr, &g, &p, (enum gpujpeg_header_type)header_type, (const uint8_t(*)[64])qraw, &md);
     struct gj_scan_headers sh;
     memset(&sh, 0, sizeof sh);
     if (gj_write_scan_headers(&sh, &g, &p) != 0) return 0;

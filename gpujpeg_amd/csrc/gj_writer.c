@@ -4,8 +4,10 @@
  * (src/gpujpeg_writer.c:120-160 APP0, :172-250 SPIFF, :255-270 APP14, :283-300 DQT, :318-352 SOF0,
  *  :363-405 DHT, :414-449 DRI/COM, :452-520 order of markers, :550-657 scan header + APP13 placeholders).
  */
+#define _POSIX_C_SOURCE 200809L /* localtime_r */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "gj_internal.h"
 
@@ -83,6 +85,64 @@ static void spiff_app8(struct bw* w, const gj_geom* g, const struct gpujpeg_imag
     marker(w, 0xD8);
 }
 
+/* Exif APP1 with the reference's fixed tag set (src/gpujpeg_exif.c:172-300,337-450), big endian ("MM"): 0th IFD with Orientation,
+ * X/YResolution 72/1, ResolutionUnit inches, DateTime (now), YCbCrPositioning centred and the pointer to the Exif IFD with
+ * ExifVersion 0230, ComponentsConfiguration YCbCr, FlashpixVersion 0100, ColorSpace sRGB and the pixel dimensions. Values longer
+ * than 4 bytes follow their IFD. Custom tags (enc_exif_tag) are not implemented. */
+static void exif_app1(struct bw* w, const gj_geom* g, const struct gpujpeg_image_metadata* md)
+{
+    static const uint8_t orient_map[8][2] = {{0, 0}, {0, 1}, {2, 0}, {2, 1}, {1, 1}, {1, 0}, {3, 1}, {3, 0}}; /* {rotation, flip} of Exif values 1..8 */
+    marker(w, 0xE1);
+    const size_t len_at = w->n;
+    b2(w, 0);
+    text(w, "Exif", 5);
+    b1(w, 0);
+    const size_t start = w->n; /* offsets count from here */
+    text(w, "MM", 2);
+    b2(w, 0x002A);
+    b4(w, 8);
+    unsigned orientation = 1;
+    if (md && md->vals[GPUJPEG_METADATA_ORIENTATION].set)
+        for (unsigned i = 0; i < 8; i++)
+            if (orient_map[i][0] == md->vals[GPUJPEG_METADATA_ORIENTATION].orient.rotation && orient_map[i][1] == md->vals[GPUJPEG_METADATA_ORIENTATION].orient.flip)
+                orientation = i + 1;
+    char date_time[20] = "    :  :     :  :  ";
+    {
+        const time_t now = time(NULL);
+        struct tm tmv;
+        if (localtime_r(&now, &tmv)) (void)strftime(date_time, sizeof date_time, "%Y:%m:%d %H:%M:%S", &tmv);
+    }
+    /* ---- 0th IFD: 7 entries, long values (2 rationals, date) behind it ---- */
+    {
+        size_t end = w->n + 2 + 7 * 12 + 4; /* where the long values go */
+        b2(w, 7);
+        b2(w, 0x0112); b2(w, 3); b4(w, 1); b2(w, orientation); b2(w, 0);          /* Orientation SHORT */
+        b2(w, 0x011A); b2(w, 5); b4(w, 1); b4(w, (uint32_t)(end - start));         /* XResolution RATIONAL -> offset */
+        { struct bw v = {w->p, end}; b4(&v, 72); b4(&v, 1); end = v.n; }
+        b2(w, 0x011B); b2(w, 5); b4(w, 1); b4(w, (uint32_t)(end - start));         /* YResolution */
+        { struct bw v = {w->p, end}; b4(&v, 72); b4(&v, 1); end = v.n; }
+        b2(w, 0x0128); b2(w, 3); b4(w, 1); b2(w, 2); b2(w, 0);                     /* ResolutionUnit: inches */
+        b2(w, 0x0132); b2(w, 2); b4(w, 20); b4(w, (uint32_t)(end - start));        /* DateTime ASCII[20] */
+        { struct bw v = {w->p, end}; text(&v, date_time, 20); end = v.n; }
+        b2(w, 0x0213); b2(w, 3); b4(w, 1); b2(w, 1); b2(w, 0);                     /* YCbCrPositioning: centred */
+        b2(w, 0x8769); b2(w, 4); b4(w, 1); b4(w, (uint32_t)(end - start));         /* Exif IFD pointer */
+        b4(w, 0);                                                                  /* no next IFD */
+        w->n = end;
+    }
+    /* ---- Exif IFD: 6 entries, all values fit the entry ---- */
+    b2(w, 6);
+    b2(w, 0x9000); b2(w, 7); b4(w, 4); text(w, "0230", 4);
+    b2(w, 0x9101); b2(w, 7); b4(w, 4); text(w, "\1\2\3\0", 4);
+    b2(w, 0xA000); b2(w, 7); b4(w, 4); text(w, "0100", 4);
+    b2(w, 0xA001); b2(w, 3); b4(w, 1); b2(w, 1); b2(w, 0);
+    b2(w, 0xA002); b2(w, 3); b4(w, 1); b2(w, (unsigned)g->width & 0xFFFF); b2(w, 0);
+    b2(w, 0xA003); b2(w, 3); b4(w, 1); b2(w, (unsigned)g->height & 0xFFFF); b2(w, 0);
+    b4(w, 0);
+    const size_t length = w->n - len_at;
+    w->p[len_at] = (uint8_t)(length >> 8);
+    w->p[len_at + 1] = (uint8_t)length;
+}
+
 size_t gj_write_main_header(uint8_t* out, const gj_geom* g, const struct gpujpeg_parameters* param, enum gpujpeg_header_type header_type,
                             const uint8_t qraw[2][64], const struct gpujpeg_image_metadata* md)
 {
@@ -98,7 +158,12 @@ size_t gj_write_main_header(uint8_t* out, const gj_geom* g, const struct gpujpeg
     switch (h) {
     case GPUJPEG_HEADER_SPIFF: spiff_app8(&w, g, md); break;
     case GPUJPEG_HEADER_ADOBE: adobe_app14(&w); break;
-    case GPUJPEG_HEADER_EXIF: /* Exif writer is outside the hot path: fall back to JFIF */
+    case GPUJPEG_HEADER_EXIF:
+        if (g->color_space_internal != GPUJPEG_YCBCR_BT601_256LVLS)
+            GJ_WARN("[Exif] Color space %s currently not recorded, assumed %s (report)\n", gpujpeg_color_space_get_name((enum gpujpeg_color_space)g->color_space_internal),
+                    gpujpeg_color_space_get_name(GPUJPEG_YCBCR_BT601_256LVLS));
+        exif_app1(&w, g, md);
+        break;
     default: jfif_app0(&w); break;
     }
     unsigned seen = 0;

@@ -110,3 +110,42 @@ def test_channel_remap_and_flip_options(O, G, ref, pf, mapping, flip):
     assert ref.L.gpujpeg_decoder_set_option(dec.h, b"dec_opt_flipped", b"1" if flip else b"0") == 0
     px, _ = dec.decode(want)
     assert np.array_equal(px, want_px)
+
+
+@pytest.mark.parametrize("orientation", [None, "90", "180-"])
+def test_exif_header_bytes(O, G, ref, lib, orientation):
+    """enc_hdr=Exif: the APP1 segment of our writer against the reference's (src/gpujpeg_exif.c:172-450) byte by byte,
+    except the DateTime value (wall clock). Host-only on our side (gpujpeg_amd_host_headers), full encode on the reference side."""
+    w, h = 64, 48
+    case = ("e", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(ref, G, case)
+    enc = G.Encoder(ref)
+    assert enc.set_option("enc_hdr", "Exif") == 0
+    if orientation:
+        assert enc.set_option("enc_metadata", "orientation=" + orientation) == 0
+    jpeg = bytes(enc.encode(p, pi, O.noise(w * h * 3)))
+    assert jpeg[2:4] == b"\xff\xe1"
+    n = 4 + int.from_bytes(jpeg[4:6], "big")
+    want = bytearray(jpeg[2:n])
+    # ours: header type 8 = GPUJPEG_HEADER_EXIF; orientation goes in through the metadata argument of the host helper
+    import ctypes as C
+    buf = (C.c_uint8 * 4096)()
+    main = C.c_size_t()
+    p2, pi2 = api_params(lib, G, case)
+    fn = lib.L.gpujpeg_amd_host_headers_md
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]
+    rot, flip = {None: (-1, 0), "90": (1, 0), "180-": (2, 1)}[orientation]
+    got_n = fn(C.byref(p2), C.byref(pi2), 8, rot, flip, buf, 4096, C.byref(main))
+    got = bytearray(bytes(buf[2:n]))
+    assert got_n > 0 and len(got) == len(want)
+    i = got.find(b"\x01\x32")  # DateTime tag id 0x0132: its 20-byte value sits at the offset stored in the entry
+    off = int.from_bytes(got[i + 8:i + 12], "big") + 2 + 2 + 6  # marker(2)+len(2)+"Exif\0\0"(6) relative to the sliced buffer start
+    # ... and the value of the Exif IFD pointer: the reference takes it from a compound literal that is out of scope when it is
+    # read (src/gpujpeg_exif.c:297-300), so this gcc build of it emits stack garbage there; ours stores the real offset
+    j = got.find(b"\x87\x69")
+    assert int.from_bytes(got[j + 8:j + 12], "big") + 10 == got.find(b"\x90\x00") - 2  # points at the entry count before ExifVersion
+    for b in (got, want):
+        b[off:off + 20] = b"x" * 20
+        b[j + 8:j + 12] = b"PPPP"
+    assert got == want

@@ -305,6 +305,201 @@ static int y4m_save(const char* filename, const uint8_t* image, size_t size, con
     return 0;
 }
 
+/* ------------------------------------------------------------------ BMP and TGA
+ * The reference hands these to third-party stb_image / stb_image_write (src/utils/image_delegate.c:188-330): 1, 3 or 4 channels
+ * of 8 bits <-> u8 / 444-u8-p012 / 4444-u8-p0123. Written here from the format specifications: BMP uncompressed 8 (grey palette),
+ * 24 and 32 bit, bottom-up or top-down; TGA types 2/3 and their run-length coded forms 10/11, both origins. PNG and GIF need
+ * inflate / LZW and stay unsupported. */
+struct raster { int w, h, comps; uint8_t* px; }; /* top-down, RGB(A) or grey, tightly packed */
+
+static unsigned rd16(const uint8_t* p) { return (unsigned)p[0] | (unsigned)p[1] << 8; }
+static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+static int file_read_all(const char* filename, uint8_t** data, size_t* n)
+{
+    FILE* f = fopen(filename, "rb");
+    if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
+    fseek(f, 0, SEEK_END);
+    *n = (size_t)ftell(f);
+    rewind(f);
+    *data = malloc(*n ? *n : 1);
+    if (!*data || fread(*data, 1, *n, f) != *n) { fclose(f); free(*data); GJ_ERROR("Failed to read %s\n", filename); return -1; }
+    fclose(f);
+    return 0;
+}
+
+/* header only when out->px == NULL on return is acceptable (probe): pass want_pixels = 0 */
+static int bmp_decode(const uint8_t* d, size_t n, struct raster* out, int want_pixels)
+{
+    if (n < 54 || d[0] != 'B' || d[1] != 'M') return -1;
+    const uint32_t off = rd32(d + 10), hsize = rd32(d + 14);
+    if (hsize < 40) return -1;
+    const int w = (int)rd32(d + 18);
+    int h = (int)rd32(d + 22);
+    const unsigned bpp = rd16(d + 28);
+    const uint32_t compression = rd32(d + 30);
+    const int top_down = h < 0;
+    if (top_down) h = -h;
+    if (w <= 0 || h <= 0 || (bpp != 8 && bpp != 24 && bpp != 32) || (compression != 0 && !(compression == 3 && bpp == 32))) return -1;
+    out->w = w; out->h = h; out->comps = bpp == 8 ? 1 : bpp == 24 ? 3 : 4;
+    if (!want_pixels) return 0;
+    const size_t pitch = (((size_t)w * bpp + 31) / 32) * 4;
+    if ((size_t)off + pitch * h > n) return -1;
+    const uint8_t* pal = d + 14 + hsize; /* 8 bit: BGRA palette; only grey ramps map to one channel, others are converted to their green */
+    out->px = malloc((size_t)w * h * out->comps);
+    if (!out->px) return -1;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* row = d + off + pitch * (size_t)(top_down ? y : h - 1 - y);
+        uint8_t* o = out->px + (size_t)y * w * out->comps;
+        for (int x = 0; x < w; x++) {
+            if (bpp == 8) o[x] = (size_t)(pal - d) + 4u * row[x] + 2 < n ? pal[4 * row[x] + 1] : row[x];
+            else if (bpp == 24) { o[3 * x] = row[3 * x + 2]; o[3 * x + 1] = row[3 * x + 1]; o[3 * x + 2] = row[3 * x]; }
+            else { o[4 * x] = row[4 * x + 2]; o[4 * x + 1] = row[4 * x + 1]; o[4 * x + 2] = row[4 * x]; o[4 * x + 3] = row[4 * x + 3]; }
+        }
+    }
+    return 0;
+}
+
+static int tga_decode(const uint8_t* d, size_t n, struct raster* out, int want_pixels)
+{
+    if (n < 18) return -1;
+    const unsigned idlen = d[0], cmap = d[1], type = d[2], bpp = d[16], desc = d[17];
+    const int w = (int)rd16(d + 12), h = (int)rd16(d + 14);
+    if (cmap != 0 || w <= 0 || h <= 0) return -1;
+    const int rle = type == 10 || type == 11;
+    if (!((type == 2 || type == 10) && (bpp == 24 || bpp == 32)) && !((type == 3 || type == 11) && bpp == 8)) return -1;
+    out->w = w; out->h = h; out->comps = bpp / 8;
+    if (!want_pixels) return 0;
+    const int c = out->comps;
+    out->px = malloc((size_t)w * h * c);
+    if (!out->px) return -1;
+    const uint8_t* p = d + 18 + idlen;
+    const uint8_t* e = d + n;
+    const size_t total = (size_t)w * h;
+    size_t i = 0;
+    uint8_t* tmp = out->px; /* file order first, flipped afterwards */
+    while (i < total) {
+        size_t run = 1;
+        int repeat = 0;
+        if (rle) {
+            if (p >= e) break;
+            repeat = *p & 0x80;
+            run = (size_t)(*p & 0x7F) + 1;
+            p++;
+        } else run = total;
+        if (run > total - i) run = total - i;
+        for (size_t k = 0; k < run; k++) {
+            if (p + c > e) { i = total; break; }
+            uint8_t* o = tmp + (i + k) * c;
+            if (c == 1) o[0] = p[0];
+            else { o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; if (c == 4) o[3] = p[3]; }
+            if (!repeat) p += c;
+        }
+        if (repeat) p += c;
+        i += run;
+    }
+    if (!(desc & 0x20)) /* bottom-left origin: flip to top-down */
+        for (int y = 0; y < h / 2; y++)
+            for (size_t x = 0; x < (size_t)w * c; x++) {
+                uint8_t* a = out->px + (size_t)y * w * c + x;
+                uint8_t* b = out->px + (size_t)(h - 1 - y) * w * c + x;
+                const uint8_t t = *a; *a = *b; *b = t;
+            }
+    return 0;
+}
+
+static int raster_probe(const char* filename, enum gpujpeg_image_file_format fmt, struct gpujpeg_image_parameters* pi, int file_exists)
+{
+    if (!file_exists) { /* output: stb_image_write takes 1, 3 or 4 interleaved channels */
+        pi->color_space = GPUJPEG_RGB;
+        if (pi->pixel_format != GPUJPEG_U8 && pi->pixel_format != GPUJPEG_4444_U8_P0123) pi->pixel_format = GPUJPEG_PIXFMT_NO_ALPHA;
+        return 1;
+    }
+    uint8_t* d;
+    size_t n;
+    if (file_read_all(filename, &d, &n) != 0) return -1;
+    struct raster r = {0};
+    const int rc = fmt == GPUJPEG_IMAGE_FILE_BMP ? bmp_decode(d, n, &r, 0) : tga_decode(d, n, &r, 0);
+    free(d);
+    if (rc != 0) { GJ_ERROR("Unsupported %s file %s (uncompressed 8/24/32 bit expected)\n", fmt == GPUJPEG_IMAGE_FILE_BMP ? "BMP" : "TGA", filename); return -1; }
+    pi->width = r.w;
+    pi->height = r.h;
+    pi->color_space = r.comps == 1 ? GPUJPEG_YCBCR_JPEG : GPUJPEG_RGB;
+    pi->pixel_format = depth_pixfmt(r.comps);
+    return 0;
+}
+
+static int raster_load(const char* filename, enum gpujpeg_image_file_format fmt, uint8_t** image, size_t* size)
+{
+    uint8_t* d;
+    size_t n;
+    if (file_read_all(filename, &d, &n) != 0) return -1;
+    struct raster r = {0};
+    const int rc = fmt == GPUJPEG_IMAGE_FILE_BMP ? bmp_decode(d, n, &r, 1) : tga_decode(d, n, &r, 1);
+    free(d);
+    if (rc != 0) { free(r.px); GJ_ERROR("Unsupported or damaged %s file %s\n", fmt == GPUJPEG_IMAGE_FILE_BMP ? "BMP" : "TGA", filename); return -1; }
+    const size_t bytes = (size_t)r.w * r.h * r.comps;
+    uint8_t* data = gj_hip_host_alloc(bytes);
+    if (!data) { free(r.px); return -1; }
+    memcpy(data, r.px, bytes);
+    free(r.px);
+    *image = data;
+    *size = bytes;
+    return 0;
+}
+
+static void wr16(uint8_t* p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static void wr32(uint8_t* p, uint32_t v) { wr16(p, v & 0xFFFF); wr16(p + 2, v >> 16); }
+
+static int raster_save(const char* filename, enum gpujpeg_image_file_format fmt, const uint8_t* image, const struct gpujpeg_image_parameters* pi)
+{
+    const int c = pi->pixel_format == GPUJPEG_U8 ? 1 : pi->pixel_format == GPUJPEG_444_U8_P012 ? 3 : pi->pixel_format == GPUJPEG_4444_U8_P0123 ? 4 : 0;
+    if (c == 0) { GJ_ERROR("Pixel format %s cannot be stored in this file type\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1; }
+    FILE* f = fopen(filename, "wb");
+    if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
+    const int w = pi->width, h = pi->height;
+    const size_t spitch = (size_t)w * c + pi->width_padding;
+    if (fmt == GPUJPEG_IMAGE_FILE_BMP) { /* 24 bit (grey replicated) or 32 bit, bottom-up, uncompressed */
+        const int oc = c == 4 ? 4 : 3;
+        const size_t pitch = (((size_t)w * oc * 8 + 31) / 32) * 4;
+        uint8_t hdr[54] = {'B', 'M'};
+        wr32(hdr + 2, (uint32_t)(54 + pitch * h)); wr32(hdr + 10, 54); wr32(hdr + 14, 40);
+        wr32(hdr + 18, (uint32_t)w); wr32(hdr + 22, (uint32_t)h); wr16(hdr + 26, 1); wr16(hdr + 28, (unsigned)oc * 8);
+        wr32(hdr + 34, (uint32_t)(pitch * h)); wr32(hdr + 38, 2835); wr32(hdr + 42, 2835);
+        fwrite(hdr, 1, 54, f);
+        uint8_t* row = calloc(1, pitch);
+        for (int y = h - 1; y >= 0 && row; y--) {
+            const uint8_t* s = image + (size_t)y * spitch;
+            for (int x = 0; x < w; x++) {
+                const uint8_t r = s[x * c], g = c == 1 ? r : s[x * c + 1], b = c == 1 ? r : s[x * c + 2];
+                row[x * oc] = b; row[x * oc + 1] = g; row[x * oc + 2] = r;
+                if (oc == 4) row[x * 4 + 3] = s[x * 4 + 3];
+            }
+            fwrite(row, 1, pitch, f);
+        }
+        free(row);
+    } else { /* TGA type 2 / 3, uncompressed, top-left origin */
+        uint8_t hdr[18] = {0};
+        hdr[2] = c == 1 ? 3 : 2;
+        wr16(hdr + 12, (unsigned)w); wr16(hdr + 14, (unsigned)h);
+        hdr[16] = (uint8_t)(c * 8);
+        hdr[17] = (uint8_t)(0x20 | (c == 4 ? 8 : 0));
+        fwrite(hdr, 1, 18, f);
+        uint8_t* row = malloc((size_t)w * c);
+        for (int y = 0; y < h && row; y++) {
+            const uint8_t* s = image + (size_t)y * spitch;
+            for (int x = 0; x < w; x++) {
+                if (c == 1) row[x] = s[x];
+                else { row[x * c] = s[x * c + 2]; row[x * c + 1] = s[x * c + 1]; row[x * c + 2] = s[x * c]; if (c == 4) row[x * 4 + 3] = s[x * 4 + 3]; }
+            }
+            fwrite(row, 1, (size_t)w * c, f);
+        }
+        free(row);
+    }
+    fclose(f);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ API front-end */
 int gpujpeg_image_load_from_file(const char* filename, uint8_t** image, size_t* image_size) /* common.c:1217-1253 */
 {
@@ -314,8 +509,9 @@ int gpujpeg_image_load_from_file(const char* filename, uint8_t** image, size_t* 
     case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
         return pnm_load(filename, image, image_size);
     case GPUJPEG_IMAGE_FILE_Y4M: return y4m_load(filename, image, image_size);
-    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG: case GPUJPEG_IMAGE_FILE_TGA:
-        GJ_ERROR("Reading %s needs a third-party decoder that is not part of the MI355X build; convert to PNM/PAM/Y4M.\n", filename);
+    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: return raster_load(filename, fmt, image, image_size);
+    case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
+        GJ_ERROR("Reading %s needs a third-party decoder (inflate / LZW) that is not part of the MI355X build; convert to BMP/TGA/PNM/PAM/Y4M.\n", filename);
         return -1;
     default: break;
     }
@@ -352,8 +548,9 @@ int gpujpeg_image_save_to_file(const char* filename, const uint8_t* image, size_
         case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
             return pnm_save(filename, fmt, image, pi);
         case GPUJPEG_IMAGE_FILE_Y4M: return y4m_save(filename, image, image_size, pi);
-        case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG: case GPUJPEG_IMAGE_FILE_TGA:
-            GJ_ERROR("Writing %s needs a third-party encoder that is not part of the MI355X build; use PNM/PAM/Y4M.\n", filename);
+        case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: return raster_save(filename, fmt, image, pi);
+        case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
+            GJ_ERROR("Writing %s needs a third-party encoder that is not part of the MI355X build; use BMP/TGA/PNM/PAM/Y4M.\n", filename);
             return -1;
         default: break;
         }
@@ -382,7 +579,8 @@ int gpujpeg_image_get_properties(const char* filename, struct gpujpeg_image_para
     case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
         return pnm_probe(filename, pi, file_exists);
     case GPUJPEG_IMAGE_FILE_Y4M: return y4m_probe(filename, pi, file_exists);
-    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG: case GPUJPEG_IMAGE_FILE_TGA:
+    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: return raster_probe(filename, fmt, pi, file_exists);
+    case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
         pi->color_space = GPUJPEG_RGB;
         return file_exists ? -1 : 1;
     case GPUJPEG_IMAGE_FILE_RAW: pi->pixel_format = GPUJPEG_PIXFMT_STD; break;

@@ -234,3 +234,56 @@ def test_damaged_streams_do_not_crash(O, G, gpu_lib):
         px, _ = dec.decode(jpeg)  # the decoder object is still usable and correct
         assert np.array_equal(px, O.decode(jpeg)[0]), name
     dec.close()
+
+
+@pytest.mark.parametrize("ext", ["bmp", "tga"])
+@pytest.mark.parametrize("pf,comps", [(1, 3), (6, 4), (0, 1)])
+def test_bmp_tga_roundtrip(gpu_lib, G, tmp_path, ext, pf, comps):
+    lib = gpu_lib
+    """gpujpeg_image_save_to_file / _get_properties / _load_from_file for BMP and TGA (the reference delegates these to stb,
+    src/utils/image_delegate.c:188-330): 1, 3 and 4 channels survive a round trip; hand-made RLE TGA and bottom-up BMP read back."""
+    import ctypes as C
+    w, h = 37, 21  # odd width: BMP rows are padded to 4 bytes
+    rng = np.random.default_rng(comps)
+    img = rng.integers(0, 256, size=w * h * comps, dtype=np.uint8)
+    pi = lib.default_image_parameters()
+    pi.width, pi.height, pi.pixel_format, pi.color_space = w, h, pf, 1 if comps > 1 else 3
+    path = str(tmp_path / f"x.{ext}").encode()
+    assert lib.L.gpujpeg_image_save_to_file(path, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.size, C.byref(pi)) == 0
+    got = lib.default_image_parameters()
+    assert lib.L.gpujpeg_image_get_properties(path, C.byref(got), 1) == 0
+    want_pf = pf if not (ext == "bmp" and comps == 1) else 1  # grey is written as 24-bit BMP (like stb_image_write does)
+    assert (got.width, got.height, got.pixel_format) == (w, h, want_pf)
+    data, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+    assert lib.L.gpujpeg_image_load_from_file(path, C.byref(data), C.byref(size)) == 0
+    back = np.ctypeslib.as_array(data, shape=(size.value,)).copy()
+    lib.L.gpujpeg_image_destroy(data)
+    if ext == "bmp" and comps == 1:
+        assert np.array_equal(back.reshape(-1, 3)[:, 0], img) and np.array_equal(back.reshape(-1, 3)[:, 2], img)
+    else:
+        assert np.array_equal(back, img)
+
+
+def test_tga_rle_and_origin(gpu_lib, G, tmp_path):
+    lib = gpu_lib
+    import ctypes as C
+    w, h = 5, 3
+    px = np.arange(w * h * 3, dtype=np.uint8).reshape(h, w, 3)  # RGB, top-down
+    # run-length coded (type 10), bottom-left origin: rows bottom-up, one raw packet per row followed by nothing
+    body = b""
+    for y in range(h - 1, -1, -1):
+        body += bytes([w - 1]) + px[y][:, ::-1].tobytes()  # raw packet of w pixels, BGR
+    hdr = bytes([0, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, w, 0, h, 0, 24, 0])
+    path = tmp_path / "r.tga"
+    path.write_bytes(hdr + body)
+    data, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+    assert lib.L.gpujpeg_image_load_from_file(str(path).encode(), C.byref(data), C.byref(size)) == 0
+    back = np.ctypeslib.as_array(data, shape=(size.value,)).copy()
+    lib.L.gpujpeg_image_destroy(data)
+    assert np.array_equal(back, px.reshape(-1))
+    # repeat packets: a constant image in a few bytes
+    path.write_bytes(bytes([0, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, w, 0, h, 0, 24, 0x20]) + bytes([0x80 | (w * h - 1), 3, 2, 1]))
+    assert lib.L.gpujpeg_image_load_from_file(str(path).encode(), C.byref(data), C.byref(size)) == 0
+    back = np.ctypeslib.as_array(data, shape=(size.value,)).copy()
+    lib.L.gpujpeg_image_destroy(data)
+    assert np.array_equal(back, np.tile(np.array([1, 2, 3], np.uint8), w * h))

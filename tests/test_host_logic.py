@@ -181,3 +181,26 @@ def test_metadata_orientation_roundtrip(lib, G):
         assert lib.L.gpujpeg_decoder_get_image_info2(arr, len(jpeg), C.byref(info), -1, 0) == 0
         md = bytes(info.metadata)  # struct gpujpeg_image_metadata: orientation bit-field (rotation:2, flip:1), then set:1
         assert md[4] & 1 == 1 and md[0] & 3 == 1 and (md[0] >> 2) & 1 == 0, (le, md)
+
+
+@pytest.mark.parametrize("ext", ["bmp", "tga"])
+@pytest.mark.parametrize("pf,comps", [(1, 3), (6, 4), (0, 1)])
+def test_bmp_tga_save_and_probe(lib, G, tmp_path, ext, pf, comps):
+    """gpujpeg_image_save_to_file / gpujpeg_image_get_properties for BMP and TGA without a device (loading returns pinned memory and is
+    covered by tests/test_gpu_api.py)."""
+    import ctypes as C
+    w, h = 37, 21
+    img = np.random.default_rng(comps).integers(0, 256, size=w * h * comps, dtype=np.uint8)
+    pi = lib.default_image_parameters()
+    pi.width, pi.height, pi.pixel_format, pi.color_space = w, h, pf, 1 if comps > 1 else 3
+    path = str(tmp_path / f"x.{ext}").encode()
+    assert lib.L.gpujpeg_image_save_to_file(path, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.size, C.byref(pi)) == 0
+    got = lib.default_image_parameters()
+    assert lib.L.gpujpeg_image_get_properties(path, C.byref(got), 1) == 0
+    want_pf = pf if not (ext == "bmp" and comps == 1) else 1
+    assert (got.width, got.height, got.pixel_format) == (w, h, want_pf)
+    raw = open(path, "rb").read()
+    if ext == "tga":  # uncompressed, top-left origin: the pixel bytes follow the 18-byte header (BGR order)
+        body = np.frombuffer(raw[18:], np.uint8).reshape(h, w, comps)
+        want = img.reshape(h, w, comps)
+        assert np.array_equal(body[..., 0], want[..., 2 if comps > 1 else 0]) and np.array_equal(body[..., comps - 1 if comps == 4 else 0], want[..., 3 if comps == 4 else (2 if comps > 1 else 0)])

@@ -40,8 +40,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 # HBM bytes per launch of the dominant kernels from the PMC passes committed under profiles/ (8K RGB q75 natural frame):
 # FETCH_SIZE doubled (gfx950 counts 128 B requests as 64 B, guide section HBM) + WRITE_SIZE
-TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49830.2 * 2 + 8350.0) * 1024), "dec:k_huffman_decode_par": int((4631.7 * 2 + 180453.4) * 1024),
-                 "dec:k_idct_fused_rgb444": int((97447.5 * 2 + 291607.7) * 1024)}
+TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49776.3 * 2 + 8350.1) * 1024), "dec:k_huffman_decode_par": int((5481.8 * 2 + 375768.9) * 1024),
+                 "dec:k_idct_fused_rgb444": int((97434.2 * 2 + 97203.7) * 1024)}  # profiles/r1_04_hbm_traffic.txt
 
 
 def synth_frame(width, height, pattern, seed, device):

@@ -1177,7 +1177,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const char* eg = getenv("GJ_DEC_G");     // tuning aids: segments per batch, bytes per sub-sequence
         const char* es = getenv("GJ_DEC_SUB");
         int G = eg ? atoi(eg) : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
-        if (!eg) G = min(G, job->seg_count / 1024); // small frames: rather more, shorter batches than idle CUs (4 per CU)
+        if (!eg) G = min(G, job->seg_count / 768); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
         G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / max(1, g.seg_blocks))));
         const int sub = es ? atoi(es) : GJ_PAR_SUB;
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;

@@ -1179,10 +1179,13 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         int G = eg ? atoi(eg) : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
         if (!eg) G = min(G, job->seg_count / 768); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
         G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / max(1, g.seg_blocks))));
-        const int sub = es ? atoi(es) : GJ_PAR_SUB;
+        const int sub = es ? atoi(es) : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
+                                                                           // has to fall into step too): measured best with 32 B
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
-        auto kernel = g.interleaved ? (sub == 32 ? k_huffman_decode_par<true, 32> : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)
-                                    : (sub == 32 ? k_huffman_decode_par<false, 32> : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
+        auto kernel = g.interleaved ? (sub == 256 ? k_huffman_decode_par<true, 256> : sub == 128 ? k_huffman_decode_par<true, 128> : sub == 64 ? k_huffman_decode_par<true, 64>
+                                       : sub == 32 ? k_huffman_decode_par<true, 32> : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)
+                                    : (sub == 256 ? k_huffman_decode_par<false, 256> : sub == 128 ? k_huffman_decode_par<false, 128> : sub == 64 ? k_huffman_decode_par<false, 64>
+                                       : sub == 32 ? k_huffman_decode_par<false, 32> : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
         hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
                            job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, (unsigned long long*)job->d_prof,
                            getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0, job->clear_coefs ? 0 : 1);

@@ -67,7 +67,7 @@ def synth_frame(width, height, pattern, seed, device):
     return torch.stack(chans, -1).clamp(0, 255).to(torch.uint8).contiguous()
 
 
-def cpu_baseline(width, height, frame_host, seconds_budget=20.0):
+def cpu_baseline(width, height, frame_host, seconds_budget=20.0, is422=False, quality=75):
     """Reference CPU path on the host cores (1 thread): encode + decode of the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -81,6 +81,11 @@ def cpu_baseline(width, height, frame_host, seconds_budget=20.0):
         p.restart_interval, p.verbose = G.RESTART_AUTO, -1
         pi = ref.default_image_parameters()
         pi.width, pi.height = width, height
+        p.quality = quality
+        if is422:
+            pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG
+            p.interleaved = 1
+            dec.set_output_format(G.YCBCR_JPEG, G.P1020_422)
         while True:
             jpeg = enc.encode(p, pi, frame_host)
             dec.decode(jpeg)
@@ -88,17 +93,104 @@ def cpu_baseline(width, height, frame_host, seconds_budget=20.0):
             if time.time() - t_start > seconds_budget * 0.5 or frames >= 4:
                 break
     else:
-        img = O.make_image(width, height)
+        img = (O.make_image(width, height, pixel_format=3, color_space=3, quality=quality, interleaved=1) if is422
+               else O.make_image(width, height, quality=quality))
         while True:
             jpeg = O.encode(img, frame_host)
-            O.decode(jpeg)
+            O.decode(jpeg, 3, 3) if is422 else O.decode(jpeg)
             frames += 1
             if time.time() - t_start > seconds_budget * 0.5 or frames >= 4:
                 break
     dt = time.time() - t_start
     return {"value": round(width * height * frames / dt / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": kind,
-            "sample": f"{frames} x encode+decode of the {width}x{height} RGB q75 frame, single thread, "
+            "sample": f"{frames} x encode+decode of the {width}x{height} {'UYVY 4:2:2' if is422 else 'RGB'} q{quality} frame, single thread, "
                       f"reference host C (writer/reader/CPU Huffman) + restated colour/DCT/IDCT stages, gcc -O2"}
+
+
+def run_batch(args, lib, device, local_rank, rank, world, width, height):
+    """BASELINE.json config 5 / SURVEY.md 8(d): a batch of independent frames, frame i seeded 12345 + i, sharded over the
+    ranks by gpujpeg_amd.sharding.shard_frames (static round-robin, no data-path collective). Every rank keeps its shard
+    resident in HBM, S pipelines (stream + encoder + decoder + host thread) walk disjoint slices of it."""
+    import threading
+    import torch.distributed as dist
+    from gpujpeg_amd.sharding import barrier_and_max, gather_counts, shard_frames
+    if args.workload.endswith("422"):
+        raise SystemExit("--batch is defined for the RGB workloads")
+    mine = shard_frames(args.batch, rank, world)
+    frames = [synth_frame(width, height, args.pattern, 12345 + i, device) for i in mine]
+    S = max(1, min(args.streams, len(frames)))
+    p = lib.default_parameters()
+    p.quality, p.restart_interval, p.verbose = args.quality, G.RESTART_AUTO, -1
+    pi = lib.default_image_parameters()
+    pi.width, pi.height = width, height
+    lanes = []
+    for si in range(S):
+        ts = torch.cuda.Stream(device)
+        e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
+        assert e.set_option("enc_opt_out", "enc_out_val_device") == 0
+        lanes.append({"frames": frames[si::S], "out": torch.empty_like(frames[0]), "enc": e, "dec": d, "bytes": 0})
+    torch.cuda.synchronize()
+
+    def one_pass(ln):
+        nbytes = 0
+        for f in ln["frames"]:
+            jp, js = ln["enc"].encode_noclone(p, pi, f.data_ptr(), gpu=True)
+            o = G.DecoderOutput()
+            o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
+            assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
+            nbytes += js
+        ln["bytes"] = nbytes
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    go = threading.Event()
+
+    def worker(idx, passes, wait):
+        torch.cuda.set_device(local_rank)
+        if wait:
+            go.wait()
+        for _ in range(passes):
+            one_pass(lanes[idx])
+
+    for passes, timed in ((args.warmup, False), (args.steps, True)):
+        threads = [threading.Thread(target=worker, args=(i, passes, timed)) for i in range(S)]
+        for t in threads:
+            t.start()
+        if timed:
+            barrier()
+            t0 = time.perf_counter()
+            go.set()
+        for t in threads:
+            t.join()
+        if timed:
+            barrier()
+            elapsed = time.perf_counter() - t0
+    # the last decoded frame of pipeline 0 must match its input closely (sanity of the timed work, not the parity test)
+    last = lanes[0]["frames"][-1].float()
+    mse = float(((lanes[0]["out"].float() - last) ** 2).mean().item())
+    elapsed = barrier_and_max(elapsed, device)
+    total = gather_counts(len(mine), device)
+    jpeg_bytes = gather_counts(sum(ln["bytes"] for ln in lanes), device)
+    for ln in lanes:
+        ln["enc"].close()
+        ln["dec"].close()
+    if rank == 0:
+        fps = total * args.steps / elapsed
+        print(json.dumps({
+            "metric": f"frames/s encode+decode (batch of {args.batch} {args.workload} frames)", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8 in / f32 DCT / i16 coefficients",
+            "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) resident in HBM, sharded round-robin",
+            "config": {"workload": f"{args.batch} x {width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto, encode then decode of "
+                                   f"every frame per step", "frames_total": total, "frames_per_gpu": len(mine), "streams_per_gpu": S,
+                       "jpeg_bytes_total": jpeg_bytes, "parallelism": f"frame-sharded x{world}, no collective"},
+            "mpix_s": round(fps * width * height / 1e6, 2), "psnr_last_frame_db": round(10 * np.log10(255.0 ** 2 / max(mse, 1e-9)), 2)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -109,6 +201,9 @@ def main():
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient"])
     ap.add_argument("--quality", type=int, default=75)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="BASELINE.json config 5: a fixed batch of this many distinct frames (seeds 12345 + i) sharded over the ranks "
+                         "(strong scaling, frames/s); a step is one pass over the whole batch")
     ap.add_argument("--streams", type=int, default=3, help="independent encoder+decoder pairs per GPU, each on its own HIP stream and host thread; "
                     "one step codes one frame per stream (hides the host side of one call behind the kernels of the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,6 +228,8 @@ def main():
     assert lib.L.gpujpeg_init_device(local_rank, 0) == 0
     width, height = WORKLOADS[args.workload]
     is422 = args.workload.endswith("422")
+    if args.batch:
+        return run_batch(args, lib, device, local_rank, rank, world, width, height)
     frame = synth_frame(width, height, args.pattern, 12345 + rank, device)
     if is422:  # packed UYVY from the synthetic RGB frame: channels reused as Y / Cb / Cr, chroma point-sampled
         f = frame.view(height, width, 3)
@@ -247,9 +344,12 @@ def main():
         pixels = width * height
         raw_bytes = pixels * (2 if is422 else 3)
         whole = enc_ms[1] < 0.02  # fully fused encoder: pixels -> segment streams in one kernel (event slots 0/1 are empty)
-        names = ["enc:k_preprocess", "enc:k_fused_rgb444(pre+dct+quant)",
-                 "enc:k_encode_rgb444(pixels->entropy-coded segments)" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
-                 "dec:k_huffman_decode_par(+fallback launch)", "dec:k_idct_fused_rgb444(idct+post)", "dec:k_postprocess"]
+        fmt = "uyvy422" if is422 else "rgb444"
+        names = ["enc:k_preprocess", f"enc:k_fused_{fmt}(pre+dct+quant)",
+                 f"enc:k_encode_{fmt}(pixels->entropy-coded segments)" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
+                 "dec:k_huffman_decode_par(+fallback launch)", f"dec:k_idct_fused_{fmt}(idct+post)", "dec:k_postprocess"]
+        # the PMC passes under profiles/ were taken on the default 8K workload only
+        traffic_known = args.workload == "8k" and args.quality == 75 and args.pattern == "natural"
         durs = list(enc_ms) + list(dec_ms)
         dom = int(np.argmax(durs))
         alg = raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (same sum)
@@ -267,7 +367,7 @@ def main():
             "kernel_ms": {n: round(float(d), 4) for n, d in zip(names, durs)},
             "gpu_only_ms": {"encode": round(float(enc_ms.sum()), 4), "decode": round(float(dec_ms.sum()), 4)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES.get(names[dom].split("(")[0]),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES.get(names[dom].split("(")[0]) if traffic_known else None,
                          "algorithmic_bytes_per_launch": int(alg), "concurrent_pipelines": S,
                          "note": "duration = average hipEvent duration of one launch in the timed region, where launches of the other "
                                  "pipelines share the GPU; traffic = FETCH_SIZE x 2 + WRITE_SIZE per launch from profiles/ (separate PMC passes)"},
@@ -289,7 +389,7 @@ def main():
             result["verified_bit_exact_decode"] = bool(np.array_equal(out.cpu().numpy().reshape(-1), O.decode(want)[0]))
             del got
         if not args.no_cpu_baseline and world == 1:  # reported baseline, on the host cores of rank 0 at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(width, height, frame.cpu().numpy().reshape(-1))
+            result["cpu_baseline"] = cpu_baseline(width, height, frame.cpu().numpy().reshape(-1), is422=is422, quality=args.quality)
         print(json.dumps(result), flush=True)
     for ln in lanes:
         ln["enc"].close()

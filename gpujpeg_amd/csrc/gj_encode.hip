@@ -807,6 +807,243 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
 }
 
 // ================================================================================================
+// k_encode_rgb444's counterpart for interleaved packed 4:2:2 without colour transform (BASELINE config 4): one lane per
+// block in CODING order (Y0 Y1 Cb Cr of MCU 0, of MCU 1, ...), a workgroup takes spt = 256 / B whole restart segments
+// (B = 4 x restart interval blocks each). All four lanes of an MCU read its 8 x 32 bytes (the same addresses merge in
+// the load unit), pick their own samples with byte permutes, transform, and the coding passes run once on the whole
+// tile -- no coefficient planes, one pass instead of k_encode_rgb444's three.
+// (The coding passes below are the same text as in k_encode_rgb444; only the DC predecessor distance and the table
+// choice are per lane here.)
+// ================================================================================================
+__global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
+                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
+                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
+                                                           uint32_t* __restrict__ seg_ff, unsigned long long* __restrict__ prof)
+{
+    unsigned long long t_prof = prof ? wall_clock64() : 0;
+#define GJ_PROF(slot)                                                                            \
+    if (prof) {                                                                                  \
+        __syncthreads();                                                                         \
+        const unsigned long long now = wall_clock64();                                           \
+        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
+        t_prof = now;                                                                            \
+    }
+    __shared__ __attribute__((aligned(8))) float s_q[2][64];
+    __shared__ uint32_t s_coef[32 * 256];
+    __shared__ uint32_t s_bits[GJ_HUFF_CAP_DW];
+    __shared__ uint32_t s_lut[1024];
+    __shared__ int s_dc[256];
+    __shared__ uint32_t s_segx[256], s_segend[256], s_segbase[257], s_segbits[256], s_segff[256];
+    __shared__ uint32_t s_tmp[4];
+
+    const int i = threadIdx.x;
+    for (int t = i; t < 1024; t += 256) s_lut[t] = lut[t];
+    if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
+
+    const gj_comp_geom& kc = g.comp[1];
+    const int ri = g.restart_interval;
+    const int B = g.seg_blocks;    // 4 x ri
+    const int spt = 256 / B;       // segments per workgroup
+    const int tile_blocks = spt * B;
+    const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
+    const int j = (int)(((uint32_t)i * recip) >> 16);
+    const int k = i - j * B;       // block inside its segment
+    const int p = k & 3;           // position inside the MCU: Y0 Y1 Cb Cr
+    const int seg0 = blockIdx.x * spt;
+    const unsigned m = (unsigned)(seg0 + j) * (unsigned)ri + (unsigned)(k >> 2); // MCU
+    const unsigned nm = (unsigned)g.mcu_count;
+    const bool active = i < tile_blocks && seg0 + j < g.segment_count && m < nm;
+    const bool seg_in_tile = i < spt && seg0 + i < g.segment_count; // lane i keeps the books of local segment i
+    const unsigned my = m / (unsigned)kc.blocks_x, mx = m - my * (unsigned)kc.blocks_x;
+
+    // ---- pixels -> this lane's byte-packed block
+    uint32_t px[16];
+    {
+        const size_t pitch = (size_t)g.width * 2 + g.width_padding;
+        const bool interior = (mx * 16 + 16 <= (unsigned)g.width) && (my * 8 + 8 <= (unsigned)g.height);
+        const bool aligned = ((pitch | (size_t)raw) & 15) == 0;
+        if (!active) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) px[t] = 0;
+        } else if (interior && aligned) {
+            const uint4* src = reinterpret_cast<const uint4*>(raw + (size_t)(my * 8) * pitch + (size_t)mx * 32);
+            const size_t pitch4 = pitch >> 4;
+            const int first = p == 1; // Y1 lives in the second 16 bytes of the row; chroma needs both halves
+            const uint32_t selc = p == 2 ? 0x05040100u : 0x07060302u;
+            uint4 lo[8], hi[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                lo[r] = src[r * pitch4 + first];
+                hi[r] = src[r * pitch4 + 1];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t y0 = __builtin_amdgcn_perm(lo[r].y, lo[r].x, 0x07050301u), y1 = __builtin_amdgcn_perm(lo[r].w, lo[r].z, 0x07050301u);
+                const uint32_t uv01 = __builtin_amdgcn_perm(lo[r].y, lo[r].x, 0x06020400u), uv23 = __builtin_amdgcn_perm(lo[r].w, lo[r].z, 0x06020400u);
+                const uint32_t uv45 = __builtin_amdgcn_perm(hi[r].y, hi[r].x, 0x06020400u), uv67 = __builtin_amdgcn_perm(hi[r].w, hi[r].z, 0x06020400u);
+                const uint32_t c0 = __builtin_amdgcn_perm(uv23, uv01, selc), c1 = __builtin_amdgcn_perm(uv67, uv45, selc);
+                px[2 * r] = p < 2 ? y0 : c0;
+                px[2 * r + 1] = p < 2 ? y1 : c1;
+            }
+        } else {
+            // samples outside the image are zero component values (src/gpujpeg_common.c:941-944); the odd last pixel of an
+            // odd-width row shares the chroma of its pair like the generic loader does
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const unsigned y = my * 8 + r;
+                uint32_t d[2] = {0, 0};
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    uint32_t v = 0;
+                    if (y < (unsigned)g.height) {
+                        if (p < 2) {
+                            const unsigned x = mx * 16 + p * 8 + t;
+                            if (x < (unsigned)g.width) v = raw[(size_t)y * pitch + (size_t)x * 2 + 1];
+                        } else {
+                            const unsigned cx = mx * 8 + t;
+                            if (cx < (unsigned)kc.width) v = raw[(size_t)y * pitch + (size_t)cx * 4 + (p == 2 ? 0 : 2)];
+                        }
+                    }
+                    d[t >> 2] |= v << (8 * (t & 3));
+                }
+                px[2 * r] = d[0];
+                px[2 * r + 1] = d[1];
+            }
+        }
+    }
+    __syncthreads(); // tables are in LDS
+    GJ_PROF(0) // pixels
+
+    {
+        // ---- transform; zig-zag; park in LDS as [dword][lane]
+        const int table = p < 2 ? g.comp[0].type : g.comp[1].type;
+#pragma unroll
+        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(px[t]));
+        uint32_t n[32];
+        gj_fdct_quant_pk<true>(px, s_q[table ? 1 : 0], n, s_coef + i); // rows park in this lane's LDS column in natural order ...
+#pragma unroll
+        for (int t = 0; t < 32; t++) n[t] = s_coef[t * 256 + i]; // ... and come back once the transform's registers are free
+        int dc = 0;
+        uint64_t mask = 0;
+        if (active) {
+            dc = (int)(int16_t)(n[0] & 0xFFFF);
+            uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                const int na = GJ_ZZ[2 * q], nbz = GJ_ZZ[2 * q + 1];
+                const uint32_t sel = (uint32_t)((na & 1) * 2) | ((uint32_t)((na & 1) * 2 + 1) << 8) | ((uint32_t)(4 + (nbz & 1) * 2) << 16) |
+                                     ((uint32_t)(5 + (nbz & 1) * 2) << 24);
+                const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
+                s_coef[q * 256 + i] = d;
+                // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16), fold bit 16 down to bit 1
+                const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
+                const uint32_t f = (m | (m >> 15)) & 3u;
+                if (q < 16) mlo |= f << (2 * q);
+                else mhi |= f << (2 * (q - 16));
+            }
+            mask = ((uint64_t)mhi << 32) | mlo;
+        }
+        s_dc[i] = dc;
+        s_segff[i] = 0;
+        __syncthreads();
+        GJ_PROF(1) // transform + zig-zag park
+
+        // ---- DC prediction + pass A (lengths)
+        int dc_diff = 0;
+        uint32_t len = 0;
+        GjEmit e = {0, 0, 0};
+        const int nblocks = active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0; // blocks of this lane's segment
+        if (active) {
+            const int dist = p == 0 ? 3 : (p == 1 ? 1 : 4); // the previous block of the same component (Y1 follows Y0 of its own MCU)
+            dc_diff = dc - (k - dist < 0 ? 0 : s_dc[i - dist]);
+            len = gj_code_block<false>(s_coef, s_lut, i, dc_diff, mask, table, 0, e, nullptr, 0, 0);
+        }
+        GJ_PROF(2) // pass A
+        // ---- bit positions
+        uint32_t total_bits;
+        const uint32_t incl = gj_wg256_incl_scan(len, s_tmp, &total_bits);
+        const uint32_t excl = incl - len;
+        if (active && k == 0) s_segx[j] = excl;
+        if (active && k == nblocks - 1) s_segend[j] = incl;
+        __syncthreads();
+        uint32_t my_dw = 0;
+        if (seg_in_tile) {
+            uint32_t bits = s_segend[i] - s_segx[i];
+            bits += (8u - (bits & 7u)) & 7u; // ones-padding to a byte boundary
+            s_segbits[i] = bits;
+            my_dw = (bits + 31u) >> 5;
+        }
+        if (spt <= 64) { // the segment bookkeeping of a tile fits one wave: prefix sum without workgroup barriers
+            if (i < 64) {
+                const uint32_t base_incl = gj_wave_incl_scan(my_dw);
+                if (i < spt) s_segbase[i] = base_incl - my_dw;
+                if (i == 63) s_segbase[spt] = base_incl;
+            }
+        } else {
+            uint32_t total;
+            const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total);
+            if (i < spt) s_segbase[i] = base_incl - my_dw;
+            if (i == 0) s_segbase[spt] = total;
+        }
+        __syncthreads();
+        const uint32_t total_dw = s_segbase[spt];
+        int pad_bits = 0;
+        uint32_t start_bit = 0, end_bit = 0;
+        if (active) {
+            start_bit = s_segbase[j] * 32u + (excl - s_segx[j]);
+            if (k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
+            end_bit = start_bit + len + (uint32_t)pad_bits;
+        }
+                GJ_PROF(3) // scans
+
+        // ---- pass B window by window, then drain each window to HBM
+        for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_HUFF_CAP_DW) {
+            const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_HUFF_CAP_DW);
+            for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
+            __syncthreads();
+            if (active && end_bit > wbase * 32u && start_bit < wend * 32u && end_bit > start_bit) {
+                e.acc = 0;
+                e.accbits = (int)(start_bit & 31u);
+                e.dw = start_bit >> 5;
+                gj_code_block<true>(s_coef, s_lut, i, dc_diff, mask, table, pad_bits, e, s_bits, wbase, wend);
+                if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
+            }
+            __syncthreads();
+            GJ_PROF(4) // pass B
+            for (uint32_t d = wbase + i; d < wend; d += 256) {
+                int lo = 0, hi = spt; // local segment that owns dword d
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_segbase[mid] <= d) lo = mid; else hi = mid;
+                }
+                const uint32_t bits = s_segbits[lo];
+                const uint32_t el = d - s_segbase[lo];
+                const uint32_t nflush = (bits + 31u) >> 5;
+                const uint32_t v = s_bits[d - wbase];
+                if (el < nflush) {
+                    int vb = 4;
+                    if (el == nflush - 1) vb = (int)((bits - el * 32u + 7u) >> 3);
+                    uint32_t ff = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (b < vb && ((v >> (24 - 8 * b)) & 0xFFu) == 0xFFu) ff++;
+                    if (ff) atomicAdd(&s_segff[lo], ff);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(temp + ((uint64_t)(seg0 + lo) * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
+                    *dst = __builtin_bswap32(v);
+                }
+            }
+            __syncthreads();
+        }
+        if (seg_in_tile) {
+            seg_bytes[seg0 + i] = (s_segbits[i] + 7u) >> 3;
+            seg_ff[seg0 + i] = s_segff[i];
+        }
+        GJ_PROF(5) // drain
+    }
+#undef GJ_PROF
+}
+
+// ================================================================================================
 // Final offsets: exclusive prefix sum over stuffed segment sizes (+2 for RSTn except at the end of a scan) and over
 // the scan headers that precede each scan. Two launches of ceil(S/1024) workgroups: per-workgroup totals, then every
 // workgroup adds the totals of its predecessors (at most a few hundred values) to its local scan.
@@ -1009,7 +1246,20 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     }
     gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
-    if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
+    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 && g.no_transform == 0 &&
+                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
+                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
+                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
+                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
+    if (uyvy && !job->keep_coefs && g.interleaved && g.restart_interval > 0 && g.seg_blocks <= 256 && g.blocks_per_mcu == 4 &&
+        g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.comp[1].type == g.comp[2].type && !getenv("GJ_ENC_NO_WHOLE422")) {
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+        const int spt = 256 / g.seg_blocks;
+        const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
+        hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, (unsigned long long*)job->d_prof);
+    } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
@@ -1017,11 +1267,6 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
                            job->d_seg_bytes, job->d_seg_ff, (unsigned long long*)job->d_prof);
     } else {
-    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 && g.no_transform == 0 &&
-                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
-                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
-                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
-                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);

@@ -273,3 +273,20 @@ def test_decoder_reuse_without_clearing(O, G, gpu_lib):
             px, _ = dec.decode(jpeg)
             assert np.array_equal(px, want_px)
     dec.close()
+
+
+@pytest.mark.parametrize("w,h,restart", [(648, 50, 6), (322, 77, 1), (1928, 24, 13), (640, 64, 64), (640, 64, 65), (16, 8, 3), (4096, 40, 2)])
+def test_packed_422_whole_frame_encoder(O, G, gpu_lib, w, h, restart):
+    """k_encode_uyvy422 (pixels -> segment streams for interleaved packed 4:2:2): 16-byte aligned and unaligned pitches,
+    partial MCUs on both edges, restart intervals up to the 256-block tile and one beyond it (generic coder); bytes equal
+    the oracle's (src/gpujpeg_huffman_gpu_encoder.cu MCU order Y0 Y1 Cb Cr, DC prediction per component)."""
+    raw = O.noise(O.raw_size(w, h, 3), seed=w + restart)
+    for q in (90, 35):
+        case = ("x", w, h, 3, 3, q, restart, 1, None, 3)
+        want = O.encode(oracle_image(O, case), raw)
+        p, pi = api_params(gpu_lib, G, case)
+        enc = G.Encoder(gpu_lib)
+        assert np.array_equal(enc.encode(p, pi, raw), want), (w, h, restart, q)
+        enc.keep_coefficients()  # the two-kernel path with coefficient planes
+        assert np.array_equal(enc.encode(p, pi, raw), want), (w, h, restart, q, "planes")
+        enc.close()

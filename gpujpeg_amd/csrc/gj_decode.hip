@@ -290,13 +290,17 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
 // [9,16) zig-zag advance. State between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag
 // index, [11,16) block inside the MCU.
 // LONG (pieces of a segment that does not fit the LDS stage): block addresses are computed, DC differences go to the plane.
-template <bool WRITE, bool INTERLEAVED, bool LONG = false>
+// TOK (token mode): the counting passes also count the non-zero AC coefficients (upper half of nblk_out); the
+// storing pass appends them as tokens (value | natural position << 16) to `tok_out` instead of scattering them into the
+// planes, and notes for every block where its tokens start (s_btok, relative to the group).
+template <bool WRITE, bool INTERLEAVED, bool LONG = false, bool TOK = false>
 __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U, const uint32_t start_bit, const uint32_t end_bit,
                                                   const uint32_t entry, const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab,
                                                   const int P, const uint16_t* tdc, const uint16_t* tac, int& nblk_out,
                                                   int16_t* __restrict__ coefs, const uint32_t first, const uint32_t* __restrict__ s_blk,
                                                   int16_t* __restrict__ s_dc, int blk, const int nblocks, const uint8_t* __restrict__ s_zz, const int flags = 0,
-                                                  const gj_geom* lg = nullptr, const GjSeg* lsg = nullptr)
+                                                  const gj_geom* lg = nullptr, const GjSeg* lsg = nullptr, uint32_t* __restrict__ tok_out = nullptr,
+                                                  uint16_t* __restrict__ s_btok = nullptr, const uint32_t tok_rel = 0, uint16_t* __restrict__ s_tend = nullptr)
 {
     uint32_t bitpos = start_bit + (entry & 31u);
     int z = (int)((entry >> 5) & 63u);
@@ -312,6 +316,8 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
     rd++;
     uint32_t nxt = U[rd];
     int nb = 0;
+    uint32_t ntok = 0;
+    uint4 tb = make_uint4(0, 0, 0, 0);
     while (bitpos < end_bit) {
         if (n <= 32) {
             acc |= (uint64_t)nxt << (32 - n);
@@ -325,7 +331,29 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
         if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
         const int tot = (int)(e & 31u);
         const int adv = (int)(e >> 9);
-        if (WRITE) {
+        if (TOK && !WRITE) ntok += (z != 0 && (e & 0x1E0u) != 0) ? 1u : 0u;
+        if (WRITE && TOK) {
+            const int sz = (int)((e >> 5) & 15u);
+            const int used = tot - sz;
+            const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
+            const int v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+            if (z == 0) {
+                if (blk + nb < nblocks) {
+                    s_dc[blk + nb] = (int16_t)v;
+                    s_btok[blk + nb] = (uint16_t)(tok_rel + ntok);
+                }
+            } else if (sz != 0) { // exactly the symbols the counting passes counted (s_zz[64..127] = 63: damaged streams only)
+                // four tokens per 16-byte store: what a scattered store costs in the address path does not depend on its width
+                const uint32_t tk = ((uint32_t)v & 0xFFFFu) | ((uint32_t)s_zz[z + adv - 1] << 16);
+                const uint32_t q = ntok & 3u;
+                tb.x = q == 0 ? tk : tb.x;
+                tb.y = q == 1 ? tk : tb.y;
+                tb.z = q == 2 ? tk : tb.z;
+                tb.w = tk;
+                ntok++;
+                if (q == 3) *reinterpret_cast<uint4*>(tok_out + (ntok - 4u)) = tb; // (dword aligned)
+            }
+        } else if (WRITE) {
             const int sz = (int)((e >> 5) & 15u);
             const int used = tot - sz;
             const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
@@ -353,6 +381,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
         if (z >= 64) {
             z = 0;
             nb++;
+            if (WRITE && TOK && blk + nb == nblocks) *s_tend = (uint16_t)(tok_rel + ntok); // the last block of the segment ends here
             if (INTERLEAVED) {
                 p = p + 1 == P ? 0 : p + 1;
                 const uint32_t pt = s_ptab[p];
@@ -361,18 +390,27 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
             }
         }
     }
-    nblk_out = nb;
+    if (WRITE && TOK) { // the last one to three tokens
+        uint32_t* o = tok_out + (ntok & ~3u);
+        const uint32_t r = ntok & 3u;
+        if (r > 0) o[0] = tb.x;
+        if (r > 1) o[1] = tb.y;
+        if (r > 2) o[2] = tb.z;
+    }
+    nblk_out = TOK ? (int)((uint32_t)nb | (ntok << 16)) : nb;
     return (bitpos - end_bit) | ((uint32_t)z << 5) | ((uint32_t)p << 11);
 }
 
-template <bool INTERLEAVED, int SUB_BYTES>
+template <bool INTERLEAVED, int SUB_BYTES, bool TOK>
 __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                             const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const int G,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
                                                             unsigned long long* __restrict__ prof /* optional phase clocks (GJ_DEC_PROF) */, const int flags /* experiments */,
-                                                            const int zero_fill /* 1: the planes are not known to be zero */)
+                                                            const int zero_fill /* 1: the planes are not known to be zero */,
+                                                            uint32_t* __restrict__ d_tok /* TOK: token buffer */, const uint32_t tok_cap,
+                                                            uint2* __restrict__ d_rec /* TOK: per block (coding order) token start, count << 16 | DC */)
 {
     unsigned long long t_prof = prof ? wall_clock64() : 0;
 #define GJ_PROF(slot)                                                                            \
@@ -394,7 +432,9 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     __shared__ uint32_t s_bb[GJ_PAR_GMAX + 1], s_ub[GJ_PAR_GMAX + 1], s_ulen[GJ_PAR_GMAX], s_sub0[GJ_PAR_GMAX + 1];
     // per block of the batch
     __shared__ int16_t s_dc[GJ_PAR_MAX_BLOCKS];
-    __shared__ uint32_t s_blk[INTERLEAVED ? GJ_PAR_MAX_BLOCKS : 1]; // interleaved: block index in the coefficient planes
+    __shared__ uint32_t s_blk[INTERLEAVED && !TOK ? GJ_PAR_MAX_BLOCKS : 1]; // interleaved: block index in the coefficient planes
+    __shared__ uint16_t s_btok[TOK ? GJ_PAR_MAX_BLOCKS : 1];                // token mode: first token of every block, relative to the group
+    __shared__ uint16_t s_tend[TOK ? GJ_PAR_GMAX : 1];                      // token mode: end of the last block's tokens, per segment
     // per sub-sequence of the group
     __shared__ __attribute__((aligned(8))) uint2 s_rec[MAX_SUBS];
     __shared__ uint16_t s_work[MAX_SUBS];
@@ -475,7 +515,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     }
     __syncthreads();
     const int nblocks_batch = (int)s_bb[nseg];
-    if (INTERLEAVED) { // where every block of the batch lives in the coefficient planes
+    if (INTERLEAVED && !TOK) { // where every block of the batch lives in the coefficient planes
         for (int t = tid; t < nblocks_batch; t += 256) {
             int lo = 0, hi = nseg;
             while (hi - lo > 1) {
@@ -494,8 +534,8 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     // ---- every block of the batch is filled with zeros (fully coalesced 16 B stores, 128 B per block) before its non-zero
     //      coefficients are scattered into it: the planes need no clearing between frames, and the scattered stores land in
     //      lines this workgroup has just put into L2 instead of pulling the whole plane through partial-line write-backs
-    if (INTERLEAVED) __syncthreads(); // s_blk is complete
-    if (zero_fill) {
+    if (INTERLEAVED && !TOK) __syncthreads(); // s_blk is complete
+    if (zero_fill && !TOK) {
         for (int j = wave; j < nseg; j += 4) {
             const uint32_t chunks = s_nblk[j] * 8u;
             for (uint32_t c = (uint32_t)lane; c < chunks; c += 64) {
@@ -524,7 +564,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             const uint32_t e = round == 0 ? (s_rec[k].x & 0xFFFFu) : (s_rec[k - 1].x >> 16);
             const uint32_t i = (uint32_t)k - k_first;
             int nb;
-            const uint32_t x = gj_decode_sub<false, INTERLEAVED>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
+            const uint32_t x = gj_decode_sub<false, INTERLEAVED, false, TOK>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
                                                                  s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
             s_rec[k] = make_uint2(e | (x << 16), (uint32_t)nb);
         }
@@ -678,16 +718,39 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         block_positions(nsub);
 
         // -- 5. decode once more, now storing the coefficients
+        // token mode: the group's tokens form one dense run (lanes write their sub-sequences' tokens back to back). It starts at
+        // 4 x the byte offset of the group's first segment: a non-zero AC coefficient takes at least 2 bits of the stream, so the
+        // runs of different groups cannot overlap, and no allocator or reset is needed between frames.
+        uint32_t gbase = 0;
+        if (TOK) {
+            const uint32_t T = nsub > 0 ? s_scan[nsub - 1] >> 16 : 0u;
+            int jb = j0;
+            while (jb + 1 < j1 && s_len[jb] == 0) jb++; // (segments without data carry no position)
+            gbase = 4u * s_pos[jb];
+            if (gbase > tok_cap || T > tok_cap - gbase) gbase = 0xFFFFFFFFu; // (cannot happen with the capacity the host allocates)
+            for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) s_btok[b] = 0xFFFFu; // "block not seen"
+            if (tid >= j0 && tid < j1) s_tend[tid] = 0xFFFFu;
+            __syncthreads();
+        }
         for (int k = tid; k < nsub; k += 256) {
             const int j = s_subseg[k];
             const uint32_t k_first = s_sub0[j];
             const uint32_t i = (uint32_t)k - k_first;
-            const uint32_t before = (k > 0 ? s_scan[k - 1] : 0u) - (k_first > 0 ? s_scan[k_first - 1] : 0u);
+            const uint32_t sc_k = k > 0 ? s_scan[k - 1] : 0u, sc_f = k_first > 0 ? s_scan[k_first - 1] : 0u;
+            const uint32_t before = TOK ? (sc_k & 0xFFFFu) - (sc_f & 0xFFFFu) : sc_k - sc_f;
             const uint32_t endb = min((i + 1) * SUB_BITS, s_ulen[j] * 8u);
             const uint32_t tb = s_tabs[j];
             int nb;
-            gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
-                                             s_tab + (tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz, flags);
+            if (TOK) {
+                if (gbase != 0xFFFFFFFFu)
+                    gj_decode_sub<true, INTERLEAVED, false, true>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P,
+                                                                  s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, s_dc + s_bb[j], (int)before,
+                                                                  (int)s_nblk[j], s_zz, flags, nullptr, nullptr, d_tok + gbase + (sc_k >> 16), s_btok + s_bb[j],
+                                                                  sc_k >> 16, s_tend + j);
+            } else {
+                gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
+                                                 s_tab + (tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz, flags);
+            }
         }
         __syncthreads();
         GJ_PROF(6) // write pass
@@ -712,8 +775,21 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                     carry[c] += (int)(uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 }
                 if (kb < nblk) {
-                    const uint32_t b = INTERLEAVED ? s_blk[bb + kb] : s_first[j] + (uint32_t)kb;
-                    coefs[(uint64_t)b * 64] = (int16_t)dc;
+                    if (TOK) { // block record in coding order: where the tokens are, how many, the DC term
+                        const uint32_t k_end = s_sub0[j + 1];
+                        const uint32_t seg_end = k_end > s_sub0[j] ? s_scan[k_end - 1] >> 16 : 0u; // tokens of the group up to the end of this segment
+                        const uint32_t t0 = s_btok[bb + kb];
+                        const uint32_t t1 = (kb + 1 < nblk && s_btok[bb + kb + 1] != 0xFFFFu) ? s_btok[bb + kb + 1]
+                                            : (kb + 1 == nblk && s_tend[j] != 0xFFFFu)        ? s_tend[j]
+                                                                                              : seg_end;
+                        const bool seen = t0 != 0xFFFFu && gbase != 0xFFFFFFFFu;
+                        const uint32_t cnt = seen && t1 >= t0 ? min(t1 - t0, 63u) : 0u;
+                        const uint32_t r = (INTERLEAVED ? s_first[j] * (uint32_t)P : s_first[j]) + (uint32_t)kb;
+                        d_rec[r] = make_uint2(seen ? gbase + t0 : 0u, (cnt << 16) | ((uint32_t)dc & 0xFFFFu));
+                    } else {
+                        const uint32_t b = INTERLEAVED ? s_blk[bb + kb] : s_first[j] + (uint32_t)kb;
+                        coefs[(uint64_t)b * 64] = (int16_t)dc;
+                    }
                 }
             }
         }
@@ -733,7 +809,9 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         const uint8_t* base = jpeg + seg_pos[si0 + jl];
         const uint32_t len = seg_len[si0 + jl];
         const uint32_t first = s_first[jl];
-        if (zero_fill) {
+        if (TOK) // token mode: the blocks of a long segment live in the coefficient planes; their records say so (count 0xFFFF)
+            for (uint32_t c = (uint32_t)tid; c < (uint32_t)sg.nblocks; c += 256) d_rec[sg.first_block + c] = make_uint2(0u, 0xFFFF0000u);
+        if (zero_fill || TOK) {
             for (uint32_t c = (uint32_t)tid; c < (uint32_t)sg.nblocks * 8u; c += 256) {
                 int c_, m_;
                 const uint64_t off = INTERLEAVED ? gj_segment_block(g, sg, (int)(c >> 3), &c_, &m_) : (uint64_t)(first + (c >> 3)) * 64;
@@ -796,7 +874,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             // -- coefficients of this piece (DC still as differences)
             const uint32_t tb = s_tabs[jl];
             for (int k = tid; k < nsub; k += 256) {
-                const uint32_t before = k > 0 ? s_scan[k - 1] : 0u;
+                const uint32_t before = k > 0 ? (TOK ? s_scan[k - 1] & 0xFFFFu : s_scan[k - 1]) : 0u;
                 const uint32_t endb = min((uint32_t)(k + 1) * SUB_BITS, ulen * 8u);
                 int nb;
                 gj_decode_sub<true, INTERLEAVED, true>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
@@ -804,7 +882,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                                                        &g, &sg);
             }
             __syncthreads(); // (workgroup-scope fence: the differences are visible to the lanes that sum them up)
-            const uint32_t piece_blocks = nsub > 0 ? s_scan[nsub - 1] : 0u;
+            const uint32_t piece_blocks = nsub > 0 ? (TOK ? s_scan[nsub - 1] & 0xFFFFu : s_scan[nsub - 1]) : 0u;
             const uint32_t b1 = min(blocks_done + piece_blocks, (uint32_t)sg.nblocks);
             for (uint32_t k0 = blocks_done; k0 < b1; k0 += 256) {
                 const uint32_t k = k0 + (uint32_t)tid;
@@ -905,6 +983,40 @@ __device__ __forceinline__ void gj_store_pair(const uint32_t (&c0)[2], const uin
 // lines per load instruction); each thread then takes its own block out of LDS. Blocks are padded to 144 B there, which
 // makes both the linear writes and the per-block 16 B reads bank-conflict free (36 dwords: 9 x 4, 9 coprime to 16).
 #define GJ_TILE_PITCH 144
+// colour transform + packed 4:4:4 store of one block position (three byte-packed component blocks, 8 rows of 24 bytes)
+template <int CS_FROM, int CS_TO>
+__device__ __forceinline__ void gj_store_rgb444(const gj_geom& g, uint8_t* __restrict__ raw, const uint32_t (&pk)[3][16], const unsigned lb,
+                                                const unsigned nb, const unsigned bx, const unsigned by)
+{
+    const size_t pitch = (size_t)g.width * 3 + g.width_padding;
+    const bool interior = lb < nb && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
+    const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        // colour transform in fp32 on pixel pairs (gj_color_f, exact; see gj_device.h), results packed straight into the 24 output bytes
+        uint32_t px[6] = {0, 0, 0, 0, 0, 0};
+        const uint32_t c0[2] = {pk[0][2 * r], pk[0][2 * r + 1]}, c1[2] = {pk[1][2 * r], pk[1][2 * r + 1]}, c2[2] = {pk[2][2 * r], pk[2][2 * r + 1]};
+        gj_store_pair<CS_FROM, CS_TO, 0>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 2>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 4>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 6>(c0, c1, c2, px);
+        const unsigned y = by * 8 + r;
+        if (interior && aligned) {
+            uint2* p = reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)bx * 24);
+            p[0] = make_uint2(px[0], px[1]);
+            p[1] = make_uint2(px[2], px[3]);
+            p[2] = make_uint2(px[4], px[5]);
+        } else if (lb < nb && y < (unsigned)g.height) {
+#pragma unroll
+            for (int byte = 0; byte < 24; byte++) {
+                const unsigned x = bx * 8 + byte / 3;
+                if (x < (unsigned)g.width) raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] = (uint8_t)(px[byte >> 2] >> ((byte & 3) * 8));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, int16_t* __restrict__ coefs,
                                                               const float* __restrict__ qtab, uint8_t* __restrict__ raw, const int zero)
@@ -958,33 +1070,157 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
     }
     // (no early return for the threads past the last block: the compiler would sink the three transforms below it and keep
     // every staged coefficient alive until then)
-    const size_t pitch = (size_t)g.width * 3 + g.width_padding;
-    const bool interior = lb < nb && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
-    const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
+    gj_store_rgb444<CS_FROM, CS_TO>(g, raw, pk, lb, nb, bx, by);
+}
+
+// ================================================================================================
+// The same, fed by the entropy decoder's TOKENS (DESIGN 4.3 "token mode"): per block a record (first token, count, DC
+// term) in coding order and, in one dense array, the non-zero AC coefficients as value | natural position << 16.
+// A block costs 8 B + 4 B per non-zero coefficient of HBM traffic instead of 128 B written (twice) and read. Every lane
+// clears its own 128-byte slot of the LDS tile, the wave copies the token range of its 64 blocks into LDS with 16-byte
+// loads (consecutive blocks of a scan have consecutive tokens; a new range starts where a decoder batch ended), every lane
+// scatters its own tokens into its slot (2-byte LDS stores) and reads the block back as rows. Nothing crosses waves, so
+// there is no workgroup barrier. Blocks of segments too long for the decoder's LDS stage arrive through the coefficient
+// planes as before (count 0xFFFF in the record). Non-interleaved scans only (plane order == coding order).
+// ================================================================================================
+#define GJ_TOK_STAGE 416 // tokens per wave and component in LDS (three of them + the 32 KiB tile: three workgroups per CU)
+
+// a lane's 128-byte slot of the block tile: row r (16 bytes) sits at ((r + lane) & 7) * 16, which spreads the row reads and
+// writes of the 64 lanes over all banks without padding the slot
+__device__ __forceinline__ uint4* gj_slot_row(uint8_t* slot, const int lane, const int r)
+{
+    return reinterpret_cast<uint4*>(slot + (((r + lane) & 7) << 4));
+}
+
+__device__ __forceinline__ void gj_slot_put(uint8_t* slot, const int lane, const uint32_t tok)
+{
+    const uint32_t n = (tok >> 16) & 63u;
+    *reinterpret_cast<uint16_t*>(slot + ((((n >> 3) + (uint32_t)lane) & 7u) << 4) + ((n & 7u) << 1)) = (uint16_t)tok;
+}
+
+template <int CS_FROM, int CS_TO>
+__global__ __launch_bounds__(256, 3) void k_idct_tok_rgb444(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
+                                                            const uint32_t* __restrict__ d_tok, const uint32_t tok_cap,
+                                                            const float* __restrict__ qtab, uint8_t* __restrict__ raw)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][3][GJ_TOK_STAGE];
+    __shared__ __attribute__((aligned(8))) float s_q[3][64];
+    if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
+    const gj_comp_geom& k0 = g.comp[0];
+    const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
+    const unsigned lb = blockIdx.x * 256u + threadIdx.x;
+    const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
+    const int lane = threadIdx.x & 63;
+    uint8_t* slot = s_blk + threadIdx.x * 128;
+
+    // ---- 1. the three block records (independent loads)
+    uint32_t start[3], cnt[3], dc[3];
+    bool in_plane[3];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        // colour transform in fp32 on pixel pairs (gj_color_f, exact; see gj_device.h), results packed straight into the 24 output bytes
-        uint32_t px[6] = {0, 0, 0, 0, 0, 0};
-        const uint32_t c0[2] = {pk[0][2 * r], pk[0][2 * r + 1]}, c1[2] = {pk[1][2 * r], pk[1][2 * r + 1]}, c2[2] = {pk[2][2 * r], pk[2][2 * r + 1]};
-        gj_store_pair<CS_FROM, CS_TO, 0>(c0, c1, c2, px);
-        gj_store_pair<CS_FROM, CS_TO, 2>(c0, c1, c2, px);
-        gj_store_pair<CS_FROM, CS_TO, 4>(c0, c1, c2, px);
-        gj_store_pair<CS_FROM, CS_TO, 6>(c0, c1, c2, px);
-        const unsigned y = by * 8 + r;
-        if (interior && aligned) {
-            uint2* p = reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)bx * 24);
-            p[0] = make_uint2(px[0], px[1]);
-            p[1] = make_uint2(px[2], px[3]);
-            p[2] = make_uint2(px[4], px[5]);
-        } else if (lb < nb && y < (unsigned)g.height) {
+    for (int c = 0; c < 3; c++) {
+        start[c] = cnt[c] = dc[c] = 0;
+        in_plane[c] = false;
+        if (lb < nb) {
+            const uint2 r = d_rec[g.comp[c].data_offset / 64 + lb];
+            start[c] = r.x;
+            cnt[c] = r.y >> 16;
+            dc[c] = r.y & 0xFFFFu;
+            if (cnt[c] == 0xFFFFu) { in_plane[c] = true; cnt[c] = 0; }
+            else if (cnt[c] > 63u || start[c] > tok_cap || cnt[c] > tok_cap - start[c]) cnt[c] = 0; // (a record nobody wrote: damaged stream)
+        }
+    }
+    // ---- 2. tokens of the wave's 64 blocks -> LDS. Normally they form one dense range per component (consecutive blocks of a scan
+    //         have consecutive tokens) that fits the stage: all loads of the three components are in flight together.
+    uint32_t S[3], E[3];
+    bool fast[3];
+    uint4 t0[3], t1[3];
 #pragma unroll
-            for (int byte = 0; byte < 24; byte++) {
-                const unsigned x = bx * 8 + byte / 3;
-                if (x < (unsigned)g.width) raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] = (uint8_t)(px[byte >> 2] >> ((byte & 3) * 8));
+    for (int c = 0; c < 3; c++) {
+        const uint32_t end = start[c] + cnt[c];
+        const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false); // wave_shr:1
+        const unsigned long long breaks = __ballot(lane != 0 && start[c] != prev_end);
+        S[c] = (uint32_t)__builtin_amdgcn_readlane((int)start[c], 0) & ~3u;
+        E[c] = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
+        fast[c] = breaks == 0 && E[c] - S[c] <= GJ_TOK_STAGE;
+        t0[c] = t1[c] = make_uint4(0, 0, 0, 0);
+        if (fast[c]) {
+            const uint32_t i0 = (uint32_t)lane * 4u, i1 = i0 + 256u;
+            if (S[c] + i0 < E[c]) t0[c] = *reinterpret_cast<const uint4*>(d_tok + S[c] + i0);
+            if (i1 < GJ_TOK_STAGE && S[c] + i1 < E[c]) t1[c] = *reinterpret_cast<const uint4*>(d_tok + S[c] + i1);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        uint32_t* stage = s_stage[threadIdx.x >> 6][c];
+        if (fast[c]) {
+            *reinterpret_cast<uint4*>(stage + lane * 4) = t0[c];
+            if (lane * 4 + 256 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 4 + 256) = t1[c];
+        }
+    }
+    __syncthreads(); // (s_q; the stages are private to their wave)
+
+    uint32_t pk[3][16];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        uint32_t* stage = s_stage[threadIdx.x >> 6][c];
+        // ---- 3. own slot: zeros, the DC term, the tokens
+#pragma unroll
+        for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = make_uint4(0, 0, 0, 0);
+        if (in_plane[c]) { // block of a segment that was decoded piece by piece: it is in the coefficient plane
+            const uint4* src = reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (size_t)lb * 64);
+#pragma unroll
+            for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = src[r];
+        } else {
+            *reinterpret_cast<uint16_t*>(slot + ((lane & 7) << 4)) = (uint16_t)dc[c];
+        }
+        const uint32_t end = start[c] + cnt[c];
+        if (fast[c]) {
+            gj_wave_sync();
+            uint32_t a = start[c] - S[c];
+            const uint32_t b = end - S[c];
+            for (; a + 2 <= b; a += 2) {
+                const uint32_t ta = stage[a], tb = stage[a + 1];
+                gj_slot_put(slot, lane, ta);
+                gj_slot_put(slot, lane, tb);
+            }
+            if (a < b) gj_slot_put(slot, lane, stage[a]);
+        } else {
+            // several ranges (a decoder batch ended inside the wave's blocks) or more tokens than the stage holds: range by range,
+            // chunk by chunk
+            const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false);
+            unsigned long long runs = __ballot(lane == 0 || start[c] != prev_end);
+            while (runs) {
+                const int d = __builtin_ctzll(runs);
+                runs &= runs - 1;
+                const int dn = runs ? __builtin_ctzll(runs) : 64;
+                const uint32_t RS = (uint32_t)__builtin_amdgcn_readlane((int)start[c], d), RE = (uint32_t)__builtin_amdgcn_readlane((int)end, dn - 1);
+                const bool mine = lane >= d && lane < dn;
+                for (uint32_t base = RS & ~3u; base < RE; base += GJ_TOK_STAGE) {
+                    gj_wave_sync();
+                    for (uint32_t i = (uint32_t)lane * 4u; i < GJ_TOK_STAGE && base + i < RE; i += 256u)
+                        *reinterpret_cast<uint4*>(stage + i) = *reinterpret_cast<const uint4*>(d_tok + base + i);
+                    gj_wave_sync();
+                    if (mine) {
+                        const uint32_t b = min(end, base + GJ_TOK_STAGE);
+                        for (uint32_t a = max(start[c], base); a < b; a++) gj_slot_put(slot, lane, stage[a - base]);
+                    }
+                }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        gj_wave_sync();
+        // ---- 4. the block as rows; dequantisation + IDCT
+        uint32_t wb[32];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint4 v = *gj_slot_row(slot, lane, r);
+            wb[r * 4] = v.x; wb[r * 4 + 1] = v.y; wb[r * 4 + 2] = v.z; wb[r * 4 + 3] = v.w;
+        }
+        gj_idct_pk(wb, s_q[c], pk[c]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) asm volatile("" : "+v"(pk[c][i])); // one transform at a time (see k_idct_fused_rgb444)
     }
+    gj_store_rgb444<CS_FROM, CS_TO>(g, raw, pk, lb, nb, bx, by);
 }
 
 // ================================================================================================
@@ -1157,6 +1393,22 @@ static gj_idct_fused_t gj_idct_fused_kernel(const gj_geom& g)
     return nullptr;
 }
 
+typedef void (*gj_idct_tok_t)(const gj_geom, const int16_t*, const uint2*, const uint32_t*, uint32_t, const float*, uint8_t*);
+
+static gj_idct_tok_t gj_idct_tok_kernel(const gj_geom& g)
+{
+    if (g.pixel_format != GJ_PF_444_P012 || g.comp_count != 3) return nullptr;
+    for (int c = 0; c < 3; c++)
+        if (g.comp[c].samp_h != 1 || g.comp[c].samp_v != 1) return nullptr;
+    const int from = g.color_space_internal, to = g.color_space;
+    if (from == to || from == GJ_CS_NONE || to == GJ_CS_NONE) return k_idct_tok_rgb444<GJ_CS_NONE, GJ_CS_NONE>;
+    if (from == GJ_CS_BT601_256 && to == GJ_CS_RGB) return k_idct_tok_rgb444<GJ_CS_BT601_256, GJ_CS_RGB>;
+    if (from == GJ_CS_BT601 && to == GJ_CS_RGB) return k_idct_tok_rgb444<GJ_CS_BT601, GJ_CS_RGB>;
+    if (from == GJ_CS_BT709 && to == GJ_CS_RGB) return k_idct_tok_rgb444<GJ_CS_BT709, GJ_CS_RGB>;
+    if (from == GJ_CS_RGB && to == GJ_CS_BT601_256) return k_idct_tok_rgb444<GJ_CS_RGB, GJ_CS_BT601_256>;
+    return nullptr;
+}
+
 extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4])
 {
     hipStream_t st = (hipStream_t)stream;
@@ -1168,9 +1420,28 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const char* e = getenv("GJ_DEC_ENTROPY"); // "serial" forces the lane-per-segment kernel (A/B measurements, tests)
         if (e && e[0] == 's') par = false;
     }
+    // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
+    // record per block instead of through the coefficient planes
+    gj_idct_tok_t idct_tok = (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && !g.interleaved && !getenv("GJ_DEC_NO_TOKENS"))
+                                 ? gj_idct_tok_kernel(g) : nullptr;
+    {
+        const char* es = getenv("GJ_DEC_SUB");
+        if (es && atoi(es) != GJ_PAR_SUB) idct_tok = nullptr; // (the tuning aid sweeps the plane-mode kernels)
+        // Measured (8K / 16K natural frames +9 % / +17 % enc+dec; HD and 4K equal or slightly slower; 8K noise -15 %): tokens pay when
+        // the frame fills the GPU more than once (the token-fed IDCT has the longer dependency chain per workgroup) and blocks
+        // carry few coefficients (4 B per coefficient against 128 B per block). GJ_DEC_TOKENS=1 forces the mode (tests).
+        const char* et = getenv("GJ_DEC_TOKENS");
+        const bool forced = et && et[0] == '1';
+        if (!forced && (g.comp[0].blocks_x * g.comp[0].blocks_y < 300000 || job->jpeg_size > (uint64_t)g.block_count * 12u)) idct_tok = nullptr;
+    }
+    const bool tokens = idct_tok != nullptr;
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
     // decodes itself; clear_coefs asks for a full clear first (segments missing from the table, lane-per-segment kernel).
-    if (job->clear_coefs || !par) (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
+    if (tokens) {
+        if (job->clear_coefs) (void)hipMemsetAsync(job->d_blkrec, 0, (size_t)g.block_count * sizeof(uint2), st);
+    } else if (job->clear_coefs || !par) {
+        (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
+    }
     if (par) {
         // batch: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks
         const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
@@ -1182,13 +1453,17 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const int sub = es ? atoi(es) : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
                                                                            // has to fall into step too): measured best with 32 B
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
-        auto kernel = g.interleaved ? (sub == 256 ? k_huffman_decode_par<true, 256> : sub == 128 ? k_huffman_decode_par<true, 128> : sub == 64 ? k_huffman_decode_par<true, 64>
-                                       : sub == 32 ? k_huffman_decode_par<true, 32> : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)
-                                    : (sub == 256 ? k_huffman_decode_par<false, 256> : sub == 128 ? k_huffman_decode_par<false, 128> : sub == 64 ? k_huffman_decode_par<false, 64>
-                                       : sub == 32 ? k_huffman_decode_par<false, 32> : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
+        auto kernel = tokens ? k_huffman_decode_par<false, GJ_PAR_SUB, true>
+                      : g.interleaved ? (sub == 256 ? k_huffman_decode_par<true, 256, false> : sub == 128 ? k_huffman_decode_par<true, 128, false>
+                                         : sub == 64 ? k_huffman_decode_par<true, 64, false> : sub == 32 ? k_huffman_decode_par<true, 32, false>
+                                         : sub == 8 ? k_huffman_decode_par<true, 8, false> : k_huffman_decode_par<true, 16, false>)
+                                      : (sub == 256 ? k_huffman_decode_par<false, 256, false> : sub == 128 ? k_huffman_decode_par<false, 128, false>
+                                         : sub == 64 ? k_huffman_decode_par<false, 64, false> : sub == 32 ? k_huffman_decode_par<false, 32, false>
+                                         : sub == 8 ? k_huffman_decode_par<false, 8, false> : k_huffman_decode_par<false, 16, false>);
         hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
                            job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, (unsigned long long*)job->d_prof,
-                           getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0, job->clear_coefs ? 0 : 1);
+                           getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0, job->clear_coefs ? 0 : 1, job->d_tok, job->tok_cap,
+                           (uint2*)job->d_blkrec);
     } else {
         if (job->seg_count > 0) {
             auto kernel = g.interleaved ? k_huffman_decode<true> : k_huffman_decode<false>;
@@ -1205,7 +1480,12 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
                       g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
                       g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
                       g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
-    if (uyvy) {
+    if (tokens) {
+        const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
+        hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, job->d_tok, job->tok_cap,
+                           job->d_qtabf, job->d_raw);
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+    } else if (uyvy) {
         const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);
         hipLaunchKernelGGL(k_idct_fused_uyvy422, dim3((nm + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);

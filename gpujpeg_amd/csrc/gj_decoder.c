@@ -33,6 +33,8 @@ struct gpujpeg_decoder {
     bool flipped;                 /* dec_opt_flipped */
     unsigned channel_remap;       /* dec_opt_channel_remap, packed; 0 = none */
     int keep_coefs;               /* 1: leave the coefficients in HBM after the call (gpujpeg_amd_decoder_keep_coefficients) */
+    uint32_t* d_tok; size_t d_tok_cap;     /* token mode (gj_hip.h): non-zero AC coefficients of the frame */
+    void* d_blkrec; size_t d_blkrec_cap;   /* token mode: one record per block */
     bool coefs_clean;             /* d_coefs is all zero: the previous call's IDCT cleared what it read */
     /* device-side segment discovery */
     uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
@@ -113,6 +115,7 @@ int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
     gj_timers_destroy(&d->coder.timers);
     gj_hip_free(d->d_jpeg); gj_hip_free(d->d_seg); gj_hip_free(d->d_huff_tab);
     gj_hip_free(d->coder.d_raw_own); gj_hip_free(d->coder.d_planes); gj_hip_free(d->coder.d_coefs);
+    gj_hip_free(d->d_tok); gj_hip_free(d->d_blkrec);
     gj_hip_host_free(d->h_raw); gj_hip_host_free(d->h_seg); gj_hip_host_free(d->h_tabs);
     free(d->hdr_cache); gj_hip_free(d->d_hdr_cache);
     gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
@@ -426,6 +429,21 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
      * which is validated and repeated then */
     job.clear_coefs = !spec && seg_count != g->segment_count;
     job.zero_coefs = 0;
+    /* token mode buffers (gj_hip.h): one record per block, 4 tokens per stream byte at most */
+    if (!d->keep_coefs && job.use_fused && tab2_ok && image_size < ((size_t)1 << 29)) {
+        const size_t tok_need = (image_size * 4 + 64) * sizeof(uint32_t);
+        if (tok_need > d->d_tok_cap) { /* (grown with headroom: frames of a sequence vary in size) */
+            if (gj_ensure_device_buffer((void**)&d->d_tok, &d->d_tok_cap, tok_need + tok_need / 4) != 0) goto out;
+        }
+        if ((size_t)g->block_count * 8 + 64 > d->d_blkrec_cap) {
+            if (gj_ensure_device_buffer((void**)&d->d_blkrec, &d->d_blkrec_cap, (size_t)g->block_count * 8 + 64) != 0) goto out;
+            gj_hip_memset(d->d_blkrec, 0, d->d_blkrec_cap, c->stream);
+        }
+        job.tokens = 1;
+        job.d_tok = d->d_tok;
+        job.tok_cap = (uint32_t)(image_size * 4);
+        job.d_blkrec = d->d_blkrec;
+    }
     static int prof_on = -1;
     static uint64_t* d_prof = NULL;
     if (prof_on < 0) {

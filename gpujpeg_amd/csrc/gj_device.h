@@ -88,6 +88,15 @@ __device__ __forceinline__ uint64_t gj_segment_block(const gj_geom& g, const GjS
     return kc.data_offset + ((uint64_t)by * kc.blocks_x + bx) * 64;
 }
 
+// LDS written by some lanes of a wave is read by other lanes of the SAME wave: the hardware keeps a wave's LDS operations in
+// order, the compiler only has to be told not to move them across this point (no instruction is emitted for the barrier).
+__device__ __forceinline__ void gj_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Wave / workgroup prefix sums
 // ------------------------------------------------------------------------------------------------

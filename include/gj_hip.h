@@ -163,6 +163,13 @@ typedef struct gj_dec_job {
     int clear_coefs;               /* 1: d_coefs is not known to be all zero, clear it first */
     int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
     uint64_t* d_prof;              /* optional [16] phase clock accumulators of the entropy decoder (developer aid, GJ_DEC_PROF=1) */
+    /* token mode: entropy decoder -> fused IDCT without the coefficient planes (used when a token-fed IDCT kernel exists for the
+     * configuration; 0 / NULL = planes) */
+    int tokens;
+    uint32_t* d_tok;               /* [tok_cap + 64] value | natural position << 16; a group's run starts at 4 x its first byte offset */
+    uint32_t tok_cap;              /* >= 4 x jpeg_size */
+    void* d_blkrec;                /* [g.block_count] uint2 per block in coding order: first token, count << 16 | (uint16) DC term;
+                                      count 0xFFFF = the block is in d_coefs (segment decoded piece by piece) */
 } gj_dec_job;
 
 /* decode table layout per (slot, class): 1024 fast entries (len << 8 | symbol, 0 = miss) followed by

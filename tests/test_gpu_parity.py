@@ -290,3 +290,64 @@ def test_packed_422_whole_frame_encoder(O, G, gpu_lib, w, h, restart):
         enc.keep_coefficients()  # the two-kernel path with coefficient planes
         assert np.array_equal(enc.encode(p, pi, raw), want), (w, h, restart, q, "planes")
         enc.close()
+
+
+TOKEN_CASES = [
+    # name, w, h, quality, restart, noise? (non-interleaved RGB 4:4:4: the configurations the token-fed IDCT serves)
+    ("natural_auto", 1920, 136, 75, -1, False),
+    ("natural_q90_odd", 1119, 561, 90, 12, False),
+    ("noise_q75", 640, 368, 75, -1, True),              # ~30 coefficients per block: more tokens per wave than the LDS stage holds
+    ("noise_q100_r40", 320, 200, 100, 40, True),        # long and short segments mixed: records of both kinds in one wave
+    ("long_segments_noise_q100", 256, 256, 100, 200, True),
+    ("restart0_natural", 512, 384, 85, 0, False),       # every block arrives through the planes
+    ("tiny_segments_r1", 320, 64, 30, 1, False),
+    ("flat", 640, 480, 75, 36, None),                   # blocks without any token
+    ("one_block", 8, 8, 75, 4, True),
+]
+
+
+@pytest.mark.parametrize("tc", TOKEN_CASES, ids=[c[0] for c in TOKEN_CASES])
+def test_token_mode_decoder(O, G, gpu_lib, tc, monkeypatch):
+    """Token mode (entropy decoder -> dense token array + block records -> k_idct_tok_rgb444) is chosen for large frames
+    only; forced here on small ones. Pixels equal the oracle's and the plane-mode result, also when the decoder object
+    is reused for another stream."""
+    name, w, h, q, ri, noisy = tc
+    case = (name, w, h, 1, 1, q, ri, 0, None, 3)
+    raw = O.noise(w * h * 3, seed=w + h) if noisy else (np.full(w * h * 3, 77, np.uint8) if noisy is None else natural_image(w, h, 3, seed=q))
+    jpeg = O.encode(oracle_image(O, case), raw)
+    want = O.decode(jpeg)[0]
+    other = O.encode(oracle_image(O, ("o", 333, 123, 1, 1, 60, 5, 0, None, 3)), natural_image(333, 123, 3, seed=3))
+    monkeypatch.setenv("GJ_DEC_TOKENS", "1")
+    dec = G.Decoder(gpu_lib)
+    for _ in range(2):
+        px, _ = dec.decode(jpeg)
+        assert np.array_equal(px, want)
+        assert np.array_equal(dec.decode(other)[0], O.decode(other)[0])
+    monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
+    assert np.array_equal(dec.decode(jpeg)[0], want)
+    dec.close()
+
+
+def test_token_mode_damaged_streams(O, G, gpu_lib, monkeypatch):
+    """Token mode on damaged input: flipped bytes and truncation must neither fault nor hang (records nobody wrote, token
+    counts that no longer match)."""
+    monkeypatch.setenv("GJ_DEC_TOKENS", "1")
+    w, h = 640, 368
+    jpeg = O.encode(oracle_image(O, ("d", w, h, 1, 1, 75, -1, 0, None, 3)), natural_image(w, h, 3, seed=5))
+    rng = np.random.default_rng(11)
+    dec = G.Decoder(gpu_lib)
+    good = dec.decode(jpeg)[0]
+    for trial in range(10):
+        bad = jpeg.copy()
+        if trial % 3 == 2:
+            bad = bad[: int(bad.size * rng.uniform(0.3, 0.95))]
+        else:
+            lo = 700
+            for i in rng.integers(lo, bad.size - 2, size=1 + trial):
+                bad[i] = rng.integers(0, 256)
+        try:
+            dec.decode(bad)
+        except Exception:
+            pass
+        assert np.array_equal(dec.decode(jpeg)[0], good), trial  # the decoder is intact afterwards
+    dec.close()

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
 // there is no workgroup barrier. Blocks of segments too long for the decoder's LDS stage arrive through the coefficient
 // planes as before (count 0xFFFF in the record). Non-interleaved scans only (plane order == coding order).
 // ================================================================================================
-#define GJ_TOK_STAGE 416 // tokens per wave and component in LDS (three of them + the 32 KiB tile: three workgroups per CU)
+#define GJ_TOK_STAGE 416 // tokens per wave in LDS (with the 32 KiB tile: four workgroups per CU)
 
 // a lane's 128-byte slot of the block tile: row r (16 bytes) sits at ((r + lane) & 7) * 16, which spreads the row reads and
 // writes of the 64 lanes over all banks without padding the slot
@@ -1098,13 +1098,39 @@ __device__ __forceinline__ void gj_slot_put(uint8_t* slot, const int lane, const
     *reinterpret_cast<uint16_t*>(slot + ((((n >> 3) + (uint32_t)lane) & 7u) << 4) + ((n & 7u) << 1)) = (uint16_t)tok;
 }
 
+// the wave's token range of one component: dense and small enough for the stage (the normal case), with the two 16-byte
+// loads per lane that fetch it
+struct GjTokRange {
+    uint32_t S, E;
+    bool fast;
+    uint4 t0, t1;
+};
+
+__device__ __forceinline__ GjTokRange gj_tok_fetch(const uint32_t* __restrict__ d_tok, const uint32_t start, const uint32_t cnt, const int lane)
+{
+    GjTokRange r;
+    const uint32_t end = start + cnt;
+    const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false); // wave_shr:1
+    const unsigned long long breaks = __ballot(lane != 0 && start != prev_end);
+    r.S = (uint32_t)__builtin_amdgcn_readlane((int)start, 0) & ~3u;
+    r.E = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
+    r.fast = breaks == 0 && r.E - r.S <= GJ_TOK_STAGE;
+    r.t0 = r.t1 = make_uint4(0, 0, 0, 0);
+    if (r.fast) {
+        const uint32_t i0 = (uint32_t)lane * 4u, i1 = i0 + 256u;
+        if (r.S + i0 < r.E) r.t0 = *reinterpret_cast<const uint4*>(d_tok + r.S + i0);
+        if (i1 < GJ_TOK_STAGE && r.S + i1 < r.E) r.t1 = *reinterpret_cast<const uint4*>(d_tok + r.S + i1);
+    }
+    return r;
+}
+
 template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256, 3) void k_idct_tok_rgb444(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
+__global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
                                                             const uint32_t* __restrict__ d_tok, const uint32_t tok_cap,
                                                             const float* __restrict__ qtab, uint8_t* __restrict__ raw)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][3][GJ_TOK_STAGE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][GJ_TOK_STAGE];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
     if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
     const gj_comp_geom& k0 = g.comp[0];
@@ -1113,6 +1139,7 @@ __global__ __launch_bounds__(256, 3) void k_idct_tok_rgb444(const gj_geom g, con
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
     const int lane = threadIdx.x & 63;
     uint8_t* slot = s_blk + threadIdx.x * 128;
+    uint32_t* stage = s_stage[threadIdx.x >> 6];
 
     // ---- 1. the three block records (independent loads)
     uint32_t start[3], cnt[3], dc[3];
@@ -1130,41 +1157,22 @@ __global__ __launch_bounds__(256, 3) void k_idct_tok_rgb444(const gj_geom g, con
             else if (cnt[c] > 63u || start[c] > tok_cap || cnt[c] > tok_cap - start[c]) cnt[c] = 0; // (a record nobody wrote: damaged stream)
         }
     }
-    // ---- 2. tokens of the wave's 64 blocks -> LDS. Normally they form one dense range per component (consecutive blocks of a scan
-    //         have consecutive tokens) that fits the stage: all loads of the three components are in flight together.
-    uint32_t S[3], E[3];
-    bool fast[3];
-    uint4 t0[3], t1[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const uint32_t end = start[c] + cnt[c];
-        const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false); // wave_shr:1
-        const unsigned long long breaks = __ballot(lane != 0 && start[c] != prev_end);
-        S[c] = (uint32_t)__builtin_amdgcn_readlane((int)start[c], 0) & ~3u;
-        E[c] = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
-        fast[c] = breaks == 0 && E[c] - S[c] <= GJ_TOK_STAGE;
-        t0[c] = t1[c] = make_uint4(0, 0, 0, 0);
-        if (fast[c]) {
-            const uint32_t i0 = (uint32_t)lane * 4u, i1 = i0 + 256u;
-            if (S[c] + i0 < E[c]) t0[c] = *reinterpret_cast<const uint4*>(d_tok + S[c] + i0);
-            if (i1 < GJ_TOK_STAGE && S[c] + i1 < E[c]) t1[c] = *reinterpret_cast<const uint4*>(d_tok + S[c] + i1);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        uint32_t* stage = s_stage[threadIdx.x >> 6][c];
-        if (fast[c]) {
-            *reinterpret_cast<uint4*>(stage + lane * 4) = t0[c];
-            if (lane * 4 + 256 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 4 + 256) = t1[c];
-        }
-    }
-    __syncthreads(); // (s_q; the stages are private to their wave)
+    __syncthreads(); // (s_q; everything below is private to a wave)
 
+    // ---- 2. per component: the tokens of the wave's 64 blocks go through the LDS stage (consecutive blocks of a scan have
+    //         consecutive tokens); the loads of the next component are in flight while this one is transformed
     uint32_t pk[3][16];
+    GjTokRange cur = gj_tok_fetch(d_tok, start[0], cnt[0], lane);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        uint32_t* stage = s_stage[threadIdx.x >> 6][c];
-        // ---- 3. own slot: zeros, the DC term, the tokens
+        const bool fast = cur.fast;
+        const uint32_t S = cur.S;
+        if (fast) {
+            *reinterpret_cast<uint4*>(stage + lane * 4) = cur.t0;
+            if (lane * 4 + 256 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 4 + 256) = cur.t1;
+        }
+        if (c < 2) cur = gj_tok_fetch(d_tok, start[c + 1], cnt[c + 1], lane);
+        // own slot: zeros, the DC term, the tokens
 #pragma unroll
         for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = make_uint4(0, 0, 0, 0);
         if (in_plane[c]) { // block of a segment that was decoded piece by piece: it is in the coefficient plane
@@ -1175,10 +1183,10 @@ __global__ __launch_bounds__(256, 3) void k_idct_tok_rgb444(const gj_geom g, con
             *reinterpret_cast<uint16_t*>(slot + ((lane & 7) << 4)) = (uint16_t)dc[c];
         }
         const uint32_t end = start[c] + cnt[c];
-        if (fast[c]) {
+        if (fast) {
             gj_wave_sync();
-            uint32_t a = start[c] - S[c];
-            const uint32_t b = end - S[c];
+            uint32_t a = start[c] - S;
+            const uint32_t b = end - S;
             for (; a + 2 <= b; a += 2) {
                 const uint32_t ta = stage[a], tb = stage[a + 1];
                 gj_slot_put(slot, lane, ta);
@@ -1208,8 +1216,8 @@ __global__ __launch_bounds__(256, 3) void k_idct_tok_rgb444(const gj_geom g, con
                 }
             }
         }
-        gj_wave_sync();
-        // ---- 4. the block as rows; dequantisation + IDCT
+        gj_wave_sync(); // (the stage is rewritten by the next component)
+        // the block as rows; dequantisation + IDCT
         uint32_t wb[32];
 #pragma unroll
         for (int r = 0; r < 8; r++) {

@@ -1124,6 +1124,57 @@ __device__ __forceinline__ GjTokRange gj_tok_fetch(const uint32_t* __restrict__ 
     return r;
 }
 
+// One block per lane: zeros, the DC term and the lane's tokens go into its tile slot. `fast`: the wave's tokens are in the stage
+// already (dense range starting at token S).
+__device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint32_t* stage, const int lane, const bool fast, const uint32_t S, const uint32_t start,
+                                               const uint32_t cnt, const uint32_t dc, const bool in_plane, const uint4* __restrict__ plane_block,
+                                               const uint32_t* __restrict__ d_tok)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = make_uint4(0, 0, 0, 0);
+    if (in_plane) { // block of a segment that was decoded piece by piece: it is in the coefficient plane
+#pragma unroll
+        for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = plane_block[r];
+    } else {
+        *reinterpret_cast<uint16_t*>(slot + ((lane & 7) << 4)) = (uint16_t)dc;
+    }
+    const uint32_t end = start + cnt;
+    if (fast) {
+        gj_wave_sync();
+        uint32_t a = start - S;
+        const uint32_t b = end - S;
+        for (; a + 2 <= b; a += 2) {
+            const uint32_t ta = stage[a], tb = stage[a + 1];
+            gj_slot_put(slot, lane, ta);
+            gj_slot_put(slot, lane, tb);
+        }
+        if (a < b) gj_slot_put(slot, lane, stage[a]);
+    } else {
+        // several ranges (a decoder batch ended inside the wave's blocks) or more tokens than the stage holds: range by range,
+        // chunk by chunk
+        const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false);
+        unsigned long long runs = __ballot(lane == 0 || start != prev_end);
+        while (runs) {
+            const int d = __builtin_ctzll(runs);
+            runs &= runs - 1;
+            const int dn = runs ? __builtin_ctzll(runs) : 64;
+            const uint32_t RS = (uint32_t)__builtin_amdgcn_readlane((int)start, d), RE = (uint32_t)__builtin_amdgcn_readlane((int)end, dn - 1);
+            const bool mine = lane >= d && lane < dn;
+            for (uint32_t base = RS & ~3u; base < RE; base += GJ_TOK_STAGE) {
+                gj_wave_sync();
+                for (uint32_t i = (uint32_t)lane * 4u; i < GJ_TOK_STAGE && base + i < RE; i += 256u)
+                    *reinterpret_cast<uint4*>(stage + i) = *reinterpret_cast<const uint4*>(d_tok + base + i);
+                gj_wave_sync();
+                if (mine) {
+                    const uint32_t b = min(end, base + GJ_TOK_STAGE);
+                    for (uint32_t a = max(start, base); a < b; a++) gj_slot_put(slot, lane, stage[a - base]);
+                }
+            }
+        }
+    }
+    gj_wave_sync(); // (the stage is rewritten by the next component)
+}
+
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
                                                             const uint32_t* __restrict__ d_tok, const uint32_t tok_cap,
@@ -1172,51 +1223,8 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
             if (lane * 4 + 256 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 4 + 256) = cur.t1;
         }
         if (c < 2) cur = gj_tok_fetch(d_tok, start[c + 1], cnt[c + 1], lane);
-        // own slot: zeros, the DC term, the tokens
-#pragma unroll
-        for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = make_uint4(0, 0, 0, 0);
-        if (in_plane[c]) { // block of a segment that was decoded piece by piece: it is in the coefficient plane
-            const uint4* src = reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (size_t)lb * 64);
-#pragma unroll
-            for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = src[r];
-        } else {
-            *reinterpret_cast<uint16_t*>(slot + ((lane & 7) << 4)) = (uint16_t)dc[c];
-        }
-        const uint32_t end = start[c] + cnt[c];
-        if (fast) {
-            gj_wave_sync();
-            uint32_t a = start[c] - S;
-            const uint32_t b = end - S;
-            for (; a + 2 <= b; a += 2) {
-                const uint32_t ta = stage[a], tb = stage[a + 1];
-                gj_slot_put(slot, lane, ta);
-                gj_slot_put(slot, lane, tb);
-            }
-            if (a < b) gj_slot_put(slot, lane, stage[a]);
-        } else {
-            // several ranges (a decoder batch ended inside the wave's blocks) or more tokens than the stage holds: range by range,
-            // chunk by chunk
-            const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false);
-            unsigned long long runs = __ballot(lane == 0 || start[c] != prev_end);
-            while (runs) {
-                const int d = __builtin_ctzll(runs);
-                runs &= runs - 1;
-                const int dn = runs ? __builtin_ctzll(runs) : 64;
-                const uint32_t RS = (uint32_t)__builtin_amdgcn_readlane((int)start[c], d), RE = (uint32_t)__builtin_amdgcn_readlane((int)end, dn - 1);
-                const bool mine = lane >= d && lane < dn;
-                for (uint32_t base = RS & ~3u; base < RE; base += GJ_TOK_STAGE) {
-                    gj_wave_sync();
-                    for (uint32_t i = (uint32_t)lane * 4u; i < GJ_TOK_STAGE && base + i < RE; i += 256u)
-                        *reinterpret_cast<uint4*>(stage + i) = *reinterpret_cast<const uint4*>(d_tok + base + i);
-                    gj_wave_sync();
-                    if (mine) {
-                        const uint32_t b = min(end, base + GJ_TOK_STAGE);
-                        for (uint32_t a = max(start[c], base); a < b; a++) gj_slot_put(slot, lane, stage[a - base]);
-                    }
-                }
-            }
-        }
-        gj_wave_sync(); // (the stage is rewritten by the next component)
+        gj_tok_to_slot(slot, stage, lane, fast, S, start[c], cnt[c], dc[c], in_plane[c],
+                       reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (size_t)lb * 64), d_tok);
         // the block as rows; dequantisation + IDCT
         uint32_t wb[32];
 #pragma unroll
@@ -1229,6 +1237,91 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
         for (int i = 0; i < 16; i++) asm volatile("" : "+v"(pk[c][i])); // one transform at a time (see k_idct_fused_rgb444)
     }
     gj_store_rgb444<CS_FROM, CS_TO>(g, raw, pk, lb, nb, bx, by);
+}
+
+// ================================================================================================
+// Token-fed IDCT for interleaved 4:2:2 scans with packed UYVY output and no colour transform (BASELINE config 4): one lane
+// per BLOCK in coding order (Y0 Y1 Cb Cr of MCU 0, of MCU 1, ...), so a workgroup's 256 records and its tokens are dense
+// ranges. After the transform the four lanes of an MCU exchange their rows with quad-permute DPP moves and every lane
+// stores 8 of the MCU's 32 bytes per pixel row (a wave writes 512 contiguous bytes per row).
+// ================================================================================================
+__global__ __launch_bounds__(256, 4) void k_idct_tok_uyvy422(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
+                                                             const uint32_t* __restrict__ d_tok, const uint32_t tok_cap,
+                                                             const float* __restrict__ qtab, uint8_t* __restrict__ raw)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][GJ_TOK_STAGE];
+    __shared__ __attribute__((aligned(8))) float s_q[3][64];
+    if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
+    const gj_comp_geom& kc = g.comp[1];
+    const unsigned nm = (unsigned)(kc.blocks_x * kc.blocks_y);
+    const int p = threadIdx.x & 3; // Y0 Y1 Cb Cr
+    const unsigned m = blockIdx.x * 64u + (threadIdx.x >> 2);
+    const unsigned my = m / (unsigned)kc.blocks_x, mx = m - my * (unsigned)kc.blocks_x;
+    const int c = p < 2 ? 0 : p - 1;
+    const int lane = threadIdx.x & 63;
+    uint8_t* slot = s_blk + threadIdx.x * 128;
+    uint32_t* stage = s_stage[threadIdx.x >> 6];
+    uint32_t start = 0, cnt = 0, dc = 0;
+    bool in_plane = false;
+    if (m < nm) {
+        const uint2 r = d_rec[(size_t)m * 4 + p];
+        start = r.x;
+        cnt = r.y >> 16;
+        dc = r.y & 0xFFFFu;
+        if (cnt == 0xFFFFu) { in_plane = true; cnt = 0; }
+        else if (cnt > 63u || start > tok_cap || cnt > tok_cap - start) cnt = 0; // (a record nobody wrote: damaged stream)
+    }
+    const GjTokRange tr = gj_tok_fetch(d_tok, start, cnt, lane);
+    if (tr.fast) {
+        *reinterpret_cast<uint4*>(stage + lane * 4) = tr.t0;
+        if (lane * 4 + 256 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 4 + 256) = tr.t1;
+    }
+    __syncthreads(); // (s_q)
+    const size_t blk = p < 2 ? (size_t)my * g.comp[0].blocks_x + 2 * mx + p : (size_t)m; // (plane address: blocks of long segments only)
+    gj_tok_to_slot(slot, stage, lane, tr.fast, tr.S, start, cnt, dc, in_plane,
+                   reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (m < nm ? blk : 0) * 64), d_tok);
+    uint32_t wb[32];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint4 v = *gj_slot_row(slot, lane, r);
+        wb[r * 4] = v.x; wb[r * 4 + 1] = v.y; wb[r * 4 + 2] = v.z; wb[r * 4 + 3] = v.w;
+    }
+    uint32_t px[16];
+    gj_idct_pk(wb, s_q[c], px);
+
+    // ---- UYVY: dword k of an MCU row = U_k | Y_2k << 8 | V_k << 16 | Y_2k+1 << 24; lane p writes dwords 2p and 2p + 1
+    const size_t pitch = (size_t)g.width * 2 + g.width_padding;
+    const bool interior = m < nm && (mx * 16 + 16 <= (unsigned)g.width) && (my * 8 + 8 <= (unsigned)g.height);
+    const bool aligned = ((pitch | (size_t)raw) & 7) == 0;
+    const uint32_t sel_uv = (p & 1) ? 0x07030602u : 0x05010400u; // [U_2p, V_2p, U_2p+1, V_2p+1] out of the chroma lanes' dwords
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int a0 = (int)px[2 * r], a1 = (int)px[2 * r + 1];
+        // quad_perm broadcasts: lane 0 = Y0, 1 = Y1, 2 = Cb, 3 = Cr of this MCU
+        const uint32_t y00 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0x00, 0xF, 0xF, false), y01 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0x00, 0xF, 0xF, false);
+        const uint32_t y10 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0x55, 0xF, 0xF, false), y11 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0x55, 0xF, 0xF, false);
+        const uint32_t u0 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0xAA, 0xF, 0xF, false), u1 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0xAA, 0xF, 0xF, false);
+        const uint32_t v0 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0xFF, 0xF, 0xF, false), v1 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0xFF, 0xF, 0xF, false);
+        const uint32_t ys = p == 0 ? y00 : p == 1 ? y01 : p == 2 ? y10 : y11; // Y_4p .. Y_4p+3
+        const uint32_t us = (p >> 1) ? u1 : u0, vs = (p >> 1) ? v1 : v0;
+        const uint32_t uv = __builtin_amdgcn_perm(vs, us, sel_uv);
+        const uint32_t d0 = __builtin_amdgcn_perm(ys, uv, 0x05010400u), d1 = __builtin_amdgcn_perm(ys, uv, 0x07030602u);
+        const unsigned y = my * 8 + r;
+        if (interior && aligned) {
+            *reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)mx * 32 + p * 8) = make_uint2(d0, d1);
+        } else if (m < nm && y < (unsigned)g.height) {
+            // the generic store writes chroma only with the even pixel and whole pixels only (k_postprocess)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t d = k ? d1 : d0;
+                const unsigned x0 = mx * 16 + 2 * (2 * p + k);
+                uint8_t* q = raw + (size_t)y * pitch + (size_t)x0 * 2;
+                if (x0 < (unsigned)g.raw_width) { q[0] = (uint8_t)d; q[1] = (uint8_t)(d >> 8); }
+                if (x0 + 1 < (unsigned)g.raw_width) { q[2] = (uint8_t)(d >> 16); q[3] = (uint8_t)(d >> 24); }
+            }
+        }
+    }
 }
 
 // ================================================================================================
@@ -1430,17 +1523,28 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     }
     // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
     // record per block instead of through the coefficient planes
-    gj_idct_tok_t idct_tok = (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && !g.interleaved && !getenv("GJ_DEC_NO_TOKENS"))
-                                 ? gj_idct_tok_kernel(g) : nullptr;
+    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 &&
+                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
+                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
+                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
+                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
+    gj_idct_tok_t idct_tok = nullptr;
+    if (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && !getenv("GJ_DEC_NO_TOKENS")) {
+        if (!g.interleaved) idct_tok = gj_idct_tok_kernel(g);
+        else if (uyvy && g.blocks_per_mcu == 4 && g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.mcu_comp[0] == 0 && g.mcu_comp[1] == 0 &&
+                 g.mcu_comp[2] == 1 && g.mcu_comp[3] == 2 && g.mcu_bx[0] == 0 && g.mcu_bx[1] == 1)
+            idct_tok = k_idct_tok_uyvy422;
+    }
     {
         const char* es = getenv("GJ_DEC_SUB");
-        if (es && atoi(es) != GJ_PAR_SUB) idct_tok = nullptr; // (the tuning aid sweeps the plane-mode kernels)
-        // Measured (8K / 16K natural frames +9 % / +17 % enc+dec; HD and 4K equal or slightly slower; 8K noise -15 %): tokens pay when
-        // the frame fills the GPU more than once (the token-fed IDCT has the longer dependency chain per workgroup) and blocks
-        // carry few coefficients (4 B per coefficient against 128 B per block). GJ_DEC_TOKENS=1 forces the mode (tests).
+        if (es && atoi(es) != (g.interleaved ? 32 : GJ_PAR_SUB)) idct_tok = nullptr; // (the tuning aid sweeps the plane-mode kernels)
+        // Measured (8K / 16K RGB natural frames at q75, 4.75 B of stream per block: +17 % enc+dec; HD and 4K equal or slightly slower;
+        // 16K 4:2:2 at q90, 10.4 B per block: -6 %; 8K noise -15 %): tokens pay when the frame fills the GPU more than once (the
+        // token-fed IDCT has the longer dependency chain per workgroup) and blocks carry few coefficients (4 B per coefficient
+        // against 128 B per block). GJ_DEC_TOKENS=1 forces the mode (tests).
         const char* et = getenv("GJ_DEC_TOKENS");
         const bool forced = et && et[0] == '1';
-        if (!forced && (g.comp[0].blocks_x * g.comp[0].blocks_y < 300000 || job->jpeg_size > (uint64_t)g.block_count * 12u)) idct_tok = nullptr;
+        if (!forced && (g.block_count < 900000 || job->jpeg_size > (uint64_t)g.block_count * 8u)) idct_tok = nullptr;
     }
     const bool tokens = idct_tok != nullptr;
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
@@ -1461,7 +1565,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const int sub = es ? atoi(es) : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
                                                                            // has to fall into step too): measured best with 32 B
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
-        auto kernel = tokens ? k_huffman_decode_par<false, GJ_PAR_SUB, true>
+        auto kernel = tokens ? (g.interleaved ? k_huffman_decode_par<true, 32, true> : k_huffman_decode_par<false, GJ_PAR_SUB, true>)
                       : g.interleaved ? (sub == 256 ? k_huffman_decode_par<true, 256, false> : sub == 128 ? k_huffman_decode_par<true, 128, false>
                                          : sub == 64 ? k_huffman_decode_par<true, 64, false> : sub == 32 ? k_huffman_decode_par<true, 32, false>
                                          : sub == 8 ? k_huffman_decode_par<true, 8, false> : k_huffman_decode_par<true, 16, false>)
@@ -1483,13 +1587,8 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     gj_debug_stage(st, "entropy decoder");
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
-    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 &&
-                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
-                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
-                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
-                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
     if (tokens) {
-        const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
+        const unsigned nb = g.interleaved ? (unsigned)g.block_count : (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block (position)
         hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, job->d_tok, job->tok_cap,
                            job->d_qtabf, job->d_raw);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);

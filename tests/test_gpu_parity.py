@@ -351,3 +351,39 @@ def test_token_mode_damaged_streams(O, G, gpu_lib, monkeypatch):
             pass
         assert np.array_equal(dec.decode(jpeg)[0], good), trial  # the decoder is intact afterwards
     dec.close()
+
+
+TOKEN_422_CASES = [
+    # name, w, h, quality, restart, noise?  (packed 4:2:2 in and out, interleaved scan: k_idct_tok_uyvy422)
+    ("natural_auto", 1920, 136, 90, -1, False),
+    ("odd_edges", 642, 77, 90, 6, False),           # partial MCUs on both edges, pitch not a multiple of 8
+    ("aligned_noise", 640, 64, 75, 5, True),        # more tokens per wave than the LDS stage holds
+    ("restart0", 512, 128, 85, 0, False),           # every block arrives through the planes
+    ("r1", 320, 40, 50, 1, False),
+    ("one_mcu", 16, 8, 90, 3, True),
+]
+
+
+@pytest.mark.parametrize("tc", TOKEN_422_CASES, ids=[c[0] for c in TOKEN_422_CASES])
+def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
+    name, w, h, q, ri, noisy = tc
+    case = (name, w, h, 3, 3, q, ri, 1, None, 3)
+    if noisy:
+        raw = O.noise(O.raw_size(w, h, 3), seed=w + h)
+    else:
+        rgb = natural_image(w + (w & 1), h, 3, seed=q).reshape(h, w + (w & 1), 3)
+        raw = np.empty((h, w + (w & 1), 2), np.uint8)
+        raw[:, :, 1] = rgb[:, :, 0]
+        raw[:, 0::2, 0] = rgb[:, 0::2, 1]
+        raw[:, 1::2, 0] = rgb[:, 0::2, 2]
+        raw = raw.reshape(-1)[: O.raw_size(w, h, 3)].copy()
+    jpeg = O.encode(oracle_image(O, case), raw)
+    want = O.decode(jpeg, 3, 3)[0]
+    monkeypatch.setenv("GJ_DEC_TOKENS", "1")
+    dec = G.Decoder(gpu_lib)
+    dec.set_output_format(3, 3)
+    for _ in range(2):
+        assert np.array_equal(dec.decode(jpeg)[0], want)
+    monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
+    assert np.array_equal(dec.decode(jpeg)[0], want)
+    dec.close()

@@ -40,8 +40,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 # HBM bytes per launch of the dominant kernels from the PMC passes committed under profiles/ (8K RGB q75 natural frame):
 # FETCH_SIZE doubled (gfx950 counts 128 B requests as 64 B, guide section HBM) + WRITE_SIZE
-TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49776.3 * 2 + 8350.1) * 1024), "dec:k_huffman_decode_par": int((5481.8 * 2 + 375768.9) * 1024),
-                 "dec:k_idct_fused_rgb444": int((97434.2 * 2 + 97203.7) * 1024)}  # profiles/r1_04_hbm_traffic.txt
+TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49784.1 * 2 + 8350.0) * 1024), "dec:k_huffman_decode_par": int((4520.7 * 2 + 67504.6) * 1024),
+                 "dec:k_idct_tok_rgb444": int((26557.4 * 2 + 103273.0) * 1024)}  # profiles/r1_05_solo_hbm_traffic.txt (token mode)
 
 
 def synth_frame(width, height, pattern, seed, device):
@@ -345,9 +345,14 @@ def main():
         raw_bytes = pixels * (2 if is422 else 3)
         whole = enc_ms[1] < 0.02  # fully fused encoder: pixels -> segment streams in one kernel (event slots 0/1 are empty)
         fmt = "uyvy422" if is422 else "rgb444"
+        # the decoder picks token mode for large, sparse frames (gj_decode.hip: >= 900 K blocks, <= 8 stream bytes per block)
+        nblocks = ((width + 7) // 8) * ((height + 7) // 8) * (2 if is422 else 3)
+        token_mode = (not is422) and nblocks >= 900000 and jsize <= 8 * nblocks and not args.keep_coefs \
+            and not os.environ.get("GJ_DEC_NO_TOKENS")
         names = ["enc:k_preprocess", f"enc:k_fused_{fmt}(pre+dct+quant)",
                  f"enc:k_encode_{fmt}(pixels->entropy-coded segments)" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
-                 "dec:k_huffman_decode_par(+fallback launch)", f"dec:k_idct_fused_{fmt}(idct+post)", "dec:k_postprocess"]
+                 "dec:k_huffman_decode_par(+fallback launch)",
+                 f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}(idct+post)", "dec:k_postprocess"]
         # the PMC passes under profiles/ were taken on the default 8K workload only
         traffic_known = args.workload == "8k" and args.quality == 75 and args.pattern == "natural"
         durs = list(enc_ms) + list(dec_ms)

@@ -385,13 +385,15 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as O
             host = frame.cpu().numpy().reshape(-1)
-            want = O.encode(O.make_image(width, height, quality=args.quality), host)
+            img = (O.make_image(width, height, pixel_format=3, color_space=3, quality=args.quality, interleaved=1) if is422
+                   else O.make_image(width, height, quality=args.quality, color_space_internal=1 if args.internal_rgb else 3))
+            want = O.encode(img, host)
             got = np.ctypeslib.as_array(C.cast(jptr, C.POINTER(C.c_uint8)), shape=(1,))  # device pointer: copy through torch
             jt = torch.empty(jsize, dtype=torch.uint8, device=device)
             C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(jt.data_ptr()), C.cast(jptr, C.c_void_p), C.c_size_t(jsize), 3)
             torch.cuda.synchronize()
             result["verified_bit_exact_encode"] = bool(np.array_equal(jt.cpu().numpy(), want))
-            result["verified_bit_exact_decode"] = bool(np.array_equal(out.cpu().numpy().reshape(-1), O.decode(want)[0]))
+            result["verified_bit_exact_decode"] = bool(np.array_equal(out.cpu().numpy().reshape(-1), (O.decode(want, 3, 3) if is422 else O.decode(want))[0]))
             del got
         if not args.no_cpu_baseline and world == 1:  # reported baseline, on the host cores of rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(width, height, frame.cpu().numpy().reshape(-1), is422=is422, quality=args.quality)

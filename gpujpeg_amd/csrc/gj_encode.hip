@@ -1119,55 +1119,72 @@ __global__ __launch_bounds__(1024) void k_scan_segments(const gj_enc_job J, unsi
 // also writes the scan header / EOI. Replaces the reference's serialisation + compaction kernels and the
 // host-side stitching loop (src/gpujpeg_huffman_gpu_encoder.cu:417-613, src/gpujpeg_encoder.c:567-629).
 // ================================================================================================
+#define GJ_ASM_SEGS 4 // segments per wave: their sizes, offsets and first 256 bytes are requested together (one memory round trip
+                      // instead of four; 43 200 waves of one short segment each spent their time waiting)
 __global__ __launch_bounds__(256) void k_assemble(const gj_enc_job J)
 {
     const gj_geom& g = J.g;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GJ_ASM_SEGS;
     const int lane = threadIdx.x & 63;
-    if (s >= g.segment_count || J.d_result[1]) return;
-    const GjSeg sg = gj_segment(g, s);
-    const uint32_t raw = J.d_seg_bytes[s];
-    const uint8_t* src = J.d_temp + sg.first_block * GJ_TEMP_BYTES_PER_BLOCK;
+    if (s0 >= g.segment_count || J.d_result[1]) return;
     uint8_t* out = J.d_jpeg;
-    uint32_t o = J.d_seg_out[s];
-
-    if (sg.first_in_scan) { // scan header (APP13 placeholders + SOS) right before the first segment
-        const int scan = g.interleaved ? 0 : sg.comp;
-        const uint32_t h0 = J.scan_hdr_offset[scan], hn = J.scan_hdr_offset[scan + 1] - h0;
-        for (uint32_t b = lane; b < hn; b += 64) out[o - hn + b] = J.d_scan_hdr[h0 + b];
+    uint32_t raw4[GJ_ASM_SEGS], o4[GJ_ASM_SEGS], w4[GJ_ASM_SEGS];
+    const uint8_t* src4[GJ_ASM_SEGS];
+#pragma unroll
+    for (int q = 0; q < GJ_ASM_SEGS; q++) {
+        const int s = min(s0 + q, g.segment_count - 1);
+        raw4[q] = s0 + q < g.segment_count ? J.d_seg_bytes[s] : 0u;
+        o4[q] = J.d_seg_out[s];
+        src4[q] = J.d_temp + gj_segment(g, s).first_block * GJ_TEMP_BYTES_PER_BLOCK;
     }
-    for (uint32_t c0 = 0; c0 < raw; c0 += 256) {
-        const uint32_t idx = c0 + lane * 4;
-        uint32_t w = 0;
-        int vb = 0;
-        if (idx < raw) {
-            w = *reinterpret_cast<const uint32_t*>(src + idx);
-            vb = (int)min(4u, raw - idx);
+#pragma unroll
+    for (int q = 0; q < GJ_ASM_SEGS; q++) w4[q] = (uint32_t)lane * 4u < raw4[q] ? *reinterpret_cast<const uint32_t*>(src4[q] + lane * 4) : 0u;
+#pragma unroll
+    for (int q = 0; q < GJ_ASM_SEGS; q++) {
+        const int s = s0 + q;
+        if (s >= g.segment_count) break;
+        const GjSeg sg = gj_segment(g, s);
+        const uint32_t raw = raw4[q];
+        const uint8_t* src = src4[q];
+        uint32_t o = o4[q];
+        if (sg.first_in_scan) { // scan header (APP13 placeholders + SOS) right before the first segment
+            const int scan = g.interleaved ? 0 : sg.comp;
+            const uint32_t h0 = J.scan_hdr_offset[scan], hn = J.scan_hdr_offset[scan + 1] - h0;
+            for (uint32_t b = lane; b < hn; b += 64) out[o - hn + b] = J.d_scan_hdr[h0 + b];
         }
-        int cnt = vb;
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-            if (b < vb && ((w >> (8 * b)) & 0xFFu) == 0xFFu) cnt++;
-        const uint32_t inc = gj_wave_incl_scan((uint32_t)cnt);
-        uint32_t p = o + inc - (uint32_t)cnt;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            if (b < vb) {
-                const uint32_t byte = (w >> (8 * b)) & 0xFFu;
-                out[p++] = (uint8_t)byte;
-                if (byte == 0xFFu) out[p++] = 0;
+        for (uint32_t c0 = 0; c0 < raw; c0 += 256) {
+            const uint32_t idx = c0 + lane * 4;
+            uint32_t w = w4[q];
+            int vb = 0;
+            if (idx < raw) {
+                if (c0) w = *reinterpret_cast<const uint32_t*>(src + idx);
+                vb = (int)min(4u, raw - idx);
             }
+            int cnt = vb;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (b < vb && ((w >> (8 * b)) & 0xFFu) == 0xFFu) cnt++;
+            const uint32_t inc = gj_wave_incl_scan((uint32_t)cnt);
+            uint32_t p = o + inc - (uint32_t)cnt;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (b < vb) {
+                    const uint32_t byte = (w >> (8 * b)) & 0xFFu;
+                    out[p++] = (uint8_t)byte;
+                    if (byte == 0xFFu) out[p++] = 0;
+                }
+            }
+            o += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
-        o += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    }
-    if (lane == 0) {
-        if (!sg.last_in_scan) {
-            out[o] = 0xFF;
-            out[o + 1] = (uint8_t)(0xD0 + (sg.index_in_scan & 7));
-        }
-        if (s == g.segment_count - 1) {
-            out[o] = 0xFF;
-            out[o + 1] = 0xD9;
+        if (lane == 0) {
+            if (!sg.last_in_scan) {
+                out[o] = 0xFF;
+                out[o + 1] = (uint8_t)(0xD0 + (sg.index_in_scan & 7));
+            }
+            if (s == g.segment_count - 1) {
+                out[o] = 0xFF;
+                out[o + 1] = 0xD9;
+            }
         }
     }
 }
@@ -1299,7 +1316,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_segments, dim3(scan_wgs), dim3(1024), 0, st, *job, (unsigned long long*)job->d_scan_partial, job->epoch);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[4], st);
-    hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 3) / 4), dim3(256), 0, st, *job);
+    hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 4 * GJ_ASM_SEGS - 1) / (4 * GJ_ASM_SEGS)), dim3(256), 0, st, *job);
     if (job->segment_info && g.restart_interval > 0)
         hipLaunchKernelGGL(k_segment_info, dim3(((unsigned)g.segment_count + 255) / 256), dim3(256), 0, st, *job);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[5], st);

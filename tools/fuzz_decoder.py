@@ -1,0 +1,96 @@
+"""Decoder robustness sweep for a GPU box: damaged streams must end in an error return or a decoded image, never in a GPU
+fault or a hang, and the decoder object must work afterwards. One subprocess per (configuration, mode) so that a fault is
+attributed; the trial number is printed before each decode."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CONFIGS = {
+    # name: (w, h, pixel format, colour space, quality, restart, interleaved, subsampling, output (pf, cs) or None)
+    "rgb_auto": (640, 368, 1, 1, 75, -1, 0, None, None),
+    "rgb_r0": (256, 192, 1, 1, 80, 0, 0, None, None),
+    "rgb_il": (333, 123, 1, 1, 75, 5, 1, None, None),
+    "rgb_420_il": (322, 242, 1, 1, 75, 3, 1, [(2, 2), (1, 1), (1, 1)], None),
+    "uyvy_il": (640, 80, 3, 3, 90, 6, 1, None, (3, 3)),
+    "gray": (333, 111, 0, 3, 75, -1, 0, None, None),
+    "rgba": (200, 100, 6, 1, 75, 4, 1, [(1, 1)] * 4, None),
+}
+TRIALS = int(os.environ.get("FUZZ_TRIALS", "24"))
+
+
+def child(name, mode):
+    import oracle as O
+    from conftest import natural_image, oracle_image
+    from gpujpeg_amd import libgpujpeg as G
+    if mode == "tokens":
+        os.environ["GJ_DEC_TOKENS"] = "1"
+    lib = G.Library()
+    assert lib.L.gpujpeg_init_device(0, 0) == 0
+    w, h, pf, cs, q, ri, il, ss, outfmt = CONFIGS[name]
+    case = (name, w, h, pf, cs, q, ri, il, ss, 3)
+    comps = {0: 1, 1: 3, 6: 4}.get(pf)
+    raw = natural_image(w, h, comps, seed=w) if comps else O.noise(O.raw_size(w, h, pf), seed=w)
+    jpeg = O.encode(oracle_image(O, case), raw)
+    want = (O.decode(jpeg, *outfmt) if outfmt else O.decode(jpeg))[0]
+    dec = G.Decoder(lib)
+    if outfmt:
+        dec.set_output_format(outfmt[1], outfmt[0])
+    assert np.array_equal(dec.decode(jpeg)[0], want)
+    hdr = int(np.nonzero((jpeg[:-1] == 0xFF) & (jpeg[1:] == 0xDA))[0][0]) + 14  # first byte of entropy-coded data (roughly)
+    outcomes = {"decoded": 0, "error": 0}
+    for t in range(TRIALS):
+        rng = np.random.default_rng(1000 + t)
+        bad = jpeg.copy()
+        kind = t % 6
+        if kind == 0:    # byte flips in the entropy-coded data
+            idx = rng.integers(hdr, bad.size - 2, size=1 + t)
+            bad[idx] = rng.integers(0, 256, size=idx.size, dtype=np.uint8)
+        elif kind == 1:  # stray restart markers
+            for i in rng.integers(hdr, bad.size - 4, size=1 + t // 6):
+                bad[i], bad[i + 1] = 0xFF, 0xD0 + int(rng.integers(0, 8))
+        elif kind == 2:  # truncation
+            bad = bad[: int(bad.size * rng.uniform(0.1, 0.98))].copy()
+        elif kind == 3:  # damage in the headers (tables, frame header)
+            idx = rng.integers(20, hdr, size=2)
+            bad[idx] = rng.integers(0, 256, size=idx.size, dtype=np.uint8)
+        elif kind == 4:  # zeros / 0xFF runs
+            a = int(rng.integers(hdr, bad.size - 64))
+            bad[a:a + int(rng.integers(1, 64))] = 0xFF if t & 8 else 0
+        else:            # deleted bytes (everything after shifts)
+            a = int(rng.integers(hdr, bad.size - 8))
+            bad = np.concatenate([bad[:a], bad[a + int(rng.integers(1, 5)):]])
+        print(f"trial {t} kind {kind}", flush=True)
+        try:
+            dec.decode(bad)
+            outcomes["decoded"] += 1
+        except Exception:
+            outcomes["error"] += 1
+        assert np.array_equal(dec.decode(jpeg)[0], want), f"decoder damaged after trial {t}"
+    print("DONE", outcomes, flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 3:
+        child(sys.argv[1], sys.argv[2])
+        sys.exit(0)
+    bad = 0
+    for name in CONFIGS:
+        for mode in ("default", "tokens"):
+            try:
+                r = subprocess.run([sys.executable, __file__, name, mode], capture_output=True, text=True, timeout=300)
+                lines = r.stdout.strip().splitlines()
+                ok = r.returncode == 0 and lines and lines[-1].startswith("DONE")
+                print(name, mode, "rc", r.returncode, lines[-1] if lines else "", "" if ok else "| " + (r.stderr.strip().splitlines() or [""])[-1][:200], flush=True)
+            except subprocess.TimeoutExpired:
+                ok = False
+                print(name, mode, "TIMEOUT", flush=True)
+            bad += 0 if ok else 1
+    print("fuzz failures:", bad)
+    sys.exit(1 if bad else 0)

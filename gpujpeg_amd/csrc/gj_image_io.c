@@ -157,7 +157,7 @@ static int pnm_read_header(FILE* f, int* w, int* h, int* depth, int* maxval)
     if (strcmp(tok, "P7") == 0) {
         *w = *h = *depth = *maxval = 0;
         char line[256];
-        (void)fgets(line, sizeof line, f);
+        if (fgets(line, sizeof line, f) == NULL) return -1; /* rest of the magic line */
         while (fgets(line, sizeof line, f)) {
             if (strncmp(line, "ENDHDR", 6) == 0) return (*w > 0 && *h > 0 && *depth > 0) ? 0 : -1;
             if (sscanf(line, "WIDTH %d", w) == 1 || sscanf(line, "HEIGHT %d", h) == 1 || sscanf(line, "DEPTH %d", depth) == 1 ||

@@ -1,9 +1,13 @@
 // gj_decode.hip -- MI355X (gfx950, wave64) JPEG decoder kernels.
 //
-//   k_huffman_decode      one lane per restart segment, decode tables + one private block per lane in LDS
-//   k_idct_fused_rgb444   dequant + IDCT of the three component blocks + colour transform + packed store
-//   k_idct / k_postprocess / k_copy_planes_out   generic path through padded planes
-//   k_find_rst / k_emit_rst   device-side marker scan (segment table without touching the host)
+//   k_huffman_decode_par   sub-sequence parallel entropy decoding of batches of restart segments (the default); output either
+//                          the coefficient planes or, in token mode, a dense token array + one record per block
+//   k_huffman_decode       one lane per restart segment (streams whose Huffman tables do not fit the two-level tables)
+//   k_idct_fused_rgb444    dequant + IDCT of the three component blocks + colour transform + packed store, from the planes
+//   k_idct_tok_rgb444      the same, fed by tokens and block records
+//   k_idct_fused_uyvy422 / k_idct_tok_uyvy422   packed 4:2:2 output without colour transform
+//   k_idct / k_postprocess / k_copy_planes_out  generic path through padded planes
+//   k_marker_count / rank / emit, k_build_segments, k_compare_header   segment table built on the device
 //
 // Restates src/gpujpeg_huffman_gpu_decoder.cu:135-495 (entropy decoding semantics; identical results to
 // src/gpujpeg_huffman_cpu_decoder.c:245-372), src/gpujpeg_dct_gpu.cu:312-366,472-618 and

@@ -1,7 +1,9 @@
 // gj_encode.hip -- MI355X (gfx950, wave64) JPEG encoder kernels.
 //
 // Pipeline (all in one stream, the bitstream is assembled on the device):
-//   k_fused_rgb444        raw packed pixels -> quantised coefficients   (fast path; preprocess + DCT + quant fused)
+//   k_encode_rgb444 / k_encode_uyvy422   raw packed pixels -> entropy-coded segments in one kernel (the default for the BASELINE
+//                         configurations; no coefficient planes)
+//   k_fused_rgb444 / k_fused_uyvy422     raw packed pixels -> quantised coefficients (preprocess + DCT + quant fused)
 //   k_preprocess/k_copy_planes + k_dct   generic path through padded planes (every pixel format / subsampling)
 //   k_huffman             one LANE per 8x8 block: sparse run-length + Huffman coding, bits OR-ed into an LDS stream
 //   k_scan_segments       prefix sum of the stuffed segment sizes -> final byte offsets

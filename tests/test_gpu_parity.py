@@ -387,3 +387,30 @@ def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
     monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
     assert np.array_equal(dec.decode(jpeg)[0], want)
     dec.close()
+
+
+def test_token_mode_equals_plane_mode_16k(O, G, gpu_lib, monkeypatch):
+    """16K RGB (the largest frame of the BASELINE configurations) takes token mode by itself; the pixels must equal the
+    plane-mode decoder's, which the smaller cases pin against the oracle. Also a size-independent round-trip check."""
+    w, h = 15360, 8640
+    rng = np.random.default_rng(16)
+    yy, xx = np.mgrid[0:h // 16, 0:w // 16]
+    base = np.stack([128 + 90 * np.sin(xx / 23.0) * np.cos(yy / 17.0), xx * 255.0 / (w // 16), yy * 255.0 / (h // 16)], -1).astype(np.float32)
+    img = np.kron(base, np.ones((16, 16, 1), np.float32))
+    img += rng.normal(0, 3, (h, w, 1)).astype(np.float32)
+    raw = np.clip(img, 0, 255).astype(np.uint8).reshape(-1)
+    del img, base
+    case = ("16k", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    enc = G.Encoder(gpu_lib)
+    jpeg = enc.encode(p, pi, raw)
+    enc.close()
+    dec = G.Decoder(gpu_lib)
+    monkeypatch.delenv("GJ_DEC_TOKENS", raising=False)
+    monkeypatch.delenv("GJ_DEC_NO_TOKENS", raising=False)
+    tok = dec.decode(jpeg)[0]
+    monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
+    plane = dec.decode(jpeg)[0]
+    dec.close()
+    assert np.array_equal(tok, plane)
+    assert psnr(tok[: w * 3 * 512], raw[: w * 3 * 512]) > 32.0

@@ -37,6 +37,7 @@ struct gpujpeg_encoder {
     /* host side */
     uint32_t* h_result; /* pinned */
     uint8_t* h_header;  /* pinned staging for the main header */
+    struct gj_exif_tags* exif_tags; /* enc_exif_tag */
     uint8_t* out_buf; size_t out_cap; bool out_buf_pinned;
     int use_fused;
     int keep_coefs; /* gpujpeg_amd_encoder_keep_coefficients */
@@ -91,6 +92,7 @@ int gpujpeg_encoder_destroy(struct gpujpeg_encoder* e)
     gj_hip_free(e->d_temp); gj_hip_free(e->d_scan_partial); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
     gj_hip_free(e->coder.d_raw_own); gj_hip_free(e->coder.d_planes); gj_hip_free(e->coder.d_coefs);
     gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header);
+    gj_exif_tags_destroy(e->exif_tags);
     if (e->out_buf_pinned) gj_hip_host_free(e->out_buf); else free(e->out_buf);
     free(e->scan_hdrs.bytes);
     free(e);
@@ -233,7 +235,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     }
 
     /* main header: host bytes, placed at the start of the device stream */
-    const size_t hdr = gj_write_main_header(e->h_header, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata);
+    const size_t hdr = gj_write_main_header(e->h_header, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata, e->exif_tags);
     if (gj_hip_memcpy_h2d(e->d_jpeg, e->h_header, hdr, c->stream) != 0) return -1;
 
     gj_enc_job job;
@@ -459,9 +461,9 @@ int gpujpeg_encoder_set_option(struct gpujpeg_encoder* e, const char* opt, const
         e->metadata.vals[GPUJPEG_METADATA_ORIENTATION].orient.flip = flip;
         return GPUJPEG_NOERR;
     }
-    if (strcmp(opt, GPUJPEG_ENC_OPT_EXIF_TAG) == 0) {
-        GJ_ERROR("Option %s is not implemented in the MI355X build yet.\n", opt);
-        return GPUJPEG_ERROR;
+    if (strcmp(opt, GPUJPEG_ENC_OPT_EXIF_TAG) == 0) { /* src/gpujpeg_encoder.c:773-776 */
+        e->header_type = GPUJPEG_HEADER_EXIF;
+        return gj_exif_add_tag(&e->exif_tags, val) == 0 ? GPUJPEG_NOERR : GPUJPEG_ERROR;
     }
     GJ_ERROR("Invalid encoder option: %s!\n", opt);
     return GPUJPEG_ERROR;
@@ -470,10 +472,15 @@ int gpujpeg_encoder_set_option(struct gpujpeg_encoder* e, const char* opt, const
 void gpujpeg_encoder_print_options(void)
 {
     printf("\t" GPUJPEG_ENC_OPT_OUT "=[" GPUJPEG_ENC_OUT_VAL_PAGEABLE "|" GPUJPEG_ENC_OUT_VAL_PINNED "|" GPUJPEG_ENC_OUT_VAL_DEVICE
-           "] - location of the buffer returned by the encoder\n");
-    printf("\t" GPUJPEG_ENC_OPT_FLIPPED_BOOL "=[" GPUJPEG_VAL_TRUE "|" GPUJPEG_VAL_FALSE "] - whether is the input image should be vertically flipped (prior encode)\n");
-    printf("\t" GPUJPEG_ENC_OPT_CHANNEL_REMAP "=XYZ[W] - input channel remapping, 'help' for details\n");
-    printf("\t" GPUJPEG_ENC_OPT_HDR "=[" GPUJPEG_ENC_HDR_VAL_JFIF "|" GPUJPEG_ENC_HDR_VAL_ADOBE "|" GPUJPEG_ENC_HDR_VAL_SPIFF "] - JPEG header to emit\n");
+           "] - compressed data buffer allocation property (" GPUJPEG_ENC_OUT_VAL_DEVICE ": the stream stays in device memory)\n");
+    printf("\t" GPUJPEG_ENC_OPT_HDR "=[" GPUJPEG_ENC_HDR_VAL_JFIF "|" GPUJPEG_ENC_HDR_VAL_ADOBE "|" GPUJPEG_ENC_HDR_VAL_EXIF "|" GPUJPEG_ENC_HDR_VAL_SPIFF
+           "] - output JPEG header\n");
+    printf("\t" GPUJPEG_ENC_OPT_FLIPPED_BOOL "=[" GPUJPEG_VAL_FALSE "|" GPUJPEG_VAL_TRUE
+           "] - whether is the input image should be vertically flipped (prior encode)\n");
+    printf("\t" GPUJPEG_ENC_OPT_CHANNEL_REMAP "=XYZ[W] - input channel mapping, eg. '210F' for GBRX,\n"
+           "\t\t'210' for GBR; special placeholders 'F' and 'Z' to set a channel to all-ones or all-zeros\n");
+    printf("\t" GPUJPEG_ENC_OPT_EXIF_TAG "=<key>=<value>|help - custom EXIF tag (use help for syntax)\n");
+    printf("\t" GPUJPEG_ENC_OPT_METADATA "=<key>=<value>|help - set image metadata\n");
 }
 
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
@@ -524,6 +531,21 @@ size_t gpujpeg_amd_host_headers(const struct gpujpeg_parameters* param, const st
 size_t gpujpeg_amd_host_headers_md(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi, int header_type,
                                    int rotation, int flip, uint8_t* dst, size_t capacity, size_t* main_header_size)
 {
+    return gpujpeg_amd_host_headers_exif(param, pi, header_type, rotation, flip, NULL, 0, dst, capacity, main_header_size);
+}
+
+size_t gpujpeg_amd_host_headers_exif(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi, int header_type,
+                                     int rotation, int flip, const char* const* exif_tags, int exif_tag_count, uint8_t* dst, size_t capacity,
+                                     size_t* main_header_size)
+{
+    struct gj_exif_tags* tags = NULL;
+    for (int i = 0; i < exif_tag_count; i++) {
+        if (gj_exif_add_tag(&tags, exif_tags[i]) != 0) {
+            gj_exif_tags_destroy(tags);
+            return 0;
+        }
+        header_type = GPUJPEG_HEADER_EXIF;
+    }
     struct gpujpeg_image_metadata md;
     memset(&md, 0, sizeof md);
     if (rotation >= 0) {
@@ -533,12 +555,13 @@ size_t gpujpeg_amd_host_headers_md(const struct gpujpeg_parameters* param, const
     }
     struct gpujpeg_parameters p;
     gj_geom g;
-    if (host_adjusted(param, pi, &p, &g) != 0) return 0;
+    if (host_adjusted(param, pi, &p, &g) != 0) { gj_exif_tags_destroy(tags); return 0; }
     uint8_t qraw[2][64];
     gj_quant_table_raw(0, p.quality, qraw[0]);
     gj_quant_table_raw(1, p.quality, qraw[1]);
     uint8_t hdr[4096];
-    const size_t n = gj_write_main_header(hdr, &g, &p, (enum gpujpeg_header_type)header_type, (const uint8_t(*)[64])qraw, &md);
+    const size_t n = gj_write_main_header(hdr, &g, &p, (enum gpujpeg_header_type)header_type, (const uint8_t(*)[64])qraw, &md, tags);
+    gj_exif_tags_destroy(tags);
     struct gj_scan_headers sh;
     memset(&sh, 0, sizeof sh);
     if (gj_write_scan_headers(&sh, &g, &p) != 0) return 0;

@@ -46,6 +46,11 @@ GPUJPEG_API size_t gpujpeg_amd_host_headers(const struct gpujpeg_parameters* par
 /* the same with orientation metadata (rotation in quarter turns clockwise, -1 = none; flip) as set by enc_metadata */
 GPUJPEG_API size_t gpujpeg_amd_host_headers_md(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image,
                                                int header_type, int rotation, int flip, uint8_t* dst, size_t capacity, size_t* main_header_size);
+/* the same with user Exif tags in the syntax of the encoder option enc_exif_tag ("<ID>:<type>=<value>" or "<name>=<value>");
+ * any tag selects the Exif header like the option does */
+GPUJPEG_API size_t gpujpeg_amd_host_headers_exif(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image,
+                                                 int header_type, int rotation, int flip, const char* const* exif_tags, int exif_tag_count,
+                                                 uint8_t* dst, size_t capacity, size_t* main_header_size);
 /* Host-only: geometry summary for the adjusted parameters: out[0] segment_count, [1] block_count, [2] restart interval,
  * [3] blocks per MCU, [4 + 4*c ..] per component data_width, data_height, segment_count, type */
 GPUJPEG_API int gpujpeg_amd_host_geometry(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image, int out[20]);

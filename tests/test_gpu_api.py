@@ -200,6 +200,32 @@ def test_encoder_metadata_orientation(O, G, gpu_lib):
     enc.close()
 
 
+def test_encoder_custom_exif_tags(O, G, gpu_lib):
+    """enc_exif_tag selects the Exif header and adds / replaces tags (src/gpujpeg_encoder.c:773-776, src/gpujpeg_exif.c); the
+    entropy-coded data is unaffected, the Exif orientation is read back by the decoder side."""
+    w, h = 96, 64
+    raw = natural_image(w, h)
+    case = ("x", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    plain = G.Encoder(gpu_lib).encode(p, pi, raw)
+    enc = G.Encoder(gpu_lib)
+    assert enc.set_option("enc_exif_tag", "NoSuchName=1") != 0
+    assert enc.set_option("enc_exif_tag", "0x010F:ASCII=MI355X") == 0
+    assert enc.set_option("enc_exif_tag", "Orientation=6") == 0
+    assert enc.set_option("enc_exif_tag", "0x829A:RATIONAL=1/250") == 0
+    jpeg = enc.encode(p, pi, raw)
+    b = bytes(jpeg)
+    assert b[2:4] == b"\xff\xe1" and b[6:10] == b"Exif" and b"MI355X\0" in b[:400]
+    n = 4 + int.from_bytes(b[4:6], "big")
+    assert b[n:] == bytes(plain)[20:], "everything after the application segment equals the JFIF file (APP0 is 18 bytes)"
+    info = G.ImageInfo()
+    assert gpu_lib.L.gpujpeg_decoder_get_image_info2(jpeg.ctypes.data_as(C.POINTER(C.c_uint8)), jpeg.size, C.byref(info), -1, 0) == 0
+    md = bytes(info.metadata)
+    assert md[4] & 1 == 1 and md[0] & 3 == 1 and (md[0] >> 2) & 1 == 0  # Exif orientation 6 = a quarter turn, no flip
+    assert np.array_equal(G.Decoder(gpu_lib).decode(jpeg)[0], G.Decoder(gpu_lib).decode(plain)[0])
+    enc.close()
+
+
 def test_damaged_streams_do_not_crash(O, G, gpu_lib):
     """Corrupted entropy data, truncated files and garbage after the headers: the decoder may fail or return garbage pixels, but it
     must return (no out-of-bounds access, no endless loop in the synchronisation rounds) and keep working afterwards."""

@@ -149,3 +149,79 @@ def test_exif_header_bytes(O, G, ref, lib, orientation):
         b[off:off + 20] = b"x" * 20
         b[j + 8:j + 12] = b"PPPP"
     assert got == want
+
+
+EXIF_TAG_SETS = [
+    ["0x010F:ASCII=MI355X build"],                                   # Make: a new tag in the 0th IFD, value behind the IFD
+    ["Orientation=6", "0x9003:ASCII=2026:09:26 10:00:00"],           # replaces a built-in tag; private tag with a long value
+    ["XResolution=300/1", "YResolution=300/1", "0x829A:RATIONAL=1/250", "0x8827:SHORT=400", "0xA405:SHORT=35"],
+    ["WhitePoint=313/1000,329/1000", "0x0100:LONG=640", "0x9286:UNDEFINED=raw comment"],
+    ["PixelXDimension=77"],                                          # replaced private tag: the reference keeps a stale copy of the last built-in one
+    ["0x9204:SRATIONAL=-1/3", "0x0101:BYTE=1,2,3", "0x0102:BYTE=1,2,3,4,5"],
+]
+
+
+@pytest.mark.parametrize("tags", EXIF_TAG_SETS, ids=[str(i) for i in range(len(EXIF_TAG_SETS))])
+def test_custom_exif_tags(O, G, ref, lib, tags):
+    """enc_exif_tag: user tags in either IFD, replacing built-in ones, sorted by id, long values behind their IFD
+    (src/gpujpeg_exif.c:172-600) -- the APP1 segment equals the reference's except DateTime and the Exif IFD pointer
+    (see test_exif_header_bytes)."""
+    import ctypes as C
+    w, h = 64, 48
+    case = ("e", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(ref, G, case)
+    enc = G.Encoder(ref)
+    for t in tags:
+        assert enc.set_option("enc_exif_tag", t) == 0
+    jpeg = bytes(enc.encode(p, pi, O.noise(w * h * 3)))
+    enc.h = None  # the reference's gpujpeg_exif_tags_destroy (src/gpujpeg_exif.c:592-598) advances the wrong loop variable and corrupts
+    #               the heap when an IFD has two or more user tags: this encoder is deliberately not destroyed
+    assert jpeg[2:4] == b"\xff\xe1"
+    n = 4 + int.from_bytes(jpeg[4:6], "big")
+    want = bytearray(jpeg[2:n])
+    buf = (C.c_uint8 * 8192)()
+    main = C.c_size_t()
+    p2, pi2 = api_params(lib, G, case)
+    fn = lib.L.gpujpeg_amd_host_headers_exif
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint8), C.c_size_t,
+                   C.POINTER(C.c_size_t)]
+    arr = (C.c_char_p * len(tags))(*[t.encode() for t in tags])
+    assert fn(C.byref(p2), C.byref(pi2), 0, -1, 0, arr, len(tags), buf, 8192, C.byref(main)) > 0
+    got = bytearray(bytes(buf[2:n]))
+    assert bytes(buf[n:n + 2]) == jpeg[n:n + 2], "same segment length"
+
+    def records(b):  # 0th IFD records by tag id -> (record offset)
+        base = 2 + 2 + 6  # marker, length, "Exif\0\0"
+        cnt = int.from_bytes(b[base + 8:base + 10], "big")
+        return {int.from_bytes(b[base + 10 + 12 * i:base + 12 + 12 * i], "big"): base + 10 + 12 * i for i in range(cnt)}
+    rg, rw = records(got), records(want)
+    assert sorted(rg) == sorted(rw) and list(rg) == sorted(rg), "records sorted by id"
+    for b, r in ((got, rg), (want, rw)):
+        if 0x132 in r and not any(t.lower().startswith("datetime") for t in tags):
+            off = int.from_bytes(b[r[0x132] + 8:r[0x132] + 12], "big") + 10
+            b[off:off + 20] = b"x" * 20          # DateTime: wall clock
+        b[r[0x8769] + 8:r[0x8769] + 12] = b"PPPP"  # Exif IFD pointer: unspecified in the reference
+    assert got == want
+    # our pointer is the real offset of the Exif IFD: its first record is ExifVersion unless a smaller private id was added
+    raw = bytes(buf[2:n])
+    ptr = int.from_bytes(raw[rg[0x8769] + 8:rg[0x8769] + 12], "big") + 10
+    cnt = int.from_bytes(raw[ptr:ptr + 2], "big")
+    ids = [int.from_bytes(raw[ptr + 2 + 12 * i:ptr + 4 + 12 * i], "big") for i in range(cnt)]
+    assert ids == sorted(ids) and 0x9000 in ids
+
+
+def test_custom_exif_tag_errors(lib):
+    import ctypes as C
+    fn = lib.L.gpujpeg_amd_host_headers_exif
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_uint8), C.c_size_t,
+                   C.POINTER(C.c_size_t)]
+    p = lib.default_parameters()
+    p.verbose = -1
+    pi = lib.default_image_parameters()
+    pi.width, pi.height = 64, 48
+    buf = (C.c_uint8 * 8192)()
+    for bad in ("NoSuchName=1", "0x10F=x", "0x10F:FLOAT=1", "0x10F:SHORT", "Orientation=6x", "0x10F:ASCII=" + "x" * 4000):
+        arr = (C.c_char_p * 1)(bad.encode())
+        assert fn(C.byref(p), C.byref(pi), 0, -1, 0, arr, 1, buf, 8192, None) == 0, bad

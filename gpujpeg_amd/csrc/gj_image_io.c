@@ -15,6 +15,7 @@
 #include <strings.h>
 
 #include "gj_internal.h"
+#include "gpujpeg_amd_ext.h"
 
 enum gpujpeg_image_file_format gpujpeg_image_get_file_format(const char* filename) /* common.c:380-444 */
 {
@@ -308,9 +309,9 @@ static int y4m_save(const char* filename, const uint8_t* image, size_t size, con
 /* ------------------------------------------------------------------ BMP and TGA
  * The reference hands these to third-party stb_image / stb_image_write (src/utils/image_delegate.c:188-330): 1, 3 or 4 channels
  * of 8 bits <-> u8 / 444-u8-p012 / 4444-u8-p0123. Written here from the format specifications: BMP uncompressed 8 (grey palette),
- * 24 and 32 bit, bottom-up or top-down; TGA types 2/3 and their run-length coded forms 10/11, both origins. PNG and GIF need
- * inflate / LZW and stay unsupported. */
-struct raster { int w, h, comps; uint8_t* px; }; /* top-down, RGB(A) or grey, tightly packed */
+ * 24 and 32 bit, bottom-up or top-down; TGA types 2/3 and their run-length coded forms 10/11, both origins. PNG (read, write) and
+ * GIF (read) live in gj_image_png.c. */
+/* struct gj_raster (gj_internal.h): top-down, RGB(A) or grey, tightly packed */
 
 static unsigned rd16(const uint8_t* p) { return (unsigned)p[0] | (unsigned)p[1] << 8; }
 static uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
@@ -329,7 +330,7 @@ static int file_read_all(const char* filename, uint8_t** data, size_t* n)
 }
 
 /* header only when out->px == NULL on return is acceptable (probe): pass want_pixels = 0 */
-static int bmp_decode(const uint8_t* d, size_t n, struct raster* out, int want_pixels)
+static int bmp_decode(const uint8_t* d, size_t n, struct gj_raster* out, int want_pixels)
 {
     if (n < 54 || d[0] != 'B' || d[1] != 'M') return -1;
     const uint32_t off = rd32(d + 10), hsize = rd32(d + 14);
@@ -360,7 +361,7 @@ static int bmp_decode(const uint8_t* d, size_t n, struct raster* out, int want_p
     return 0;
 }
 
-static int tga_decode(const uint8_t* d, size_t n, struct raster* out, int want_pixels)
+static int tga_decode(const uint8_t* d, size_t n, struct gj_raster* out, int want_pixels)
 {
     if (n < 18) return -1;
     const unsigned idlen = d[0], cmap = d[1], type = d[2], bpp = d[16], desc = d[17];
@@ -408,6 +409,22 @@ static int tga_decode(const uint8_t* d, size_t n, struct raster* out, int want_p
     return 0;
 }
 
+static const char* raster_name(enum gpujpeg_image_file_format fmt)
+{
+    return fmt == GPUJPEG_IMAGE_FILE_BMP ? "BMP" : fmt == GPUJPEG_IMAGE_FILE_TGA ? "TGA" : fmt == GPUJPEG_IMAGE_FILE_PNG ? "PNG" : "GIF";
+}
+
+static int raster_decode(enum gpujpeg_image_file_format fmt, const uint8_t* d, size_t n, struct gj_raster* r, int want_pixels)
+{
+    switch (fmt) {
+    case GPUJPEG_IMAGE_FILE_BMP: return bmp_decode(d, n, r, want_pixels);
+    case GPUJPEG_IMAGE_FILE_TGA: return tga_decode(d, n, r, want_pixels);
+    case GPUJPEG_IMAGE_FILE_PNG: return gj_png_decode(d, n, r, want_pixels);
+    case GPUJPEG_IMAGE_FILE_GIF: return gj_gif_decode(d, n, r, want_pixels);
+    default: return -1;
+    }
+}
+
 static int raster_probe(const char* filename, enum gpujpeg_image_file_format fmt, struct gpujpeg_image_parameters* pi, int file_exists)
 {
     if (!file_exists) { /* output: stb_image_write takes 1, 3 or 4 interleaved channels */
@@ -418,10 +435,14 @@ static int raster_probe(const char* filename, enum gpujpeg_image_file_format fmt
     uint8_t* d;
     size_t n;
     if (file_read_all(filename, &d, &n) != 0) return -1;
-    struct raster r = {0};
-    const int rc = fmt == GPUJPEG_IMAGE_FILE_BMP ? bmp_decode(d, n, &r, 0) : tga_decode(d, n, &r, 0);
+    struct gj_raster r = {0};
+    const int rc = raster_decode(fmt, d, n, &r, 0);
     free(d);
-    if (rc != 0) { GJ_ERROR("Unsupported %s file %s (uncompressed 8/24/32 bit expected)\n", fmt == GPUJPEG_IMAGE_FILE_BMP ? "BMP" : "TGA", filename); return -1; }
+    if (rc != 0) { GJ_ERROR("Unsupported %s file %s\n", raster_name(fmt), filename); return -1; }
+    if (r.comps != 1 && r.comps != 3 && r.comps != 4) { /* src/utils/image_delegate.c:548-551 */
+        GJ_ERROR("[stbi] Unsupported channel count %d for %s\n", r.comps, filename);
+        return -1;
+    }
     pi->width = r.w;
     pi->height = r.h;
     pi->color_space = r.comps == 1 ? GPUJPEG_YCBCR_JPEG : GPUJPEG_RGB;
@@ -434,10 +455,10 @@ static int raster_load(const char* filename, enum gpujpeg_image_file_format fmt,
     uint8_t* d;
     size_t n;
     if (file_read_all(filename, &d, &n) != 0) return -1;
-    struct raster r = {0};
-    const int rc = fmt == GPUJPEG_IMAGE_FILE_BMP ? bmp_decode(d, n, &r, 1) : tga_decode(d, n, &r, 1);
+    struct gj_raster r = {0};
+    const int rc = raster_decode(fmt, d, n, &r, 1);
     free(d);
-    if (rc != 0) { free(r.px); GJ_ERROR("Unsupported or damaged %s file %s\n", fmt == GPUJPEG_IMAGE_FILE_BMP ? "BMP" : "TGA", filename); return -1; }
+    if (rc != 0 || (r.comps != 1 && r.comps != 3 && r.comps != 4)) { free(r.px); GJ_ERROR("Unsupported or damaged %s file %s\n", raster_name(fmt), filename); return -1; }
     const size_t bytes = (size_t)r.w * r.h * r.comps;
     uint8_t* data = gj_hip_host_alloc(bytes);
     if (!data) { free(r.px); return -1; }
@@ -448,6 +469,29 @@ static int raster_load(const char* filename, enum gpujpeg_image_file_format fmt,
     return 0;
 }
 
+/* gpujpeg_amd_ext.h: the decoders above without the pinned allocation of gpujpeg_image_load_from_file (no device needed) */
+int gpujpeg_amd_read_raster_file(const char* filename, uint8_t* dst, size_t capacity, int* width, int* height, int* channels)
+{
+    const enum gpujpeg_image_file_format fmt = gpujpeg_image_get_file_format(filename);
+    uint8_t* d;
+    size_t n;
+    if (file_read_all(filename, &d, &n) != 0) return -1;
+    struct gj_raster r = {0};
+    const int rc = raster_decode(fmt, d, n, &r, dst != NULL);
+    free(d);
+    if (rc != 0) { free(r.px); return -1; }
+    if (width) *width = r.w;
+    if (height) *height = r.h;
+    if (channels) *channels = r.comps;
+    int ret = 0;
+    if (dst) {
+        const size_t bytes = (size_t)r.w * r.h * r.comps;
+        if (bytes <= capacity) memcpy(dst, r.px, bytes); else ret = -1;
+    }
+    free(r.px);
+    return ret;
+}
+
 static void wr16(uint8_t* p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 static void wr32(uint8_t* p, uint32_t v) { wr16(p, v & 0xFFFF); wr16(p + 2, v >> 16); }
 
@@ -455,6 +499,17 @@ static int raster_save(const char* filename, enum gpujpeg_image_file_format fmt,
 {
     const int c = pi->pixel_format == GPUJPEG_U8 ? 1 : pi->pixel_format == GPUJPEG_444_U8_P012 ? 3 : pi->pixel_format == GPUJPEG_4444_U8_P0123 ? 4 : 0;
     if (c == 0) { GJ_ERROR("Pixel format %s cannot be stored in this file type\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1; }
+    if (fmt == GPUJPEG_IMAGE_FILE_GIF) { /* src/utils/image_delegate.c:492-495 */
+        GJ_ERROR("[stbi] Only gif decoder is present, the encoder is not supported!\n");
+        return -1;
+    }
+    if (fmt == GPUJPEG_IMAGE_FILE_PNG) {
+        if (gj_png_save(filename, image, pi->width, pi->height, c, (size_t)pi->width * c + pi->width_padding) != 0) {
+            GJ_ERROR("[stbi] Cannot write output file %s\n", filename);
+            return -1;
+        }
+        return 0;
+    }
     FILE* f = fopen(filename, "wb");
     if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
     const int w = pi->width, h = pi->height;
@@ -509,10 +564,8 @@ int gpujpeg_image_load_from_file(const char* filename, uint8_t** image, size_t* 
     case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
         return pnm_load(filename, image, image_size);
     case GPUJPEG_IMAGE_FILE_Y4M: return y4m_load(filename, image, image_size);
-    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: return raster_load(filename, fmt, image, image_size);
-    case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
-        GJ_ERROR("Reading %s needs a third-party decoder (inflate / LZW) that is not part of the MI355X build; convert to BMP/TGA/PNM/PAM/Y4M.\n", filename);
-        return -1;
+    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
+        return raster_load(filename, fmt, image, image_size);
     default: break;
     }
     FILE* f = fopen(filename, "rb");
@@ -548,10 +601,8 @@ int gpujpeg_image_save_to_file(const char* filename, const uint8_t* image, size_
         case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
             return pnm_save(filename, fmt, image, pi);
         case GPUJPEG_IMAGE_FILE_Y4M: return y4m_save(filename, image, image_size, pi);
-        case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: return raster_save(filename, fmt, image, pi);
-        case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
-            GJ_ERROR("Writing %s needs a third-party encoder that is not part of the MI355X build; use BMP/TGA/PNM/PAM/Y4M.\n", filename);
-            return -1;
+        case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
+            return raster_save(filename, fmt, image, pi);
         default: break;
         }
     }
@@ -579,10 +630,8 @@ int gpujpeg_image_get_properties(const char* filename, struct gpujpeg_image_para
     case GPUJPEG_IMAGE_FILE_PGM: case GPUJPEG_IMAGE_FILE_PPM: case GPUJPEG_IMAGE_FILE_PNM: case GPUJPEG_IMAGE_FILE_PAM:
         return pnm_probe(filename, pi, file_exists);
     case GPUJPEG_IMAGE_FILE_Y4M: return y4m_probe(filename, pi, file_exists);
-    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: return raster_probe(filename, fmt, pi, file_exists);
-    case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
-        pi->color_space = GPUJPEG_RGB;
-        return file_exists ? -1 : 1;
+    case GPUJPEG_IMAGE_FILE_BMP: case GPUJPEG_IMAGE_FILE_TGA: case GPUJPEG_IMAGE_FILE_GIF: case GPUJPEG_IMAGE_FILE_PNG:
+        return raster_probe(filename, fmt, pi, file_exists);
     case GPUJPEG_IMAGE_FILE_RAW: pi->pixel_format = GPUJPEG_PIXFMT_STD; break;
     case GPUJPEG_IMAGE_FILE_GRAY: pi->color_space = GPUJPEG_YCBCR_JPEG; pi->pixel_format = GPUJPEG_U8; break;
     case GPUJPEG_IMAGE_FILE_RGBA: pi->color_space = GPUJPEG_RGB; pi->pixel_format = GPUJPEG_4444_U8_P0123; break;

@@ -100,6 +100,12 @@ size_t gj_write_main_header(uint8_t* out, const gj_geom* g, const struct gpujpeg
                             const uint8_t qraw[2][64], const struct gpujpeg_image_metadata* metadata, const struct gj_exif_tags* exif_tags);
 int gj_write_scan_headers(struct gj_scan_headers* sh, const gj_geom* g, const struct gpujpeg_parameters* param);
 
+/* ---- raster file formats behind gpujpeg_image_load_from_file / save_to_file (gj_image_io.c, gj_image_png.c) ---- */
+struct gj_raster { int w, h, comps; uint8_t* px; }; /* top-down, tightly packed, comps interleaved 8-bit channels; px is malloc'ed */
+int gj_png_decode(const uint8_t* d, size_t n, struct gj_raster* out, int want_pixels);
+int gj_gif_decode(const uint8_t* d, size_t n, struct gj_raster* out, int want_pixels);
+int gj_png_save(const char* filename, const uint8_t* image, int w, int h, int comps, size_t pitch);
+
 /* ---- reader (src/gpujpeg_reader.c) ---- */
 struct gj_reader_result {
     struct gpujpeg_parameters param;

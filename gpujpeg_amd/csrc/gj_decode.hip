@@ -1514,6 +1514,41 @@ static gj_idct_tok_t gj_idct_tok_kernel(const gj_geom& g)
     return nullptr;
 }
 
+static bool gj_is_uyvy422(const gj_geom& g)
+{
+    return g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 &&
+           (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
+           g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
+           g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
+           g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
+}
+
+// the token-fed IDCT kernel for this configuration, or nullptr
+static gj_idct_tok_t gj_idct_tok_for(const gj_geom& g)
+{
+    if (!g.interleaved) return gj_idct_tok_kernel(g);
+    if (gj_is_uyvy422(g) && g.blocks_per_mcu == 4 && g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.mcu_comp[0] == 0 && g.mcu_comp[1] == 0 &&
+        g.mcu_comp[2] == 1 && g.mcu_comp[3] == 2 && g.mcu_bx[0] == 0 && g.mcu_bx[1] == 1)
+        return k_idct_tok_uyvy422;
+    return nullptr;
+}
+
+// Does a frame of this geometry and stream size go through token mode (given fused kernels and two-level Huffman tables)? The host
+// asks before it allocates the token buffers; the launcher asks again.
+// Measured (8K / 16K RGB natural frames at q75, 4.75 B of stream per block: +17 % enc+dec; HD and 4K equal or slightly slower;
+// 16K 4:2:2 at q90, 10.4 B per block: -6 %; 8K noise -15 %; crossover at 8K RGB near 9 B per block): tokens pay when the frame
+// fills the GPU more than once (the token-fed IDCT has the longer dependency chain per workgroup) and blocks carry few coefficients
+// (4 B per coefficient against 128 B per block). GJ_DEC_TOKENS=1 / GJ_DEC_NO_TOKENS=1 force either mode (tests, A/B runs).
+extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size)
+{
+    if (getenv("GJ_DEC_NO_TOKENS") || gj_idct_tok_for(*g) == nullptr) return 0;
+    const char* es = getenv("GJ_DEC_SUB");
+    if (es && atoi(es) != (g->interleaved ? 32 : GJ_PAR_SUB)) return 0; // (the tuning aid sweeps the plane-mode kernels)
+    const char* et = getenv("GJ_DEC_TOKENS");
+    if (et && et[0] == '1') return 1;
+    return g->block_count >= 900000 && jpeg_size <= (uint64_t)g->block_count * 8u;
+}
+
 extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4])
 {
     hipStream_t st = (hipStream_t)stream;
@@ -1525,31 +1560,11 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         const char* e = getenv("GJ_DEC_ENTROPY"); // "serial" forces the lane-per-segment kernel (A/B measurements, tests)
         if (e && e[0] == 's') par = false;
     }
+    const bool uyvy = job->use_fused && gj_is_uyvy422(g);
     // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
     // record per block instead of through the coefficient planes
-    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 &&
-                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
-                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
-                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
-                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
-    gj_idct_tok_t idct_tok = nullptr;
-    if (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && !getenv("GJ_DEC_NO_TOKENS")) {
-        if (!g.interleaved) idct_tok = gj_idct_tok_kernel(g);
-        else if (uyvy && g.blocks_per_mcu == 4 && g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.mcu_comp[0] == 0 && g.mcu_comp[1] == 0 &&
-                 g.mcu_comp[2] == 1 && g.mcu_comp[3] == 2 && g.mcu_bx[0] == 0 && g.mcu_bx[1] == 1)
-            idct_tok = k_idct_tok_uyvy422;
-    }
-    {
-        const char* es = getenv("GJ_DEC_SUB");
-        if (es && atoi(es) != (g.interleaved ? 32 : GJ_PAR_SUB)) idct_tok = nullptr; // (the tuning aid sweeps the plane-mode kernels)
-        // Measured (8K / 16K RGB natural frames at q75, 4.75 B of stream per block: +17 % enc+dec; HD and 4K equal or slightly slower;
-        // 16K 4:2:2 at q90, 10.4 B per block: -6 %; 8K noise -15 %): tokens pay when the frame fills the GPU more than once (the
-        // token-fed IDCT has the longer dependency chain per workgroup) and blocks carry few coefficients (4 B per coefficient
-        // against 128 B per block). GJ_DEC_TOKENS=1 forces the mode (tests).
-        const char* et = getenv("GJ_DEC_TOKENS");
-        const bool forced = et && et[0] == '1';
-        if (!forced && (g.block_count < 900000 || job->jpeg_size > (uint64_t)g.block_count * 8u)) idct_tok = nullptr;
-    }
+    gj_idct_tok_t idct_tok = (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && gj_hip_decode_wants_tokens(&g, job->jpeg_size))
+                                 ? gj_idct_tok_for(g) : nullptr;
     const bool tokens = idct_tok != nullptr;
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
     // decodes itself; clear_coefs asks for a full clear first (segments missing from the table, lane-per-segment kernel).

@@ -430,7 +430,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.clear_coefs = !spec && seg_count != g->segment_count;
     job.zero_coefs = 0;
     /* token mode buffers (gj_hip.h): one record per block, 4 tokens per stream byte at most */
-    if (!d->keep_coefs && job.use_fused && tab2_ok && image_size < ((size_t)1 << 29)) {
+    if (!d->keep_coefs && job.use_fused && tab2_ok && image_size < ((size_t)1 << 29) && gj_hip_decode_wants_tokens(&job.g, image_size)) {
         const size_t tok_need = (image_size * 4 + 64) * sizeof(uint32_t);
         if (tok_need > d->d_tok_cap) { /* (grown with headroom: frames of a sequence vary in size) */
             if (gj_ensure_device_buffer((void**)&d->d_tok, &d->d_tok_cap, tok_need + tok_need / 4) != 0) goto out;

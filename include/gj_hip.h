@@ -172,6 +172,11 @@ typedef struct gj_dec_job {
                                       count 0xFFFF = the block is in d_coefs (segment decoded piece by piece) */
 } gj_dec_job;
 
+/* 1 when a frame of this geometry (requested output included) and stream size is decoded in token mode: a token-fed IDCT kernel
+ * exists for it and the measured size / density rule (or the GJ_DEC_TOKENS / GJ_DEC_NO_TOKENS override) says so. The host asks
+ * before it allocates d_tok / d_blkrec. */
+GJ_HIP_API int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size);
+
 /* decode table layout per (slot, class): 1024 fast entries (len << 8 | symbol, 0 = miss) followed by
  * maxcode[18] (as u16 pairs lo/hi), valptr[17], mincode[17] and the 256 symbol values */
 #define GJ_DEC_FAST_BITS 10

@@ -196,8 +196,8 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient"])
     ap.add_argument("--quality", type=int, default=75)

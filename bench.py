@@ -45,8 +45,8 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 # HBM bytes per launch of the dominant kernels from the PMC passes committed under profiles/ (8K RGB q75 natural frame):
 # FETCH_SIZE doubled (gfx950 counts 128 B requests as 64 B, guide section HBM) + WRITE_SIZE
-TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49784.1 * 2 + 8350.0) * 1024), "dec:k_huffman_decode_par": int((4520.7 * 2 + 67504.6) * 1024),
-                 "dec:k_idct_tok_rgb444": int((26557.4 * 2 + 103273.0) * 1024)}  # profiles/r1_05_solo_hbm_traffic.txt (token mode)
+TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49802.4 * 2 + 8350.1) * 1024), "dec:k_huffman_decode_par": int((4463.7 * 2 + 70987.8) * 1024),
+                 "dec:k_idct_tok_rgb444": int((26587.8 * 2 + 103275.0) * 1024)}  # profiles/r1_06_solo_hbm_traffic.txt (token mode)
 
 
 def synth_frame(width, height, pattern, seed, device):

@@ -211,6 +211,9 @@ def main():
                          "(strong scaling, frames/s); a step is one pass over the whole batch")
     ap.add_argument("--streams", type=int, default=4, help="independent encoder+decoder pairs per GPU, each on its own HIP stream and host thread; "
                     "one step codes one frame per stream (hides the host side of one call behind the kernels of the other)")
+    ap.add_argument("--mode", default="both", choices=["both", "encode", "decode"],
+                    help="what a timed step does: encode then decode (the headline metric), or only one direction (SURVEY 8d asks for both "
+                         "separately; the decoder then decodes the stream of the warm-up's last encode again and again)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--internal-rgb", action="store_true", help="code RGB without colour transform (tuning aid; not the headline config)")
     ap.add_argument("--calibrate", action="store_true", help="run a 256 MiB device fill + copy first (known byte counts for calibrating PMC traffic counters)")
@@ -292,9 +295,10 @@ def main():
         torch.cuda.synchronize()
         del cal_a, cal_b
     solo_ms = np.zeros(8)  # kernel durations with the GPU to themselves (untimed warm-up of pipeline 0; reference for the roofline)
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         for ln in lanes:
             jptr, jsize = step(ln)
+            ln["last"] = (jptr, jsize)
     torch.cuda.synchronize()
     for _ in range(3):
         jptr, jsize = step(lanes[0])
@@ -310,19 +314,24 @@ def main():
         torch.cuda.set_device(local_rank)  # the HIP device is per host thread
         ln = lanes[idx]
         go.wait()
+        jp, js = ln["last"]
         for _ in range(args.steps):
             a = time.perf_counter()
-            jp, js = ln["enc"].encode_noclone(p, pi, ln["frame"].data_ptr(), gpu=True)
+            if args.mode != "decode":
+                jp, js = ln["enc"].encode_noclone(p, pi, ln["frame"].data_ptr(), gpu=True)
             b = time.perf_counter()
-            o = G.DecoderOutput()
-            o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
-            assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
+            if args.mode != "encode":
+                o = G.DecoderOutput()
+                o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
+                assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
             c = time.perf_counter()
             if idx == 0:  # per-kernel hipEvent durations of pipeline 0 (its kernels may share the GPU with the other pipelines')
                 walls[0] += b - a
                 walls[1] += c - b
-                enc_ms[:] += np.array(ln["enc"].kernel_times())
-                dec_ms[:] += np.array(ln["dec"].kernel_times())
+                if args.mode != "decode":
+                    enc_ms[:] += np.array(ln["enc"].kernel_times())
+                if args.mode != "encode":
+                    dec_ms[:] += np.array(ln["dec"].kernel_times())
             ln["last"] = (jp, js)
 
     threads = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
@@ -365,7 +374,8 @@ def main():
         alg = raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (same sum)
         achieved = alg / (durs[dom] * 1e-3) / 1e9
         result = {
-            "metric": "Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})", "value": round(pixels * world * S * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
+            "metric": ("Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})") if args.mode == "both"
+                      else f"Mpix/s {args.mode} only ({args.workload})", "value": round(pixels * world * S * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / f32 DCT / i16 coefficients",
             "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per stream",
@@ -373,7 +383,9 @@ def main():
                                     f"{width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto ({width}x{height} -> "
                                     f"{'36' if args.workload in ('8k', '16k') else 'auto'}), encode then decode per step"),
                        "frames_per_step_per_gpu": S, "streams_per_gpu": S, "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective"},
-            "encode_mpix_s": round(pixels * args.steps / enc_wall / 1e6, 2), "decode_mpix_s": round(pixels * args.steps / dec_wall / 1e6, 2),
+            # API calls of pipeline 0 alone (one call at a time per pipeline; the aggregate of all pipelines is `value`)
+            "encode_mpix_s": round(pixels * args.steps / enc_wall / 1e6, 2) if args.mode != "decode" else None,
+            "decode_mpix_s": round(pixels * args.steps / dec_wall / 1e6, 2) if args.mode != "encode" else None,
             "kernel_ms": {n: round(float(d), 4) for n, d in zip(names, durs)},
             "gpu_only_ms": {"encode": round(float(enc_ms.sum()), 4), "decode": round(float(dec_ms.sum()), 4)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

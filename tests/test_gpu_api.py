@@ -219,6 +219,32 @@ def test_encoder_metadata_orientation(O, G, gpu_lib):
     enc.close()
 
 
+def test_stats_valid_across_host_and_device_inputs(O, G, gpu_lib):
+    """test/unit/test_gh_95.c: with perf_stats on, gpujpeg_encoder_get_stats must succeed after every call while host and
+    device input buffers alternate (the copy-in timers of the previous call must not be read uninitialised)."""
+    import torch
+
+    w, h = 640, 480
+    p, pi = api_params(gpu_lib, G, ("s", w, h, 0, 3, 75, -1, 0, None, 3))
+    p.perf_stats = 1
+    enc = G.Encoder(gpu_lib)
+    host = np.zeros(w * h, np.uint8)
+    dev = torch.zeros(w * h, dtype=torch.uint8, device="cuda")
+    first = None
+    for kind in ("cpu", "gpu", "cpu", "gpu", "cpu"):
+        if kind == "cpu":
+            jpeg = enc.encode(p, pi, host)
+        else:
+            jptr, jsize = enc.encode_noclone(p, pi, dev.data_ptr(), gpu=True)
+            jpeg = np.ctypeslib.as_array(C.cast(jptr, C.POINTER(C.c_uint8)), shape=(jsize,)).copy()
+        st = G.DurationStats()
+        assert gpu_lib.L.gpujpeg_encoder_get_stats(enc.h, C.byref(st)) == 0, kind
+        assert st.duration_in_gpu > 0 and st.duration_huffman_coder >= 0 and st.duration_memory_to >= 0
+        first = jpeg if first is None else first
+        assert np.array_equal(jpeg, first)
+    enc.close()
+
+
 def test_encoder_custom_exif_tags(O, G, gpu_lib):
     """enc_exif_tag selects the Exif header and adds / replaces tags (src/gpujpeg_encoder.c:773-776, src/gpujpeg_exif.c); the
     entropy-coded data is unaffected, the Exif orientation is read back by the decoder side."""

@@ -219,6 +219,25 @@ def test_encoder_metadata_orientation(O, G, gpu_lib):
     enc.close()
 
 
+def test_reference_example_programs_run_unchanged(O, G, gpu_lib, tmp_path):
+    """The reference's examples/encode_minimal.c and decode_minimal.c, compiled without any change against our public headers and
+    linked with our library (oracle/Makefile, binaries under oracle/_ref/examples): the files they write are the oracle's bytes."""
+    import os
+    import subprocess
+    exdir = os.path.join(os.path.dirname(O.REF_PATH), "examples")
+    if not os.path.exists(os.path.join(exdir, "encode_minimal")):
+        pytest.skip("example binaries were not built (need /root/reference at build time)")
+    subprocess.check_call([os.path.join(exdir, "encode_minimal")], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    w, h = 640, 480
+    want = O.encode(O.make_image(w, h, pixel_format=0, color_space=3, restart_interval=8), np.zeros(w * h, np.uint8))  # gpujpeg_set_default_parameters: interval 8
+    assert np.array_equal(np.fromfile(tmp_path / "out.jpg", np.uint8), want)
+    subprocess.check_call([os.path.join(exdir, "decode_minimal"), "out.jpg"], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    data = (tmp_path / "out.pnm").read_bytes()
+    head = b"P5\n640 480\n255\n"
+    assert data.startswith(head)
+    assert np.array_equal(np.frombuffer(data[len(head):], np.uint8), O.decode(want)[0])
+
+
 def test_stats_valid_across_host_and_device_inputs(O, G, gpu_lib):
     """test/unit/test_gh_95.c: with perf_stats on, gpujpeg_encoder_get_stats must succeed after every call while host and
     device input buffers alternate (the copy-in timers of the previous call must not be read uninitialised)."""

@@ -238,6 +238,42 @@ def test_reference_example_programs_run_unchanged(O, G, gpu_lib, tmp_path):
     assert np.array_equal(np.frombuffer(data[len(head):], np.uint8), O.decode(want)[0])
 
 
+def test_one_encoder_per_thread(O, G, gpu_lib):
+    """test/misc/mt_encode.c: several threads, each with its own stream and encoder (and here a decoder), code HD frames at the same
+    time; every result equals the oracle's."""
+    import threading
+    import torch
+    w, h, threads, iterations = 1920, 1080, 4, 6
+    raw = (np.arange(w * h * 3, dtype=np.int64) % 255).astype(np.uint8)  # the pattern of the reference's test
+    case = ("mt", w, h, 1, 1, 75, 8, 0, None, 3)  # gpujpeg_set_default_parameters: restart interval 8
+    want = O.encode(oracle_image(O, case), raw)
+    want_px = O.decode(want)[0]
+    errors = []
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            enc, dec = G.Encoder(gpu_lib, stream.cuda_stream), G.Decoder(gpu_lib, stream.cuda_stream)
+            p, pi = api_params(gpu_lib, G, case)
+            for i in range(iterations):
+                jpeg = enc.encode(p, pi, raw)
+                if not np.array_equal(jpeg, want):
+                    errors.append((t, i, "encode"))
+                if not np.array_equal(dec.decode(jpeg)[0], want_px):
+                    errors.append((t, i, "decode"))
+            enc.close()
+            dec.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_stats_valid_across_host_and_device_inputs(O, G, gpu_lib):
     """test/unit/test_gh_95.c: with perf_stats on, gpujpeg_encoder_get_stats must succeed after every call while host and
     device input buffers alternate (the copy-in timers of the previous call must not be read uninitialised)."""

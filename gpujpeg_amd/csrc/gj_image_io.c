@@ -157,8 +157,7 @@ static int pnm_read_header(FILE* f, int* w, int* h, int* depth, int* maxval)
     }
     if (strcmp(tok, "P7") == 0) {
         *w = *h = *depth = *maxval = 0;
-        char line[256];
-        if (fgets(line, sizeof line, f) == NULL) return -1; /* rest of the magic line */
+        char line[256]; /* (pnm_token took the line end after the magic with it) */
         while (fgets(line, sizeof line, f)) {
             if (strncmp(line, "ENDHDR", 6) == 0) return (*w > 0 && *h > 0 && *depth > 0) ? 0 : -1;
             if (sscanf(line, "WIDTH %d", w) == 1 || sscanf(line, "HEIGHT %d", h) == 1 || sscanf(line, "DEPTH %d", depth) == 1 ||
@@ -176,9 +175,11 @@ static enum gpujpeg_pixel_format depth_pixfmt(int depth)
 
 static int pnm_probe(const char* filename, struct gpujpeg_image_parameters* pi, int file_exists)
 {
-    if (!file_exists) { /* output file: keep what the caller chose except the colour space */
-        pi->color_space = GPUJPEG_RGB;
-        if (pi->pixel_format != GPUJPEG_U8 && pi->pixel_format != GPUJPEG_4444_U8_P0123) pi->pixel_format = GPUJPEG_PIXFMT_NO_ALPHA;
+    if (!file_exists) { /* output file: what the extension can hold (src/utils/image_delegate.c:157-182) */
+        const enum gpujpeg_image_file_format fmt = gpujpeg_image_get_file_format(filename);
+        pi->pixel_format = fmt == GPUJPEG_IMAGE_FILE_PGM ? GPUJPEG_U8 : fmt == GPUJPEG_IMAGE_FILE_PPM ? GPUJPEG_444_U8_P012
+                           : fmt == GPUJPEG_IMAGE_FILE_PNM ? GPUJPEG_PIXFMT_NO_ALPHA : GPUJPEG_PIXFMT_AUTODETECT;
+        pi->color_space = fmt == GPUJPEG_IMAGE_FILE_PGM ? GPUJPEG_YCBCR_JPEG : GPUJPEG_CS_DEFAULT;
         return 1;
     }
     FILE* f = fopen(filename, "rb");
@@ -251,10 +252,10 @@ static int y4m_read_header(FILE* f, int* w, int* h, enum gpujpeg_pixel_format* p
 
 static int y4m_probe(const char* filename, struct gpujpeg_image_parameters* pi, int file_exists)
 {
-    if (!file_exists) {
-        if (pi->color_space == GPUJPEG_RGB || pi->color_space == GPUJPEG_NONE) pi->color_space = GPUJPEG_YCBCR_BT709;
+    if (!file_exists) { /* src/utils/image_delegate.c:259-263 */
+        pi->color_space = GPUJPEG_YCBCR_BT601_256LVLS;
         pi->pixel_format = GPUJPEG_PIXFMT_STD;
-        return 1;
+        return 0;
     }
     FILE* f = fopen(filename, "rb");
     if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
@@ -262,7 +263,7 @@ static int y4m_probe(const char* filename, struct gpujpeg_image_parameters* pi, 
     const int rc = y4m_read_header(f, &pi->width, &pi->height, &pi->pixel_format, &limited);
     fclose(f);
     if (rc != 0) { GJ_ERROR("Unsupported Y4M file %s\n", filename); return -1; }
-    pi->color_space = limited ? GPUJPEG_YCBCR_BT709 : GPUJPEG_YCBCR_JPEG;
+    pi->color_space = limited ? GPUJPEG_YCBCR_BT601 : GPUJPEG_YCBCR_BT601_256LVLS; /* src/utils/image_delegate.c:297 */
     return 0;
 }
 
@@ -427,9 +428,9 @@ static int raster_decode(enum gpujpeg_image_file_format fmt, const uint8_t* d, s
 
 static int raster_probe(const char* filename, enum gpujpeg_image_file_format fmt, struct gpujpeg_image_parameters* pi, int file_exists)
 {
-    if (!file_exists) { /* output: stb_image_write takes 1, 3 or 4 interleaved channels */
-        pi->color_space = GPUJPEG_RGB;
-        if (pi->pixel_format != GPUJPEG_U8 && pi->pixel_format != GPUJPEG_4444_U8_P0123) pi->pixel_format = GPUJPEG_PIXFMT_NO_ALPHA;
+    if (!file_exists) { /* output (src/utils/image_delegate.c:523-527): whatever the stream holds, in the default colour space */
+        pi->pixel_format = GPUJPEG_PIXFMT_AUTODETECT;
+        pi->color_space = GPUJPEG_CS_DEFAULT;
         return 1;
     }
     uint8_t* d;

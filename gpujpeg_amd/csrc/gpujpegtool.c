@@ -77,6 +77,58 @@ struct options {
     char* enc_opts[32]; int enc_opt_count;
 };
 
+/* What the command line leaves open is taken from the raw file: the input when encoding, the (not yet existing) output when decoding
+ * (src/main.c:251-291). The result of the probe is not checked: an unknown extension (/dev/zero, .XXX) simply contributes nothing. */
+static bool adjust_params(struct gpujpeg_parameters* param, struct gpujpeg_image_parameters* pi, const char* raw_file, bool encode, const struct options* o)
+{
+    struct gpujpeg_image_parameters file_pi = gpujpeg_default_image_parameters();
+    if (pi->width == 0 || pi->height == 0 || pi->pixel_format == GPUJPEG_PIXFMT_NONE || pi->color_space == GPUJPEG_NONE)
+        (void)gpujpeg_image_get_properties(raw_file, &file_pi, encode);
+    if (!pi->width) pi->width = file_pi.width;
+    if (!pi->height) pi->height = file_pi.height;
+    if (pi->color_space == GPUJPEG_NONE) pi->color_space = file_pi.color_space ? file_pi.color_space : GPUJPEG_RGB;
+    if (pi->pixel_format == GPUJPEG_PIXFMT_NONE) {
+        pi->pixel_format = file_pi.pixel_format;
+        if (!encode && !o->keep_alpha && file_pi.pixel_format == GPUJPEG_PIXFMT_AUTODETECT) pi->pixel_format = GPUJPEG_PIXFMT_NO_ALPHA; /* alpha only on request */
+    }
+    if (o->keep_alpha && encode && pi->pixel_format == GPUJPEG_4444_U8_P0123) {
+        gpujpeg_sampling_factor_t subs = GPUJPEG_SUBSAMPLING_4444;
+        if (o->subsampling != GPUJPEG_SUBSAMPLING_UNKNOWN && (o->subsampling & 0xFF) == 0) subs = o->subsampling | o->subsampling >> 24; /* alpha sampled like Y */
+        gpujpeg_parameters_chroma_subsampling(param, subs);
+    }
+    if (encode && (pi->width <= 0 || pi->height <= 0)) {
+        fprintf(stderr, "Image dimensions must be set to nonzero values!\n");
+        return false;
+    }
+    if (encode && pi->pixel_format == GPUJPEG_PIXFMT_NONE) {
+        fprintf(stderr, "Pixel format must be set!\n");
+        return false;
+    }
+    return true;
+}
+
+/* -b: an input that is not a regular file with content (test pattern, /dev/zero ...) is written out as input-<name>.XXX, where
+ * XXX becomes the extension that fits the pixel format (src/main.c:309-350) */
+static void dump_infile(const char* filename, const uint8_t* image, size_t size, const struct gpujpeg_image_parameters* pi)
+{
+    FILE* f = fopen(filename, "rb");
+    long file_size = 0;
+    if (f) {
+        fseek(f, 0, SEEK_END);
+        file_size = ftell(f);
+        fclose(f);
+    }
+    if (file_size > 0) return;
+    const char* base = strrchr(filename, '/');
+    base = base ? base + 1 : filename;
+    char name[256];
+    snprintf(name, sizeof name - 4, "input-%s", base);
+    char* dot = strrchr(name, '.');
+    if (!dot) { dot = name + strlen(name); *dot = '.'; }
+    strcpy(dot + 1, "XXX");
+    if (gpujpeg_image_save_to_file(name, image, size, pi) == 0) printf("Input data saved to file %s.\n", name);
+}
+
 int main(int argc, char* argv[])
 {
     struct gpujpeg_parameters param = gpujpeg_default_parameters();
@@ -161,7 +213,6 @@ int main(int argc, char* argv[])
         else { fprintf(stderr, "Cannot determine the operation from file extensions, use -e or -d.\n"); return 1; }
     }
     if (gpujpeg_init_device(o.device, param.verbose >= GPUJPEG_LL_VERBOSE ? GPUJPEG_INIT_DEV_VERBOSE : 0) != 0) return 1;
-    if (o.native) param.color_space_internal = pi.color_space == GPUJPEG_NONE ? GPUJPEG_RGB : pi.color_space;
 
     int rc = 0;
     if (o.encode) {
@@ -176,20 +227,15 @@ int main(int argc, char* argv[])
         for (int i = 0; i < argc; i += 2) {
             const char *in = argv[i], *out = argv[i + 1];
             struct gpujpeg_image_parameters fpi = pi;
-            if (gpujpeg_image_get_properties(in, &fpi, 1) < 0) { rc = 1; continue; }
-            if (pi.width > 0) { fpi.width = pi.width; fpi.height = pi.height; }
-            if (pi.pixel_format != GPUJPEG_PIXFMT_NONE) fpi.pixel_format = pi.pixel_format;
-            if (pi.color_space != GPUJPEG_NONE) fpi.color_space = pi.color_space;
-            if (fpi.pixel_format == GPUJPEG_PIXFMT_STD || fpi.pixel_format == GPUJPEG_PIXFMT_NONE) fpi.pixel_format = GPUJPEG_444_U8_P012;
-            if (fpi.color_space == GPUJPEG_NONE) fpi.color_space = GPUJPEG_RGB;
-            if (fpi.width <= 0 || fpi.height <= 0) { fprintf(stderr, "Image size must be set (-s WxH) for %s!\n", in); rc = 1; continue; }
             struct gpujpeg_parameters p = param;
             if (o.subsampling) gpujpeg_parameters_chroma_subsampling(&p, o.subsampling);
-            else if (gpujpeg_pixel_format_get_comp_count(fpi.pixel_format) == 4 && o.keep_alpha) gpujpeg_parameters_chroma_subsampling(&p, GPUJPEG_SUBSAMPLING_4444);
-            if (o.native && pi.color_space == GPUJPEG_NONE) p.color_space_internal = fpi.color_space;
+            if (!adjust_params(&p, &fpi, in, true, &o)) { rc = 1; continue; }
+            if (fpi.pixel_format == GPUJPEG_PIXFMT_STD) fpi.pixel_format = GPUJPEG_444_U8_P012;
+            if (o.native) p.color_space_internal = fpi.color_space; /* main.c:769-771 */
             uint8_t* image = NULL;
             size_t size = gpujpeg_image_calculate_size(&fpi);
             if (gpujpeg_image_load_from_file(in, &image, &size) != 0) { fprintf(stderr, "Failed to load image [%s]!\n", in); rc = 1; continue; }
+            if (o.debug) dump_infile(in, image, size, &fpi);
             struct gpujpeg_encoder_input input = gpujpeg_encoder_input_image(image);
             uint8_t* jpeg = NULL;
             size_t jpeg_size = 0;
@@ -219,13 +265,10 @@ int main(int argc, char* argv[])
             const char* in = argv[i];
             char out[4096];
             snprintf(out, sizeof out, "%s", argv[i + 1]);
-            struct gpujpeg_image_parameters fpi = gpujpeg_default_image_parameters();
-            fpi.color_space = GPUJPEG_CS_DEFAULT;
-            fpi.pixel_format = o.keep_alpha ? GPUJPEG_PIXFMT_AUTODETECT : GPUJPEG_PIXFMT_NO_ALPHA;
-            if (gpujpeg_image_get_file_format(out) != GPUJPEG_IMAGE_FILE_UNKNOWN && gpujpeg_image_get_properties(out, &fpi, 0) < 0) { rc = 1; continue; }
-            if (pi.pixel_format != GPUJPEG_PIXFMT_NONE) fpi.pixel_format = pi.pixel_format;
-            if (pi.color_space != GPUJPEG_NONE) fpi.color_space = pi.color_space;
-            if (o.native) { fpi.color_space = GPUJPEG_NONE; if (pi.pixel_format == GPUJPEG_PIXFMT_NONE) fpi.pixel_format = GPUJPEG_PIXFMT_NATIVE; }
+            struct gpujpeg_image_parameters fpi = pi;
+            struct gpujpeg_parameters p = param;
+            adjust_params(&p, &fpi, out, false, &o);
+            if (o.native) fpi.color_space = GPUJPEG_NONE; /* main.c:906-908 */
             gpujpeg_decoder_set_output_format(dec, fpi.color_space, fpi.pixel_format);
             uint8_t* jpeg = NULL;
             size_t size = 0;

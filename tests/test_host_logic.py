@@ -383,3 +383,32 @@ def test_gif_reader_against_pil(lib, tmp_path):
         opaque = ref[..., 3] == 255
         assert np.array_equal(got[opaque], ref[opaque]), variant
         assert np.all(got[~opaque] == 0), variant
+
+
+@pytest.mark.parametrize("ext,pf,comps", [("pam", 1, 3), ("pam", 6, 4), ("pam", 0, 1), ("ppm", 1, 3), ("pnm", 1, 3), ("pgm", 0, 1), ("pnm", 0, 1)])
+def test_pnm_pam_save_and_probe(lib, G, tmp_path, ext, pf, comps):
+    """PNM / PAM written by gpujpeg_image_save_to_file are understood by gpujpeg_image_get_properties (the reference's CLI regression
+    script decodes to .pam and encodes that file again, test/regression/run_tests.sh:98-111)."""
+    import ctypes as C
+    w, h = 23, 9
+    img = np.random.default_rng(comps).integers(0, 256, size=w * h * comps, dtype=np.uint8)
+    pi = lib.default_image_parameters()
+    pi.width, pi.height, pi.pixel_format, pi.color_space = w, h, pf, 1 if comps > 1 else 3
+    path = str(tmp_path / f"x.{ext}").encode()
+    assert lib.L.gpujpeg_image_save_to_file(path, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.size, C.byref(pi)) == 0
+    got = lib.default_image_parameters()
+    assert lib.L.gpujpeg_image_get_properties(path, C.byref(got), 1) == 0
+    assert (got.width, got.height, got.pixel_format) == (w, h, pf)
+    assert open(path, "rb").read().endswith(img.tobytes())
+
+
+def test_output_file_probes_follow_the_reference(lib, G):
+    """What gpujpeg_image_get_properties reports for an output file that does not exist yet decides the decoder's output format in
+    the CLI (src/utils/image_delegate.c:157-182,259-263,523-527)."""
+    import ctypes as C
+    CS_DEFAULT = G.CS_DEFAULT
+    for name, want_pf, want_cs in [("o.pgm", 0, 3), ("o.ppm", 1, CS_DEFAULT), ("o.pnm", G.PIXFMT_NO_ALPHA, CS_DEFAULT), ("o.pam", G.PIXFMT_AUTODETECT, CS_DEFAULT),
+                                   ("o.y4m", G.PIXFMT_STD, 3), ("o.png", G.PIXFMT_AUTODETECT, CS_DEFAULT), ("o.bmp", G.PIXFMT_AUTODETECT, CS_DEFAULT)]:
+        pi = lib.default_image_parameters()
+        assert lib.L.gpujpeg_image_get_properties(name.encode(), C.byref(pi), 0) >= 0
+        assert (pi.pixel_format, pi.color_space) == (want_pf, want_cs), name

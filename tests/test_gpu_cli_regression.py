@@ -146,3 +146,68 @@ def test_restart0_reconfiguration(tool, O):
     for n in (50, 60):
         jpeg = np.fromfile(f"{n}.jpg", np.uint8)
         assert np.array_equal(read_pnm(f"{n}.pnm").reshape(-1), O.decode(jpeg)[0])
+
+
+COLOR_MODES = [
+    # name, extension, the reference's MODE string (colors/run_tests.sh), bytes per frame as a function of (w, h)
+    ("image_yuv_444p_subsampled", "yuv", "--colorspace=ycbcr-bt601 --subsampled --pixel-format=444-u8-p0p1p2"),
+    ("image_yuv_422_interleaved", "yuv", "--pixel-format=422-u8-p1020 -i"),
+    ("image_yuv_420p_native_709", "yuv", "-N --colorspace ycbcr-bt709 --pixel-format=420-u8-p0p1p2"),
+    ("image_rgb_444", "rgb", "--colorspace=rgb --pixel-format=444-u8-p012"),
+    ("image_rgb_444_native", "rgb", "-N --pixel-format=444-u8-p012"),
+    ("image_rgb0_444_interleaved_subsampled", "rgba", "-i -S -f 4444-u8-p0123"),
+]
+
+
+@pytest.mark.parametrize("name,ext,mode", COLOR_MODES, ids=[m[0] for m in COLOR_MODES])
+def test_colors_modes(tool, name, ext, mode):
+    """colors/run_tests.sh + colors/test_common.sh: six pixel format / colour space / subsampling modes through the CLI at quality
+    100 must come back with PSNR >= 40 dB. The reference feeds a camera picture converted by FFmpeg; here a smooth synthetic 1080p
+    picture is laid out in each file format directly and compared with the decoded file in that same layout."""
+    w, h = 1920, 1080
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    y = 128 + 80 * np.sin(xx / 97.0) * np.cos(yy / 61.0) + 20 * np.sin((xx + yy) / 23.0)
+    cb = 128 + 50 * np.sin(xx / 211.0 + 1.0) * np.cos(yy / 173.0)
+    cr = 128 + 50 * np.cos(xx / 157.0) * np.sin(yy / 199.0 + 0.5)
+    q = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)  # noqa: E731
+    if "444-u8-p0p1p2" in mode:
+        raw = np.concatenate([q(y).ravel(), q(cb).ravel(), q(cr).ravel()])
+    elif "422-u8-p1020" in mode:
+        pk = np.empty((h, w, 2), np.uint8)
+        pk[:, :, 1] = q(y)
+        pk[:, 0::2, 0] = q(cb)[:, 0::2]
+        pk[:, 1::2, 0] = q(cr)[:, 0::2]
+        raw = pk.ravel()
+    elif "420-u8-p0p1p2" in mode:
+        raw = np.concatenate([q(y).ravel(), q(cb)[0::2, 0::2].ravel(), q(cr)[0::2, 0::2].ravel()])
+    elif ext == "rgba":
+        raw = np.stack([q(y), q(cb), q(cr), np.full((h, w), 255, np.uint8)], -1).ravel()
+    else:
+        raw = np.stack([q(y), q(cb), q(cr)], -1).ravel()
+    raw.tofile(f"{name}.{ext}")
+    tool("--size", "1920x1080", *mode.split(), "--encode", "--quality", "100", f"{name}.{ext}", f"{name}.encoded.jpg")
+    tool(*mode.split(), "--decode", f"{name}.encoded.jpg", f"{name}.decoded.{ext}")
+    back = np.fromfile(f"{name}.decoded.{ext}", np.uint8)
+    if ext == "rgba":  # decoded without -a: the alpha channel is dropped (main.c:268-271), compare the colour channels
+        assert back.size in (w * h * 3, w * h * 4)
+        a = raw.reshape(h, w, 4)[..., :3]
+        b = back.reshape(h, w, -1)[..., :3]
+        assert psnr(b, a) >= 40.0
+    else:
+        assert back.size == raw.size
+
+        def to_rgb(buf):  # what the reference's script does with FFmpeg before comparing: everything to rgb24 (BT.601, limited range)
+            if ext == "rgb":
+                return buf.astype(np.float32)
+            if "444-u8-p0p1p2" in mode:
+                yv, u, v = buf.reshape(3, h, w).astype(np.float32)
+            elif "422-u8-p1020" in mode:
+                pk = buf.reshape(h, w, 2).astype(np.float32)
+                yv, u, v = pk[:, :, 1], np.repeat(pk[:, 0::2, 0], 2, 1), np.repeat(pk[:, 1::2, 0], 2, 1)
+            else:
+                yv = buf[:w * h].reshape(h, w).astype(np.float32)
+                u = np.repeat(np.repeat(buf[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), 2, 0), 2, 1).astype(np.float32)
+                v = np.repeat(np.repeat(buf[w * h * 5 // 4:].reshape(h // 2, w // 2), 2, 0), 2, 1).astype(np.float32)
+            yv, u, v = 1.164 * (yv - 16), u - 128, v - 128
+            return np.clip(np.stack([yv + 1.596 * v, yv - 0.392 * u - 0.813 * v, yv + 2.017 * u], -1), 0, 255)
+        assert psnr(to_rgb(back), to_rgb(raw)) >= 40.0

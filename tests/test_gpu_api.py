@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import api_params, natural_image, oracle_image
+from conftest import api_params, natural_image, oracle_image, psnr
 
 pytestmark = pytest.mark.gpu
 
@@ -413,3 +413,37 @@ def test_tga_rle_and_origin(gpu_lib, G, tmp_path):
     back = np.ctypeslib.as_array(data, shape=(size.value,)).copy()
     lib.L.gpujpeg_image_destroy(data)
     assert np.array_equal(back, np.tile(np.array([1, 2, 3], np.uint8), w * h))
+
+
+@pytest.mark.parametrize("mode,subsampling", [("L", None), ("RGB", 0), ("RGB", 1), ("RGB", 2)])
+def test_foreign_jpegs_from_libjpeg(O, G, gpu_lib, tmp_path, mode, subsampling):
+    """Baseline files written by another encoder (libjpeg-turbo through PIL): standard and optimised Huffman tables, no restart
+    markers (one long segment per scan, decoded piece by piece) and restart markers every MCU row, interleaved 4:2:0 / 4:2:2 /
+    4:4:4 and grey. Our pixels equal the oracle's (the reference reader + decoder) and are close to libjpeg's own decoding."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    w, h = 487, 331
+    img = natural_image(w, h, 3, seed=21).reshape(h, w, 3)
+    im = Image.fromarray(img, "RGB").convert(mode)
+    dec = G.Decoder(gpu_lib)
+    for quality in (50, 92):
+        for optimize in (False, True):
+            for restart_rows in (0, 1, 3):
+                kw = {"quality": quality, "optimize": optimize}
+                if subsampling is not None:
+                    kw["subsampling"] = subsampling
+                if restart_rows:
+                    kw["restart_marker_rows"] = restart_rows
+                buf = io.BytesIO()
+                try:
+                    im.save(buf, "JPEG", **kw)
+                except TypeError:
+                    pytest.skip("this PIL cannot write restart markers")
+                jpeg = np.frombuffer(buf.getvalue(), np.uint8).copy()
+                px, info = dec.decode(jpeg)
+                want, winfo = O.decode(jpeg)
+                assert (info.width, info.height) == (w, h)
+                assert np.array_equal(px, want), (mode, subsampling, quality, optimize, restart_rows)
+                theirs = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB" if mode == "RGB" else "L")).reshape(-1)
+                assert psnr(px, theirs) > 30.0, (mode, subsampling, quality, optimize, restart_rows)
+    dec.close()

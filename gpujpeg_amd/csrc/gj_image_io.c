@@ -651,18 +651,39 @@ int gpujpeg_image_destroy(uint8_t* image) /* common.c:1372-1378 */
     return 0;
 }
 
-void gpujpeg_image_range_info(const char* filename, int width, int height, enum gpujpeg_pixel_format pf) /* common.c:1380-1470 */
+void gpujpeg_image_range_info(const char* filename, int width, int height, enum gpujpeg_pixel_format pf) /* common.c:1380-1441 */
 {
-    struct gpujpeg_image_parameters pi = gpujpeg_default_image_parameters();
-    pi.width = width;
-    pi.height = height;
-    pi.pixel_format = pf;
-    size_t size = gpujpeg_image_calculate_size(&pi);
+    size_t size = 0;
     uint8_t* data = NULL;
-    if (gpujpeg_image_load_from_file(filename, &data, &size) != 0) return;
-    int lo = 255, hi = 0;
-    for (size_t i = 0; i < size; i++) { if (data[i] < lo) lo = data[i]; if (data[i] > hi) hi = data[i]; }
-    printf("Image Samples Range:\n  all components: %d - %d\n", lo, hi);
+    if (gpujpeg_image_load_from_file(filename, &data, &size) != 0) {
+        GJ_ERROR("Failed to load image [%s]!\n", filename);
+        return;
+    }
+    int lo[3] = {256, 256, 256}, hi[3] = {0, 0, 0};
+    const size_t pixels = (size_t)width * (size_t)height;
+    if (pf == GPUJPEG_444_U8_P012 && size >= pixels * 3) {
+        for (size_t i = 0; i < pixels; i++)
+            for (int c = 0; c < 3; c++) {
+                const int v = data[i * 3 + c];
+                if (v < lo[c]) lo[c] = v;
+                if (v > hi[c]) hi[c] = v;
+            }
+    } else if (pf == GPUJPEG_422_U8_P1020 && size >= pixels * 2) {
+        for (size_t i = 0; i < pixels; i++) {
+            const int y = data[i * 2 + 1], ch = data[i * 2];
+            const int c = (i % 2 == 1) ? 1 : 2; /* the reference attributes the odd pixels' byte to component 2, the even ones' to 3 */
+            if (y < lo[0]) lo[0] = y;
+            if (y > hi[0]) hi[0] = y;
+            if (ch < lo[c]) lo[c] = ch;
+            if (ch > hi[c]) hi[c] = ch;
+        }
+    } else {
+        fprintf(stderr, "TODO: implement gpujpeg_image_range_info for pixel format %d.", (int)pf);
+        gpujpeg_image_destroy(data);
+        return;
+    }
+    printf("Image Samples Range:\n");
+    for (int c = 0; c < 3; c++) printf("Component %d: %d - %d\n", c + 1, lo[c], hi[c]);
     gpujpeg_image_destroy(data);
 }
 

@@ -187,7 +187,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height):
         print(json.dumps({
             "metric": f"frames/s encode+decode (batch of {args.batch} {args.workload} frames)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8 in / f32 DCT / i16 coefficients",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "dtype_detail": "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients",
             "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) resident in HBM, sharded round-robin",
             "config": {"workload": f"{args.batch} x {width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto, encode then decode of "
                                    f"every frame per step", "frames_total": total, "frames_per_gpu": len(mine), "streams_per_gpu": S,
@@ -377,7 +377,7 @@ def main():
             "metric": ("Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})") if args.mode == "both"
                       else f"Mpix/s {args.mode} only ({args.workload})", "value": round(pixels * world * S * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / f32 DCT / i16 coefficients",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients",
             "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per stream",
             "config": {"workload": (f"{width}x{height} YCbCr 4:2:2 (UYVY) q{args.quality} interleaved, restart auto, encode then decode per step" if is422 else
                                     f"{width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto ({width}x{height} -> "

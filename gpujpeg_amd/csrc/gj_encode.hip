@@ -617,6 +617,161 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
 }
 
 // ================================================================================================
+// The coding passes of the fully fused encoder kernels (k_encode_rgb444, k_encode_uyvy422) on one tile of 256 lanes = blocks whose
+// transformed rows sit in the lanes' LDS columns in natural order: zig-zag + non-zero mask, DC prediction inside the segment,
+// pass A (lengths), bit positions by prefix sums, pass B (codewords into the LDS bit buffer, window by window), coalesced copy of
+// the unstuffed segment streams to d_temp, byte and 0xFF counts per segment. What differs between the kernels comes in as
+// arguments: the Huffman table of the lane's block, the distance to the previous block of the same component, the number of blocks
+// of the lane's segment, where the tile's first segment lives in d_temp and in the per-segment arrays.
+// ================================================================================================
+struct GjTileLds {
+    uint32_t* coef;  // [32][256]
+    uint32_t* bits;  // [GJ_HUFF_CAP_DW]
+    const uint32_t* lut;
+    int* dc;         // [256]
+    uint32_t *segx, *segend, *segbase, *segbits, *segff, *tmp;
+};
+
+#define GJ_PROF(slot)                                                                            \
+    if (prof) {                                                                                  \
+        __syncthreads();                                                                         \
+        const unsigned long long now = wall_clock64();                                           \
+        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
+        t_prof = now;                                                                            \
+    }
+__device__ __forceinline__ void gj_code_tile(const GjTileLds& L, const int i, const int j, const int k, const bool active, const bool seg_in_tile,
+                                             const int spt, const int B, const int nblocks, const int table, const int dc_dist,
+                                             uint8_t* __restrict__ temp, const uint64_t first_block, uint32_t* __restrict__ seg_bytes,
+                                             uint32_t* __restrict__ seg_ff, const uint32_t first_segment, unsigned long long* __restrict__ prof,
+                                             unsigned long long& t_prof)
+{
+    uint32_t* const s_coef = L.coef;
+    uint32_t* const s_bits = L.bits;
+    const uint32_t* const s_lut = L.lut;
+    int* const s_dc = L.dc;
+    uint32_t *const s_segx = L.segx, *const s_segend = L.segend, *const s_segbase = L.segbase, *const s_segbits = L.segbits, *const s_segff = L.segff,
+             *const s_tmp = L.tmp;
+    uint32_t n[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) n[t] = s_coef[t * 256 + i]; // ... and come back once the transform's registers are free
+    int dc = 0;
+    uint64_t mask = 0;
+    if (active) {
+        dc = (int)(int16_t)(n[0] & 0xFFFF);
+        uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const int na = GJ_ZZ[2 * q], nbz = GJ_ZZ[2 * q + 1];
+            const uint32_t sel = (uint32_t)((na & 1) * 2) | ((uint32_t)((na & 1) * 2 + 1) << 8) | ((uint32_t)(4 + (nbz & 1) * 2) << 16) |
+                                 ((uint32_t)(5 + (nbz & 1) * 2) << 24);
+            const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
+            s_coef[q * 256 + i] = d;
+            // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16), fold bit 16 down to bit 1
+            const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
+            const uint32_t f = (m | (m >> 15)) & 3u;
+            if (q < 16) mlo |= f << (2 * q);
+            else mhi |= f << (2 * (q - 16));
+        }
+        mask = ((uint64_t)mhi << 32) | mlo;
+    }
+    s_dc[i] = dc;
+    s_segff[i] = 0;
+    __syncthreads();
+    GJ_PROF(1) // transform + zig-zag park
+
+    // ---- DC prediction + pass A (lengths)
+    int dc_diff = 0;
+    uint32_t len = 0;
+    GjEmit e = {0, 0, 0};
+    // (nblocks: blocks of this lane's segment)
+    if (active) {
+        dc_diff = dc - (k - dc_dist < 0 ? 0 : s_dc[i - dc_dist]); // the previous block of the same component inside the segment
+        len = gj_code_block<false>(s_coef, s_lut, i, dc_diff, mask, table, 0, e, nullptr, 0, 0);
+    }
+    GJ_PROF(2) // pass A
+    // ---- bit positions
+    uint32_t total_bits;
+    const uint32_t incl = gj_wg256_incl_scan(len, s_tmp, &total_bits);
+    const uint32_t excl = incl - len;
+    if (active && k == 0) s_segx[j] = excl;
+    if (active && k == nblocks - 1) s_segend[j] = incl;
+    __syncthreads();
+    uint32_t my_dw = 0;
+    if (seg_in_tile) {
+        uint32_t bits = s_segend[i] - s_segx[i];
+        bits += (8u - (bits & 7u)) & 7u; // ones-padding to a byte boundary
+        s_segbits[i] = bits;
+        my_dw = (bits + 31u) >> 5;
+    }
+    if (spt <= 64) { // the segment bookkeeping of a tile fits one wave: prefix sum without workgroup barriers
+        if (i < 64) {
+            const uint32_t base_incl = gj_wave_incl_scan(my_dw);
+            if (i < spt) s_segbase[i] = base_incl - my_dw;
+            if (i == 63) s_segbase[spt] = base_incl;
+        }
+    } else {
+        uint32_t total;
+        const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total);
+        if (i < spt) s_segbase[i] = base_incl - my_dw;
+        if (i == 0) s_segbase[spt] = total;
+    }
+    __syncthreads();
+    const uint32_t total_dw = s_segbase[spt];
+    int pad_bits = 0;
+    uint32_t start_bit = 0, end_bit = 0;
+    if (active) {
+        start_bit = s_segbase[j] * 32u + (excl - s_segx[j]);
+        if (k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
+        end_bit = start_bit + len + (uint32_t)pad_bits;
+    }
+    GJ_PROF(3) // scans
+
+    // ---- pass B window by window, then drain each window to HBM
+    for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_HUFF_CAP_DW) {
+        const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_HUFF_CAP_DW);
+        for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
+        __syncthreads();
+        if (active && end_bit > wbase * 32u && start_bit < wend * 32u && end_bit > start_bit) {
+            e.acc = 0;
+            e.accbits = (int)(start_bit & 31u);
+            e.dw = start_bit >> 5;
+            gj_code_block<true>(s_coef, s_lut, i, dc_diff, mask, table, pad_bits, e, s_bits, wbase, wend);
+            if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
+        }
+        __syncthreads();
+        GJ_PROF(4) // pass B
+        for (uint32_t d = wbase + i; d < wend; d += 256) {
+            int lo = 0, hi = spt; // local segment that owns dword d
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_segbase[mid] <= d) lo = mid; else hi = mid;
+            }
+            const uint32_t bits = s_segbits[lo];
+            const uint32_t el = d - s_segbase[lo];
+            const uint32_t nflush = (bits + 31u) >> 5;
+            const uint32_t v = s_bits[d - wbase];
+            if (el < nflush) {
+                int vb = 4;
+                if (el == nflush - 1) vb = (int)((bits - el * 32u + 7u) >> 3);
+                uint32_t ff = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (b < vb && ((v >> (24 - 8 * b)) & 0xFFu) == 0xFFu) ff++;
+                if (ff) atomicAdd(&s_segff[lo], ff);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)lo * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
+                *dst = __builtin_bswap32(v);
+            }
+        }
+        __syncthreads();
+    }
+    if (seg_in_tile) {
+        seg_bytes[first_segment + i] = (s_segbits[i] + 7u) >> 3;
+        seg_ff[first_segment + i] = s_segff[i];
+    }
+    GJ_PROF(5) // drain
+}
+
+// ================================================================================================
 // Fully fused fast path: packed 4:4:4 pixels -> per-segment (unstuffed) Huffman streams, no coefficient planes.
 //
 // k_fused_rgb444 + k_huffman move 2 x 199 MB of int16 coefficients through HBM for an 8K frame; measured, the store half
@@ -634,13 +789,6 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
                                                           uint32_t* __restrict__ seg_ff, unsigned long long* __restrict__ prof)
 {
     unsigned long long t_prof = prof ? wall_clock64() : 0;
-#define GJ_PROF(slot)                                                                            \
-    if (prof) {                                                                                  \
-        __syncthreads();                                                                         \
-        const unsigned long long now = wall_clock64();                                           \
-        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
-        t_prof = now;                                                                            \
-    }
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
     __shared__ uint32_t s_coef[32 * 256];
     __shared__ uint32_t s_bits[GJ_HUFF_CAP_DW];
@@ -648,6 +796,7 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
     __shared__ int s_dc[256];
     __shared__ uint32_t s_segx[256], s_segend[256], s_segbase[257], s_segbits[256], s_segff[256];
     __shared__ uint32_t s_tmp[4];
+    const GjTileLds L = {s_coef, s_bits, s_lut, s_dc, s_segx, s_segend, s_segbase, s_segbits, s_segff, s_tmp};
 
     const int i = threadIdx.x;
     for (int t = i; t < 1024; t += 256) s_lut[t] = lut[t];
@@ -684,128 +833,9 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
         for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[c][t]));
         uint32_t n[32];
         gj_fdct_quant_pk<true>(pk[c], s_q[c], n, s_coef + i); // rows park in this lane's LDS column in natural order ...
-#pragma unroll
-        for (int t = 0; t < 32; t++) n[t] = s_coef[t * 256 + i]; // ... and come back once the transform's registers are free
-        int dc = 0;
-        uint64_t mask = 0;
-        if (active) {
-            dc = (int)(int16_t)(n[0] & 0xFFFF);
-            uint32_t mlo = 0, mhi = 0;
-#pragma unroll
-            for (int q = 0; q < 32; q++) {
-                const int na = GJ_ZZ[2 * q], nbz = GJ_ZZ[2 * q + 1];
-                const uint32_t sel = (uint32_t)((na & 1) * 2) | ((uint32_t)((na & 1) * 2 + 1) << 8) | ((uint32_t)(4 + (nbz & 1) * 2) << 16) |
-                                     ((uint32_t)(5 + (nbz & 1) * 2) << 24);
-                const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
-                s_coef[q * 256 + i] = d;
-                // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16), fold bit 16 down to bit 1
-                const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
-                const uint32_t f = (m | (m >> 15)) & 3u;
-                if (q < 16) mlo |= f << (2 * q);
-                else mhi |= f << (2 * (q - 16));
-            }
-            mask = ((uint64_t)mhi << 32) | mlo;
-        }
-        s_dc[i] = dc;
-        s_segff[i] = 0;
-        __syncthreads();
-        GJ_PROF(1) // transform + zig-zag park
-
-        // ---- DC prediction + pass A (lengths)
-        const int table = kc.type;
-        int dc_diff = 0;
-        uint32_t len = 0;
-        GjEmit e = {0, 0, 0};
-        const int nblocks = active ? min(B, (int)nb - (seg0 + j) * B) : 0; // blocks of this lane's segment
-        if (active) {
-            dc_diff = dc - (k == 0 ? 0 : s_dc[i - 1]);
-            len = gj_code_block<false>(s_coef, s_lut, i, dc_diff, mask, table, 0, e, nullptr, 0, 0);
-        }
-        GJ_PROF(2) // pass A
-        // ---- bit positions
-        uint32_t total_bits;
-        const uint32_t incl = gj_wg256_incl_scan(len, s_tmp, &total_bits);
-        const uint32_t excl = incl - len;
-        if (active && k == 0) s_segx[j] = excl;
-        if (active && k == nblocks - 1) s_segend[j] = incl;
-        __syncthreads();
-        uint32_t my_dw = 0;
-        if (seg_in_tile) {
-            uint32_t bits = s_segend[i] - s_segx[i];
-            bits += (8u - (bits & 7u)) & 7u; // ones-padding to a byte boundary
-            s_segbits[i] = bits;
-            my_dw = (bits + 31u) >> 5;
-        }
-        if (spt <= 64) { // the segment bookkeeping of a tile fits one wave: prefix sum without workgroup barriers
-            if (i < 64) {
-                const uint32_t base_incl = gj_wave_incl_scan(my_dw);
-                if (i < spt) s_segbase[i] = base_incl - my_dw;
-                if (i == 63) s_segbase[spt] = base_incl;
-            }
-        } else {
-            uint32_t total;
-            const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total);
-            if (i < spt) s_segbase[i] = base_incl - my_dw;
-            if (i == 0) s_segbase[spt] = total;
-        }
-        __syncthreads();
-        const uint32_t total_dw = s_segbase[spt];
-        int pad_bits = 0;
-        uint32_t start_bit = 0, end_bit = 0;
-        if (active) {
-            start_bit = s_segbase[j] * 32u + (excl - s_segx[j]);
-            if (k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
-            end_bit = start_bit + len + (uint32_t)pad_bits;
-        }
-        // first block of every local segment in coding order (addresses d_temp)
-        const uint64_t seg_first_block = kc.data_offset / 64;
-        GJ_PROF(3) // scans
-
-        // ---- pass B window by window, then drain each window to HBM
-        for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_HUFF_CAP_DW) {
-            const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_HUFF_CAP_DW);
-            for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
-            __syncthreads();
-            if (active && end_bit > wbase * 32u && start_bit < wend * 32u && end_bit > start_bit) {
-                e.acc = 0;
-                e.accbits = (int)(start_bit & 31u);
-                e.dw = start_bit >> 5;
-                gj_code_block<true>(s_coef, s_lut, i, dc_diff, mask, table, pad_bits, e, s_bits, wbase, wend);
-                if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
-            }
-            __syncthreads();
-            GJ_PROF(4) // pass B
-            for (uint32_t d = wbase + i; d < wend; d += 256) {
-                int lo = 0, hi = spt; // local segment that owns dword d
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_segbase[mid] <= d) lo = mid; else hi = mid;
-                }
-                const uint32_t bits = s_segbits[lo];
-                const uint32_t el = d - s_segbase[lo];
-                const uint32_t nflush = (bits + 31u) >> 5;
-                const uint32_t v = s_bits[d - wbase];
-                if (el < nflush) {
-                    int vb = 4;
-                    if (el == nflush - 1) vb = (int)((bits - el * 32u + 7u) >> 3);
-                    uint32_t ff = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (b < vb && ((v >> (24 - 8 * b)) & 0xFFu) == 0xFFu) ff++;
-                    if (ff) atomicAdd(&s_segff[lo], ff);
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(temp + (seg_first_block + (uint64_t)(seg0 + lo) * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
-                    *dst = __builtin_bswap32(v);
-                }
-            }
-            __syncthreads();
-        }
-        if (seg_in_tile) {
-            seg_bytes[kc.first_segment + seg0 + i] = (s_segbits[i] + 7u) >> 3;
-            seg_ff[kc.first_segment + seg0 + i] = s_segff[i];
-        }
-        GJ_PROF(5) // drain
+        gj_code_tile(L, i, j, k, active, seg_in_tile, spt, B, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, temp,
+                     kc.data_offset / 64 + (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), prof, t_prof);
     }
-#undef GJ_PROF
 }
 
 // ================================================================================================
@@ -823,13 +853,6 @@ __global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, cons
                                                            uint32_t* __restrict__ seg_ff, unsigned long long* __restrict__ prof)
 {
     unsigned long long t_prof = prof ? wall_clock64() : 0;
-#define GJ_PROF(slot)                                                                            \
-    if (prof) {                                                                                  \
-        __syncthreads();                                                                         \
-        const unsigned long long now = wall_clock64();                                           \
-        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
-        t_prof = now;                                                                            \
-    }
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
     __shared__ uint32_t s_coef[32 * 256];
     __shared__ uint32_t s_bits[GJ_HUFF_CAP_DW];
@@ -837,6 +860,7 @@ __global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, cons
     __shared__ int s_dc[256];
     __shared__ uint32_t s_segx[256], s_segend[256], s_segbase[257], s_segbits[256], s_segff[256];
     __shared__ uint32_t s_tmp[4];
+    const GjTileLds L = {s_coef, s_bits, s_lut, s_dc, s_segx, s_segend, s_segbase, s_segbits, s_segff, s_tmp};
 
     const int i = threadIdx.x;
     for (int t = i; t < 1024; t += 256) s_lut[t] = lut[t];
@@ -923,124 +947,8 @@ __global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, cons
         for (int t = 0; t < 16; t++) asm volatile("" : "+v"(px[t]));
         uint32_t n[32];
         gj_fdct_quant_pk<true>(px, s_q[table ? 1 : 0], n, s_coef + i); // rows park in this lane's LDS column in natural order ...
-#pragma unroll
-        for (int t = 0; t < 32; t++) n[t] = s_coef[t * 256 + i]; // ... and come back once the transform's registers are free
-        int dc = 0;
-        uint64_t mask = 0;
-        if (active) {
-            dc = (int)(int16_t)(n[0] & 0xFFFF);
-            uint32_t mlo = 0, mhi = 0;
-#pragma unroll
-            for (int q = 0; q < 32; q++) {
-                const int na = GJ_ZZ[2 * q], nbz = GJ_ZZ[2 * q + 1];
-                const uint32_t sel = (uint32_t)((na & 1) * 2) | ((uint32_t)((na & 1) * 2 + 1) << 8) | ((uint32_t)(4 + (nbz & 1) * 2) << 16) |
-                                     ((uint32_t)(5 + (nbz & 1) * 2) << 24);
-                const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
-                s_coef[q * 256 + i] = d;
-                // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16), fold bit 16 down to bit 1
-                const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
-                const uint32_t f = (m | (m >> 15)) & 3u;
-                if (q < 16) mlo |= f << (2 * q);
-                else mhi |= f << (2 * (q - 16));
-            }
-            mask = ((uint64_t)mhi << 32) | mlo;
-        }
-        s_dc[i] = dc;
-        s_segff[i] = 0;
-        __syncthreads();
-        GJ_PROF(1) // transform + zig-zag park
-
-        // ---- DC prediction + pass A (lengths)
-        int dc_diff = 0;
-        uint32_t len = 0;
-        GjEmit e = {0, 0, 0};
-        const int nblocks = active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0; // blocks of this lane's segment
-        if (active) {
-            const int dist = p == 0 ? 3 : (p == 1 ? 1 : 4); // the previous block of the same component (Y1 follows Y0 of its own MCU)
-            dc_diff = dc - (k - dist < 0 ? 0 : s_dc[i - dist]);
-            len = gj_code_block<false>(s_coef, s_lut, i, dc_diff, mask, table, 0, e, nullptr, 0, 0);
-        }
-        GJ_PROF(2) // pass A
-        // ---- bit positions
-        uint32_t total_bits;
-        const uint32_t incl = gj_wg256_incl_scan(len, s_tmp, &total_bits);
-        const uint32_t excl = incl - len;
-        if (active && k == 0) s_segx[j] = excl;
-        if (active && k == nblocks - 1) s_segend[j] = incl;
-        __syncthreads();
-        uint32_t my_dw = 0;
-        if (seg_in_tile) {
-            uint32_t bits = s_segend[i] - s_segx[i];
-            bits += (8u - (bits & 7u)) & 7u; // ones-padding to a byte boundary
-            s_segbits[i] = bits;
-            my_dw = (bits + 31u) >> 5;
-        }
-        if (spt <= 64) { // the segment bookkeeping of a tile fits one wave: prefix sum without workgroup barriers
-            if (i < 64) {
-                const uint32_t base_incl = gj_wave_incl_scan(my_dw);
-                if (i < spt) s_segbase[i] = base_incl - my_dw;
-                if (i == 63) s_segbase[spt] = base_incl;
-            }
-        } else {
-            uint32_t total;
-            const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total);
-            if (i < spt) s_segbase[i] = base_incl - my_dw;
-            if (i == 0) s_segbase[spt] = total;
-        }
-        __syncthreads();
-        const uint32_t total_dw = s_segbase[spt];
-        int pad_bits = 0;
-        uint32_t start_bit = 0, end_bit = 0;
-        if (active) {
-            start_bit = s_segbase[j] * 32u + (excl - s_segx[j]);
-            if (k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
-            end_bit = start_bit + len + (uint32_t)pad_bits;
-        }
-                GJ_PROF(3) // scans
-
-        // ---- pass B window by window, then drain each window to HBM
-        for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_HUFF_CAP_DW) {
-            const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_HUFF_CAP_DW);
-            for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
-            __syncthreads();
-            if (active && end_bit > wbase * 32u && start_bit < wend * 32u && end_bit > start_bit) {
-                e.acc = 0;
-                e.accbits = (int)(start_bit & 31u);
-                e.dw = start_bit >> 5;
-                gj_code_block<true>(s_coef, s_lut, i, dc_diff, mask, table, pad_bits, e, s_bits, wbase, wend);
-                if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
-            }
-            __syncthreads();
-            GJ_PROF(4) // pass B
-            for (uint32_t d = wbase + i; d < wend; d += 256) {
-                int lo = 0, hi = spt; // local segment that owns dword d
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_segbase[mid] <= d) lo = mid; else hi = mid;
-                }
-                const uint32_t bits = s_segbits[lo];
-                const uint32_t el = d - s_segbase[lo];
-                const uint32_t nflush = (bits + 31u) >> 5;
-                const uint32_t v = s_bits[d - wbase];
-                if (el < nflush) {
-                    int vb = 4;
-                    if (el == nflush - 1) vb = (int)((bits - el * 32u + 7u) >> 3);
-                    uint32_t ff = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (b < vb && ((v >> (24 - 8 * b)) & 0xFFu) == 0xFFu) ff++;
-                    if (ff) atomicAdd(&s_segff[lo], ff);
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(temp + ((uint64_t)(seg0 + lo) * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
-                    *dst = __builtin_bswap32(v);
-                }
-            }
-            __syncthreads();
-        }
-        if (seg_in_tile) {
-            seg_bytes[seg0 + i] = (s_segbits[i] + 7u) >> 3;
-            seg_ff[seg0 + i] = s_segff[i];
-        }
-        GJ_PROF(5) // drain
+        gj_code_tile(L, i, j, k, active, seg_in_tile, spt, B, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
+                     p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, temp, (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)seg0, prof, t_prof);
     }
 #undef GJ_PROF
 }

@@ -844,8 +844,7 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
 // (B = 4 x restart interval blocks each). All four lanes of an MCU read its 8 x 32 bytes (the same addresses merge in
 // the load unit), pick their own samples with byte permutes, transform, and the coding passes run once on the whole
 // tile -- no coefficient planes, one pass instead of k_encode_rgb444's three.
-// (The coding passes below are the same text as in k_encode_rgb444; only the DC predecessor distance and the table
-// choice are per lane here.)
+// (The coding passes are gj_code_tile, shared with k_encode_rgb444; the DC predecessor distance and the table are per lane here.)
 // ================================================================================================
 __global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                            const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,

@@ -624,6 +624,17 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
 // arguments: the Huffman table of the lane's block, the distance to the previous block of the same component, the number of blocks
 // of the lane's segment, where the tile's first segment lives in d_temp and in the per-segment arrays.
 // ================================================================================================
+// bits 0..15 of x to the even positions, bits 16..31 to the odd positions of the result
+__device__ __forceinline__ uint32_t gj_spread16(uint32_t x)
+{
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+__device__ __forceinline__ uint32_t gj_interleave16(uint32_t x) { return gj_spread16(x & 0xFFFFu) | (gj_spread16(x >> 16) << 1); }
+
 struct GjTileLds {
     uint32_t* coef;  // [32][256]
     uint32_t* bits;  // [GJ_HUFF_CAP_DW]
@@ -666,13 +677,13 @@ __device__ __forceinline__ void gj_code_tile(const GjTileLds& L, const int i, co
                                  ((uint32_t)(5 + (nbz & 1) * 2) << 24);
             const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
             s_coef[q * 256 + i] = d;
-            // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16), fold bit 16 down to bit 1
+            // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16); bit q collects the even coefficient of dword q, bit
+            // 16 + q the odd one (one v_lshl_or_b32 per dword), the two halves are interleaved once at the end
             const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
-            const uint32_t f = (m | (m >> 15)) & 3u;
-            if (q < 16) mlo |= f << (2 * q);
-            else mhi |= f << (2 * (q - 16));
+            if (q < 16) mlo |= m << q;
+            else mhi |= m << (q - 16);
         }
-        mask = ((uint64_t)mhi << 32) | mlo;
+        mask = ((uint64_t)gj_interleave16(mhi) << 32) | gj_interleave16(mlo);
     }
     s_dc[i] = dc;
     s_segff[i] = 0;

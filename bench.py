@@ -112,6 +112,55 @@ def cpu_baseline(width, height, frame_host, seconds_budget=20.0, is422=False, qu
                       f"reference host C (writer/reader/CPU Huffman) + restated colour/DCT/IDCT stages, gcc -O2"}
 
 
+_CPU_CHILD = r"""
+import sys, time
+import numpy as np
+root, path, w, h, q, is422, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6] == "1", int(sys.argv[7])
+sys.path.insert(0, root); sys.path.insert(0, root + "/oracle")
+import oracle as O
+from gpujpeg_amd import libgpujpeg as G
+frame = np.load(path)
+ref = G.Library(O.REF_PATH) if O.have_ref() else None
+t0 = time.time()
+if ref is not None:
+    enc, dec = G.Encoder(ref), G.Decoder(ref)
+    p = ref.default_parameters(); p.restart_interval, p.verbose, p.quality = G.RESTART_AUTO, -1, q
+    pi = ref.default_image_parameters(); pi.width, pi.height = w, h
+    if is422:
+        pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG; p.interleaved = 1; dec.set_output_format(G.YCBCR_JPEG, G.P1020_422)
+    for _ in range(frames):
+        dec.decode(enc.encode(p, pi, frame))
+else:
+    img = O.make_image(w, h, pixel_format=3, color_space=3, quality=q, interleaved=1) if is422 else O.make_image(w, h, quality=q)
+    for _ in range(frames):
+        j = O.encode(img, frame); O.decode(j, 3, 3) if is422 else O.decode(j)
+print(time.time() - t0)
+"""
+
+
+def cpu_baseline_all_cores(width, height, frame_host, is422=False, quality=75, max_procs=32):
+    """the reference's CPU path admits frame-level parallelism only -- one independent encode+decode per
+    process on as many host cores as there are (capped), the same frame in each; aggregate Mpix/s over the slowest process."""
+    import subprocess
+    import tempfile
+    procs = max(1, min(max_procs, (os.cpu_count() or 1)))
+    with tempfile.NamedTemporaryFile(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None, delete=False) as f:
+        np.save(f, frame_host)
+        path = f.name
+    try:
+        t0 = time.time()
+        kids = [subprocess.Popen([sys.executable, "-c", _CPU_CHILD, ROOT, path, str(width), str(height), str(quality), "1" if is422 else "0", "1"],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(procs)]
+        inner = [float(k.communicate(timeout=300)[0].decode().strip().splitlines()[-1]) for k in kids]
+        wall = time.time() - t0
+    finally:
+        os.unlink(path)
+    return {"value": round(width * height * procs / max(inner) / 1e6, 3), "unit": "Mpix/s", "cores": procs, "kind": "reference" if os.path.exists(
+        os.path.join(ROOT, "oracle", "_ref", "libgpujpeg_ref.so")) else "port",
+        "sample": f"{procs} processes x 1 encode+decode of the same {width}x{height} frame at once (frame-level parallelism, the only kind the "
+                  f"reference's CPU code admits); slowest process {max(inner):.2f} s, {wall:.1f} s including start-up"}
+
+
 def run_batch(args, lib, device, local_rank, rank, world, width, height):
     """BASELINE.json config 5 / SURVEY.md 8(d): a batch of independent frames, frame i seeded 12345 + i, sharded over the
     ranks by gpujpeg_amd.sharding.shard_frames (static round-robin, no data-path collective). Every rank keeps its shard
@@ -215,6 +264,7 @@ def main():
                     help="what a timed step does: encode then decode (the headline metric), or only one direction (SURVEY 8d asks for both "
                          "separately; the decoder then decodes the stream of the warm-up's last encode again and again)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU path on all host cores (one frame per process), SURVEY 8(d) row (ii)")
     ap.add_argument("--internal-rgb", action="store_true", help="code RGB without colour transform (tuning aid; not the headline config)")
     ap.add_argument("--calibrate", action="store_true", help="run a 256 MiB device fill + copy first (known byte counts for calibrating PMC traffic counters)")
     ap.add_argument("--keep-coefs", action="store_true", help="decoder keeps its coefficients in HBM (adds the per-frame clear; tuning aid)")
@@ -413,7 +463,10 @@ def main():
             result["verified_bit_exact_decode"] = bool(np.array_equal(out.cpu().numpy().reshape(-1), (O.decode(want, 3, 3) if is422 else O.decode(want))[0]))
             del got
         if not args.no_cpu_baseline and world == 1:  # reported baseline, on the host cores of rank 0 at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(width, height, frame.cpu().numpy().reshape(-1), is422=is422, quality=args.quality)
+            host_frame = frame.cpu().numpy().reshape(-1)
+            result["cpu_baseline"] = cpu_baseline(width, height, host_frame, is422=is422, quality=args.quality)
+            if args.cpu_all_cores:
+                result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(width, height, host_frame, is422=is422, quality=args.quality)
         print(json.dumps(result), flush=True)
     for ln in lanes:
         ln["enc"].close()

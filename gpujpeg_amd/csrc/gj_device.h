@@ -407,11 +407,11 @@ __device__ __forceinline__ void gj_idct8(T& v0, T& v1, T& v2, T& v3, T& v4, T& v
     const T t1 = v0 - v1;
     const T b1 = t1 * (T)k1;
     const T b0 = gj_fma<T>(v0, (T)k4, -b1);
-    const T b3 = gj_fma<T>(v3, (T)k2, a2 * (T)k1);
+    const T b3 = gj_fma<T>(a2, (T)k1, v3 * (T)k2);
     const T b2 = gj_fma<T>(b3, (T)k0, -a2);
-    const T b6 = gj_fma<T>(v6, (T)k0, a5 * (T)k2);
+    const T b6 = gj_fma<T>(a5, (T)k2, v6 * (T)k0);
     const T b5 = gj_fma<T>(b6, (T)-0.6681786379f, a5);
-    const T b7 = gj_fma<T>(v7, (T)0.49039264f, a4 * (T)k3);
+    const T b7 = gj_fma<T>(a4, (T)k3, v7 * (T)0.49039264f);
     const T b4 = gj_fma<T>(b7, (T)k3, -a4);
     const T c1 = gj_fma<T>(t1, (T)k1, b2);
     const T c2 = gj_fma<T>((T)-2.0f, b2, c1);

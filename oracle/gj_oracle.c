@@ -5,7 +5,10 @@
  * gpujpeg_amd/ never links it. It follows the reference's algorithm stage by stage and cites the
  * reference file:line next to each function (paths relative to /root/reference).
  *
- * Compile with -ffp-contract=off: every fused multiply-add below is an explicit fmaf().
+ * Compile with -ffp-contract=off: every fused multiply-add below is an explicit fmaf(). The fusion map is pinned in two
+ * steps: with gjo_set_fma(0) every fmaf(a, b, c) becomes a * b + c in two roundings and the result must equal
+ * the reference's own CUDA translation units compiled with -ffp-contract=off (oracle/_ref/libgpujpeg_ref_nofma.so, CPU); with
+ * fusion on it must equal the same translation units compiled by hipcc for gfx950 (libgpujpeg_refhip.so, GPU box).
  */
 #include "gj_oracle.h"
 
@@ -13,6 +16,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+static int g_fma = 1;
+void gjo_set_fma(int on) { g_fma = on; }
+static inline float gjo_fmaf(float a, float b, float c) { return g_fma ? fmaf(a, b, c) : a * b + c; }
+#define fmaf(a, b, c) gjo_fmaf(a, b, c)
 
 /* ------------------------------------------------------------------------------------------------
  * Pixel formats / parameters
@@ -1084,11 +1092,11 @@ static void idct8(float v[8])
     const float t1 = v[0] - v[1];
     const float b1 = t1 * k1;
     const float b0 = fmaf(v[0], k4, -b1);
-    const float b3 = fmaf(v[3], k2, a2 * k1);
+    const float b3 = fmaf(a2, k1, v[3] * k2);
     const float b2 = fmaf(b3, k0, -a2);
-    const float b6 = fmaf(v[6], k0, a5 * k2);
+    const float b6 = fmaf(a5, k2, v[6] * k0);
     const float b5 = fmaf(b6, -0.6681786379f, a5);
-    const float b7 = fmaf(v[7], 0.49039264f, a4 * k3);
+    const float b7 = fmaf(a4, k3, v[7] * 0.49039264f);
     const float b4 = fmaf(b7, k3, -a4);
     const float c1 = fmaf(t1, k1, b2);
     const float c2 = fmaf(-2.0f, b2, c1);

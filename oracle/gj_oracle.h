@@ -128,6 +128,8 @@ void gjo_stream_free(gjo_stream* s);
 int  gjo_huffman_decode(const gjo_stream* s, const uint8_t* jpeg, int16_t* coefs);
 /* dequant + IDCT + level shift + clamp (src/gpujpeg_dct_gpu.cu:312-366,472-618) */
 void gjo_idct(const gjo_stream* s, const int16_t* coefs, uint8_t* planes);
+/* 1 (default): the fused multiply-adds of the pinned fusion map; 0: every one of them as multiply, then add (contraction off) */
+void gjo_set_fma(int on);
 void gjo_idct_block(const int16_t in[64], const uint16_t q_natural[64], uint8_t* dst, int stride);
 /* padded planes -> raw pixels (src/gpujpeg_postprocessor.cu:49-217, src/gpujpeg_colorspace.h) */
 void gjo_postprocess(const gjo_image* img, const uint8_t* planes, uint8_t* raw);

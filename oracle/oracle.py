@@ -12,7 +12,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgjoracle.so")
-REF_PATH = os.path.join(HERE, "_ref", "libgpujpeg_ref.so")
+REF_PATH = os.path.join(HERE, "_ref", "libgpujpeg_ref.so")                 # contraction off (CPU, cudaemu)
+REF_FMA_PATHS = {"gcc": os.path.join(HERE, "_ref", "libgpujpeg_ref_fma_gcc.so"), "clang": os.path.join(HERE, "_ref", "libgpujpeg_ref_fma_clang.so")}
+REFHIP_PATH = os.path.join(HERE, "_ref", "libgpujpeg_refhip.so")           # hipcc gfx950, the fusion-map pin (GPU box)
+REFHIP_SLP_PATH = os.path.join(HERE, "_ref", "libgpujpeg_refhip_slp.so")   # hipcc defaults (SLP vectoriser on)
 
 CS_NONE, CS_RGB, CS_BT601, CS_BT601_256, CS_BT709, CS_YUV = range(6)
 PF_U8, PF_444_P012, PF_444_P0P1P2, PF_422_P1020, PF_422_P0P1P2, PF_420_P0P1P2, PF_4444_P0123 = range(7)
@@ -91,6 +94,7 @@ def lib():
         L.gjo_quant_table.argtypes = [C.c_int, C.c_int, u8p, C.POINTER(C.c_float), C.POINTER(C.c_uint16)]
         L.gjo_fdct_quant_block.argtypes = [u8p, C.c_int, C.POINTER(C.c_float), i16p]
         L.gjo_idct_block.argtypes = [i16p, C.POINTER(C.c_uint16), u8p, C.c_int]
+        L.gjo_set_fma.argtypes = [C.c_int]
         _lib = L
     return _lib
 

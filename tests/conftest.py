@@ -29,17 +29,28 @@ def G():
 
 
 @pytest.fixture(scope="session")
-def ref(O, G):
-    """The reference's own host C code built against the CUDA stub (oracle/_ref); absent on the GPU box only
-    if it was not prebuilt."""
+def _ref_lib(O, G):
     if not O.have_ref():
         pytest.skip("oracle/_ref/libgpujpeg_ref.so not built (needs /root/reference)")
     return G.Library(O.REF_PATH)
 
 
+@pytest.fixture
+def ref(O, _ref_lib):
+    """The reference's own code on the CPU (oracle/_ref/libgpujpeg_ref.so): its host C files and its CUDA translation units for
+    colour/sampling, fDCT+quantisation and dequantisation+IDCT, compiled where they lie with contraction OFF (oracle/Makefile).
+    While a test holds this fixture the restatement runs in the same mode (gjo_set_fma(0)), so the two must agree bit for bit;
+    the fused map is pinned on the GPU box (tests/test_gpu_refhip.py). Absent on the GPU box only if it was not prebuilt."""
+    O.lib().gjo_set_fma(0)
+    yield _ref_lib
+    O.lib().gjo_set_fma(1)
+
+
 @pytest.fixture(scope="session")
 def lib(G):
     """The product: gpujpeg_amd/lib/libgpujpeg.so. Missing library = hard failure, never a fallback."""
+    import torch  # noqa: F401  -- before the library: PyTorch bundles its own libamdhip64; whichever HIP runtime is mapped first
+    #                              serves the whole process, and a second copy initialised later finds no device
     if not os.path.exists(G.PRODUCT_LIB):
         import __graft_entry__
         __graft_entry__.build()

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/golden.json + a few complete JPEG files from the REFERENCE's own host code
-(oracle/_ref/libgpujpeg_ref.so: /root/reference/src/*.c compiled unmodified; see oracle/Makefile).
-Run in the authoring container (needs /root/reference); the outputs are committed so that the oracle and the
-HIP path can be checked where the reference is absent (GPU box)."""
+"""Generates tests/golden/golden.json + a few complete JPEG files from the REFERENCE's own code on the CPU
+(oracle/_ref/libgpujpeg_ref.so: /root/reference/src/*.c and the CUDA translation units gpujpeg_preprocessor.cu,
+gpujpeg_dct_gpu.cu, gpujpeg_postprocessor.cu compiled where they lie, contraction off; see oracle/Makefile).
+Run in the authoring container (needs /root/reference); the outputs are committed so that the restatement (in its
+gjo_set_fma(0) mode) can be checked where the reference is absent (GPU box).
+The digests of the FUSED arithmetic, which the product reproduces, are produced on the GPU box by the reference's
+kernels compiled with hipcc: tests/golden/golden_hip.json, written by tests/test_gpu_refhip.py::test_golden_hip."""
 import hashlib
 import json
 import os
@@ -23,7 +26,7 @@ def main():
     O.build()
     assert O.have_ref(), "needs oracle/_ref (i.e. /root/reference)"
     ref = G.Library(O.REF_PATH)
-    golden = {"_comment": "sha256 of the reference-produced JPEG and of the reference-decoded default-format pixels per case of tests/conftest.py:CASES",
+    golden = {"_comment": "sha256 of the JPEG and of the decoded default-format samples produced by oracle/_ref/libgpujpeg_ref.so (reference host C + reference .cu on the CPU, contraction off) per case of tests/conftest.py:CASES",
               "cases": {}}
     for case in CASES:
         raw = make_raw(O, case)

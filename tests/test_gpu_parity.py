@@ -12,7 +12,9 @@ from conftest import CASES, api_params, make_raw, natural_image, oracle_image, p
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))["cases"]
+# digests produced on an MI355X by the reference's own kernels compiled with hipcc (tests/test_gpu_refhip.py::test_golden_hip)
+_GOLDEN_PATH = os.path.join(HERE, "golden", "golden_hip.json")
+GOLDEN = json.load(open(_GOLDEN_PATH))["cases"] if os.path.exists(_GOLDEN_PATH) else None
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "generic"])
@@ -32,6 +34,7 @@ def test_encode_decode_bit_exact(O, G, gpu_lib, case, fused):
     jpeg = enc.encode(p, pi, raw)
     assert np.array_equal(enc.coefficients(img.data_size), coefs), "quantised coefficients differ"
     assert np.array_equal(jpeg, want), "JPEG bytes differ"
+    assert GOLDEN is not None, "tests/golden/golden_hip.json is missing"
     g = GOLDEN[case[0]]
     assert hashlib.sha256(jpeg.tobytes()).hexdigest() == g["jpeg_sha256"], "differs from the reference-produced golden stream"
     dec = G.Decoder(gpu_lib)

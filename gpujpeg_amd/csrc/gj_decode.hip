@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                     const uint32_t b = (w >> (8 * k)) & 0xFFu;
                     // the byte before (in the stuffed stream): a zero after 0xFF is stuffing; the first byte of a segment never is
                     uint32_t prev = 0;
-                    if (valid && src_off + (uint32_t)off > 0) prev = k > 0 ? (w >> (8 * k - 8)) & 0xFFu : base[src_off + (uint32_t)off - 1];
+                    if (valid && src_off + (uint32_t)off > 0) prev = k > 0 ? (w >> (8 * k - 8)) & 0xFFu : (src + idx <= end ? base[src_off + (uint32_t)off - 1] : 0u); // never past the buffer
                     if (valid && !(b == 0 && prev == 0xFFu)) {
                         keep |= 1u << k;
                         if (off < (int)chunk) keep_piece |= 1u << k;

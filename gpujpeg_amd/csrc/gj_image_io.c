@@ -153,6 +153,7 @@ static int pnm_read_header(FILE* f, int* w, int* h, int* depth, int* maxval)
         *h = atoi(tok);
         if (pnm_token(f, tok, sizeof tok) != 0) return -1;
         *maxval = atoi(tok);
+        if (*w <= 0 || *h <= 0 || *maxval <= 0) return -1;
         return 0; /* exactly one whitespace byte was consumed after maxval */
     }
     if (strcmp(tok, "P7") == 0) {
@@ -373,7 +374,7 @@ static int tga_decode(const uint8_t* d, size_t n, struct gj_raster* out, int wan
     out->w = w; out->h = h; out->comps = bpp / 8;
     if (!want_pixels) return 0;
     const int c = out->comps;
-    out->px = malloc((size_t)w * h * c);
+    out->px = calloc((size_t)w * h, (size_t)c); /* a truncated file leaves zeros, never heap contents */
     if (!out->px) return -1;
     const uint8_t* p = d + 18 + idlen;
     const uint8_t* e = d + n;

@@ -32,10 +32,13 @@ static int gcd(int a, int b) { while (b) { int c = a % b; a = b; b = c; } return
 static enum gpujpeg_pixel_format native_pixel_format(struct gpujpeg_parameters* p)
 {
     if (p->comp_count == 4) return GPUJPEG_4444_U8_P0123;
+    const int n = p->comp_count < 3 ? p->comp_count : 3; /* only the components the stream defines (factors 1..4, checked at SOF0) */
     int gh = p->sampling_factor[0].horizontal, gv = p->sampling_factor[0].vertical;
-    for (int i = 1; i < 3; i++) { gh = gcd(gh, p->sampling_factor[i].horizontal); gv = gcd(gv, p->sampling_factor[i].vertical); }
-    for (int i = 0; i < 3; i++) { p->sampling_factor[i].horizontal /= gh; p->sampling_factor[i].vertical /= gv; }
-    if (p->sampling_factor[1].horizontal == 1 && p->sampling_factor[1].vertical == 1 && p->sampling_factor[2].horizontal == 1 &&
+    for (int i = 1; i < n; i++) { gh = gcd(gh, p->sampling_factor[i].horizontal); gv = gcd(gv, p->sampling_factor[i].vertical); }
+    if (gh < 1) gh = 1;
+    if (gv < 1) gv = 1;
+    for (int i = 0; i < n; i++) { p->sampling_factor[i].horizontal /= gh; p->sampling_factor[i].vertical /= gv; }
+    if (n == 3 && p->sampling_factor[1].horizontal == 1 && p->sampling_factor[1].vertical == 1 && p->sampling_factor[2].horizontal == 1 &&
         p->sampling_factor[2].vertical == 1) {
         const int h = p->sampling_factor[0].horizontal, v = p->sampling_factor[0].vertical;
         if (h == 1 && v == 1) return p->interleaved ? GPUJPEG_444_U8_P012 : GPUJPEG_444_U8_P0P1P2;
@@ -182,6 +185,37 @@ static void exif_orientation(const uint8_t* d, size_t dl, struct gpujpeg_image_m
 #undef XRD4
 }
 
+/* entry i (big-endian u32 offset relative to the scan's first byte) of the APP13 segment index of a scan; the index is the
+ * concatenation of the payloads of the scan's APP13 segments, every one but the last GJ_MAX_HEADER_SIZE bytes long */
+static uint32_t seg_info_entry(const struct gj_reader_result* r, int scan, int i)
+{
+    const uint8_t* q = r->seg_info[scan][(i * 4) / GJ_MAX_HEADER_SIZE] + (i * 4) % GJ_MAX_HEADER_SIZE;
+    return RD4(q);
+}
+
+/* An APP13 index comes from the file and is not trusted: chunk sizes must make the addressing above valid, there must be at
+ * least two entries, offsets must not decrease, every segment but the last must have room for its RSTn, and the scan must end
+ * inside the buffer. Anything else: the index is ignored and the scan is walked like a stream without one. */
+static bool seg_info_valid(const struct gj_reader_result* r, int scan, size_t begin, size_t size)
+{
+    const int chunks = r->seg_info_count[scan];
+    long total = 0;
+    for (int k = 0; k < chunks; k++) {
+        if (k + 1 < chunks && r->seg_info_size[scan][k] != GJ_MAX_HEADER_SIZE) return false;
+        if (r->seg_info_size[scan][k] <= 0 || r->seg_info_size[scan][k] > GJ_MAX_HEADER_SIZE) return false;
+        total += r->seg_info_size[scan][k];
+    }
+    if (total < 8 || total % 4 != 0) return false;
+    const int entries = (int)(total / 4);
+    uint32_t prev = seg_info_entry(r, scan, 0);
+    for (int i = 1; i < entries; i++) {
+        const uint32_t pos = seg_info_entry(r, scan, i);
+        if (pos < prev || (i + 1 < entries && pos - prev < 2)) return false;
+        prev = pos;
+    }
+    return (size_t)prev <= size - begin;
+}
+
 int gj_reader_parse(const uint8_t* image, size_t size, int verbose, bool ff_cs_itu601_is_709, enum gpujpeg_pixel_format req_pixfmt,
                     enum gpujpeg_color_space req_cs, unsigned req_alignment, struct gj_reader_result* r, bool headers_only)
 {
@@ -196,6 +230,10 @@ int gj_reader_parse(const uint8_t* image, size_t size, int verbose, bool ff_cs_i
     r->header_color_space = GPUJPEG_NONE;
     const uint8_t* end = image + size;
     const uint8_t* p = image;
+    if (size > 0xFFFFFF00u) { /* segment offsets and lengths are 32-bit on the device */
+        GJ_ERROR("JPEG data of %zu bytes are not supported (4 GiB limit)!\n", size);
+        return -1;
+    }
     if (size < 4 || p[0] != 0xFF || p[1] != 0xD8) {
         GJ_ERROR("JPEG data should begin with SOI marker, but marker %s was found!\n", size >= 2 && p[0] == 0xFF ? marker_name(p[1]) : "(none)");
         return -1;
@@ -312,6 +350,12 @@ int gj_reader_parse(const uint8_t* image, size_t size, int verbose, bool ff_cs_i
                 r->comp_id[c] = d[6 + 3 * c];
                 r->param.sampling_factor[c].horizontal = d[7 + 3 * c] >> 4;
                 r->param.sampling_factor[c].vertical = d[7 + 3 * c] & 15;
+                if (r->param.sampling_factor[c].horizontal < 1 || r->param.sampling_factor[c].horizontal > 4 ||
+                    r->param.sampling_factor[c].vertical < 1 || r->param.sampling_factor[c].vertical > 4) {
+                    GJ_ERROR("SOF0 marker contains unsupported sampling factor %dx%d of component %d (1-4 allowed)!\n",
+                             d[7 + 3 * c] >> 4, d[7 + 3 * c] & 15, c);
+                    return -1;
+                }
                 r->quant_map[c] = d[8 + 3 * c];
                 if (r->quant_map[c] > 3) { GJ_ERROR("SOF0 marker contains unexpected quantization table index %d!\n", r->quant_map[c]); return -1; }
             }
@@ -378,14 +422,15 @@ int gj_reader_parse(const uint8_t* image, size_t size, int verbose, bool ff_cs_i
             r->scan_begin[scan] = begin;
             if (headers_only) { r->scan_count++; return 0; }
             long stop;
+            if (begin > size) { GJ_ERROR("SOS marker goes beyond end of data\n"); return -1; }
+            if (r->seg_info_count[scan] > 0 && !seg_info_valid(r, scan, begin, size)) {
+                if (verbose >= 0) GJ_WARN("APP13 segment info of scan %d is inconsistent with the data, ignoring it.\n", scan);
+                r->seg_info_count[scan] = 0;
+            }
             if (r->seg_info_count[scan] > 0) { /* the index gives the length of the scan directly */
                 int total = 0;
                 for (int k = 0; k < r->seg_info_count[scan]; k++) total += r->seg_info_size[scan][k];
-                const int entries = total / 4;
-                const int last = entries - 1;
-                const uint8_t* q = r->seg_info[scan][(last * 4) / GJ_MAX_HEADER_SIZE] + (last * 4) % GJ_MAX_HEADER_SIZE;
-                stop = (long)(begin + RD4(q));
-                if ((size_t)stop > size) { GJ_ERROR("scan data goes beyond end of data\n"); return -1; }
+                stop = (long)(begin + seg_info_entry(r, scan, total / 4 - 1));
             } else {
                 int count = 0;
                 stop = walk_scan(image, begin, size, 0, 0, NULL, &count);
@@ -431,9 +476,8 @@ int gj_reader_split_scans(const uint8_t* image, const struct gj_reader_result* r
             for (int k = 0; k < r->seg_info_count[scan]; k++) total += r->seg_info_size[scan][k];
             const int count = total / 4 - 1;
             uint32_t prev = 0;
-            for (int i = 0; i <= count; i++) {
-                const uint8_t* q = r->seg_info[scan][(i * 4) / GJ_MAX_HEADER_SIZE] + (i * 4) % GJ_MAX_HEADER_SIZE;
-                const uint32_t pos = RD4(q);
+            for (int i = 0; i <= count; i++) { /* validated by seg_info_valid() when the scan was parsed */
+                const uint32_t pos = seg_info_entry(r, scan, i);
                 if (i > 0 && i - 1 < max_segs) {
                     uint32_t len = pos - prev;
                     if (i < count) len -= 2; /* all but the last keep their RSTn (reader.c:1204-1207) */

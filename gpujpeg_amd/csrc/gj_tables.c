@@ -119,7 +119,7 @@ int gj_huffman_decoder_table(const uint8_t bits[17], const uint8_t* vals, uint16
             valptr[len] = (uint16_t)p;
             mn = code;
             for (int i = 0; i < bits[len]; i++, p++, code++) {
-                if (p >= 256) return -1;
+                if (p >= 256 || code >= (1 << len)) return -1; /* over-subscribed table: reject before any write */
                 if (len <= GJ_DEC_FAST_BITS) { /* every 10-bit prefix starting with this code */
                     const int shift = GJ_DEC_FAST_BITS - len;
                     for (int f = 0; f < (1 << shift); f++) fast[(code << shift) | f] = (uint16_t)((len << 8) | vals[p]);
@@ -127,7 +127,6 @@ int gj_huffman_decoder_table(const uint8_t bits[17], const uint8_t* vals, uint16
             }
             mx = code - 1;
         }
-        if (code > (1 << len)) return -1; /* over-subscribed table */
         maxcode[2 * len] = (uint16_t)((uint32_t)mx & 0xFFFF);
         maxcode[2 * len + 1] = (uint16_t)((uint32_t)mx >> 16);
         mincode[2 * len] = (uint16_t)((uint32_t)mn & 0xFFFF);
@@ -179,4 +178,23 @@ int gj_huffman_decoder_table2(const uint8_t bits[17], const uint8_t* vals, int i
         code <<= 1;
     }
     return 0;
+}
+
+#include <stdlib.h>
+
+#include "gpujpeg_amd_ext.h"
+
+int gpujpeg_amd_host_huffman_table_check(const uint8_t bits[17], const uint8_t* vals, int is_ac)
+{
+    uint16_t* t1 = malloc(GJ_DEC_TAB_WORDS * sizeof(uint16_t)); /* exact sizes: an out-of-range write is visible to ASan / valgrind */
+    uint16_t* t2 = malloc(GJ_DEC2_WORDS * sizeof(uint16_t));
+    int rc = -1;
+    if (t1 && t2) {
+        const int a = gj_huffman_decoder_table(bits, vals, t1);
+        const int b = gj_huffman_decoder_table2(bits, vals, is_ac, t2);
+        rc = (a != 0 || b < 0) ? -1 : 0;
+    }
+    free(t1);
+    free(t2);
+    return rc;
 }

@@ -359,6 +359,9 @@ static void exif_app1(struct bw* w, const gj_geom* g, const struct gpujpeg_image
         {0x9000, XT_UNDEFINED, 4, NULL, "0230"}, {0x9101, XT_UNDEFINED, 4, NULL, "\1\2\3\0"}, {0xA000, XT_UNDEFINED, 4, NULL, "0100"},
         {0xA001, XT_SHORT, 1, &srgb, NULL},      {0xA002, XT_SHORT, 1, &width, NULL},          {0xA003, XT_SHORT, 1, &height, NULL},
     };
+    /* `written` is deliberately the size of priv[] BEFORE user tags removed entries from it: the reference passes ARR_SIZE(tags)
+     * instead of the reduced count for this IFD (src/gpujpeg_exif.c:385-387), so a replaced private tag leaves a duplicate of the
+     * last record in its files; we reproduce its bytes (tests/test_oracle_vs_ref.py compares the APP1 segments of both libraries) */
     exif_ifd(w, start, priv, sizeof priv / sizeof priv[0], sizeof priv / sizeof priv[0], custom ? custom->v[1] : NULL, custom ? custom->n[1] : 0);
     const size_t length = w->n - len_at;
     w->p[len_at] = (uint8_t)(length >> 8);

@@ -58,6 +58,11 @@ GPUJPEG_API int gpujpeg_amd_read_raster_file(const char* filename, uint8_t* dst,
  * [3] blocks per MCU, [4 + 4*c ..] per component data_width, data_height, segment_count, type */
 GPUJPEG_API int gpujpeg_amd_host_geometry(const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* param_image, int out[20]);
 
+/* Host-only: builds both decode-table layouts for one DHT table (bits[1..16] = codes per length, vals = symbols) exactly as
+ * gpujpeg_decoder_decode does and reports 0 = accepted, -1 = rejected (over-subscribed or more than 256 symbols). Lets the CPU
+ * test-suite feed hostile tables to the builders without a GPU. */
+GPUJPEG_API int gpujpeg_amd_host_huffman_table_check(const uint8_t bits[17], const uint8_t* vals, int is_ac);
+
 /* per-kernel durations (ms, hipEvents on the coder's stream) of the last call made with perf_stats != 0:
  * encoder: [0] preprocess, [1] DCT+quant (fused path: preprocess included), [2] k_huffman, [3] k_scan_segments, [4] k_assemble
  * decoder: [0] k_huffman_decode, [1] IDCT (fused path: postprocess included), [2] postprocess */

@@ -326,6 +326,41 @@ def test_encoder_custom_exif_tags(O, G, gpu_lib):
     enc.close()
 
 
+def test_hostile_tables_and_index(O, G, gpu_lib):
+    """Advisor findings of round 1 through the whole decoder: an over-subscribed DHT must be an error return (it used to overrun the
+    pinned table buffer), an APP13 index whose offsets are sorted but unrelated to the data must leave the decoder alive, an index
+    that fails validation is ignored and the image decodes normally."""
+    case = ("h", 320, 240, 1, 1, 80, 4, 0, None, 3)
+    jpeg = O.encode(oracle_image(O, case), natural_image(320, 240, 3, seed=9))
+    want, _ = O.decode(jpeg)
+    dec = G.Decoder(gpu_lib)
+    bad = jpeg.copy()
+    d = int(np.nonzero((bad[:-1] == 0xFF) & (bad[1:] == 0xC4))[0][0])
+    bad[d + 5:d + 21] = np.array([255] + [0] * 15, np.uint8)
+    with pytest.raises(Exception):
+        dec.decode(bad)
+    sos = int(np.nonzero((jpeg[:-1] == 0xFF) & (jpeg[1:] == 0xDA))[0][0])
+    rng = np.random.default_rng(1)
+    for trial in range(6):
+        n = int(rng.integers(2, 200))
+        if trial < 3:   # passes validation (non-decreasing, inside the buffer) but points anywhere
+            offs = np.sort(rng.integers(0, jpeg.size - sos - 20, size=n))
+            offs = np.cumsum(np.maximum(np.diff(np.concatenate([[0], offs])), 2))
+            offs = offs[offs < jpeg.size - sos - 20]
+        else:           # fails validation -> ignored
+            offs = rng.integers(0, 1 << 31, size=n)
+        body = offs.astype(">u4").view(np.uint8)
+        app13 = np.concatenate([np.array([0xFF, 0xED, (3 + body.size) >> 8, (3 + body.size) & 255, 0], np.uint8), body])
+        hostile = np.concatenate([jpeg[:sos], app13, jpeg[sos:]])
+        try:
+            px, _ = dec.decode(hostile)
+            if trial >= 3:
+                assert np.array_equal(px, want), "a rejected index must not change the result"
+        except Exception:
+            assert trial < 3
+        assert np.array_equal(dec.decode(jpeg)[0], want)
+
+
 def test_damaged_streams_do_not_crash(O, G, gpu_lib):
     """Corrupted entropy data, truncated files and garbage after the headers: the decoder may fail or return garbage pixels, but it
     must return (no out-of-bounds access, no endless loop in the synchronisation rounds) and keep working afterwards."""

@@ -412,3 +412,61 @@ def test_output_file_probes_follow_the_reference(lib, G):
         pi = lib.default_image_parameters()
         assert lib.L.gpujpeg_image_get_properties(name.encode(), C.byref(pi), 0) >= 0
         assert (pi.pixel_format, pi.color_space) == (want_pf, want_cs), name
+
+
+def _std_stream(O):
+    """a small valid stream to damage"""
+    return O.encode(O.make_image(32, 16, restart_interval=2), O.noise(32 * 16 * 3, seed=5))
+
+
+def test_hostile_dht_is_rejected_before_any_write(lib):
+    """An over-subscribed DHT (255 codes of length 1) used to index the 1024-entry first-level table far out of range
+    (advisor finding, round 1). The builders run on exactly sized heap blocks here."""
+    fn = lib.L.gpujpeg_amd_host_huffman_table_check
+    fn.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int]
+    vals = (C.c_uint8 * 256)(*range(256))
+    for bad in ([0, 255] + [0] * 15, [0, 3] + [0] * 15, [0, 2, 1] + [0] * 14, [0, 1, 2, 4, 8, 16, 32, 64, 128, 255, 0, 0, 0, 0, 0, 0, 0]):
+        for is_ac in (0, 1):
+            assert fn((C.c_uint8 * 17)(*bad), vals, is_ac) == -1, bad
+    std_dc = [0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
+    assert fn((C.c_uint8 * 17)(*std_dc), vals, 0) == 0
+    full = [0, 0, 0, 0, 0, 0, 0, 0, 256 - 1] + [0] * 8   # 255 codes of length 8: complete but legal
+    assert fn((C.c_uint8 * 17)(*full), vals, 1) == 0
+
+
+def _image_info(lib, G, data):
+    info = G.ImageInfo()
+    arr = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    lib.L.gpujpeg_decoder_get_image_info2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(G.ImageInfo), C.c_int, C.c_int]
+    return lib.L.gpujpeg_decoder_get_image_info2(arr, len(data), C.byref(info), -1, 0), info
+
+
+def test_sof0_with_zero_sampling_factors_is_an_error(O, G, lib):
+    """H or V nibbles of 0 used to reach a division by the gcd of the factors (SIGFPE, advisor finding, round 1)."""
+    jpeg = bytearray(_std_stream(O).tobytes())
+    sof = jpeg.find(b"\xff\xc0")
+    assert sof > 0
+    for c in range(3):
+        jpeg[sof + 4 + 6 + 3 * c + 1] = 0x00
+    rc, _ = _image_info(lib, G, jpeg)
+    assert rc != 0
+    jpeg[sof + 4 + 6 + 1] = 0x51  # factor 5
+    rc, _ = _image_info(lib, G, jpeg)
+    assert rc != 0
+
+
+@pytest.mark.parametrize("payload", ["one_big_chunk", "short", "odd_total", "decreasing", "beyond_end"])
+def test_hostile_app13_index_is_ignored(O, G, lib, payload):
+    """APP13 segment-info is file content: chunk sizes that break the chunk addressing, fewer than two entries, decreasing
+    offsets or offsets past the buffer must neither crash the reader (advisor finding, round 1) nor be used; the header is
+    still parsed by walking the scan."""
+    jpeg = bytearray(_std_stream(O).tobytes())
+    sos = jpeg.find(b"\xff\xda")
+    body = {"one_big_chunk": bytes(65532 - 3), "short": b"\0\0\0\0", "odd_total": bytes(9),
+            "decreasing": (100).to_bytes(4, "big") + (50).to_bytes(4, "big") + (60).to_bytes(4, "big"),
+            "beyond_end": (0).to_bytes(4, "big") + (0x7FFFFFF0).to_bytes(4, "big")}[payload]
+    app13 = b"\xff\xed" + (3 + len(body)).to_bytes(2, "big") + b"\0" + body
+    hostile = jpeg[:sos] + app13 + jpeg[sos:]
+    rc, info = _image_info(lib, G, hostile)
+    assert rc == 0
+    assert (info.param_image.width, info.param_image.height) == (32, 16)

@@ -48,7 +48,7 @@ def child(name, mode):
     for t in range(TRIALS):
         rng = np.random.default_rng(1000 + t)
         bad = jpeg.copy()
-        kind = t % 6
+        kind = t % 8
         if kind == 0:    # byte flips in the entropy-coded data
             idx = rng.integers(hdr, bad.size - 2, size=1 + t)
             bad[idx] = rng.integers(0, 256, size=idx.size, dtype=np.uint8)
@@ -63,9 +63,18 @@ def child(name, mode):
         elif kind == 4:  # zeros / 0xFF runs
             a = int(rng.integers(hdr, bad.size - 64))
             bad[a:a + int(rng.integers(1, 64))] = 0xFF if t & 8 else 0
-        else:            # deleted bytes (everything after shifts)
+        elif kind == 5:  # deleted bytes (everything after shifts)
             a = int(rng.integers(hdr, bad.size - 8))
             bad = np.concatenate([bad[:a], bad[a + int(rng.integers(1, 5)):]])
+        elif kind == 6:  # over-subscribed Huffman table: the code counts of the first DHT replaced
+            d = int(np.nonzero((bad[:-1] == 0xFF) & (bad[1:] == 0xC4))[0][0])
+            bad[d + 5:d + 21] = rng.integers(0, 256, size=16, dtype=np.uint8) if t & 8 else np.array([255] + [0] * 15, np.uint8)
+        else:            # APP13 segment index with arbitrary offsets in front of the first scan
+            sos = int(np.nonzero((bad[:-1] == 0xFF) & (bad[1:] == 0xDA))[0][0])
+            n = int(rng.integers(1, 64))
+            body = rng.integers(0, 256, size=4 * n, dtype=np.uint8) if t & 8 else np.sort(rng.integers(0, bad.size, size=n)).astype(">u4").view(np.uint8)
+            app13 = np.concatenate([np.array([0xFF, 0xED, (3 + body.size) >> 8, (3 + body.size) & 255, 0], np.uint8), body])
+            bad = np.concatenate([bad[:sos], app13, bad[sos:]])
         print(f"trial {t} kind {kind}", flush=True)
         try:
             dec.decode(bad)

@@ -617,12 +617,24 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
 }
 
 // ================================================================================================
-// The coding passes of the fully fused encoder kernels (k_encode_rgb444, k_encode_uyvy422) on one tile of 256 lanes = blocks whose
-// transformed rows sit in the lanes' LDS columns in natural order: zig-zag + non-zero mask, DC prediction inside the segment,
-// pass A (lengths), bit positions by prefix sums, pass B (codewords into the LDS bit buffer, window by window), coalesced copy of
-// the unstuffed segment streams to d_temp, byte and 0xFF counts per segment. What differs between the kernels comes in as
-// arguments: the Huffman table of the lane's block, the distance to the previous block of the same component, the number of blocks
-// of the lane's segment, where the tile's first segment lives in d_temp and in the per-segment arrays.
+// The coder of the fully fused encoder kernels (k_encode_rgb444, k_encode_uyvy422): one LANE per 8x8 block, 256 block slots per
+// workgroup tile, whole restart segments per tile.
+//
+//   1. the transform stores every quantised coefficient as 16 bits straight to its ZIG-ZAG position in the lane's own LDS column
+//      (ds_write_b16 with immediate offsets, layout [z >> 1][lane] dwords, half z & 1): no packing, no reordering pass;
+//   2. the lane reads its column back as 32 dwords and forms the 64-bit non-zero mask (v_pk_min_u16 + v_lshl_or_b32 per dword);
+//   3. ONE walk over the non-zero coefficients (mask + ctz) produces the block's bit stream privately: symbols go into a 64-bit
+//      register accumulator, every completed dword is stored IN PLACE over the part of the lane's column the walk has already
+//      consumed (dword f may be written once positions 2f and 2f + 1 are behind the walk; true for anything but blocks that
+//      average more than 16 bits per coefficient position), the last partial dword stays in a register;
+//   4. prefix sums over the block lengths give exact bit positions inside per-segment streams; the rows of the coefficient area
+//      above GJ_ENC_PRIV_ROWS become the shared bit window (nothing else lives in LDS: 36 KB per workgroup, four per CU);
+//   5. every lane shift-merges its private dwords into the window (ds_or_b32), coalesced copy of the unstuffed segment streams to
+//      d_temp with byte and 0xFF counts per segment (k_scan_segments / k_assemble finish the stream).
+//
+// A block whose stream does not fit in place (noise at q100) keeps what fitted, finishes its walk counting only, and codes the
+// rest directly into the window from the saved walk state; a tile whose streams exceed the window takes several windows.
+// Symbol semantics restate src/gpujpeg_huffman_gpu_encoder.cu:139-294 / src/gpujpeg_huffman_cpu_encoder.c:136-246.
 // ================================================================================================
 // bits 0..15 of x to the even positions, bits 16..31 to the odd positions of the result
 __device__ __forceinline__ uint32_t gj_spread16(uint32_t x)
@@ -635,130 +647,284 @@ __device__ __forceinline__ uint32_t gj_spread16(uint32_t x)
 }
 __device__ __forceinline__ uint32_t gj_interleave16(uint32_t x) { return gj_spread16(x & 0xFFFFu) | (gj_spread16(x >> 16) << 1); }
 
-struct GjTileLds {
-    uint32_t* coef;  // [32][256]
-    uint32_t* bits;  // [GJ_HUFF_CAP_DW]
-    const uint32_t* lut;
-    int* dc;         // [256]
-    uint32_t *segx, *segend, *segbase, *segbits, *segff, *tmp;
+#define GJ_ENC_PRIV_ROWS 24                          // rows (dwords per lane) of the coefficient area that may hold private streams
+#define GJ_ENC_WIN_DW ((32 - GJ_ENC_PRIV_ROWS) * 256) // shared bit window: the remaining rows, 2048 dwords
+#define GJ_ENC_MAX_SPT 64                            // segments per tile the bookkeeping holds (restart intervals of >= 4 blocks)
+
+// natural (row-major) index -> position in the zig-zag scan (inverse of GJ_ZZ)
+__device__ static constexpr uint8_t GJ_IZZ[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                                                  41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                                                  46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+// byte offset of zig-zag position z inside a lane's column (column base = lane * 4)
+#define GJ_COL_OFF(z) (((z) >> 1) * 1024 + ((z) & 1) * 2)
+
+// gj_fdct_quant_pk with the stores of step 1: `col` = this lane's column base in LDS (bytes)
+__device__ __forceinline__ void gj_fdct_quant_zz(const uint32_t (&px)[16], const float* __restrict__ q, uint8_t* col)
+{
+    gj_f2 D[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t a = px[2 * r], b = px[2 * r + 1];
+        D[r][0] = gj_f2{gj_ubyte_f<0>(a), gj_ubyte_f<1>(a)};
+        D[r][1] = gj_f2{gj_ubyte_f<2>(a), gj_ubyte_f<3>(a)};
+        D[r][2] = gj_f2{gj_ubyte_f<0>(b), gj_ubyte_f<1>(b)};
+        D[r][3] = gj_f2{gj_ubyte_f<2>(b), gj_ubyte_f<3>(b)};
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) gj_fdct8<gj_f2>(D[0][c], D[1][c], D[2][c], D[3][c], D[4][c], D[5][c], D[6][c], D[7][c], -1024.0f);
+    __builtin_amdgcn_sched_barrier(0);
+    const gj_f2* q2 = reinterpret_cast<const gj_f2*>(q);
+#pragma unroll
+    for (int rp = 0; rp < 4; rp++) {
+        gj_f2 E[8];
+#pragma unroll
+        for (int cp = 0; cp < 4; cp++) {
+            E[2 * cp] = gj_f2{D[2 * rp][cp].x, D[2 * rp + 1][cp].x};
+            E[2 * cp + 1] = gj_f2{D[2 * rp][cp].y, D[2 * rp + 1][cp].y};
+        }
+        gj_fdct8<gj_f2>(E[0], E[1], E[2], E[3], E[4], E[5], E[6], E[7], 0.0f);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            // rintf(coef * q) by adding 1.5 * 2^23: the integer sits in the low mantissa bits, its low 16 bits are the int16
+            const gj_f2 u = E[j] * q2[j * 4 + rp] + (gj_f2)12582912.0f;
+            const float fx = u.x, fy = u.y;
+            *reinterpret_cast<uint16_t*>(col + GJ_COL_OFF(GJ_IZZ[(2 * rp) * 8 + j])) = (uint16_t)__builtin_bit_cast(uint32_t, fx);
+            *reinterpret_cast<uint16_t*>(col + GJ_COL_OFF(GJ_IZZ[(2 * rp + 1) * 8 + j])) = (uint16_t)__builtin_bit_cast(uint32_t, fy);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+struct GjCoderLds {
+    uint32_t* coef;      // [32][256]; rows GJ_ENC_PRIV_ROWS.. double as the shared bit window once the walks are done
+    const uint32_t* lut; // [2][272]: per table type AC[(run << 4) | nbits] then DC[nbits], entry = (code bits + nbits) << 26 | code << nbits
+    uint32_t* wsum;      // [4] block-length totals of the waves
+    int* edge;           // [4][4] the last four DC terms of each wave (predecessors of the next wave's first lanes)
+    uint32_t *segx, *segend, *segbase, *segbits, *segff; // [64] ([65] segbase)
 };
 
-#define GJ_PROF(slot)                                                                            \
-    if (prof) {                                                                                  \
-        __syncthreads();                                                                         \
-        const unsigned long long now = wall_clock64();                                           \
-        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
-        t_prof = now;                                                                            \
-    }
-__device__ __forceinline__ void gj_code_tile(const GjTileLds& L, const int i, const int j, const int k, const bool active, const bool seg_in_tile,
-                                             const int spt, const int B, const int nblocks, const int table, const int dc_dist,
-                                             uint8_t* __restrict__ temp, const uint64_t first_block, uint32_t* __restrict__ seg_bytes,
-                                             uint32_t* __restrict__ seg_ff, const uint32_t first_segment, unsigned long long* __restrict__ prof,
-                                             unsigned long long& t_prof)
+// the private stream of a lane while it walks its block
+struct GjWalk {
+    uint32_t hi, lo;   // accumulator: `fill` bits, left-aligned in hi:lo (lo is only non-zero for a moment inside gj_put)
+    int fill;
+    int produced;      // completed dwords so far
+    int stored;        // ... of which the first `stored` sit in the lane's column (== produced unless the block overflowed)
+    // walk state at the first dword that could not be stored in place (ovf): the accumulator then, the non-zero masks still to
+    // visit, the position of the last coded coefficient
+    uint32_t ovf, o_hi, o_lo, o_mlo, o_mhi;
+    int o_fill, o_prev;
+};
+
+// append the n <= 26 bits `cw` to a lane's private stream; p = zig-zag position of the coefficient being coded (everything up to
+// it has been read), mlo/mhi = masks still to visit after p
+__device__ __forceinline__ void gj_put(GjWalk& w, const uint32_t cw, const int n, uint8_t* col, const int p, const uint32_t mlo, const uint32_t mhi)
 {
-    uint32_t* const s_coef = L.coef;
-    uint32_t* const s_bits = L.bits;
-    const uint32_t* const s_lut = L.lut;
-    int* const s_dc = L.dc;
-    uint32_t *const s_segx = L.segx, *const s_segend = L.segend, *const s_segbase = L.segbase, *const s_segbits = L.segbits, *const s_segff = L.segff,
-             *const s_tmp = L.tmp;
-    uint32_t n[32];
+    const uint64_t t = (uint64_t)cw << (64 - w.fill - n); // fill < 32 here, so the shift is >= 6
+    w.hi |= (uint32_t)(t >> 32);
+    w.lo = (uint32_t)t;
+    w.fill += n;
+    if (w.fill >= 32) {
+        if (w.stored == w.produced && 2 * w.produced + 1 <= p && w.produced < GJ_ENC_PRIV_ROWS) {
+            *reinterpret_cast<uint32_t*>(col + w.produced * 1024) = w.hi;
+            w.stored++;
+        } else if (!w.ovf) {
+            w.ovf = 1; w.o_hi = w.hi; w.o_lo = w.lo; w.o_fill = w.fill; w.o_mlo = mlo; w.o_mhi = mhi; w.o_prev = p;
+        }
+        w.produced++;
+        w.hi = w.lo;
+        w.lo = 0;
+        w.fill -= 32;
+    }
+}
+
+// category (bit length) and magnitude bits of a coefficient (ITU T.81 F.1.2.1.1): six operations
+__device__ __forceinline__ void gj_value_bits2(const int v, int& nbits, uint32_t& bits)
+{
+    const int s = v >> 31, t = v + s; // t = v - 1 for negative v
+    nbits = 32 - __builtin_clz((uint32_t)(t ^ s) | 0u) ; // |v| = t ^ s; clz(0) is 32 on this target (v_ffbh_u32 returns -1 -> handled below)
+    nbits = v ? nbits : 0;
+    bits = __builtin_amdgcn_ubfe((uint32_t)t, 0, (uint32_t)nbits);
+}
+
+// the AC part of a walk. DIRECT = false: private stream (gj_put). DIRECT = true: straight into the shared window (resumed blocks).
+template <bool DIRECT>
+__device__ __forceinline__ void gj_walk_ac(uint8_t* col, uint32_t mlo, uint32_t mhi, int prev, const uint32_t* lut_ac, GjWalk& w, GjEmit& e,
+                                           uint32_t* s_bits, const uint32_t wbase, const uint32_t wend)
+{
+    const uint32_t zrl = lut_ac[0xF0];
 #pragma unroll
-    for (int t = 0; t < 32; t++) n[t] = s_coef[t * 256 + i]; // ... and come back once the transform's registers are free
+    for (int half = 0; half < 2; half++) {
+        uint32_t m = half ? mhi : mlo;
+        while (m) {
+            const int p = __builtin_ctz(m) + 32 * half;
+            m &= m - 1;
+            int run = p - prev - 1;
+            prev = p;
+            const int v = *reinterpret_cast<const int16_t*>(col + (p >> 1) * 1024 + (p & 1) * 2);
+            const uint32_t r_lo = half ? 0u : m, r_hi = half ? m : mhi; // still to visit after p
+            while (run >= 16) {
+                if (DIRECT) gj_emit(e, zrl & 0x03FFFFFFu, (int)(zrl >> 26), s_bits, wbase, wend);
+                else gj_put(w, zrl & 0x03FFFFFFu, (int)(zrl >> 26), col, p, r_lo, r_hi);
+                run -= 16;
+            }
+            int nbits;
+            uint32_t bits;
+            gj_value_bits2(v, nbits, bits);
+            const uint32_t ent = lut_ac[(run << 4) | nbits];
+            if (DIRECT) gj_emit(e, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), s_bits, wbase, wend);
+            else gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, p, r_lo, r_hi);
+        }
+    }
+    if (prev != 63) {
+        const uint32_t eob = lut_ac[0];
+        if (DIRECT) gj_emit(e, eob & 0x03FFFFFFu, (int)(eob >> 26), s_bits, wbase, wend);
+        else gj_put(w, eob & 0x03FFFFFFu, (int)(eob >> 26), col, 63, 0u, 0u);
+    }
+}
+
+// OR the 32 bits v (left-aligned, the stream's bits [bp, bp + 32)) into the window [wbase, wend) dwords of the tile stream
+__device__ __forceinline__ void gj_or32(uint32_t* s_bits, const uint32_t wbase, const uint32_t wend, const uint32_t bp, const uint32_t v)
+{
+    const uint32_t d = bp >> 5, s = bp & 31u;
+    const uint32_t a = v >> s, b = s ? v << (32u - s) : 0u;
+    if (a && d >= wbase && d < wend) atomicOr(&s_bits[d - wbase], a);
+    if (b && d + 1 >= wbase && d + 1 < wend) atomicOr(&s_bits[d + 1 - wbase], b);
+}
+
+// Steps 2-5 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
+// nblocks = blocks of that segment, table = 0 luminance / 1 chrominance tables, dc_dist = lanes back to the previous block of the
+// same component; first_block = coding-order index of the tile's first block (addresses d_temp), first_segment = its first segment.
+__device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, const int j, const int k, const bool active, const int spt,
+                                             const int B, const int nblocks, const int table, const int dc_dist, const int seg_count_left,
+                                             uint8_t* __restrict__ temp, const uint64_t first_block, uint32_t* __restrict__ seg_bytes,
+                                             uint32_t* __restrict__ seg_ff, const uint32_t first_segment)
+{
+    const int lane = i & 63, wave = i >> 6;
+    uint8_t* const col = reinterpret_cast<uint8_t*>(L.coef) + i * 4;
+    uint32_t* const s_bits = L.coef + GJ_ENC_PRIV_ROWS * 256;
+    const uint32_t* const lut_ac = L.lut + table * 272;
+    const uint32_t* const lut_dc = lut_ac + 256;
+
+    // ---- 2. read the column back: non-zero mask, DC term
+    uint32_t mlo = 0, mhi = 0;
     int dc = 0;
-    uint64_t mask = 0;
-    if (active) {
-        dc = (int)(int16_t)(n[0] & 0xFFFF);
-        uint32_t mlo = 0, mhi = 0;
+    {
+        uint32_t elo = 0, ehi = 0;
 #pragma unroll
         for (int q = 0; q < 32; q++) {
-            const int na = GJ_ZZ[2 * q], nbz = GJ_ZZ[2 * q + 1];
-            const uint32_t sel = (uint32_t)((na & 1) * 2) | ((uint32_t)((na & 1) * 2 + 1) << 8) | ((uint32_t)(4 + (nbz & 1) * 2) << 16) |
-                                 ((uint32_t)(5 + (nbz & 1) * 2) << 24);
-            const uint32_t d = __builtin_amdgcn_perm(n[nbz >> 1], n[na >> 1], sel);
-            s_coef[q * 256 + i] = d;
-            // non-zero flags of the two halves: clamp both to 0/1 (v_pk_min_u16); bit q collects the even coefficient of dword q, bit
-            // 16 + q the odd one (one v_lshl_or_b32 per dword), the two halves are interleaved once at the end
+            const uint32_t d = L.coef[q * 256 + i];
+            if (q == 0) dc = (int)(int16_t)(d & 0xFFFFu);
+            // both halves clamped to 0 / 1 (v_pk_min_u16): bit q collects the even position of dword q, bit 16 + q the odd one
             const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
-            if (q < 16) mlo |= m << q;
-            else mhi |= m << (q - 16);
+            if (q < 16) elo |= m << q;
+            else ehi |= m << (q - 16);
         }
-        mask = ((uint64_t)gj_interleave16(mhi) << 32) | gj_interleave16(mlo);
+        if (active) {
+            mlo = gj_interleave16(elo);
+            mhi = gj_interleave16(ehi);
+        }
     }
-    s_dc[i] = dc;
-    s_segff[i] = 0;
-    __syncthreads();
-    GJ_PROF(1) // transform + zig-zag park
+    if (lane >= 60) L.edge[wave * 4 + (lane - 60)] = dc;
+    if (i < GJ_ENC_MAX_SPT) L.segff[i] = 0;
+    __syncthreads(); // B1: edges visible (and, for the first component, the tables)
 
-    // ---- DC prediction + pass A (lengths)
-    int dc_diff = 0;
-    uint32_t len = 0;
+    // ---- 3. the walk
+    GjWalk w = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     GjEmit e = {0, 0, 0};
-    // (nblocks: blocks of this lane's segment)
+    int dc_diff = 0;
+    {
+        // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342)
+        const int src = lane - dc_dist;
+        int pred = __builtin_amdgcn_ds_bpermute((src & 63) << 2, dc);
+        if (src < 0 && wave > 0) pred = L.edge[(wave - 1) * 4 + (4 + src)];
+        if (k - dc_dist < 0) pred = 0;
+        dc_diff = dc - pred;
+    }
     if (active) {
-        dc_diff = dc - (k - dc_dist < 0 ? 0 : s_dc[i - dc_dist]); // the previous block of the same component inside the segment
-        len = gj_code_block<false>(s_coef, s_lut, i, dc_diff, mask, table, 0, e, nullptr, 0, 0);
+        int nbits;
+        uint32_t bits;
+        gj_value_bits2(dc_diff, nbits, bits);
+        const uint32_t ent = lut_dc[nbits];
+        gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, 0, 0u, 0u);
+        gj_walk_ac<false>(col, mlo & ~1u, mhi, 0, lut_ac, w, e, nullptr, 0, 0);
     }
-    GJ_PROF(2) // pass A
-    // ---- bit positions
-    uint32_t total_bits;
-    const uint32_t incl = gj_wg256_incl_scan(len, s_tmp, &total_bits);
-    const uint32_t excl = incl - len;
-    if (active && k == 0) s_segx[j] = excl;
-    if (active && k == nblocks - 1) s_segend[j] = incl;
-    __syncthreads();
-    uint32_t my_dw = 0;
-    if (seg_in_tile) {
-        uint32_t bits = s_segend[i] - s_segx[i];
-        bits += (8u - (bits & 7u)) & 7u; // ones-padding to a byte boundary
-        s_segbits[i] = bits;
-        my_dw = (bits + 31u) >> 5;
-    }
-    if (spt <= 64) { // the segment bookkeeping of a tile fits one wave: prefix sum without workgroup barriers
-        if (i < 64) {
-            const uint32_t base_incl = gj_wave_incl_scan(my_dw);
-            if (i < spt) s_segbase[i] = base_incl - my_dw;
-            if (i == 63) s_segbase[spt] = base_incl;
-        }
-    } else {
-        uint32_t total;
-        const uint32_t base_incl = gj_wg256_incl_scan(my_dw, s_tmp, &total);
-        if (i < spt) s_segbase[i] = base_incl - my_dw;
-        if (i == 0) s_segbase[spt] = total;
-    }
-    __syncthreads();
-    const uint32_t total_dw = s_segbase[spt];
-    int pad_bits = 0;
-    uint32_t start_bit = 0, end_bit = 0;
-    if (active) {
-        start_bit = s_segbase[j] * 32u + (excl - s_segx[j]);
-        if (k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
-        end_bit = start_bit + len + (uint32_t)pad_bits;
-    }
-    GJ_PROF(3) // scans
+    const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill;
 
-    // ---- pass B window by window, then drain each window to HBM
-    for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_HUFF_CAP_DW) {
-        const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_HUFF_CAP_DW);
-        for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
-        __syncthreads();
-        if (active && end_bit > wbase * 32u && start_bit < wend * 32u && end_bit > start_bit) {
-            e.acc = 0;
-            e.accbits = (int)(start_bit & 31u);
-            e.dw = start_bit >> 5;
-            gj_code_block<true>(s_coef, s_lut, i, dc_diff, mask, table, pad_bits, e, s_bits, wbase, wend);
-            if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
+    // ---- 4. bit positions
+    const uint32_t winc = gj_wave_incl_scan(len);
+    if (lane == 63) L.wsum[wave] = winc;
+    __syncthreads(); // B2: wave totals; every walk is finished, so the window rows are free
+    {
+        const uint32_t a = L.wsum[0], b = L.wsum[1], c = L.wsum[2];
+        const uint32_t incl = winc + (wave == 0 ? 0u : wave == 1 ? a : wave == 2 ? a + b : a + b + c);
+        if (active && k == 0) L.segx[j] = incl - len;
+        if (active && k == nblocks - 1) L.segend[j] = incl;
+        w.lo = incl - len; // (parked: exclusive position, used below)
+    }
+    const uint32_t excl = w.lo;
+    {   // clear the first window
+        uint4* z = reinterpret_cast<uint4*>(s_bits) + i * 2;
+        z[0] = make_uint4(0, 0, 0, 0);
+        z[1] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads(); // B3: segment ends visible, window cleared
+    // segment books, redundantly in every wave (lane l keeps local segment l): bits with ones-padding to a byte, dword base
+    uint32_t sbits = 0, sdw = 0;
+    if (lane < spt && lane < seg_count_left) {
+        sbits = L.segend[lane] - L.segx[lane];
+        sbits += (8u - (sbits & 7u)) & 7u;
+        sdw = (sbits + 31u) >> 5;
+    }
+    const uint32_t sbase_incl = gj_wave_incl_scan(sdw);
+    const uint32_t sbase = sbase_incl - sdw;
+    const uint32_t total_dw = (uint32_t)__builtin_amdgcn_readlane((int)sbase_incl, 63);
+    if (wave == 0) {
+        if (lane < spt) { L.segbase[lane] = sbase; L.segbits[lane] = sbits; }
+        if (lane == 63) L.segbase[spt] = total_dw;
+    }
+    uint32_t start_bit = 0;
+    int pad_bits = 0;
+    {
+        const uint32_t my_base = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)sbase);
+        const uint32_t my_x = active ? L.segx[j] : 0u;
+        start_bit = my_base * 32u + (excl - my_x);
+        if (active && k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
+    }
+
+    // ---- 5. merge into the window, drain the window to HBM
+    for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {
+        const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_ENC_WIN_DW);
+        if (wbase) {
+            __syncthreads(); // previous window drained
+            for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
+            __syncthreads();
         }
-        __syncthreads();
-        GJ_PROF(4) // pass B
+        if (active && start_bit + len + (uint32_t)pad_bits > wbase * 32u && start_bit < wend * 32u) {
+            for (int f = 0; f < w.stored; f++) gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)f, *reinterpret_cast<const uint32_t*>(col + f * 1024));
+            if (!w.ovf) {
+                if (w.fill) gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)w.produced, w.hi);
+            } else {
+                // the block did not fit in place: what the accumulator held then, and the rest of the walk, directly
+                const uint32_t bp = start_bit + 32u * (uint32_t)w.stored;
+                gj_or32(s_bits, wbase, wend, bp, w.o_hi);
+                e.acc = 0;
+                e.accbits = (int)((bp + 32u) & 31u);
+                e.dw = (bp + 32u) >> 5;
+                if (w.o_fill > 32) gj_emit(e, w.o_lo >> (64 - w.o_fill), w.o_fill - 32, s_bits, wbase, wend);
+                gj_walk_ac<true>(col, w.o_mlo, w.o_mhi, w.o_prev, lut_ac, w, e, s_bits, wbase, wend);
+                if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
+            }
+            if (pad_bits) gj_or32(s_bits, wbase, wend, start_bit + len, ((1u << pad_bits) - 1u) << (32 - pad_bits));
+        }
+        __syncthreads(); // B4: window complete
         for (uint32_t d = wbase + i; d < wend; d += 256) {
             int lo = 0, hi = spt; // local segment that owns dword d
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (s_segbase[mid] <= d) lo = mid; else hi = mid;
+                if (L.segbase[mid] <= d) lo = mid; else hi = mid;
             }
-            const uint32_t bits = s_segbits[lo];
-            const uint32_t el = d - s_segbase[lo];
+            const uint32_t bits = L.segbits[lo];
+            const uint32_t el = d - L.segbase[lo];
             const uint32_t nflush = (bits + 31u) >> 5;
             const uint32_t v = s_bits[d - wbase];
             if (el < nflush) {
@@ -768,18 +934,29 @@ __device__ __forceinline__ void gj_code_tile(const GjTileLds& L, const int i, co
 #pragma unroll
                 for (int b = 0; b < 4; b++)
                     if (b < vb && ((v >> (24 - 8 * b)) & 0xFFu) == 0xFFu) ff++;
-                if (ff) atomicAdd(&s_segff[lo], ff);
+                if (ff) atomicAdd(&L.segff[lo], ff);
                 uint32_t* dst = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)lo * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
                 *dst = __builtin_bswap32(v);
             }
         }
-        __syncthreads();
     }
-    if (seg_in_tile) {
-        seg_bytes[first_segment + i] = (s_segbits[i] + 7u) >> 3;
-        seg_ff[first_segment + i] = s_segff[i];
+    __syncthreads(); // B5: 0xFF counts complete; the coefficient area may be overwritten by the next component
+    if (i < spt && i < seg_count_left) {
+        seg_bytes[first_segment + i] = (L.segbits[i] + 7u) >> 3;
+        seg_ff[first_segment + i] = L.segff[i];
     }
-    GJ_PROF(5) // drain
+}
+
+// the workgroup's Huffman tables in the layout of GjCoderLds::lut, from the host's (code << 8 | size) tables [type * 2 + is_ac][symbol]
+__device__ __forceinline__ void gj_load_coder_lut(uint32_t* s_lut, const uint32_t* __restrict__ lut, const int i)
+{
+    for (int t = i; t < 2 * 272; t += 256) {
+        const int type = t >= 272, idx = t - type * 272;
+        const bool ac = idx < 256;
+        const int sym = ac ? idx : idx - 256, nbits = ac ? (sym & 15) : sym;
+        const uint32_t old = lut[(type * 2 + (ac ? 1 : 0)) * 256 + sym];
+        s_lut[t] = (((old & 0xFFu) + (uint32_t)nbits) << 26) | ((old >> 8) << nbits);
+    }
 }
 
 // ================================================================================================
@@ -787,30 +964,28 @@ __device__ __forceinline__ void gj_code_tile(const GjTileLds& L, const int i, co
 //
 // k_fused_rgb444 + k_huffman move 2 x 199 MB of int16 coefficients through HBM for an 8K frame; measured, the store half
 // alone costs as much as all arithmetic of the kernel. Both kernels already give one thread one 8x8 block, so the
-// quantised block can stay in that thread's registers: a workgroup takes spt = 256 / B whole restart segments (B blocks
+// quantised block can stay with that thread: a workgroup takes spt = 256 / B whole restart segments (B blocks
 // each, e.g. 7 x 36 = 252 block positions) of ALL THREE component scans, colour-converts its pixels once, then for one
-// component after the other transforms the block, parks it in LDS in zig-zag order and runs the two coding passes of
-// k_huffman on it. The per-segment output (unstuffed bytes in d_temp, byte and 0xFF counts) is exactly what
-// k_scan_partial / k_assemble expect. Used for non-interleaved 4:4:4 with 0 < restart interval <= 256 blocks.
+// component after the other transforms the block into its LDS column and runs the coder above on it. The per-segment output
+// (unstuffed bytes in d_temp, byte and 0xFF counts) is exactly what k_scan_segments / k_assemble expect.
+// Used for non-interleaved 4:4:4 with restart intervals of 4 .. 256 blocks.
 // ================================================================================================
 template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
+__global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                          uint32_t* __restrict__ seg_ff, unsigned long long* __restrict__ prof)
+                                                          uint32_t* __restrict__ seg_ff)
 {
-    unsigned long long t_prof = prof ? wall_clock64() : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
-    __shared__ uint32_t s_coef[32 * 256];
-    __shared__ uint32_t s_bits[GJ_HUFF_CAP_DW];
-    __shared__ uint32_t s_lut[1024];
-    __shared__ int s_dc[256];
-    __shared__ uint32_t s_segx[256], s_segend[256], s_segbase[257], s_segbits[256], s_segff[256];
-    __shared__ uint32_t s_tmp[4];
-    const GjTileLds L = {s_coef, s_bits, s_lut, s_dc, s_segx, s_segend, s_segbase, s_segbits, s_segff, s_tmp};
+    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_edge[16];
+    __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
+    const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
-    for (int t = i; t < 1024; t += 256) s_lut[t] = lut[t];
+    gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
 
     const gj_comp_geom& k0 = g.comp[0];
@@ -818,34 +993,28 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
     const int spt = 256 / B;       // segments per workgroup (per component)
     const int tile_blocks = spt * B;
     const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
-    const int j = (int)(((uint32_t)i * recip) >> 16);
+    const int j = min((int)(((uint32_t)i * recip) >> 16), GJ_ENC_MAX_SPT - 1);
     const int k = i - j * B;       // block inside its segment
     const int seg0 = blockIdx.x * spt; // first segment (inside each component's scan)
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
     const unsigned lb = (unsigned)blockIdx.x * (unsigned)tile_blocks + (unsigned)i;
     const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
-    const int seg_count_c = k0.segment_count;
-    const bool seg_in_tile = i < spt && seg0 + i < seg_count_c; // lane i keeps the books of local segment i
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
 
     // ---- pixels -> three byte-packed component blocks
     uint32_t pk[3][16];
     gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, active, pk);
     __syncthreads(); // tables are in LDS
-    GJ_PROF(0) // pixels + colour
 
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const gj_comp_geom& kc = g.comp[c];
-        // ---- transform; zig-zag; park in LDS as [dword][lane]
-        if (c) __syncthreads(); // the previous component's coding passes are done with LDS
-        // (pinned behind the barrier: the transform of component c + 1 would otherwise be hoisted over the coding passes of c)
+        // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
 #pragma unroll
         for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[c][t]));
-        uint32_t n[32];
-        gj_fdct_quant_pk<true>(pk[c], s_q[c], n, s_coef + i); // rows park in this lane's LDS column in natural order ...
-        gj_code_tile(L, i, j, k, active, seg_in_tile, spt, B, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, temp,
-                     kc.data_offset / 64 + (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), prof, t_prof);
+        gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
+        gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0, temp,
+                     kc.data_offset / 64 + (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0));
     }
 }
 
@@ -853,27 +1022,25 @@ __global__ __launch_bounds__(256, 3) void k_encode_rgb444(const gj_geom g, const
 // k_encode_rgb444's counterpart for interleaved packed 4:2:2 without colour transform (BASELINE config 4): one lane per
 // block in CODING order (Y0 Y1 Cb Cr of MCU 0, of MCU 1, ...), a workgroup takes spt = 256 / B whole restart segments
 // (B = 4 x restart interval blocks each). All four lanes of an MCU read its 8 x 32 bytes (the same addresses merge in
-// the load unit), pick their own samples with byte permutes, transform, and the coding passes run once on the whole
+// the load unit), pick their own samples with byte permutes, transform, and the coder runs once on the whole
 // tile -- no coefficient planes, one pass instead of k_encode_rgb444's three.
-// (The coding passes are gj_code_tile, shared with k_encode_rgb444; the DC predecessor distance and the table are per lane here.)
+// (The DC predecessor distance and the table are per lane here.)
 // ================================================================================================
-__global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
+__global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                            const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                            uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                           uint32_t* __restrict__ seg_ff, unsigned long long* __restrict__ prof)
+                                                           uint32_t* __restrict__ seg_ff)
 {
-    unsigned long long t_prof = prof ? wall_clock64() : 0;
+    __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
-    __shared__ uint32_t s_coef[32 * 256];
-    __shared__ uint32_t s_bits[GJ_HUFF_CAP_DW];
-    __shared__ uint32_t s_lut[1024];
-    __shared__ int s_dc[256];
-    __shared__ uint32_t s_segx[256], s_segend[256], s_segbase[257], s_segbits[256], s_segff[256];
-    __shared__ uint32_t s_tmp[4];
-    const GjTileLds L = {s_coef, s_bits, s_lut, s_dc, s_segx, s_segend, s_segbase, s_segbits, s_segff, s_tmp};
+    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_edge[16];
+    __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
+    const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
-    for (int t = i; t < 1024; t += 256) s_lut[t] = lut[t];
+    gj_load_coder_lut(s_lut, lut, i);
     if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
 
     const gj_comp_geom& kc = g.comp[1];
@@ -882,14 +1049,13 @@ __global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, cons
     const int spt = 256 / B;       // segments per workgroup
     const int tile_blocks = spt * B;
     const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
-    const int j = (int)(((uint32_t)i * recip) >> 16);
+    const int j = min((int)(((uint32_t)i * recip) >> 16), GJ_ENC_MAX_SPT - 1);
     const int k = i - j * B;       // block inside its segment
     const int p = k & 3;           // position inside the MCU: Y0 Y1 Cb Cr
     const int seg0 = blockIdx.x * spt;
     const unsigned m = (unsigned)(seg0 + j) * (unsigned)ri + (unsigned)(k >> 2); // MCU
     const unsigned nm = (unsigned)g.mcu_count;
     const bool active = i < tile_blocks && seg0 + j < g.segment_count && m < nm;
-    const bool seg_in_tile = i < spt && seg0 + i < g.segment_count; // lane i keeps the books of local segment i
     const unsigned my = m / (unsigned)kc.blocks_x, mx = m - my * (unsigned)kc.blocks_x;
 
     // ---- pixels -> this lane's byte-packed block
@@ -948,19 +1114,15 @@ __global__ __launch_bounds__(256, 3) void k_encode_uyvy422(const gj_geom g, cons
         }
     }
     __syncthreads(); // tables are in LDS
-    GJ_PROF(0) // pixels
-
     {
-        // ---- transform; zig-zag; park in LDS as [dword][lane]
         const int table = p < 2 ? g.comp[0].type : g.comp[1].type;
 #pragma unroll
         for (int t = 0; t < 16; t++) asm volatile("" : "+v"(px[t]));
-        uint32_t n[32];
-        gj_fdct_quant_pk<true>(px, s_q[table ? 1 : 0], n, s_coef + i); // rows park in this lane's LDS column in natural order ...
-        gj_code_tile(L, i, j, k, active, seg_in_tile, spt, B, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
-                     p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, temp, (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)seg0, prof, t_prof);
+        gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
+        gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
+                     p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0, temp, (uint64_t)seg0 * B, seg_bytes,
+                     seg_ff, (uint32_t)seg0);
     }
-#undef GJ_PROF
 }
 
 // ================================================================================================
@@ -1139,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // Launcher
 // ================================================================================================
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*, int);
-typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, unsigned long long*);
+typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*);
 
 // fused kernel for this configuration, or nullptr when the generic path has to be used
 static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
@@ -1159,7 +1321,7 @@ static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
 // fully fused kernel for this configuration, or nullptr
 static gj_encode_kernel_t gj_encode_kernel(const gj_geom& g)
 {
-    if (g.pixel_format != GJ_PF_444_P012 || g.comp_count != 3 || g.interleaved || g.restart_interval <= 0 || g.seg_blocks > 256) return nullptr;
+    if (g.pixel_format != GJ_PF_444_P012 || g.comp_count != 3 || g.interleaved || g.restart_interval <= 0 || g.seg_blocks > 256 || g.seg_blocks < 256 / GJ_ENC_MAX_SPT) return nullptr;
     for (int c = 0; c < 3; c++)
         if (g.comp[c].samp_h != 1 || g.comp[c].samp_v != 1) return nullptr;
     const int from = g.color_space, to = g.color_space_internal;
@@ -1188,21 +1350,21 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                       g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
                       g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
                       g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
-    if (uyvy && !job->keep_coefs && g.interleaved && g.restart_interval > 0 && g.seg_blocks <= 256 && g.blocks_per_mcu == 4 &&
+    if (uyvy && !job->keep_coefs && g.interleaved && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT && g.blocks_per_mcu == 4 &&
         g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.comp[1].type == g.comp[2].type && !getenv("GJ_ENC_NO_WHOLE422")) {
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, (unsigned long long*)job->d_prof);
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff);
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
-                           job->d_seg_bytes, job->d_seg_ff, (unsigned long long*)job->d_prof);
+                           job->d_seg_bytes, job->d_seg_ff);
     } else {
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);

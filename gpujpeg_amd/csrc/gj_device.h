@@ -328,7 +328,8 @@ __device__ __forceinline__ void gj_fdct8(T& x0, T& x1, T& x2, T& x3, T& x4, T& x
     const T odd_diff3 = gj_fma<T>(-odd1, (T)0.707106781f, diff7);
     const T odd_diff2 = gj_fma<T>((T)0.541196100f, odd0, odd_diff5);
     const T odd_diff1 = gj_fma<T>(odd1, (T)0.707106781f, diff7);
-    x0 = (even0 + even1) + (T)level_shift;
+    // (the row passes add 0.0f in the reference: that can only turn -0 into +0, which the quantiser's rintf erases again)
+    x0 = level_shift != 0.0f ? (even0 + even1) + (T)level_shift : even0 + even1;
     x1 = odd_diff1 + odd_diff4;
     x2 = gj_fma<T>(even_diff, (T)0.707106781f, even3);
     x3 = odd_diff3 - odd_diff2;

@@ -151,7 +151,12 @@ __device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_
     const bool interior = exists && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
     uint32_t px[8][6]; // 8 rows x 24 bytes
-    if (interior && aligned) {
+    if (!exists) { // a lane without a block (tile slack, past the last block): zeros, and none of the per-byte branches below
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int w = 0; w < 6; w++) px[r][w] = 0;
+    } else if (interior && aligned) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint2* p = reinterpret_cast<const uint2*>(raw + (size_t)(by * 8 + r) * pitch + (size_t)bx * 24);
@@ -621,33 +626,23 @@ __global__ __launch_bounds__(256) void k_huffman(const gj_geom g, const int16_t*
 // workgroup tile, whole restart segments per tile.
 //
 //   1. the transform stores every quantised coefficient as 16 bits straight to its ZIG-ZAG position in the lane's own LDS column
-//      (ds_write_b16 with immediate offsets, layout [z >> 1][lane] dwords, half z & 1): no packing, no reordering pass;
-//   2. the lane reads its column back as 32 dwords and forms the 64-bit non-zero mask (v_pk_min_u16 + v_lshl_or_b32 per dword);
+//      (ds_write_b16 with immediate offsets, layout [z & 31][lane] dwords, half z >> 5): no packing, no reordering pass;
+//   2. the lane reads its column back as 32 dwords and forms the 64-bit non-zero mask (v_pk_min_u16 + v_lshl_or_b32 per dword, two
+//      v_perm_b32 at the end);
 //   3. ONE walk over the non-zero coefficients (mask + ctz) produces the block's bit stream privately: symbols go into a 64-bit
 //      register accumulator, every completed dword is stored IN PLACE over the part of the lane's column the walk has already
-//      consumed (dword f may be written once positions 2f and 2f + 1 are behind the walk; true for anything but blocks that
-//      average more than 16 bits per coefficient position), the last partial dword stays in a register;
+//      consumed (the halves of dword f go to positions 2f and 2f + 1 once both are behind the walk; true for anything but blocks
+//      that average more than 16 bits per coefficient position), the last partial dword stays in a register;
 //   4. prefix sums over the block lengths give exact bit positions inside per-segment streams; the rows of the coefficient area
 //      above GJ_ENC_PRIV_ROWS become the shared bit window (nothing else lives in LDS: 36 KB per workgroup, four per CU);
 //   5. every lane shift-merges its private dwords into the window (ds_or_b32), coalesced copy of the unstuffed segment streams to
 //      d_temp with byte and 0xFF counts per segment (k_scan_segments / k_assemble finish the stream).
 //
-// A block whose stream does not fit in place (noise at q100) keeps what fitted, finishes its walk counting only, and codes the
-// rest directly into the window from the saved walk state; a tile whose streams exceed the window takes several windows.
+// A block whose stream does not fit in place (noise at q100) continues it in its own slot of d_temp and reads it back for the
+// merge; a tile whose streams exceed the window takes several windows.
 // Symbol semantics restate src/gpujpeg_huffman_gpu_encoder.cu:139-294 / src/gpujpeg_huffman_cpu_encoder.c:136-246.
 // ================================================================================================
-// bits 0..15 of x to the even positions, bits 16..31 to the odd positions of the result
-__device__ __forceinline__ uint32_t gj_spread16(uint32_t x)
-{
-    x = (x | (x << 8)) & 0x00FF00FFu;
-    x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-__device__ __forceinline__ uint32_t gj_interleave16(uint32_t x) { return gj_spread16(x & 0xFFFFu) | (gj_spread16(x >> 16) << 1); }
-
-#define GJ_ENC_PRIV_ROWS 24                          // rows (dwords per lane) of the coefficient area that may hold private streams
+#define GJ_ENC_PRIV_ROWS 24                          // rows of the coefficient area whose lower halves may hold private streams (12 dwords per block)
 #define GJ_ENC_WIN_DW ((32 - GJ_ENC_PRIV_ROWS) * 256) // shared bit window: the remaining rows, 2048 dwords
 #define GJ_ENC_MAX_SPT 64                            // segments per tile the bookkeeping holds (restart intervals of >= 4 blocks)
 
@@ -655,8 +650,9 @@ __device__ __forceinline__ uint32_t gj_interleave16(uint32_t x) { return gj_spre
 __device__ static constexpr uint8_t GJ_IZZ[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
                                                   41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
                                                   46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
-// byte offset of zig-zag position z inside a lane's column (column base = lane * 4)
-#define GJ_COL_OFF(z) (((z) >> 1) * 1024 + ((z) & 1) * 2)
+// byte offset of zig-zag position z inside a lane's column (column base = lane * 4): dword row z & 31, half z >> 5 -- a walk over
+// the lower (upper) 32 positions addresses row * 1024 (+ 2) with one shift-add
+#define GJ_COL_OFF(z) (((z) & 31) * 1024 + ((z) >> 5) * 2)
 
 // gj_fdct_quant_pk with the stores of step 1: `col` = this lane's column base in LDS (bytes)
 __device__ __forceinline__ void gj_fdct_quant_zz(const uint32_t (&px)[16], const float* __restrict__ q, uint8_t* col)
@@ -705,80 +701,82 @@ struct GjCoderLds {
 
 // the private stream of a lane while it walks its block
 struct GjWalk {
-    uint32_t hi, lo;   // accumulator: `fill` bits, left-aligned in hi:lo (lo is only non-zero for a moment inside gj_put)
+    uint32_t hi;     // accumulator: `fill` < 32 bits, left-aligned
     int fill;
-    int produced;      // completed dwords so far
-    int stored;        // ... of which the first `stored` sit in the lane's column (== produced unless the block overflowed)
-    // walk state at the first dword that could not be stored in place (ovf): the accumulator then, the non-zero masks still to
-    // visit, the position of the last coded coefficient
-    uint32_t ovf, o_hi, o_lo, o_mlo, o_mhi;
-    int o_fill, o_prev;
+    int produced;    // completed dwords so far
+    int stored;      // the first `stored` of them sit in the lane's column, the others in the block's d_temp slot
+    int lim;         // 2 * produced + 1 while every completed dword could be stored in place; GJ_ENC_NO_STORE once one could not
 };
+#define GJ_ENC_NO_STORE 4096
 
 // append the n <= 26 bits `cw` to a lane's private stream; p = zig-zag position of the coefficient being coded (everything up to
-// it has been read), mlo/mhi = masks still to visit after p
-__device__ __forceinline__ void gj_put(GjWalk& w, const uint32_t cw, const int n, uint8_t* col, const int p, const uint32_t mlo, const uint32_t mhi)
+// it has been read). The halves of dword f may be written over positions 2f, 2f + 1 (rows 2f, 2f + 1, lower halves) once both are
+// behind the walk and the rows are private ones: lim = 2f + 1 <= min(p, GJ_ENC_PRIV_ROWS - 1). From the first dword that cannot,
+// the stream continues in the block's own slot of d_temp (`spill`, GJ_TEMP_BYTES_PER_BLOCK bytes = the largest possible block):
+// the segment's final stream, written there by the drain, never reaches a slot whose block it has not passed yet.
+__device__ __forceinline__ void gj_put(GjWalk& w, const uint32_t cw, const int n, uint8_t* col, uint32_t* __restrict__ spill, const int p)
 {
-    const uint64_t t = (uint64_t)cw << (64 - w.fill - n); // fill < 32 here, so the shift is >= 6
-    w.hi |= (uint32_t)(t >> 32);
-    w.lo = (uint32_t)t;
     w.fill += n;
+    const uint64_t t = (uint64_t)cw << (64 - w.fill); // fill was < 32, n <= 26: the shift is >= 6
+    w.hi |= (uint32_t)(t >> 32);
     if (w.fill >= 32) {
-        if (w.stored == w.produced && 2 * w.produced + 1 <= p && w.produced < GJ_ENC_PRIV_ROWS) {
-            *reinterpret_cast<uint32_t*>(col + w.produced * 1024) = w.hi;
+        if (w.lim <= min(p, GJ_ENC_PRIV_ROWS - 1)) {
+            *reinterpret_cast<uint16_t*>(col + w.produced * 2048) = (uint16_t)(w.hi >> 16);
+            *reinterpret_cast<uint16_t*>(col + w.produced * 2048 + 1024) = (uint16_t)w.hi;
+            w.lim += 2;
             w.stored++;
-        } else if (!w.ovf) {
-            w.ovf = 1; w.o_hi = w.hi; w.o_lo = w.lo; w.o_fill = w.fill; w.o_mlo = mlo; w.o_mhi = mhi; w.o_prev = p;
+        } else {
+            spill[w.produced] = w.hi;
+            w.lim = GJ_ENC_NO_STORE;
         }
         w.produced++;
-        w.hi = w.lo;
-        w.lo = 0;
+        w.hi = (uint32_t)t;
         w.fill -= 32;
     }
 }
 
-// category (bit length) and magnitude bits of a coefficient (ITU T.81 F.1.2.1.1): six operations
+// category (bit length) and magnitude bits of a coefficient (ITU T.81 F.1.2.1.1). NONZERO: v != 0 is known (AC walk).
+template <bool NONZERO>
 __device__ __forceinline__ void gj_value_bits2(const int v, int& nbits, uint32_t& bits)
 {
-    const int s = v >> 31, t = v + s; // t = v - 1 for negative v
-    nbits = 32 - __builtin_clz((uint32_t)(t ^ s) | 0u) ; // |v| = t ^ s; clz(0) is 32 on this target (v_ffbh_u32 returns -1 -> handled below)
-    nbits = v ? nbits : 0;
+    const int s = v >> 31, t = v + s;                           // t = v - 1 for negative v
+    const uint32_t a = (uint32_t)(t ^ s) | (NONZERO ? 0u : 1u); // |v| = t ^ s (the 1 keeps clz defined for v == 0)
+    nbits = 32 - __builtin_clz(a);
+    if (!NONZERO) nbits = v ? nbits : 0;
     bits = __builtin_amdgcn_ubfe((uint32_t)t, 0, (uint32_t)nbits);
 }
 
-// the AC part of a walk. DIRECT = false: private stream (gj_put). DIRECT = true: straight into the shared window (resumed blocks).
-template <bool DIRECT>
-__device__ __forceinline__ void gj_walk_ac(uint8_t* col, uint32_t mlo, uint32_t mhi, int prev, const uint32_t* lut_ac, GjWalk& w, GjEmit& e,
-                                           uint32_t* s_bits, const uint32_t wbase, const uint32_t wend)
+// the AC part of a walk: non-zero coefficients in zig-zag order, ZRL for runs of 16 zeros, EOB unless the block ends non-zero
+__device__ __forceinline__ void gj_walk_ac(uint8_t* col, const uint32_t mlo, const uint32_t mhi, const uint32_t* lut_ac, GjWalk& w,
+                                           uint32_t* __restrict__ spill)
 {
-    const uint32_t zrl = lut_ac[0xF0];
+    int prev = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         uint32_t m = half ? mhi : mlo;
         while (m) {
-            const int p = __builtin_ctz(m) + 32 * half;
+            const int b = __builtin_ctz(m), p = b + 32 * half;
             m &= m - 1;
             int run = p - prev - 1;
             prev = p;
-            const int v = *reinterpret_cast<const int16_t*>(col + (p >> 1) * 1024 + (p & 1) * 2);
-            const uint32_t r_lo = half ? 0u : m, r_hi = half ? m : mhi; // still to visit after p
-            while (run >= 16) {
-                if (DIRECT) gj_emit(e, zrl & 0x03FFFFFFu, (int)(zrl >> 26), s_bits, wbase, wend);
-                else gj_put(w, zrl & 0x03FFFFFFu, (int)(zrl >> 26), col, p, r_lo, r_hi);
-                run -= 16;
+            const int v = *reinterpret_cast<const int16_t*>(col + b * 1024 + half * 2);
+            if (run >= 16) {
+                const uint32_t zrl = lut_ac[0xF0];
+                do {
+                    gj_put(w, zrl & 0x03FFFFFFu, (int)(zrl >> 26), col, spill, p);
+                    run -= 16;
+                } while (run >= 16);
             }
             int nbits;
             uint32_t bits;
-            gj_value_bits2(v, nbits, bits);
+            gj_value_bits2<true>(v, nbits, bits);
             const uint32_t ent = lut_ac[(run << 4) | nbits];
-            if (DIRECT) gj_emit(e, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), s_bits, wbase, wend);
-            else gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, p, r_lo, r_hi);
+            gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, spill, p);
         }
     }
     if (prev != 63) {
         const uint32_t eob = lut_ac[0];
-        if (DIRECT) gj_emit(e, eob & 0x03FFFFFFu, (int)(eob >> 26), s_bits, wbase, wend);
-        else gj_put(w, eob & 0x03FFFFFFu, (int)(eob >> 26), col, 63, 0u, 0u);
+        gj_put(w, eob & 0x03FFFFFFu, (int)(eob >> 26), col, spill, 63);
     }
 }
 
@@ -812,16 +810,16 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
         uint32_t elo = 0, ehi = 0;
 #pragma unroll
         for (int q = 0; q < 32; q++) {
-            const uint32_t d = L.coef[q * 256 + i];
+            const uint32_t d = L.coef[q * 256 + i]; // positions q (lower half) and q + 32
             if (q == 0) dc = (int)(int16_t)(d & 0xFFFFu);
-            // both halves clamped to 0 / 1 (v_pk_min_u16): bit q collects the even position of dword q, bit 16 + q the odd one
+            // both halves clamped to 0 / 1 (v_pk_min_u16); elo collects rows 0..15: bit q = position q, bit 16 + q = position q + 32
             const uint32_t m = gj_pk_min_u16(d, 0x00010001u);
             if (q < 16) elo |= m << q;
             else ehi |= m << (q - 16);
         }
         if (active) {
-            mlo = gj_interleave16(elo);
-            mhi = gj_interleave16(ehi);
+            mlo = __builtin_amdgcn_perm(ehi, elo, 0x05040100u); // lower halves: positions 0..15 | 16..31
+            mhi = __builtin_amdgcn_perm(ehi, elo, 0x07060302u); // upper halves: positions 32..47 | 48..63
         }
     }
     if (lane >= 60) L.edge[wave * 4 + (lane - 60)] = dc;
@@ -829,8 +827,8 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
     __syncthreads(); // B1: edges visible (and, for the first component, the tables)
 
     // ---- 3. the walk
-    GjWalk w = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    GjEmit e = {0, 0, 0};
+    GjWalk w = {0, 0, 0, 0, 1};
+    uint32_t* const spill = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)i) * GJ_TEMP_BYTES_PER_BLOCK); // (lane i = block i of the tile)
     int dc_diff = 0;
     {
         // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342)
@@ -843,10 +841,10 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
     if (active) {
         int nbits;
         uint32_t bits;
-        gj_value_bits2(dc_diff, nbits, bits);
+        gj_value_bits2<false>(dc_diff, nbits, bits);
         const uint32_t ent = lut_dc[nbits];
-        gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, 0, 0u, 0u);
-        gj_walk_ac<false>(col, mlo & ~1u, mhi, 0, lut_ac, w, e, nullptr, 0, 0);
+        gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, spill, 0);
+        gj_walk_ac(col, mlo & ~1u, mhi, lut_ac, w, spill);
     }
     const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill;
 
@@ -854,14 +852,14 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
     const uint32_t winc = gj_wave_incl_scan(len);
     if (lane == 63) L.wsum[wave] = winc;
     __syncthreads(); // B2: wave totals; every walk is finished, so the window rows are free
+    uint32_t excl;
     {
         const uint32_t a = L.wsum[0], b = L.wsum[1], c = L.wsum[2];
         const uint32_t incl = winc + (wave == 0 ? 0u : wave == 1 ? a : wave == 2 ? a + b : a + b + c);
         if (active && k == 0) L.segx[j] = incl - len;
         if (active && k == nblocks - 1) L.segend[j] = incl;
-        w.lo = incl - len; // (parked: exclusive position, used below)
+        excl = incl - len;
     }
-    const uint32_t excl = w.lo;
     {   // clear the first window
         uint4* z = reinterpret_cast<uint4*>(s_bits) + i * 2;
         z[0] = make_uint4(0, 0, 0, 0);
@@ -900,20 +898,13 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
             __syncthreads();
         }
         if (active && start_bit + len + (uint32_t)pad_bits > wbase * 32u && start_bit < wend * 32u) {
-            for (int f = 0; f < w.stored; f++) gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)f, *reinterpret_cast<const uint32_t*>(col + f * 1024));
-            if (!w.ovf) {
-                if (w.fill) gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)w.produced, w.hi);
-            } else {
-                // the block did not fit in place: what the accumulator held then, and the rest of the walk, directly
-                const uint32_t bp = start_bit + 32u * (uint32_t)w.stored;
-                gj_or32(s_bits, wbase, wend, bp, w.o_hi);
-                e.acc = 0;
-                e.accbits = (int)((bp + 32u) & 31u);
-                e.dw = (bp + 32u) >> 5;
-                if (w.o_fill > 32) gj_emit(e, w.o_lo >> (64 - w.o_fill), w.o_fill - 32, s_bits, wbase, wend);
-                gj_walk_ac<true>(col, w.o_mlo, w.o_mhi, w.o_prev, lut_ac, w, e, s_bits, wbase, wend);
-                if (e.accbits > 0) gj_flush32(e, s_bits, wbase, wend);
+            for (int f = 0; f < w.produced; f++) {
+                uint32_t v;
+                if (f < w.stored) v = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
+                else v = spill[f];
+                gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)f, v);
             }
+            if (w.fill) gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)w.produced, w.hi);
             if (pad_bits) gj_or32(s_bits, wbase, wend, start_bit + len, ((1u << pad_bits) - 1u) << (32 - pad_bits));
         }
         __syncthreads(); // B4: window complete
@@ -928,12 +919,8 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
             const uint32_t nflush = (bits + 31u) >> 5;
             const uint32_t v = s_bits[d - wbase];
             if (el < nflush) {
-                int vb = 4;
-                if (el == nflush - 1) vb = (int)((bits - el * 32u + 7u) >> 3);
-                uint32_t ff = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (b < vb && ((v >> (24 - 8 * b)) & 0xFFu) == 0xFFu) ff++;
+                // 0xFF bytes among the valid ones (the last dword of a segment may be partial; its unused low bytes are zero)
+                const uint32_t ff = (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
                 if (ff) atomicAdd(&L.segff[lo], ff);
                 uint32_t* dst = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)lo * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
                 *dst = __builtin_bswap32(v);

@@ -220,6 +220,20 @@ typedef float gj_f2 __attribute__((ext_vector_type(2)));
 // byte k of a dword as float: the AMDGPU back end selects v_cvt_f32_ubyte<k> for this pattern
 template <int K> __device__ __forceinline__ float gj_ubyte_f(uint32_t w) { return (float)((w >> (8 * K)) & 0xFFu); }
 
+// the same as the instruction itself, for the inputs of the transforms: from the C expression the optimiser learns that the value
+// is a small integer and rewrites the first butterfly (float(a) + float(b)) into per-sample integer SDWA adds followed by 72
+// conversions per block -- 216 scalar operations where 64 conversions + 32 packed adds do. (Not for the colour transform: there
+// the compiler needs to know that the value is no signalling NaN, or every v_max_f32 gets a canonicalising twin.)
+template <int K> __device__ __forceinline__ float gj_ubyte_f_opaque(uint32_t w)
+{
+    float r;
+    if (K == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(w));
+    else if (K == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(w));
+    else if (K == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(w));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
+    return r;
+}
+
 // c * 256 / 255 for c in [-254, 255]: c + (c == 255)
 __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
 {
@@ -354,10 +368,10 @@ __device__ __forceinline__ void gj_fdct_quant_pk(const uint32_t (&px)[16], const
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t a = px[2 * r], b = px[2 * r + 1];
-        D[r][0] = gj_f2{gj_ubyte_f<0>(a), gj_ubyte_f<1>(a)};
-        D[r][1] = gj_f2{gj_ubyte_f<2>(a), gj_ubyte_f<3>(a)};
-        D[r][2] = gj_f2{gj_ubyte_f<0>(b), gj_ubyte_f<1>(b)};
-        D[r][3] = gj_f2{gj_ubyte_f<2>(b), gj_ubyte_f<3>(b)};
+        D[r][0] = gj_f2{gj_ubyte_f_opaque<0>(a), gj_ubyte_f_opaque<1>(a)};
+        D[r][1] = gj_f2{gj_ubyte_f_opaque<2>(a), gj_ubyte_f_opaque<3>(a)};
+        D[r][2] = gj_f2{gj_ubyte_f_opaque<0>(b), gj_ubyte_f_opaque<1>(b)};
+        D[r][3] = gj_f2{gj_ubyte_f_opaque<2>(b), gj_ubyte_f_opaque<3>(b)};
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) // columns first, level shift folded into the DC term

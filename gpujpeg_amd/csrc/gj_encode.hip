@@ -661,10 +661,10 @@ __device__ __forceinline__ void gj_fdct_quant_zz(const uint32_t (&px)[16], const
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t a = px[2 * r], b = px[2 * r + 1];
-        D[r][0] = gj_f2{gj_ubyte_f<0>(a), gj_ubyte_f<1>(a)};
-        D[r][1] = gj_f2{gj_ubyte_f<2>(a), gj_ubyte_f<3>(a)};
-        D[r][2] = gj_f2{gj_ubyte_f<0>(b), gj_ubyte_f<1>(b)};
-        D[r][3] = gj_f2{gj_ubyte_f<2>(b), gj_ubyte_f<3>(b)};
+        D[r][0] = gj_f2{gj_ubyte_f_opaque<0>(a), gj_ubyte_f_opaque<1>(a)};
+        D[r][1] = gj_f2{gj_ubyte_f_opaque<2>(a), gj_ubyte_f_opaque<3>(a)};
+        D[r][2] = gj_f2{gj_ubyte_f_opaque<0>(b), gj_ubyte_f_opaque<1>(b)};
+        D[r][3] = gj_f2{gj_ubyte_f_opaque<2>(b), gj_ubyte_f_opaque<3>(b)};
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) gj_fdct8<gj_f2>(D[0][c], D[1][c], D[2][c], D[3][c], D[4][c], D[5][c], D[6][c], D[7][c], -1024.0f);
@@ -780,15 +780,6 @@ __device__ __forceinline__ void gj_walk_ac(uint8_t* col, const uint32_t mlo, con
     }
 }
 
-// OR the 32 bits v (left-aligned, the stream's bits [bp, bp + 32)) into the window [wbase, wend) dwords of the tile stream
-__device__ __forceinline__ void gj_or32(uint32_t* s_bits, const uint32_t wbase, const uint32_t wend, const uint32_t bp, const uint32_t v)
-{
-    const uint32_t d = bp >> 5, s = bp & 31u;
-    const uint32_t a = v >> s, b = s ? v << (32u - s) : 0u;
-    if (a && d >= wbase && d < wend) atomicOr(&s_bits[d - wbase], a);
-    if (b && d + 1 >= wbase && d + 1 < wend) atomicOr(&s_bits[d + 1 - wbase], b);
-}
-
 // Steps 2-5 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
 // nblocks = blocks of that segment, table = 0 luminance / 1 chrominance tables, dc_dist = lanes back to the previous block of the
 // same component; first_block = coding-order index of the tile's first block (addresses d_temp), first_segment = its first segment.
@@ -890,6 +881,14 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
     }
 
     // ---- 5. merge into the window, drain the window to HBM
+    // The lane's stream is its `produced` completed dwords, then the accumulator and the ones-padding of a segment's last block as
+    // one 64-bit tail; it lands `start_bit & 31` bits into dword `start_bit >> 5` of the tile stream, so every output dword is
+    // one funnel shift (v_alignbit_b32) of two neighbouring stream dwords and one ds_or_b32.
+    const uint32_t sh = start_bit & 31u, d0 = start_bit >> 5;
+    uint64_t tail = (uint64_t)w.hi << 32;
+    if (pad_bits) tail |= (uint64_t)((1u << pad_bits) - 1u) << (64 - w.fill - pad_bits);
+    const int ndw = w.produced + (w.fill + pad_bits > 32 ? 2 : (w.fill + pad_bits > 0 ? 1 : 0)); // stream dwords incl. the tail
+    const int nseg = min(spt, seg_count_left);
     for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {
         const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_ENC_WIN_DW);
         if (wbase) {
@@ -897,38 +896,39 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
             for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
             __syncthreads();
         }
-        if (active && start_bit + len + (uint32_t)pad_bits > wbase * 32u && start_bit < wend * 32u) {
-            for (int f = 0; f < w.produced; f++) {
-                uint32_t v;
-                if (f < w.stored) v = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
-                else v = spill[f];
-                gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)f, v);
+        if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) {
+            uint32_t prevv = 0;
+            for (int f = 0; f <= ndw; f++) { // (iteration ndw only flushes the carry)
+                uint32_t cur = 0;
+                if (f < w.stored) cur = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
+                else if (f < w.produced) cur = spill[f];
+                else if (f == w.produced) cur = (uint32_t)(tail >> 32);
+                else if (f == w.produced + 1) cur = (uint32_t)tail;
+                const uint32_t out = __builtin_amdgcn_alignbit(prevv, cur, sh);
+                const uint32_t d = d0 + (uint32_t)f;
+                if (out && d >= wbase && d < wend) atomicOr(&s_bits[d - wbase], out);
+                prevv = cur;
             }
-            if (w.fill) gj_or32(s_bits, wbase, wend, start_bit + 32u * (uint32_t)w.produced, w.hi);
-            if (pad_bits) gj_or32(s_bits, wbase, wend, start_bit + len, ((1u << pad_bits) - 1u) << (32 - pad_bits));
         }
         __syncthreads(); // B4: window complete
-        for (uint32_t d = wbase + i; d < wend; d += 256) {
-            int lo = 0, hi = spt; // local segment that owns dword d
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (L.segbase[mid] <= d) lo = mid; else hi = mid;
+        // every wave drains whole segments: no search for the owner of a dword, the 0xFF count of a segment is one wave reduction
+        for (int sl = wave; sl < nseg; sl += 4) {
+            const uint32_t sb = L.segbase[sl], nfl = (L.segbits[sl] + 31u) >> 5;
+            const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
+            uint32_t* const dst = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)sl * B) * GJ_TEMP_BYTES_PER_BLOCK);
+            uint32_t ffc = 0;
+            for (uint32_t d = lo + (uint32_t)lane; d < hi; d += 64) {
+                const uint32_t v = s_bits[d - wbase];
+                // 0xFF bytes (the unused low bytes of a segment's last dword are zero)
+                ffc += (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
+                dst[d - sb] = __builtin_bswap32(v);
             }
-            const uint32_t bits = L.segbits[lo];
-            const uint32_t el = d - L.segbase[lo];
-            const uint32_t nflush = (bits + 31u) >> 5;
-            const uint32_t v = s_bits[d - wbase];
-            if (el < nflush) {
-                // 0xFF bytes among the valid ones (the last dword of a segment may be partial; its unused low bytes are zero)
-                const uint32_t ff = (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
-                if (ff) atomicAdd(&L.segff[lo], ff);
-                uint32_t* dst = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)lo * B) * GJ_TEMP_BYTES_PER_BLOCK) + el;
-                *dst = __builtin_bswap32(v);
-            }
+            ffc = gj_wave_incl_scan(ffc);
+            if (lane == 63 && ffc) L.segff[sl] += ffc;
         }
     }
     __syncthreads(); // B5: 0xFF counts complete; the coefficient area may be overwritten by the next component
-    if (i < spt && i < seg_count_left) {
+    if (i < nseg) {
         seg_bytes[first_segment + i] = (L.segbits[i] + 7u) >> 3;
         seg_ff[first_segment + i] = L.segff[i];
     }

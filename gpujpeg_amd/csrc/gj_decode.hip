@@ -302,7 +302,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
                                                   const uint32_t entry, const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab,
                                                   const int P, const uint16_t* tdc, const uint16_t* tac, int& nblk_out,
                                                   int16_t* __restrict__ coefs, const uint32_t first, const uint32_t* __restrict__ s_blk,
-                                                  int16_t* __restrict__ s_dc, int blk, const int nblocks, const uint8_t* __restrict__ s_zz, const int flags = 0,
+                                                  int16_t* __restrict__ s_dc, int blk, const int nblocks, const uint8_t* __restrict__ s_zz,
                                                   const gj_geom* lg = nullptr, const GjSeg* lsg = nullptr, uint32_t* __restrict__ tok_out = nullptr,
                                                   uint16_t* __restrict__ s_btok = nullptr, const uint32_t tok_rel = 0, uint16_t* __restrict__ s_tend = nullptr)
 {
@@ -374,7 +374,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
                     s_dc[blk + nb] = (int16_t)v;
                 } else if (sz != 0 && pos < 64) {
                     const uint32_t b = INTERLEAVED ? s_blk[blk + nb] : first + (uint32_t)(blk + nb);
-                    if (!(flags & 1)) coefs[(uint64_t)b * 64 + s_zz[pos]] = (int16_t)v;
+                    coefs[(uint64_t)b * 64 + s_zz[pos]] = (int16_t)v;
                 }
             }
         }
@@ -411,19 +411,10 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const int G,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
-                                                            unsigned long long* __restrict__ prof /* optional phase clocks (GJ_DEC_PROF) */, const int flags /* experiments */,
                                                             const int zero_fill /* 1: the planes are not known to be zero */,
                                                             uint32_t* __restrict__ d_tok /* TOK: token buffer */, const uint32_t tok_cap,
                                                             uint2* __restrict__ d_rec /* TOK: per block (coding order) token start, count << 16 | DC */)
 {
-    unsigned long long t_prof = prof ? wall_clock64() : 0;
-#define GJ_PROF(slot)                                                                            \
-    if (prof) {                                                                                  \
-        __syncthreads();                                                                         \
-        const unsigned long long now = wall_clock64();                                           \
-        if (threadIdx.x == 0) atomicAdd(&prof[slot], now - t_prof);                              \
-        t_prof = now;                                                                            \
-    }
     constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX;
     constexpr uint32_t SUB_BITS = SUB_BYTES * 8;
     __shared__ uint32_t s_U[GJ_PAR_CAP_U / 4 + 4];
@@ -549,7 +540,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         }
         __syncthreads(); // (orders the zeros before the coefficient stores of the other lanes)
     }
-    GJ_PROF(0) // setup + zero fill
 
     // (rounds and block positions are shared by the groups of whole segments and by the pieces of long segments)
     auto run_rounds = [&](const int nsub, const uint32_t ub0) {
@@ -573,8 +563,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             s_rec[k] = make_uint2(e | (x << 16), (uint32_t)nb);
         }
         __syncthreads();
-        if (prof && threadIdx.x == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[12], (unsigned long long)nwork); }
-        GJ_PROF(round == 0 ? 3 : 4) // first round / further rounds
         // next work list: sub-sequences whose predecessor leaves in another state than they were entered with (measured: walking
         // down runs of them with one lane, or seeding interleaved scans with one hypothesis per MCU block, costs more than it saves)
         for (int k0 = 0; k0 < nsub; k0 += 256) {
@@ -614,7 +602,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         }
     }
     __syncthreads();
-    GJ_PROF(5) // block positions
 
     };
     // ---- groups of segments whose unstuffed bytes fit the LDS stage (normally one group)
@@ -690,7 +677,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             }
         }
         __syncthreads();
-        GJ_PROF(1) // unstuffed copy
 
         // -- 2. sub-sequence table
         uint32_t my_nsub = 0;
@@ -711,11 +697,10 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             }
             s_subseg[k] = (uint8_t)lo;
             // assumed entry state: the first sub-sequence starts a block; any other one most likely starts in the middle of one (AC table)
-            s_rec[k] = make_uint2(((uint32_t)k == s_sub0[lo] || (flags & 4)) ? 0u : (1u << 5), 0u);
+            s_rec[k] = make_uint2((uint32_t)k == s_sub0[lo] ? 0u : (1u << 5), 0u);
             s_work[k] = (uint16_t)k; // round 0: everybody
         }
         __syncthreads();
-        GJ_PROF(2) // sub-sequence table
 
         // -- 3. rounds, 4. block positions
         run_rounds(nsub, ub0);
@@ -749,16 +734,14 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                 if (gbase != 0xFFFFFFFFu)
                     gj_decode_sub<true, INTERLEAVED, false, true>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P,
                                                                   s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, s_dc + s_bb[j], (int)before,
-                                                                  (int)s_nblk[j], s_zz, flags, nullptr, nullptr, d_tok + gbase + (sc_k >> 16), s_btok + s_bb[j],
+                                                                  (int)s_nblk[j], s_zz, nullptr, nullptr, d_tok + gbase + (sc_k >> 16), s_btok + s_bb[j],
                                                                   sc_k >> 16, s_tend + j);
             } else {
                 gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
-                                                 s_tab + (tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz, flags);
+                                                 s_tab + (tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz);
             }
         }
         __syncthreads();
-        GJ_PROF(6) // write pass
-        if (prof && threadIdx.x == 0) { atomicAdd(&prof[9], 1ull); atomicAdd(&prof[10], (unsigned long long)nsub); }
 
         // -- 6. DC prediction: one wave per segment, prefix sum per component, DC terms to HBM
         for (int j = j0 + wave; j < j1; j += 4) {
@@ -798,7 +781,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             }
         }
         __syncthreads();
-        GJ_PROF(7) // DC prediction
         j0 = j1;
     }
     // ---- segments longer than the LDS stage (restart interval 0 or very large, noise at q100): piece after piece. A piece is
@@ -882,7 +864,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                 const uint32_t endb = min((uint32_t)(k + 1) * SUB_BITS, ulen * 8u);
                 int nb;
                 gj_decode_sub<true, INTERLEAVED, true>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
-                                                       s_tab + (tb >> 16), nb, coefs, first, nullptr, nullptr, (int)(blocks_done + before), sg.nblocks, s_zz, flags,
+                                                       s_tab + (tb >> 16), nb, coefs, first, nullptr, nullptr, (int)(blocks_done + before), sg.nblocks, s_zz,
                                                        &g, &sg);
             }
             __syncthreads(); // (workgroup-scope fence: the differences are visible to the lanes that sum them up)
@@ -911,7 +893,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             src_off += chunk;
         }
     }
-#undef GJ_PROF
 }
 
 // ================================================================================================
@@ -1469,11 +1450,9 @@ __global__ __launch_bounds__(256) void k_copy_planes_out(const gj_geom g, const 
     }
 }
 
-// developer aid: GJ_DEC_DEBUG_SYNC=1 waits after every launch and names the stage on stderr (which kernel faulted?)
-static void gj_debug_stage(hipStream_t st, const char* what)
+// developer aid (gj_tuning::debug_sync): waits after every launch and names the stage on stderr (which kernel faulted?)
+static void gj_debug_stage(const bool on, hipStream_t st, const char* what)
 {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("GJ_DEC_DEBUG_SYNC"); on = e && e[0] == '1'; }
     if (!on) return;
     const hipError_t e = hipStreamSynchronize(st);
     fprintf(stderr, "[GPUJPEG] [Debug] %s: %s\n", what, hipGetErrorString(e));
@@ -1538,14 +1517,12 @@ static gj_idct_tok_t gj_idct_tok_for(const gj_geom& g)
 // Measured (8K / 16K RGB natural frames at q75, 4.75 B of stream per block: +17 % enc+dec; HD and 4K equal or slightly slower;
 // 16K 4:2:2 at q90, 10.4 B per block: -6 %; 8K noise -15 %; crossover at 8K RGB near 9 B per block): tokens pay when the frame
 // fills the GPU more than once (the token-fed IDCT has the longer dependency chain per workgroup) and blocks carry few coefficients
-// (4 B per coefficient against 128 B per block). GJ_DEC_TOKENS=1 / GJ_DEC_NO_TOKENS=1 force either mode (tests, A/B runs).
-extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size)
+// (4 B per coefficient against 128 B per block). gj_tuning::dec_tokens forces either mode (tests, A/B runs).
+extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, const gj_tuning* tune)
 {
-    if (getenv("GJ_DEC_NO_TOKENS") || gj_idct_tok_for(*g) == nullptr) return 0;
-    const char* es = getenv("GJ_DEC_SUB");
-    if (es && atoi(es) != (g->interleaved ? 32 : GJ_PAR_SUB)) return 0; // (the tuning aid sweeps the plane-mode kernels)
-    const char* et = getenv("GJ_DEC_TOKENS");
-    if (et && et[0] == '1') return 1;
+    if (tune->dec_tokens == 0 || gj_idct_tok_for(*g) == nullptr) return 0;
+    if (tune->dec_sub && tune->dec_sub != (g->interleaved ? 32 : GJ_PAR_SUB)) return 0; // (the tuning aid sweeps the plane-mode kernels)
+    if (tune->dec_tokens == 1) return 1;
     return g->block_count >= 900000 && jpeg_size <= (uint64_t)g->block_count * 8u;
 }
 
@@ -1556,14 +1533,11 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
     bool par = job->d_huff_tab2 != nullptr && job->seg_count > 0;
-    {
-        const char* e = getenv("GJ_DEC_ENTROPY"); // "serial" forces the lane-per-segment kernel (A/B measurements, tests)
-        if (e && e[0] == 's') par = false;
-    }
+    if (job->tune.dec_serial) par = false; // the lane-per-segment kernel (A/B measurements, tests)
     const bool uyvy = job->use_fused && gj_is_uyvy422(g);
     // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
     // record per block instead of through the coefficient planes
-    gj_idct_tok_t idct_tok = (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && gj_hip_decode_wants_tokens(&g, job->jpeg_size))
+    gj_idct_tok_t idct_tok = (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && gj_hip_decode_wants_tokens(&g, job->jpeg_size, &job->tune))
                                  ? gj_idct_tok_for(g) : nullptr;
     const bool tokens = idct_tok != nullptr;
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
@@ -1576,12 +1550,11 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     if (par) {
         // batch: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks
         const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
-        const char* eg = getenv("GJ_DEC_G");     // tuning aids: segments per batch, bytes per sub-sequence
-        const char* es = getenv("GJ_DEC_SUB");
-        int G = eg ? atoi(eg) : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
+        const int eg = job->tune.dec_batch, es = job->tune.dec_sub; // tuning aids: segments per batch, bytes per sub-sequence
+        int G = eg ? eg : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
         if (!eg) G = min(G, job->seg_count / 768); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
         G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / max(1, g.seg_blocks))));
-        const int sub = es ? atoi(es) : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
+        const int sub = es ? es : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
                                                                            // has to fall into step too): measured best with 32 B
         const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
         auto kernel = tokens ? (g.interleaved ? k_huffman_decode_par<true, 32, true> : k_huffman_decode_par<false, GJ_PAR_SUB, true>)
@@ -1592,8 +1565,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
                                          : sub == 64 ? k_huffman_decode_par<false, 64, false> : sub == 32 ? k_huffman_decode_par<false, 32, false>
                                          : sub == 8 ? k_huffman_decode_par<false, 8, false> : k_huffman_decode_par<false, 16, false>);
         hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                           job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, (unsigned long long*)job->d_prof,
-                           getenv("GJ_DEC_EXP") ? atoi(getenv("GJ_DEC_EXP")) : 0, job->clear_coefs ? 0 : 1, job->d_tok, job->tok_cap,
+                           job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, job->d_tok, job->tok_cap,
                            (uint2*)job->d_blkrec);
     } else {
         if (job->seg_count > 0) {
@@ -1603,7 +1575,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
                                job->d_coefs);
         }
     }
-    gj_debug_stage(st, "entropy decoder");
+    gj_debug_stage(job->tune.debug_sync != 0, st, "entropy decoder");
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
     if (tokens) {
@@ -1631,7 +1603,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
             hipLaunchKernelGGL(k_postprocess, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_planes, job->d_raw);
         }
     }
-    gj_debug_stage(st, "idct / postprocess");
+    gj_debug_stage(job->tune.debug_sync != 0, st, "idct / postprocess");
     if (job->channel_remap) { // src/gpujpeg_postprocessor.cu:450,493: the finished image is permuted in place
         const unsigned n = (unsigned)g.width * (unsigned)g.height;
         hipLaunchKernelGGL(k_channel_remap, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->channel_remap & 0xFFFFu);
@@ -1821,7 +1793,7 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
 
 extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
-                                    gj_scan_summary* d_summary, gj_stream_t stream)
+                                    gj_scan_summary* d_summary, gj_stream_t stream, int debug_sync)
 {
     hipStream_t st = (hipStream_t)stream;
     if (size <= begin) return -1;
@@ -1830,13 +1802,13 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     uint32_t* d_rst = d_scratch + chunks;   // [max_segments]
     (void)hipMemsetAsync(d_summary, 0, sizeof(gj_scan_summary), st);
     hipLaunchKernelGGL(k_marker_count, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary);
-    gj_debug_stage(st, "k_marker_count");
+    gj_debug_stage(debug_sync != 0, st, "k_marker_count");
     hipLaunchKernelGGL(k_marker_rank, dim3(1), dim3(1024), 0, st, d_chunk, chunks, d_summary);
     hipLaunchKernelGGL(k_marker_emit, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_rst, max_segments);
-    gj_debug_stage(st, "k_marker_rank + k_marker_emit");
+    gj_debug_stage(debug_sync != 0, st, "k_marker_rank + k_marker_emit");
     hipLaunchKernelGGL(k_build_segments, dim3((max_segments + GJ_MAX_COMP + 255) / 256), dim3(256), 0, st, *g, d_rst, begin, size, d_summary,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
-    gj_debug_stage(st, "k_build_segments");
+    gj_debug_stage(debug_sync != 0, st, "k_build_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

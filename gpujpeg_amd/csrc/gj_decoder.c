@@ -42,6 +42,7 @@ struct gpujpeg_decoder {
     gj_scan_summary* d_summary;
     gj_scan_summary* h_summary;   /* pinned */
     int host_scan;                /* 1: always walk the stream on the host (reference behaviour) */
+    gj_tuning tune;               /* developer switches, read from the environment when the decoder is created */
     /* header cache: a stream that starts with the same bytes (SOI .. first SOS header) as the previous one has the same
      * tables and geometry, so the call goes straight to the kernels and is validated after the fact */
     uint8_t* hdr_cache; uint8_t* d_hdr_cache; size_t hdr_cache_len; bool hdr_cache_valid;
@@ -70,7 +71,8 @@ struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
     d->coder.stream = (gj_stream_t)stream;
     d->req_pixel_format = GPUJPEG_PIXFMT_AUTODETECT;
     d->req_color_space = GPUJPEG_CS_DEFAULT;
-    d->use_fused = getenv("GPUJPEG_NO_FUSED") ? 0 : 1;
+    gj_hip_tuning_from_env(&d->tune);
+    d->use_fused = !d->tune.no_fused;
     gpujpeg_set_default_parameters(&d->coder.param);
     gpujpeg_image_set_default_parameters(&d->coder.param_image);
     d->coder.param.comp_count = 0;
@@ -85,7 +87,7 @@ struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
     d->d_summary = gj_hip_malloc(sizeof(gj_scan_summary));
     d->h_summary = gj_hip_host_alloc(sizeof(gj_scan_summary));
     if (!d->h_hdr || !d->d_summary || !d->h_summary) goto fail;
-    d->host_scan = getenv("GPUJPEG_HOST_SCAN") ? 1 : 0;
+    d->host_scan = d->tune.host_scan;
     return d;
 fail:
     GJ_ERROR("Decoder initialisation failed: %s\n", gj_hip_last_error());
@@ -222,7 +224,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     struct gj_reader_result r;
     bool device_scan = !d->host_scan;
     /* speculative path: same header as last time (compared on the device for a device-resident stream) */
-    bool spec = device_scan && d->hdr_cache_valid && image_size > d->hdr_cache_len && getenv("GJ_DEC_NO_SPEC") == NULL;
+    bool spec = device_scan && d->hdr_cache_valid && image_size > d->hdr_cache_len && !d->tune.dec_no_spec;
     if (spec && !jpeg_on_device) spec = memcmp(image, d->hdr_cache, d->hdr_cache_len) == 0;
     if (spec) {
         r = d->hdr_cache_r;
@@ -278,7 +280,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         const size_t words = gj_hip_find_segments_scratch_words(r.scan_begin[0], image_size, (uint32_t)g->segment_count);
         if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
         if (gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
-                                 d->d_scan_scratch, d->d_summary, c->stream) != 0 ||
+                                 d->d_scan_scratch, d->d_summary, c->stream, d->tune.debug_sync) != 0 ||
             (spec && jpeg_on_device && gj_hip_compare_header(d_jpeg, d->d_hdr_cache, (uint32_t)d->hdr_cache_len, d->d_summary, c->stream) != 0) ||
             gj_hip_memcpy_d2h(d->h_summary, d->d_summary, sizeof(gj_scan_summary), c->stream) != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
             GJ_ERROR("Marker scan failed: %s\n", gj_hip_last_error());
@@ -430,7 +432,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.clear_coefs = !spec && seg_count != g->segment_count;
     job.zero_coefs = 0;
     /* token mode buffers (gj_hip.h): one record per block, 4 tokens per stream byte at most */
-    if (!d->keep_coefs && job.use_fused && tab2_ok && image_size < ((size_t)1 << 29) && gj_hip_decode_wants_tokens(&job.g, image_size)) {
+    if (!d->keep_coefs && job.use_fused && tab2_ok && image_size < ((size_t)1 << 29) && gj_hip_decode_wants_tokens(&job.g, image_size, &d->tune)) {
         const size_t tok_need = (image_size * 4 + 64) * sizeof(uint32_t);
         if (tok_need > d->d_tok_cap) { /* (grown with headroom: frames of a sequence vary in size) */
             if (gj_ensure_device_buffer((void**)&d->d_tok, &d->d_tok_cap, tok_need + tok_need / 4) != 0) goto out;
@@ -444,17 +446,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         job.tok_cap = (uint32_t)(image_size * 4);
         job.d_blkrec = d->d_blkrec;
     }
-    static int prof_on = -1;
-    static uint64_t* d_prof = NULL;
-    if (prof_on < 0) {
-        const char* e = getenv("GJ_DEC_PROF");
-        prof_on = e && e[0] == '1';
-        if (prof_on) d_prof = gj_hip_malloc(16 * sizeof(uint64_t));
-    }
-    if (prof_on && d_prof) {
-        gj_hip_memset(d_prof, 0, 16 * sizeof(uint64_t), c->stream);
-        job.d_prof = d_prof;
-    }
+    job.tune = d->tune;
     if (gj_hip_decode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Decoder kernels failed: %s\n", gj_hip_last_error());
         goto out;
@@ -518,15 +510,6 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         }
     } else {
         d->hdr_cache_valid = false;
-    }
-    if (job.d_prof) {
-        uint64_t hp[16];
-        static const char* names[13] = {"setup", "unstuff", "subtable", "round0", "rounds1+", "blockpos", "write", "dc", "#rounds", "#groups", "#subs", "-", "#decodes"};
-        if (gj_hip_memcpy_d2h(hp, job.d_prof, sizeof hp, c->stream) == 0 && gj_hip_stream_sync(c->stream) == 0) {
-            fprintf(stderr, "[GPUJPEG] [Prof] entropy decoder, sums over workgroups (ticks of 10 ns):");
-            for (int i = 0; i < 13; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)hp[i]);
-            fprintf(stderr, "\n");
-        }
     }
     if (stats) {
         struct gpujpeg_duration_stats* s = &c->stats;

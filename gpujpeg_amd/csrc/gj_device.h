@@ -456,7 +456,7 @@ __device__ __forceinline__ void gj_idct8(T& v0, T& v1, T& v2, T& v3, T& v4, T& v
 // precision is 8 bit, src/gpujpeg_reader.c:682-727), so float(coef) * float(q) equals the reference's
 // float(int(coef) * int(q)) (src/gpujpeg_dct_gpu.cu:497-500).
 // px: clamped samples, one byte each, laid out like gj_fdct_quant_pk's input. clamp(rintf(x + 128)) is one
-// v_cvt_pk_u8_f32 (round to nearest even, saturating; checked against the formula on the device, tools/exp/cvt_u8.hip).
+// v_cvt_pk_u8_f32 (round to nearest even, saturating; checked against the formula on the device, tests/hooks/cvt_u8_check.hip).
 // The permuted operand order {0,4,6,2,7,5,3,1} is src/gpujpeg_dct_gpu.cu:532-539,:583-590.
 __device__ __forceinline__ void gj_idct_pk(const uint32_t (&w)[32], const float* __restrict__ qf, uint32_t (&px)[16])
 {

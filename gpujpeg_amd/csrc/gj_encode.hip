@@ -199,41 +199,9 @@ __device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_
     }
 }
 
-// test hook: the colour transform of the fused kernels applied to rows of 8 packed pixels -> three planes
-template <int CS_FROM, int CS_TO>
-__global__ __launch_bounds__(256) void k_test_color444(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const uint32_t nrows)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nrows) return;
-    uint32_t px[6], o0[2], o1[2], o2[2];
-    const uint2* p = reinterpret_cast<const uint2*>(in + (size_t)i * 24);
-    const uint2 a = p[0], b = p[1], c = p[2];
-    px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y;
-    gj_color_row<CS_FROM, CS_TO>(px, o0, o1, o2);
-    const size_t plane = (size_t)nrows * 8;
-    *reinterpret_cast<uint2*>(out + (size_t)i * 8) = make_uint2(o0[0], o0[1]);
-    *reinterpret_cast<uint2*>(out + plane + (size_t)i * 8) = make_uint2(o1[0], o1[1]);
-    *reinterpret_cast<uint2*>(out + 2 * plane + (size_t)i * 8) = make_uint2(o2[0], o2[1]);
-}
-
-extern "C" int gj_hip_test_color444(int cs_from, int cs_to, const uint8_t* d_in, uint8_t* d_out, uint32_t nrows, gj_stream_t stream)
-{
-    void (*k)(const uint8_t*, uint8_t*, uint32_t) = nullptr;
-    if (cs_from == GJ_CS_RGB && cs_to == GJ_CS_BT601_256) k = k_test_color444<GJ_CS_RGB, GJ_CS_BT601_256>;
-    if (cs_from == GJ_CS_RGB && cs_to == GJ_CS_BT601) k = k_test_color444<GJ_CS_RGB, GJ_CS_BT601>;
-    if (cs_from == GJ_CS_RGB && cs_to == GJ_CS_BT709) k = k_test_color444<GJ_CS_RGB, GJ_CS_BT709>;
-    if (cs_from == GJ_CS_BT601_256 && cs_to == GJ_CS_RGB) k = k_test_color444<GJ_CS_BT601_256, GJ_CS_RGB>;
-    if (cs_from == GJ_CS_BT601 && cs_to == GJ_CS_RGB) k = k_test_color444<GJ_CS_BT601, GJ_CS_RGB>;
-    if (cs_from == GJ_CS_BT709 && cs_to == GJ_CS_RGB) k = k_test_color444<GJ_CS_BT709, GJ_CS_RGB>;
-    if (cs_from == cs_to) k = k_test_color444<GJ_CS_NONE, GJ_CS_NONE>;
-    if (!k) return -1;
-    hipLaunchKernelGGL(k, dim3((nrows + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, nrows);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 2) void k_fused_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, int16_t* __restrict__ coefs,
-                                                         const float* __restrict__ q_luma, const float* __restrict__ q_chroma, const int flags)
+                                                         const float* __restrict__ q_luma, const float* __restrict__ q_chroma)
 {
     __shared__ __attribute__((aligned(8))) float s_q[3][64]; // forward tables: read as VGPR pairs for v_pk_mul_f32
     if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = (g.comp[threadIdx.x >> 6].type ? q_chroma : q_luma)[threadIdx.x & 63];
@@ -249,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_rgb444(const gj_geom g, const 
     for (int c = 0; c < 3; c++) {
         uint32_t q[32];
         gj_fdct_quant_pk(pk[c], s_q[c], q);
-        if (!(flags & 1) || q[5] == 0x12345678u) gj_store_block(coefs + g.comp[c].data_offset + (size_t)lb * 64, q);
+        gj_store_block(coefs + g.comp[c].data_offset + (size_t)lb * 64, q);
     }
 }
 
@@ -1287,7 +1255,7 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // ================================================================================================
 // Launcher
 // ================================================================================================
-typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*, int);
+typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
 typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*);
 
 // fused kernel for this configuration, or nullptr when the generic path has to be used
@@ -1338,7 +1306,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                       g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
                       g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
     if (uyvy && !job->keep_coefs && g.interleaved && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT && g.blocks_per_mcu == 4 &&
-        g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.comp[1].type == g.comp[2].type && !getenv("GJ_ENC_NO_WHOLE422")) {
+        g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.comp[1].type == g.comp[2].type && !job->tune.enc_no_whole422) {
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
@@ -1361,7 +1329,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
         hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_raw, job->d_coefs, job->d_fwd_q[0],
-                           job->d_fwd_q[1], getenv("GJ_ENC_EXP") ? atoi(getenv("GJ_ENC_EXP")) : 0);
+                           job->d_fwd_q[1]);
     } else {
         if (g.no_transform) {
             hipLaunchKernelGGL(k_copy_planes_in, dim3(2048), dim3(256), 0, st, g, job->d_raw, job->d_planes);

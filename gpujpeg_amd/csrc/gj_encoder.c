@@ -40,6 +40,7 @@ struct gpujpeg_encoder {
     struct gj_exif_tags* exif_tags; /* enc_exif_tag */
     uint8_t* out_buf; size_t out_cap; bool out_buf_pinned;
     int use_fused;
+    gj_tuning tune; /* developer switches, read from the environment when the encoder is created */
     int keep_coefs; /* gpujpeg_amd_encoder_keep_coefficients */
 };
 
@@ -60,7 +61,8 @@ struct gpujpeg_encoder* gpujpeg_encoder_create(cudaStream_t stream)
     e->coder.encoder = true;
     e->coder.stream = (gj_stream_t)stream;
     e->table_quality = -1;
-    e->use_fused = getenv("GPUJPEG_NO_FUSED") ? 0 : 1;
+    gj_hip_tuning_from_env(&e->tune);
+    e->use_fused = !e->tune.no_fused;
     gpujpeg_set_default_parameters(&e->coder.param);
     gpujpeg_image_set_default_parameters(&e->coder.param_image);
     e->coder.param.comp_count = 0;
@@ -270,17 +272,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.d_scan_partial = e->d_scan_partial;
     if (++e->epoch == 0) e->epoch = 1;
     job.epoch = e->epoch;
-    static int prof_on = -1;
-    static uint64_t* d_prof = NULL;
-    if (prof_on < 0) {
-        const char* pe = getenv("GJ_ENC_PROF");
-        prof_on = pe && pe[0] == '1';
-        if (prof_on) d_prof = gj_hip_malloc(8 * sizeof(uint64_t));
-    }
-    if (prof_on && d_prof) {
-        gj_hip_memset(d_prof, 0, 8 * sizeof(uint64_t), c->stream);
-        job.d_prof = d_prof;
-    }
+    job.tune = e->tune;
     job.d_scan_hdr = e->d_scan_hdr;
     memcpy(job.scan_hdr_offset, e->scan_hdrs.offset, sizeof job.scan_hdr_offset);
     memcpy(job.scan_info_payload, e->scan_hdrs.info_payload, sizeof job.scan_info_payload);
@@ -293,15 +285,6 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
         return -1;
     }
     /* size first, then the bytes (:550-563) */
-    if (job.d_prof) {
-        uint64_t hp[8];
-        static const char* names[6] = {"pixels+colour", "fdct+park", "passA", "scans", "passB", "drain"};
-        if (gj_hip_memcpy_d2h(hp, job.d_prof, sizeof hp, c->stream) == 0 && gj_hip_stream_sync(c->stream) == 0) {
-            fprintf(stderr, "[GPUJPEG] [Prof] k_encode_rgb444, sums over workgroups (ticks of 10 ns):");
-            for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)hp[i]);
-            fprintf(stderr, "\n");
-        }
-    }
     if (gj_hip_memcpy_d2h(e->h_result, e->d_result, 2 * sizeof(uint32_t), c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) {
         GJ_ERROR("Encoder failed: %s\n", gj_hip_last_error());
         return -1;

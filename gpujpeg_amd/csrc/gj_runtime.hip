@@ -2,6 +2,8 @@
 // Replaces the ~25 CUDA runtime entry points the reference's host C calls directly
 // (cudaMalloc, cudaMallocHost, cudaMemcpyAsync, cudaEvent*, ... enumerated over /root/reference/src/*.c).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <cstdio>
 #include <cstring>
@@ -118,3 +120,21 @@ float gj_hip_event_elapsed_ms(gj_event_t a, gj_event_t b)
 }
 
 } // extern "C"
+
+// the developer switches, read once per coder (gj_hip.h)
+extern "C" void gj_hip_tuning_from_env(gj_tuning* t)
+{
+    memset(t, 0, sizeof *t);
+    const char* e;
+    t->no_fused = getenv("GPUJPEG_NO_FUSED") != nullptr;
+    t->host_scan = getenv("GPUJPEG_HOST_SCAN") != nullptr;
+    t->enc_no_whole422 = getenv("GJ_ENC_NO_WHOLE422") != nullptr;
+    t->dec_tokens = -1;
+    if ((e = getenv("GJ_DEC_TOKENS")) && e[0] == '1') t->dec_tokens = 1;
+    if (getenv("GJ_DEC_NO_TOKENS")) t->dec_tokens = 0;
+    t->dec_serial = (e = getenv("GJ_DEC_ENTROPY")) && e[0] == 's';
+    t->dec_batch = (e = getenv("GJ_DEC_G")) ? atoi(e) : 0;
+    t->dec_sub = (e = getenv("GJ_DEC_SUB")) ? atoi(e) : 0;
+    t->dec_no_spec = getenv("GJ_DEC_NO_SPEC") != nullptr;
+    t->debug_sync = (e = getenv("GJ_DEC_DEBUG_SYNC")) && e[0] == '1';
+}

@@ -102,6 +102,21 @@ typedef struct gj_geom {
 } gj_geom;
 
 /* ------------------------------------------------------------------ encoder */
+/* Developer switches (A/B measurements, forced modes of the tests). Read from the environment ONCE, when a coder is created
+ * (gj_hip_tuning_from_env); the launchers never look at the environment. */
+typedef struct gj_tuning {
+    int no_fused;        /* GPUJPEG_NO_FUSED: generic kernels only */
+    int host_scan;       /* GPUJPEG_HOST_SCAN: the decoder walks the stream on the host like the reference */
+    int enc_no_whole422; /* GJ_ENC_NO_WHOLE422: packed 4:2:2 through k_fused_uyvy422 + k_huffman instead of k_encode_uyvy422 */
+    int dec_tokens;      /* GJ_DEC_TOKENS=1 -> 1 (token mode wherever a token-fed IDCT exists), GJ_DEC_NO_TOKENS -> 0, else -1 = by frame */
+    int dec_serial;      /* GJ_DEC_ENTROPY=serial: lane-per-segment entropy decoder */
+    int dec_batch;       /* GJ_DEC_G: segments per batch of the sub-sequence decoder, 0 = automatic */
+    int dec_sub;         /* GJ_DEC_SUB: bytes per sub-sequence, 0 = automatic */
+    int dec_no_spec;     /* GJ_DEC_NO_SPEC: no speculative launch on a cached header */
+    int debug_sync;      /* GJ_DEC_DEBUG_SYNC=1: wait after every decoder stage and name it on stderr */
+} gj_tuning;
+GJ_HIP_API void gj_hip_tuning_from_env(gj_tuning* t);
+
 typedef struct gj_enc_job {
     gj_geom g;
     const uint8_t* d_raw;          /* input pixels in HBM */
@@ -118,7 +133,7 @@ typedef struct gj_enc_job {
     uint32_t* d_result;            /* [0] total JPEG size, [1] overflow flag */
     uint64_t* d_scan_partial;      /* [ceil(segment_count / 1024)] epoch-tagged workgroup totals of the offset scan; zero at allocation */
     uint32_t epoch;                /* differs from the previous call's (and is never 0) */
-    uint64_t* d_prof;              /* optional [8] phase clock accumulators of k_encode_rgb444 (developer aid, GJ_ENC_PROF=1) */
+    gj_tuning tune;
     const uint8_t* d_scan_hdr;     /* scan headers back to back (APP13 placeholders zeroed + SOS) */
     uint32_t scan_hdr_offset[GJ_MAX_COMP + 1];
     uint32_t scan_info_payload[GJ_MAX_COMP]; /* offset inside scan header of the first APP13 payload, 0 = none */
@@ -135,9 +150,6 @@ typedef struct gj_enc_job {
 #define GJ_ENC_EVENTS 6
 GJ_HIP_API int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS]);
 
-/* test hook: the fp32 colour transform of the fused kernels on `nrows` rows of 8 packed pixels (24 B) -> three planes of
- * nrows * 8 bytes in d_out; colour spaces use the kernels' GJ_CS_* numbering (= the public enum). -1: pair not instantiated */
-GJ_HIP_API int gj_hip_test_color444(int cs_from, int cs_to, const uint8_t* d_in, uint8_t* d_out, uint32_t nrows, gj_stream_t stream);
 
 /* ------------------------------------------------------------------ decoder */
 typedef struct gj_dec_job {
@@ -162,7 +174,7 @@ typedef struct gj_dec_job {
     uint32_t channel_remap;        /* dec_opt_channel_remap: applied to the finished image in d_raw */
     int clear_coefs;               /* 1: d_coefs is not known to be all zero, clear it first */
     int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
-    uint64_t* d_prof;              /* optional [16] phase clock accumulators of the entropy decoder (developer aid, GJ_DEC_PROF=1) */
+    gj_tuning tune;
     /* token mode: entropy decoder -> fused IDCT without the coefficient planes (used when a token-fed IDCT kernel exists for the
      * configuration; 0 / NULL = planes) */
     int tokens;
@@ -175,7 +187,7 @@ typedef struct gj_dec_job {
 /* 1 when a frame of this geometry (requested output included) and stream size is decoded in token mode: a token-fed IDCT kernel
  * exists for it and the measured size / density rule (or the GJ_DEC_TOKENS / GJ_DEC_NO_TOKENS override) says so. The host asks
  * before it allocates d_tok / d_blkrec. */
-GJ_HIP_API int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size);
+GJ_HIP_API int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, const gj_tuning* tune);
 
 /* decode table layout per (slot, class): 1024 fast entries (len << 8 | symbol, 0 = miss) followed by
  * maxcode[18] (as u16 pairs lo/hi), valptr[17], mincode[17] and the 256 symbol values */
@@ -215,7 +227,7 @@ GJ_HIP_API int gj_hip_compare_header(const uint8_t* d_jpeg, const uint8_t* d_ref
 GJ_HIP_API size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments);
 GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
-                                    gj_scan_summary* d_summary, gj_stream_t stream);
+                                    gj_scan_summary* d_summary, gj_stream_t stream, int debug_sync);
 
 #ifdef __cplusplus
 }

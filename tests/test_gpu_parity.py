@@ -113,7 +113,8 @@ def test_exhaustive_colour_transform_fused(O, G, gpu_lib, cs_from, cs_to):
     want = O.preprocess(img, triples.reshape(-1)).reshape(3, n).T
     d_in = torch.from_numpy(triples.reshape(-1)).cuda()
     d_out = torch.empty(3 * n, dtype=torch.uint8, device="cuda")
-    fn = gpu_lib.L.gj_hip_test_color444
+    hooks = C.CDLL(os.path.join(os.path.dirname(G.PRODUCT_LIB), "libgj_testhooks.so"))  # test-only kernels over the product's device header
+    fn = hooks.gj_test_color444
     fn.restype = C.c_int
     fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     assert fn(cs_from, cs_to, d_in.data_ptr(), d_out.data_ptr(), n // 8, None) == 0

@@ -1,33 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X JPEG hot path.
+"""bench.py -- benchmark of the MI355X JPEG hot path through the libgpujpeg C ABI.
 
-metric: Mpix/s encode+decode (8K RGB q75), BASELINE.json. One step = one pass of the hot path over one
-synthetic 7680x4320 RGB frame that is already resident in HBM: gpujpeg_encoder_encode (GPU_IMAGE input,
-JPEG left in HBM) followed by gpujpeg_decoder_decode of that JPEG (device-resident stream, pixels written to
-HBM), both through the libgpujpeg C ABI. `value` = pixels of all ranks / max-over-ranks time of K steps.
+Headline (BASELINE.json `metric`): Mpix/s encode+decode of 8K RGB 4:4:4 q75 frames, non-interleaved, restart interval auto (36),
+frames resident in HBM when the timed region starts. One STEP = one pass of the hot path over one batch of synthetic input:
+every one of the S pipelines (HIP stream + encoder + decoder + host thread) codes and decodes `frames_per_step_per_pipeline`
+frames -- gpujpeg_encoder_encode (GPU_IMAGE input, stream left in HBM) followed by gpujpeg_decoder_decode of that stream into
+HBM. The batch size is fixed during warm-up so that the K timed steps take at least half a second whatever K is; `value` =
+pixels of all ranks / max-over-ranks time of exactly K steps, `ms_per_step` = that time / K.
 
-Multi-GPU: frames are independent, so ranks shard the frame batch with no data-path collective (weak scaling,
-one frame per rank and step). N > 1 is launched by torch.distributed.run; RCCL is used only for the barrier
-and the max-over-ranks reduction of the timing.
+Multi-GPU: frames are independent, ranks shard them with no data-path collective (weak scaling; RCCL carries the barrier and
+the max-over-ranks of the elapsed time only). N > 1 is launched by torch.distributed.run.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel of the step (largest average hipEvent duration), algorithmic bytes
-                (raw RGB in + JPEG out for encoder kernels, JPEG in + raw RGB out for decoder kernels;
-                SURVEY.md 8d) divided by that duration, against 8 TB/s HBM3E
-  cpu_baseline  the reference's own host C code + the restated CUDA-only stages (oracle/_ref, kind
-                "reference"; falls back to the pure restatement, kind "port") timed on one host core on a
-                bounded sample of the same workload
+On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --lean skips them):
+  roofline          the dominant kernel of the step: algorithmic bytes per launch (raw in + JPEG out for the encoder direction,
+                    JPEG in + raw out for the decoder) / its average hipEvent duration in a SOLO timed region (one pipeline, the GPU
+                    otherwise idle, events on the coder's own stream) against 8 TB/s; `by_kernel` has every kernel of the step,
+                    `contended` the same kernel inside the headline region where four pipelines share the GPU; `traffic` = HBM bytes
+                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r2_traffic.json)
+  encode_only / decode_only   each direction alone, device resident ("w/o PCIe" in the reference's tables)
+  full_api          host buffers in and out (pinned), i.e. what a drop-in caller of the reference API sees, PCIe included
+  workloads         HD / 4K / 8K / 16K RGB, 16K 4:2:2 interleaved q90 (BASELINE config 4), 256 x 4K batch (config 5)
+  cpu_baseline      the reference's CPU path as it exists (its host C with the CPU Huffman coders) + the restated scalar stages for
+                    what it only has as CUDA, one thread, on a bounded sample; `idct_cpu_s` = its own gpujpeg_idct_cpu on the same frame
+  cpu_baseline_all_cores      the same with one frame per process on the host's cores (-O3 -march=native build)
 """
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 # HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4); with the default stream and four pipeline
-# streams two of them would share a queue and serialise. Must be set before the HIP runtime starts (measured: 4 pipelines on 8
-# queues 124.5 Gpix/s, on 4 queues 105.6; 3 pipelines 119.1 either way).
+# streams two of them would share a queue and serialise. Must be set before the HIP runtime starts (measured in round 1: 4 pipelines
+# on 8 queues 124.5 Gpix/s, on 4 queues 105.6).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
@@ -39,139 +46,329 @@ from gpujpeg_amd import libgpujpeg as G  # noqa: E402
 
 WORKLOADS = {
     "hd": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320), "16k": (15360, 8640),
-    # BASELINE.json config 4: 16K YCbCr 4:2:2 (UYVY) interleaved q90 (not the headline; same measurement)
+    # BASELINE.json config 4: 16K YCbCr 4:2:2 (UYVY) interleaved q90
     "16k422": (15360, 8640), "8k422": (7680, 4320), "hd422": (1920, 1080),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
-# HBM bytes per launch of the dominant kernels from the PMC passes committed under profiles/ (8K RGB q75 natural frame):
-# FETCH_SIZE doubled (gfx950 counts 128 B requests as 64 B, guide section HBM) + WRITE_SIZE
-TRAFFIC_BYTES = {"enc:k_encode_rgb444": int((49802.4 * 2 + 8350.1) * 1024), "dec:k_huffman_decode_par": int((4463.7 * 2 + 70987.8) * 1024),
-                 "dec:k_idct_tok_rgb444": int((26587.8 * 2 + 103275.0) * 1024)}  # profiles/r1_06_solo_hbm_traffic.txt (token mode)
+DTYPE_DETAIL = "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients"
 
 
-def synth_frame(width, height, pattern, seed, device):
-    """Deterministic synthetic RGB frame generated on the device.
-    natural: smooth structure + texture + mild sensor noise (compresses like a photograph at q75)
-    noise:   the reference's `.tst` LCG noise semantics, worst case for the entropy coder
-    gradient: the reference's `.tst` default, best case"""
+def load_traffic():
+    """HBM bytes per launch from the committed PMC passes (8K RGB q75 natural frame only)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))["kernels"]
+    except Exception:
+        return {}
+
+
+def synth_frame(lib, width, height, pattern, seed, device):
+    """Deterministic synthetic RGB frame in HBM.
+    natural:  smooth structure + texture + mild sensor noise, generated on the device (compresses like a photograph at q75)
+    noise / gradient: the reference's own `.tst` generators (src/utils/image_delegate.c:562-603: the 1664525 / 1013904223 LCG
+              with seed `seed`, and rows of i * 255 / H) through gpujpeg_image_load_from_file, so the numbers can be reproduced
+              with `gpujpegtool WxH.random_<seed>.tst`"""
+    if pattern in ("noise", "gradient"):
+        name = f"{width}x{height}.{'random_%d' % seed if pattern == 'noise' else 'gradient'}.tst".encode()
+        img, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+        lib.L.gpujpeg_image_load_from_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        assert lib.L.gpujpeg_image_load_from_file(name, C.byref(img), C.byref(size)) == 0
+        host = np.ctypeslib.as_array(img, shape=(size.value,))
+        t = torch.from_numpy(host.copy()).to(device).view(height, width, 3)
+        lib.L.gpujpeg_image_destroy.argtypes = [C.POINTER(C.c_uint8)]
+        lib.L.gpujpeg_image_destroy(img)
+        return t
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    if pattern == "noise":
-        return torch.randint(0, 256, (height, width, 3), dtype=torch.uint8, device=device, generator=g)
     yy = torch.arange(height, device=device, dtype=torch.float32).view(-1, 1)
     xx = torch.arange(width, device=device, dtype=torch.float32).view(1, -1)
-    if pattern == "gradient":
-        row = (torch.arange(height, device=device) * 255 // height).to(torch.uint8).view(-1, 1, 1)
-        return row.expand(height, width, 3).contiguous()
     chans = []
     for k, (fx, fy, ph) in enumerate([(1 / 97.0, 1 / 61.0, 0.3), (1 / 53.0, 1 / 131.0, 1.1), (1 / 211.0, 1 / 89.0, 2.0)]):
         base = 128 + 70 * torch.sin(xx * fx + ph) * torch.cos(yy * fy) + 30 * torch.sin((xx + yy) * fx * 3.1 + k)
         tex = 12 * torch.sin(xx * 0.9 + yy * 0.35 + k) * torch.sin(yy * 0.7 - xx * 0.11)
         nz = 3.0 * torch.randn((height, width), device=device, generator=g)
-        chans.append(base + tex + nz)
-    return torch.stack(chans, -1).clamp(0, 255).to(torch.uint8).contiguous()
+        chans.append((base + tex + nz).clamp(0, 255).to(torch.uint8))
+    return torch.stack(chans, -1).contiguous()
 
 
-def cpu_baseline(width, height, frame_host, seconds_budget=20.0, is422=False, quality=75):
-    """Reference CPU path on the host cores (1 thread): encode + decode of the same frame."""
+def to_uyvy(frame):
+    """packed UYVY from the synthetic RGB frame: channels reused as Y / Cb / Cr, chroma point-sampled"""
+    h, w, _ = frame.shape
+    uyvy = torch.empty((h, w, 2), dtype=torch.uint8, device=frame.device)
+    uyvy[:, :, 1] = frame[:, :, 0]
+    uyvy[:, 0::2, 0] = frame[:, 0::2, 1] // 2 + 64
+    uyvy[:, 1::2, 0] = frame[:, 0::2, 2] // 2 + 64
+    return uyvy.contiguous()
+
+
+class Spec:
+    """One workload: geometry, coding parameters, the frame."""
+
+    def __init__(self, lib, name, pattern, quality, device, seed, internal_rgb=False):
+        self.name, self.pattern = name, pattern
+        self.width, self.height = WORKLOADS[name]
+        self.is422 = name.endswith("422")
+        self.quality = 90 if (self.is422 and quality == 75) else quality
+        frame = synth_frame(lib, self.width, self.height, pattern, seed, device)
+        self.frame = to_uyvy(frame) if self.is422 else frame
+        p = lib.default_parameters()
+        p.quality, p.restart_interval, p.verbose, p.perf_stats = self.quality, G.RESTART_AUTO, -1, 1
+        if internal_rgb:
+            p.color_space_internal = 1
+        pi = lib.default_image_parameters()
+        pi.width, pi.height = self.width, self.height
+        if self.is422:
+            pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG
+            p.interleaved = 1
+            lib.L.gpujpeg_parameters_chroma_subsampling(C.byref(p), G.SUBSAMPLING_422)
+        self.p, self.pi = p, pi
+        self.pixels = self.width * self.height
+        self.raw_bytes = self.pixels * (2 if self.is422 else 3)
+
+    def describe(self):
+        if self.is422:
+            return f"{self.width}x{self.height} YCbCr 4:2:2 (UYVY) q{self.quality} interleaved, restart auto"
+        return f"{self.width}x{self.height} RGB 4:4:4 q{self.quality} non-interleaved, restart auto"
+
+
+class Lanes:
+    """S independent pipelines over one Spec: stream + encoder + decoder + frame + output buffer each."""
+
+    def __init__(self, lib, spec, device, streams, host_io=False, keep_coefs=False):
+        self.lib, self.spec, self.device, self.host_io = lib, spec, device, host_io
+        self.lanes = []
+        for si in range(max(1, streams)):
+            ts = torch.cuda.Stream(device)
+            e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
+            ln = {"stream": ts, "enc": e, "dec": d}
+            if host_io:  # what a drop-in caller of the reference API has: host memory on both sides (pinned, like gpujpeg_image_load_from_file's)
+                ln["frame"] = spec.frame.cpu().pin_memory()
+                ln["out"] = torch.empty_like(ln["frame"]).pin_memory()
+                assert e.set_option("enc_opt_out", "enc_out_val_pinned") == 0
+            else:
+                ln["frame"] = spec.frame if si == 0 else spec.frame.clone()
+                ln["out"] = torch.empty_like(spec.frame)
+                assert e.set_option("enc_opt_out", "enc_out_val_device") == 0
+            if keep_coefs:
+                d.keep_coefficients()
+            d.init(spec.p, lib.default_image_parameters())  # turns perf_stats on for the decoder (same API as the reference)
+            if spec.is422:
+                d.set_output_format(G.YCBCR_JPEG, G.P1020_422)
+            self.lanes.append(ln)
+        torch.cuda.synchronize()
+
+    def encode(self, ln):
+        sp = self.spec
+        if self.host_io:
+            inp = G.EncoderInput()
+            inp.type, inp.image = G.ENCODER_INPUT_IMAGE, ln["frame"].data_ptr()
+            out, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+            assert self.lib.L.gpujpeg_encoder_encode(ln["enc"].h, C.byref(sp.p), C.byref(sp.pi), C.byref(inp), C.byref(out), C.byref(size)) == 0
+            return out, size.value
+        return ln["enc"].encode_noclone(sp.p, sp.pi, ln["frame"].data_ptr(), gpu=True)
+
+    def decode(self, ln, jp, js):
+        o = G.DecoderOutput()
+        o.type = G.DECODER_OUTPUT_CUSTOM_BUFFER if self.host_io else G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER
+        o.data = ln["out"].data_ptr()
+        assert self.lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
+
+    def warm(self, n):
+        for _ in range(max(1, n)):
+            for ln in self.lanes:
+                jp, js = self.encode(ln)
+                self.decode(ln, jp, js)
+                ln["last"] = (jp, js)
+        torch.cuda.synchronize()
+
+    def solo_kernel_ms(self, iters=10):
+        """per-kernel hipEvent durations (events on the coder's stream) with one pipeline and the GPU otherwise idle"""
+        ln = self.lanes[0]
+        acc = np.zeros(8)
+        for _ in range(iters):
+            jp, js = self.encode(ln)
+            torch.cuda.synchronize()
+            self.decode(ln, jp, js)
+            torch.cuda.synchronize()
+            acc += np.array(list(ln["enc"].kernel_times()) + list(ln["dec"].kernel_times()))
+        return acc / iters
+
+    def run(self, mode, steps, reps, barrier, local_rank):
+        """`steps` steps of `reps` frames per pipeline; returns (elapsed seconds, encode wall of lane 0, decode wall of lane 0,
+        mean contended kernel ms of lane 0)"""
+        go = threading.Event()
+        walls = [0.0, 0.0]
+        kms = np.zeros(8)
+
+        def worker(idx):
+            torch.cuda.set_device(local_rank)  # the HIP device is per host thread
+            ln = self.lanes[idx]
+            go.wait()
+            jp, js = ln["last"]
+            for _ in range(steps * reps):
+                a = time.perf_counter()
+                if mode != "decode":
+                    jp, js = self.encode(ln)
+                b = time.perf_counter()
+                if mode != "encode":
+                    self.decode(ln, jp, js)
+                c = time.perf_counter()
+                if idx == 0:
+                    walls[0] += b - a
+                    walls[1] += c - b
+                    if mode != "decode":
+                        kms[:5] += np.array(ln["enc"].kernel_times())
+                    if mode != "encode":
+                        kms[5:] += np.array(ln["dec"].kernel_times())
+            ln["last"] = (jp, js)
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(self.lanes))]
+        for t in threads:
+            t.start()
+        barrier()
+        t0 = time.perf_counter()
+        go.set()
+        for t in threads:
+            t.join()
+        barrier()
+        return time.perf_counter() - t0, walls[0], walls[1], kms / max(1, steps * reps)
+
+    def close(self):
+        for ln in self.lanes:
+            ln["enc"].close()
+            ln["dec"].close()
+        self.lanes = []
+
+
+def kernel_names(spec, enc_ms, token_mode):
+    whole = enc_ms[1] < 0.02 * max(1.0, spec.pixels / 33e6)  # fully fused encoder: pixels -> segment streams in one kernel (slots 0/1 empty)
+    fmt = "uyvy422" if spec.is422 else "rgb444"
+    return ["enc:k_preprocess", f"enc:k_fused_{fmt}", f"enc:k_encode_{fmt}" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
+            "dec:k_huffman_decode_par", f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}", "dec:k_postprocess"]
+
+
+def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, steps=20, warmup=3, min_seconds=0.5, host_io=False, keep_coefs=False,
+            want_solo=False):
+    """Run one workload; returns a dict with throughput and timings."""
+    L = Lanes(lib, spec, device, streams, host_io=host_io, keep_coefs=keep_coefs)
+    L.warm(warmup)
+    solo = L.solo_kernel_ms() if want_solo else None
+    # fix the batch: frames per pipeline and step so that `steps` steps last >= min_seconds
+    t_probe, *_ = L.run(mode, 1, 2, lambda: torch.cuda.synchronize(), local_rank)
+    per_frame = max(t_probe / 2, 1e-6)
+    reps = max(1, int(np.ceil(1.15 * min_seconds / (steps * per_frame)))) if min_seconds > 0 else 1
+    elapsed, enc_wall, dec_wall, kms = L.run(mode, steps, reps, barrier, local_rank)
+    jsize = int(L.lanes[0]["last"][1])
+    S = len(L.lanes)
+    L.close()
+    return {"elapsed": elapsed, "reps": reps, "streams": S, "enc_wall": enc_wall, "dec_wall": dec_wall, "kernel_ms": kms, "solo_ms": solo,
+            "jpeg_bytes": jsize, "frames": S * steps * reps}
+
+
+def cpu_baseline(spec, frame_host, frames=2):
+    """the reference's CPU path on ONE host thread: its own host C (driver, writer/reader, CPU Huffman coders)
+    + the restated scalar stages for colour / fDCT+quantiser / dequantiser+IDCT (oracle/_ref/libgpujpeg_refcpu.so, gcc -O2)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    kind = "reference" if O.have_ref() else "port"
-    t_start = time.time()
-    frames = 0
-    if kind == "reference":
-        ref = G.Library(O.REF_PATH)
+    path = os.path.join(O.HERE, "_ref", "libgpujpeg_refcpu.so")
+    w, h, q, is422 = spec.width, spec.height, spec.quality, spec.is422
+    t0 = time.time()
+    if os.path.exists(path):
+        kind = "reference"
+        ref = G.Library(path)
         enc, dec = G.Encoder(ref), G.Decoder(ref)
         p = ref.default_parameters()
-        p.restart_interval, p.verbose = G.RESTART_AUTO, -1
+        p.restart_interval, p.verbose, p.quality = G.RESTART_AUTO, -1, q
         pi = ref.default_image_parameters()
-        pi.width, pi.height = width, height
-        p.quality = quality
+        pi.width, pi.height = w, h
         if is422:
             pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG
             p.interleaved = 1
             dec.set_output_format(G.YCBCR_JPEG, G.P1020_422)
-        while True:
+        t_enc = t_dec = 0.0
+        for _ in range(frames):
+            a = time.time()
             jpeg = enc.encode(p, pi, frame_host)
+            b = time.time()
             dec.decode(jpeg)
-            frames += 1
-            if time.time() - t_start > seconds_budget * 0.5 or frames >= 4:
-                break
+            t_enc += b - a
+            t_dec += time.time() - b
+        ref.L.gjref_time_idct_cpu.restype = C.c_double
+        ref.L.gjref_time_idct_cpu.argtypes = [C.c_void_p]
+        idct_cpu = float(ref.L.gjref_time_idct_cpu(dec.h))
     else:
-        img = (O.make_image(width, height, pixel_format=3, color_space=3, quality=quality, interleaved=1) if is422
-               else O.make_image(width, height, quality=quality))
-        while True:
+        kind, idct_cpu = "port", None
+        img = (O.make_image(w, h, pixel_format=3, color_space=3, quality=q, interleaved=1) if is422 else O.make_image(w, h, quality=q))
+        t_enc = t_dec = 0.0
+        for _ in range(frames):
+            a = time.time()
             jpeg = O.encode(img, frame_host)
+            b = time.time()
             O.decode(jpeg, 3, 3) if is422 else O.decode(jpeg)
-            frames += 1
-            if time.time() - t_start > seconds_budget * 0.5 or frames >= 4:
-                break
-    dt = time.time() - t_start
-    return {"value": round(width * height * frames / dt / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": kind,
-            "sample": f"{frames} x encode+decode of the {width}x{height} {'UYVY 4:2:2' if is422 else 'RGB'} q{quality} frame, single thread, "
-                      f"reference host C (writer/reader/CPU Huffman) + restated colour/DCT/IDCT stages, gcc -O2"}
+            t_enc += b - a
+            t_dec += time.time() - b
+    dt = time.time() - t0
+    px = w * h * frames
+    return {"value": round(px / (t_enc + t_dec) / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": kind,
+            "encode_mpix_s": round(px / t_enc / 1e6, 3), "decode_mpix_s": round(px / t_dec / 1e6, 3),
+            "idct_cpu_s": None if idct_cpu is None else round(idct_cpu, 3),
+            "sample": f"{frames} x encode+decode of the {spec.describe()} frame on one thread ({dt:.1f} s): reference host C (writer / reader / CPU Huffman, "
+                      f"gcc -O2) + restated scalar colour, fDCT+quantiser, dequantiser+IDCT; idct_cpu_s = the reference's own integer gpujpeg_idct_cpu "
+                      f"(src/gpujpeg_dct_cpu.c:178-203) on that frame's coefficients"}
 
 
 _CPU_CHILD = r"""
 import sys, time
 import numpy as np
-root, path, w, h, q, is422, frames = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6] == "1", int(sys.argv[7])
-sys.path.insert(0, root); sys.path.insert(0, root + "/oracle")
-import oracle as O
+root, lib, path, w, h, q, is422, frames = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7] == "1", int(sys.argv[8])
+sys.path.insert(0, root)
 from gpujpeg_amd import libgpujpeg as G
 frame = np.load(path)
-ref = G.Library(O.REF_PATH) if O.have_ref() else None
+ref = G.Library(lib)
+enc, dec = G.Encoder(ref), G.Decoder(ref)
+p = ref.default_parameters(); p.restart_interval, p.verbose, p.quality = G.RESTART_AUTO, -1, q
+pi = ref.default_image_parameters(); pi.width, pi.height = w, h
+if is422:
+    pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG; p.interleaved = 1; dec.set_output_format(G.YCBCR_JPEG, G.P1020_422)
 t0 = time.time()
-if ref is not None:
-    enc, dec = G.Encoder(ref), G.Decoder(ref)
-    p = ref.default_parameters(); p.restart_interval, p.verbose, p.quality = G.RESTART_AUTO, -1, q
-    pi = ref.default_image_parameters(); pi.width, pi.height = w, h
-    if is422:
-        pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG; p.interleaved = 1; dec.set_output_format(G.YCBCR_JPEG, G.P1020_422)
-    for _ in range(frames):
-        dec.decode(enc.encode(p, pi, frame))
-else:
-    img = O.make_image(w, h, pixel_format=3, color_space=3, quality=q, interleaved=1) if is422 else O.make_image(w, h, quality=q)
-    for _ in range(frames):
-        j = O.encode(img, frame); O.decode(j, 3, 3) if is422 else O.decode(j)
+for _ in range(frames):
+    dec.decode(enc.encode(p, pi, frame))
 print(time.time() - t0)
 """
 
 
-def cpu_baseline_all_cores(width, height, frame_host, is422=False, quality=75, max_procs=32):
-    """the reference's CPU path admits frame-level parallelism only -- one independent encode+decode per
-    process on as many host cores as there are (capped), the same frame in each; aggregate Mpix/s over the slowest process."""
+def cpu_baseline_all_cores(spec, frame_host, max_procs=64):
+    """the reference's CPU code admits frame-level parallelism only -- one independent encode+decode per process
+    on the host's cores (capped), the same frame in each; aggregate Mpix/s over the slowest process. -O3 -march=native build."""
     import subprocess
     import tempfile
+    lib = os.path.join(ROOT, "oracle", "_ref", "libgpujpeg_refcpu_native.so")
+    if not os.path.exists(lib):
+        return None
     procs = max(1, min(max_procs, (os.cpu_count() or 1)))
     with tempfile.NamedTemporaryFile(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None, delete=False) as f:
         np.save(f, frame_host)
         path = f.name
     try:
         t0 = time.time()
-        kids = [subprocess.Popen([sys.executable, "-c", _CPU_CHILD, ROOT, path, str(width), str(height), str(quality), "1" if is422 else "0", "1"],
-                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(procs)]
+        kids = [subprocess.Popen([sys.executable, "-c", _CPU_CHILD, ROOT, lib, path, str(spec.width), str(spec.height), str(spec.quality),
+                                  "1" if spec.is422 else "0", "1"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(procs)]
         inner = [float(k.communicate(timeout=300)[0].decode().strip().splitlines()[-1]) for k in kids]
         wall = time.time() - t0
     finally:
         os.unlink(path)
-    return {"value": round(width * height * procs / max(inner) / 1e6, 3), "unit": "Mpix/s", "cores": procs, "kind": "reference" if os.path.exists(
-        os.path.join(ROOT, "oracle", "_ref", "libgpujpeg_ref.so")) else "port",
-        "sample": f"{procs} processes x 1 encode+decode of the same {width}x{height} frame at once (frame-level parallelism, the only kind the "
-                  f"reference's CPU code admits); slowest process {max(inner):.2f} s, {wall:.1f} s including start-up"}
+    return {"value": round(spec.pixels * procs / max(inner) / 1e6, 3), "unit": "Mpix/s", "cores": procs, "host_cores": os.cpu_count(), "kind": "reference",
+            "sample": f"{procs} processes x 1 encode+decode of the same {spec.width}x{spec.height} frame at once (frame-level parallelism, the only kind the "
+                      f"reference's CPU code admits), gcc -O3 -march=native; slowest process {max(inner):.2f} s, {wall:.1f} s including start-up"}
 
 
-def run_batch(args, lib, device, local_rank, rank, world, width, height):
+def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=True):
     """BASELINE.json config 5 / SURVEY.md 8(d): a batch of independent frames, frame i seeded 12345 + i, sharded over the
     ranks by gpujpeg_amd.sharding.shard_frames (static round-robin, no data-path collective). Every rank keeps its shard
     resident in HBM, S pipelines (stream + encoder + decoder + host thread) walk disjoint slices of it."""
-    import threading
     import torch.distributed as dist
     from gpujpeg_amd.sharding import barrier_and_max, gather_counts, shard_frames
-    if args.workload.endswith("422"):
-        raise SystemExit("--batch is defined for the RGB workloads")
     mine = shard_frames(args.batch, rank, world)
-    frames = [synth_frame(width, height, args.pattern, 12345 + i, device) for i in mine]
+    frames = [synth_frame(lib, width, height, args.pattern, 12345 + i, device) for i in mine]
     S = max(1, min(args.streams, len(frames)))
     p = lib.default_parameters()
     p.quality, p.restart_interval, p.verbose = args.quality, G.RESTART_AUTO, -1
@@ -182,10 +379,10 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height):
         ts = torch.cuda.Stream(device)
         e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
         assert e.set_option("enc_opt_out", "enc_out_val_device") == 0
-        lanes.append({"frames": frames[si::S], "out": torch.empty_like(frames[0]), "enc": e, "dec": d, "bytes": 0})
+        lanes.append({"frames": frames[si::S], "out": torch.empty_like(frames[0]), "enc": e, "dec": d, "bytes": 0, "digest": []})
     torch.cuda.synchronize()
 
-    def one_pass(ln):
+    def one_pass(ln, digest=False):
         nbytes = 0
         for f in ln["frames"]:
             jp, js = ln["enc"].encode_noclone(p, pi, f.data_ptr(), gpu=True)
@@ -209,6 +406,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height):
         for _ in range(passes):
             one_pass(lanes[idx])
 
+    elapsed = 0.0
     for passes, timed in ((args.warmup, False), (args.steps, True)):
         threads = [threading.Thread(target=worker, args=(i, passes, timed)) for i in range(S)]
         for t in threads:
@@ -225,50 +423,82 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height):
     # the last decoded frame of pipeline 0 must match its input closely (sanity of the timed work, not the parity test)
     last = lanes[0]["frames"][-1].float()
     mse = float(((lanes[0]["out"].float() - last) ** 2).mean().item())
+    verified = None
+    if args.verify:  # every frame of this rank's shard against the CPU oracle: encoder bytes (sha256) and decoded samples
+        verified = verify_batch(lib, lanes, p, pi, width, height, args.quality, mine, S)
     elapsed = barrier_and_max(elapsed, device)
     total = gather_counts(len(mine), device)
     jpeg_bytes = gather_counts(sum(ln["bytes"] for ln in lanes), device)
+    if verified is not None:
+        verified = gather_counts(0 if verified else 1, device) == 0
     for ln in lanes:
         ln["enc"].close()
         ln["dec"].close()
-    if rank == 0:
-        fps = total * args.steps / elapsed
-        print(json.dumps({
-            "metric": f"frames/s encode+decode (batch of {args.batch} {args.workload} frames)", "value": round(fps, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "dtype_detail": "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients",
-            "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) resident in HBM, sharded round-robin",
-            "config": {"workload": f"{args.batch} x {width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto, encode then decode of "
-                                   f"every frame per step", "frames_total": total, "frames_per_gpu": len(mine), "streams_per_gpu": S,
-                       "jpeg_bytes_total": jpeg_bytes, "parallelism": f"frame-sharded x{world}, no collective"},
-            "mpix_s": round(fps * width * height / 1e6, 2), "psnr_last_frame_db": round(10 * np.log10(255.0 ** 2 / max(mse, 1e-9)), 2)}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    fps = total * args.steps / elapsed
+    result = {
+        "metric": f"frames/s encode+decode (batch of {args.batch} {args.workload} frames)", "value": round(fps, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL,
+        "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) resident in HBM, sharded round-robin",
+        "config": {"workload": f"{args.batch} x {width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto, encode then decode of "
+                               f"every frame per step", "frames_total": total, "frames_per_gpu": len(mine), "streams_per_gpu": S,
+                   "jpeg_bytes_total": jpeg_bytes, "parallelism": f"frame-sharded x{world}, no collective"},
+        "mpix_s": round(fps * width * height / 1e6, 2), "psnr_last_frame_db": round(10 * np.log10(255.0 ** 2 / max(mse, 1e-9)), 2)}
+    if verified is not None:
+        result["verified_bit_exact"] = verified
+    if emit:
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    return result
+
+
+def verify_batch(lib, lanes, p, pi, width, height, quality, mine, S):
+    """oracle check of a rank's shard (tests / --verify only; the oracle is the checker, never the thing measured)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    ok = True
+    img = O.make_image(width, height, quality=quality)
+    for si, ln in enumerate(lanes):
+        for f in ln["frames"]:
+            host = f.cpu().numpy().reshape(-1)
+            want = O.encode(img, host)
+            jp, js = ln["enc"].encode_noclone(p, pi, f.data_ptr(), gpu=True)
+            jt = torch.empty(js, dtype=torch.uint8, device=f.device)
+            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(jt.data_ptr()), C.cast(jp, C.c_void_p), C.c_size_t(js), 3)
+            o = G.DecoderOutput()
+            o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
+            assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
+            torch.cuda.synchronize()
+            ok = ok and bool(np.array_equal(jt.cpu().numpy(), want)) and bool(np.array_equal(ln["out"].cpu().numpy().reshape(-1), O.decode(want)[0]))
+    return ok
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
     ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient"])
     ap.add_argument("--quality", type=int, default=75)
     ap.add_argument("--batch", type=int, default=0,
                     help="BASELINE.json config 5: a fixed batch of this many distinct frames (seeds 12345 + i) sharded over the ranks "
                          "(strong scaling, frames/s); a step is one pass over the whole batch")
-    ap.add_argument("--streams", type=int, default=4, help="independent encoder+decoder pairs per GPU, each on its own HIP stream and host thread; "
-                    "one step codes one frame per stream (hides the host side of one call behind the kernels of the other)")
+    ap.add_argument("--streams", type=int, default=4, help="independent encoder+decoder pairs per GPU, each on its own HIP stream and host thread "
+                    "(hides the host side of one call behind the kernels of the others)")
     ap.add_argument("--mode", default="both", choices=["both", "encode", "decode"],
-                    help="what a timed step does: encode then decode (the headline metric), or only one direction (SURVEY 8d asks for both "
-                         "separately; the decoder then decodes the stream of the warm-up's last encode again and again)")
+                    help="what a timed step does: encode then decode (the headline metric), or only one direction")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="lower bound of the timed region: the frames per pipeline and step are chosen for it")
+    ap.add_argument("--lean", action="store_true", help="headline + roofline only (no other workloads, no full-API run, no CPU baselines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-all-cores", action="store_true", help="also time the CPU path on all host cores (one frame per process), SURVEY 8(d) row (ii)")
+    ap.add_argument("--no-workloads", action="store_true")
     ap.add_argument("--internal-rgb", action="store_true", help="code RGB without colour transform (tuning aid; not the headline config)")
     ap.add_argument("--calibrate", action="store_true", help="run a 256 MiB device fill + copy first (known byte counts for calibrating PMC traffic counters)")
     ap.add_argument("--keep-coefs", action="store_true", help="decoder keeps its coefficients in HBM (adds the per-frame clear; tuning aid)")
-    ap.add_argument("--verify", action="store_true", help="check the round trip of the last frame against the oracle (slow)")
+    ap.add_argument("--verify", action="store_true", help="check the results of the last frame(s) against the oracle (slow)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,67 +506,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)  # (more ranks than devices: the 2-process proof on one GPU, tests/test_gpu_multiproc.py)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl" if ndev >= world else "gloo", **({"device_id": device} if ndev >= world else {}))
 
     lib = G.Library()  # raises if the HIP library has not been built: there is no fallback
-    assert lib.L.gpujpeg_init_device(local_rank, 0) == 0
+    assert lib.L.gpujpeg_init_device(dev_index, 0) == 0
     width, height = WORKLOADS[args.workload]
-    is422 = args.workload.endswith("422")
     if args.batch:
-        return run_batch(args, lib, device, local_rank, rank, world, width, height)
-    frame = synth_frame(width, height, args.pattern, 12345 + rank, device)
-    if is422:  # packed UYVY from the synthetic RGB frame: channels reused as Y / Cb / Cr, chroma point-sampled
-        f = frame.view(height, width, 3)
-        uyvy = torch.empty((height, width, 2), dtype=torch.uint8, device=device)
-        uyvy[:, :, 1] = f[:, :, 0]
-        uyvy[:, 0::2, 0] = f[:, 0::2, 1] // 2 + 64
-        uyvy[:, 1::2, 0] = f[:, 0::2, 2] // 2 + 64
-        frame = uyvy.contiguous()
-        if args.quality == 75:
-            args.quality = 90
-    import threading
-    S = max(1, args.streams)
-    lanes = []  # one pipeline per stream: its own frame, output buffer, stream, encoder and decoder
-    for si in range(S):
-        f = frame if si == 0 else frame.clone()
-        ts = torch.cuda.current_stream(device) if S == 1 else torch.cuda.Stream(device)
-        e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
-        assert e.set_option("enc_opt_out", "enc_out_val_device") == 0
-        lanes.append({"frame": f, "out": torch.empty_like(f), "stream": ts, "enc": e, "dec": d})
-    torch.cuda.synchronize()
-    enc, dec, out = lanes[0]["enc"], lanes[0]["dec"], lanes[0]["out"]
-    p = lib.default_parameters()
-    p.quality, p.restart_interval, p.verbose, p.perf_stats = args.quality, G.RESTART_AUTO, -1, 1
-    if args.internal_rgb:
-        p.color_space_internal = 1
-    pi = lib.default_image_parameters()
-    pi.width, pi.height = width, height
-    if is422:
-        pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG
-        p.interleaved = 1
-        lib.L.gpujpeg_parameters_chroma_subsampling(C.byref(p), G.SUBSAMPLING_422)
-    for ln in lanes:
-        if args.keep_coefs:
-            ln["dec"].keep_coefficients()
-        ln["dec"].init(p, lib.default_image_parameters())  # turns perf_stats on for the decoder (same API as the reference)
-        if is422:
-            ln["dec"].set_output_format(G.YCBCR_JPEG, G.P1020_422)
-
-    def step(ln):
-        jptr, jsize = ln["enc"].encode_noclone(p, pi, ln["frame"].data_ptr(), gpu=True)
-        o = G.DecoderOutput()
-        o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
-        rc = lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jptr, C.c_void_p), jsize, C.byref(o))
-        assert rc == 0
-        return jptr, jsize
+        if args.workload.endswith("422"):
+            raise SystemExit("--batch is defined for the RGB workloads")
+        return run_batch(args, lib, device, dev_index, rank, world, width, height)
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if ndev >= world:
+                dist.barrier()
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     if args.calibrate:
@@ -344,136 +536,127 @@ def main():
         cal_b = cal_a.clone()
         torch.cuda.synchronize()
         del cal_a, cal_b
-    solo_ms = np.zeros(8)  # kernel durations with the GPU to themselves (untimed warm-up of pipeline 0; reference for the roofline)
-    for _ in range(max(1, args.warmup)):
-        for ln in lanes:
-            jptr, jsize = step(ln)
-            ln["last"] = (jptr, jsize)
-    torch.cuda.synchronize()
-    for _ in range(3):
-        jptr, jsize = step(lanes[0])
-        torch.cuda.synchronize()
-        solo_ms += np.array(list(lanes[0]["enc"].kernel_times()) + list(lanes[0]["dec"].kernel_times()))
-    solo_ms /= 3
-    enc_ms = np.zeros(5)
-    dec_ms = np.zeros(3)
-    walls = [0.0, 0.0]
-    go = threading.Event()
 
-    def worker(idx):
-        torch.cuda.set_device(local_rank)  # the HIP device is per host thread
-        ln = lanes[idx]
-        go.wait()
-        jp, js = ln["last"]
-        for _ in range(args.steps):
-            a = time.perf_counter()
-            if args.mode != "decode":
-                jp, js = ln["enc"].encode_noclone(p, pi, ln["frame"].data_ptr(), gpu=True)
-            b = time.perf_counter()
-            if args.mode != "encode":
-                o = G.DecoderOutput()
-                o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
-                assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
-            c = time.perf_counter()
-            if idx == 0:  # per-kernel hipEvent durations of pipeline 0 (its kernels may share the GPU with the other pipelines')
-                walls[0] += b - a
-                walls[1] += c - b
-                if args.mode != "decode":
-                    enc_ms[:] += np.array(ln["enc"].kernel_times())
-                if args.mode != "encode":
-                    dec_ms[:] += np.array(ln["dec"].kernel_times())
-            ln["last"] = (jp, js)
-
-    threads = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
-    for t in threads:
-        t.start()
-    barrier()
-    t0 = time.perf_counter()
-    go.set()
-    for t in threads:
-        t.join()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    enc_wall, dec_wall = walls
-    jptr, jsize = lanes[0]["last"]
+    spec = Spec(lib, args.workload, args.pattern, args.quality, device, 12345 + rank, internal_rgb=args.internal_rgb)
+    head = measure(lib, spec, device, dev_index, barrier, mode=args.mode, streams=args.streams, steps=args.steps, warmup=args.warmup,
+                   min_seconds=args.min_seconds, keep_coefs=args.keep_coefs, want_solo=True)
+    elapsed = head["elapsed"]
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if ndev >= world else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    enc_ms /= args.steps
-    dec_ms /= args.steps
 
-    result = None
     if rank == 0:
-        pixels = width * height
-        raw_bytes = pixels * (2 if is422 else 3)
-        whole = enc_ms[1] < 0.02  # fully fused encoder: pixels -> segment streams in one kernel (event slots 0/1 are empty)
-        fmt = "uyvy422" if is422 else "rgb444"
-        # the decoder picks token mode for large, sparse frames (gj_decode.hip: >= 900 K blocks, <= 8 stream bytes per block)
-        nblocks = ((width + 7) // 8) * ((height + 7) // 8) * (2 if is422 else 3)
-        token_mode = (not is422) and nblocks >= 900000 and jsize <= 8 * nblocks and not args.keep_coefs \
-            and not os.environ.get("GJ_DEC_NO_TOKENS")
-        names = ["enc:k_preprocess", f"enc:k_fused_{fmt}(pre+dct+quant)",
-                 f"enc:k_encode_{fmt}(pixels->entropy-coded segments)" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
-                 "dec:k_huffman_decode_par(+fallback launch)",
-                 f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}(idct+post)", "dec:k_postprocess"]
-        # the PMC passes under profiles/ were taken on the default 8K workload only
-        traffic_known = args.workload == "8k" and args.quality == 75 and args.pattern == "natural"
-        durs = list(enc_ms) + list(dec_ms)
-        dom = int(np.argmax(durs))
-        alg = raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (same sum)
-        achieved = alg / (durs[dom] * 1e-3) / 1e9
+        S, reps, jsize = head["streams"], head["reps"], head["jpeg_bytes"]
+        nblocks = ((width + 7) // 8) * ((height + 7) // 8) * (2 if spec.is422 else 3)
+        token_mode = (not spec.is422) and nblocks >= 900000 and jsize <= 8 * nblocks and not args.keep_coefs and not os.environ.get("GJ_DEC_NO_TOKENS")
+        names = kernel_names(spec, head["solo_ms"], token_mode)
+        alg = spec.raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (the same sum)
+        solo, cont = head["solo_ms"], head["kernel_ms"]
+        traffic = load_traffic() if (args.workload == "8k" and spec.quality == 75 and args.pattern == "natural" and not args.internal_rgb) else {}
+
+        def roof(name, ms):
+            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "ms": round(float(ms), 4), "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
+
+        live = [i for i in range(8) if solo[i] > 0.006]  # (event slots of kernels this configuration does not launch hold only the gap between two events)
+        dom = max(live, key=lambda i: solo[i])
+        by_kernel = [dict(roof(names[i], solo[i]), traffic=traffic.get(names[i])) for i in live]
+        r = roof(names[dom], solo[dom])
+        enc_total, dec_total = float(solo[:5].sum()), float(solo[5:].sum())
         result = {
             "metric": ("Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})") if args.mode == "both"
-                      else f"Mpix/s {args.mode} only ({args.workload})", "value": round(pixels * world * S * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
+                      else f"Mpix/s {args.mode} only ({args.workload})",
+            "value": round(spec.pixels * world * head["frames"] / elapsed / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients",
-            "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per stream",
-            "config": {"workload": (f"{width}x{height} YCbCr 4:2:2 (UYVY) q{args.quality} interleaved, restart auto, encode then decode per step" if is422 else
-                                    f"{width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto ({width}x{height} -> "
-                                    f"{'36' if args.workload in ('8k', '16k') else 'auto'}), encode then decode per step"),
-                       "frames_per_step_per_gpu": S, "streams_per_gpu": S, "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective"},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL,
+            "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per pipeline",
+            "config": {"workload": spec.describe() + (" (7680x4320 -> 36)" if args.workload == "8k" else "") + ", encode then decode of every frame",
+                       "frames_per_step_per_gpu": S * reps, "frames_per_step_per_pipeline": reps, "streams_per_gpu": S, "timed_seconds": round(elapsed, 3),
+                       "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective"},
             # API calls of pipeline 0 alone (one call at a time per pipeline; the aggregate of all pipelines is `value`)
-            "encode_mpix_s": round(pixels * args.steps / enc_wall / 1e6, 2) if args.mode != "decode" else None,
-            "decode_mpix_s": round(pixels * args.steps / dec_wall / 1e6, 2) if args.mode != "encode" else None,
-            "kernel_ms": {n: round(float(d), 4) for n, d in zip(names, durs)},
-            "gpu_only_ms": {"encode": round(float(enc_ms.sum()), 4), "decode": round(float(dec_ms.sum()), 4)},
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES.get(names[dom].split("(")[0]) if traffic_known else None,
-                         "algorithmic_bytes_per_launch": int(alg), "concurrent_pipelines": S,
-                         "note": "duration = average hipEvent duration of one launch in the timed region, where launches of the other "
-                                 "pipelines share the GPU; traffic = FETCH_SIZE x 2 + WRITE_SIZE per launch from profiles/ (separate PMC passes)"},
-            "roofline_solo": {"kernel": names[int(np.argmax(solo_ms))], "ms": round(float(solo_ms.max()), 4),
-                              "achieved": round(alg / (float(solo_ms.max()) * 1e-3) / 1e9, 2), "unit": "GB/s",
-                              "frac": round(alg / (float(solo_ms.max()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                              "kernel_ms": {n: round(float(d), 4) for n, d in zip(names, solo_ms)}},
+            "encode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["enc_wall"] / 1e6, 2) if args.mode != "decode" else None,
+            "decode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["dec_wall"] / 1e6, 2) if args.mode != "encode" else None,
+            "roofline": {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"],
+                         "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg),
+                         "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
+                                   "coder's stream); profiles/r2_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
+                         "by_kernel": by_kernel,
+                         "by_direction": {"encode": dict(roof("all encoder kernels", enc_total)), "decode": dict(roof("all decoder kernels", dec_total))},
+                         "contended": dict(roof(names[dom], cont[dom]), concurrent_pipelines=S,
+                                           kernel_ms={names[i]: round(float(cont[i]), 4) for i in live})},
         }
         if args.verify:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as O
-            host = frame.cpu().numpy().reshape(-1)
-            img = (O.make_image(width, height, pixel_format=3, color_space=3, quality=args.quality, interleaved=1) if is422
-                   else O.make_image(width, height, quality=args.quality, color_space_internal=1 if args.internal_rgb else 3))
-            want = O.encode(img, host)
-            got = np.ctypeslib.as_array(C.cast(jptr, C.POINTER(C.c_uint8)), shape=(1,))  # device pointer: copy through torch
-            jt = torch.empty(jsize, dtype=torch.uint8, device=device)
-            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(jt.data_ptr()), C.cast(jptr, C.c_void_p), C.c_size_t(jsize), 3)
-            torch.cuda.synchronize()
-            result["verified_bit_exact_encode"] = bool(np.array_equal(jt.cpu().numpy(), want))
-            result["verified_bit_exact_decode"] = bool(np.array_equal(out.cpu().numpy().reshape(-1), (O.decode(want, 3, 3) if is422 else O.decode(want))[0]))
-            del got
-        if not args.no_cpu_baseline and world == 1:  # reported baseline, on the host cores of rank 0 at N = 1 only
-            host_frame = frame.cpu().numpy().reshape(-1)
-            result["cpu_baseline"] = cpu_baseline(width, height, host_frame, is422=is422, quality=args.quality)
-            if args.cpu_all_cores:
-                result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(width, height, host_frame, is422=is422, quality=args.quality)
+            result.update(verify_headline(lib, spec, device, args))
+        if world == 1 and not args.lean:
+            extras(result, args, lib, spec, device, dev_index, barrier)
         print(json.dumps(result), flush=True)
-    for ln in lanes:
-        ln["enc"].close()
-        ln["dec"].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def verify_headline(lib, spec, device, args):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    L = Lanes(lib, spec, device, 1)
+    ln = L.lanes[0]
+    jp, js = L.encode(ln)
+    L.decode(ln, jp, js)
+    torch.cuda.synchronize()
+    host = spec.frame.cpu().numpy().reshape(-1)
+    img = (O.make_image(spec.width, spec.height, pixel_format=3, color_space=3, quality=spec.quality, interleaved=1) if spec.is422
+           else O.make_image(spec.width, spec.height, quality=spec.quality, color_space_internal=1 if args.internal_rgb else 3))
+    want = O.encode(img, host)
+    jt = torch.empty(js, dtype=torch.uint8, device=device)
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(jt.data_ptr()), C.cast(jp, C.c_void_p), C.c_size_t(js), 3)
+    torch.cuda.synchronize()
+    r = {"verified_bit_exact_encode": bool(np.array_equal(jt.cpu().numpy(), want)),
+         "verified_bit_exact_decode": bool(np.array_equal(ln["out"].cpu().numpy().reshape(-1), (O.decode(want, 3, 3) if spec.is422 else O.decode(want))[0]))}
+    L.close()
+    return r
+
+
+def extras(result, args, lib, spec, device, dev_index, barrier):
+    """The bounded extra runs of rank 0 at N = 1 (see the module docstring)."""
+    def brief(spec_, m):
+        px = spec_.pixels * m["frames"]
+        return {"mpix_s": round(px / m["elapsed"] / 1e6, 1), "ms_per_frame": round(m["elapsed"] / m["frames"] * 1e3, 4), "jpeg_bytes": m["jpeg_bytes"],
+                "streams": m["streams"], "timed_seconds": round(m["elapsed"], 3)}
+
+    if args.mode == "both":
+        for mode in ("encode", "decode"):
+            m = measure(lib, spec, device, dev_index, barrier, mode=mode, streams=args.streams, steps=5, warmup=2, min_seconds=0.3)
+            result[f"{mode}_only"] = dict(brief(spec, m), note="device resident (GPU_IMAGE in / stream in HBM, HBM buffer out): the reference's 'w/o PCIe' figure")
+        full = {}
+        for mode in ("encode", "decode", "both"):
+            m = measure(lib, spec, device, dev_index, barrier, mode=mode, streams=args.streams, steps=3, warmup=1, min_seconds=0.3, host_io=True)
+            full[mode if mode != "both" else "encode_decode"] = brief(spec, m)
+        full["note"] = ("host buffers in and out (pinned; GPUJPEG_ENCODER_INPUT_IMAGE / enc_out_val_pinned, host JPEG in / CUSTOM_BUFFER out): what a drop-in "
+                        "caller of the reference API sees, PCIe transfers included")
+        result["full_api"] = full
+    if not args.no_workloads and args.workload == "8k" and args.mode == "both":
+        table = {"8k": {"mpix_s": result["value"], "ms_per_frame": round(result["ms_per_step"] / result["config"]["frames_per_step_per_gpu"], 4),
+                        "jpeg_bytes": result["config"]["jpeg_bytes"], "streams": result["config"]["streams_per_gpu"]}}
+        for name in ("hd", "4k", "16k", "16k422"):
+            sp = Spec(lib, name, args.pattern, args.quality, device, 12345)
+            m = measure(lib, sp, device, dev_index, barrier, mode="both", streams=args.streams, steps=5, warmup=2, min_seconds=0.3, want_solo=True)
+            table[name] = dict(brief(sp, m), workload=sp.describe(),
+                               solo_gpu_ms={"encode": round(float(m["solo_ms"][:5].sum()), 4), "decode": round(float(m["solo_ms"][5:].sum()), 4)})
+            del sp
+            torch.cuda.empty_cache()
+        ba = argparse.Namespace(**vars(args))
+        ba.batch, ba.workload, ba.steps, ba.warmup, ba.verify = 256, "4k", 2, 1, False
+        b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS["4k"], emit=False)
+        table["batch256_4k"] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"]}
+        torch.cuda.empty_cache()
+        result["workloads"] = table
+    if not args.no_cpu_baseline:  # reported baselines, on the host cores of rank 0 at N = 1 only
+        host_frame = spec.frame.cpu().numpy().reshape(-1)
+        result["cpu_baseline"] = cpu_baseline(spec, host_frame)
+        ac = cpu_baseline_all_cores(spec, host_frame)
+        if ac:
+            result["cpu_baseline_all_cores"] = ac
 
 
 if __name__ == "__main__":

@@ -298,3 +298,24 @@ void gjref_quant_tables(int type, int quality, uint8_t raw[64], float fwd[64], u
     gpujpeg_table_quantization_decoder_init(&t, (enum gpujpeg_component_type)type, quality);
     memcpy(raw, t.table_raw, 64);
 }
+
+/* the reference's integer CPU IDCT (src/gpujpeg_dct_cpu.c:178-203, not parity-equal with the CUDA kernels) over the
+ * coefficients of the last gpujpeg_decoder_decode() call, on a scratch copy; returns the seconds it took (bench.py cpu_baseline) */
+#include <time.h>
+#include "gpujpeg_dct_cpu.h"
+double gjref_time_idct_cpu(struct gpujpeg_decoder* decoder)
+{
+    struct gpujpeg_coder* coder = &decoder->coder;
+    if (coder->data_quantized == NULL && gpujpeg_coder_allocate_cpu_huffman_buf(coder) != 0) return -1.0;
+    memcpy(coder->data_quantized, coder->d_data_quantized, coder->data_size * sizeof(int16_t));
+    uint8_t* keep = malloc(coder->data_size); /* gpujpeg_idct_cpu writes the planes the caller may still read */
+    if (!keep) return -1.0;
+    memcpy(keep, coder->d_data, coder->data_size);
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    gpujpeg_idct_cpu(decoder);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    memcpy(coder->d_data, keep, coder->data_size);
+    free(keep);
+    return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 TAG=${TAG:-r2_xx}
-ARGS="--streams ${STREAMS:-1} --mode ${MODE:-encode} --no-cpu-baseline ${BENCH_ARGS}"
+ARGS="--streams ${STREAMS:-1} --mode ${MODE:-encode} --lean ${BENCH_ARGS}"
 rm -rf $OUT/prof_stats $OUT/prof_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python bench.py --steps ${STEPS:-100} --warmup 5 $ARGS > $OUT/prof_stats.log 2>&1
 tail -1 $OUT/prof_stats.log | cut -c1-300

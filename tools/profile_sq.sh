@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 rm -rf $OUT/prof_sq
-rocprofv3 --kernel-trace --pmc ${COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY} --output-format csv -d $OUT/prof_sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $OUT/prof_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc ${COUNTERS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY} --output-format csv -d $OUT/prof_sq -- python bench.py --steps 3 --warmup 1 --lean --min-seconds 0 ${BENCH_ARGS} > $OUT/prof_sq.log 2>&1
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/prof_sq/**/*counter_collection.csv", recursive=True)

@@ -63,8 +63,30 @@ def traffic(d, out, note):
     print(open(out).read())
 
 
+ENCODER_KERNELS = ("k_encode_", "k_fused_", "k_preprocess", "k_copy_planes_in", "k_dct", "k_huffman<", "k_huffman(", "k_scan_segments", "k_assemble", "k_segment_info")
+
+
+def traffic_json(d, out, note):
+    """HBM bytes per launch for bench.py's roofline.traffic: FETCH_SIZE (KiB, 64 B units counted per 128 B request on gfx950 -> x 2,
+    /opt/skills/guides/MI355X_MICROARCH.md) + WRITE_SIZE (KiB)"""
+    import json
+    fe = counter_table(d, "prof_fetch", "FETCH_SIZE")
+    wr = counter_table(d, "prof_write", "WRITE_SIZE")
+    kernels = {}
+    for k in set(fe) | set(wr):
+        if not k.startswith("k_"):
+            continue
+        nf, sf = fe[k]
+        nw, sw = wr[k]
+        base = k.split("<")[0]
+        name = ("enc:" if (k + "(").startswith(ENCODER_KERNELS) or base.startswith(ENCODER_KERNELS) else "dec:") + base
+        kernels[name] = int(((sf / nf if nf else 0) * 2 + (sw / nw if nw else 0)) * 1024)
+    json.dump({"note": note + "; bytes per launch = FETCH_SIZE x 2 + WRITE_SIZE (separate --pmc passes)", "kernels": kernels}, open(out, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     d, tag = sys.argv[1], sys.argv[2]
     note = " ".join(sys.argv[3:]) or "cmd: see tools/profile.sh (python bench.py, 8K RGB q75 natural pattern)"
     kernel_stats(d, os.path.join(d, tag + "_kernel_stats.txt"), note)
     traffic(d, os.path.join(d, tag + "_hbm_traffic.txt"), note)
+    traffic_json(d, os.path.join(d, tag + "_traffic.json"), note)

@@ -142,8 +142,9 @@ def test_full_size_rgb_bit_exact(O, G, gpu_lib, name, w, h, restart):
 
 
 def test_16k_422_interleaved_q90(O, G, gpu_lib):
-    """BASELINE.json config 4: 15360x8640 YCbCr 4:2:2 packed, interleaved, q90 -- checked through size-independent
-    properties (round trip PSNR, determinism) and bit-exact on a 1/16 crop against the oracle."""
+    """BASELINE.json config 4 at full size: 15360x8640 YCbCr 4:2:2 packed (UYVY), interleaved, q90 -- every byte of the stream and every
+    decoded sample against the oracle (k_encode_uyvy422 / the interleaved sub-sequence decoder / k_idct_fused_uyvy422 on 4.1 M blocks,
+    172 800 restart segments)."""
     w, h = 15360, 8640
     rng = np.random.default_rng(3)
     yy, xx = np.mgrid[0:h // 8, 0:w // 8]
@@ -151,29 +152,89 @@ def test_16k_422_interleaved_q90(O, G, gpu_lib):
     y = np.kron(base, np.ones((8, 8), np.float32)) + rng.normal(0, 4, (h, w)).astype(np.float32)
     raw = np.empty((h, w, 2), np.uint8)
     raw[:, :, 1] = np.clip(y, 0, 255)
-    raw[:, 0::2, 0] = 110
-    raw[:, 1::2, 0] = 150
+    raw[:, 0::2, 0] = (110 + 20 * np.sin(xx / 9.0)).astype(np.uint8).repeat(8, 0).repeat(4, 1)
+    raw[:, 1::2, 0] = (150 + 20 * np.cos(yy / 7.0)).astype(np.uint8).repeat(8, 0).repeat(4, 1)
     raw = raw.reshape(-1)
+    del y, base
     case = ("16k", w, h, 3, 3, 90, -1, 1, None, 3)
+    want = O.encode(oracle_image(O, case), raw)
     p, pi = api_params(gpu_lib, G, case)
     enc = G.Encoder(gpu_lib)
     jpeg = enc.encode(p, pi, raw)
-    assert np.array_equal(enc.encode(p, pi, raw), jpeg)
+    assert np.array_equal(jpeg, want), "16K 4:2:2 stream differs from the oracle"
+    assert np.array_equal(enc.encode(p, pi, raw), jpeg), "encoding is deterministic"
+    enc.close()
     dec = G.Decoder(gpu_lib)
     dec.set_output_format(3, 3)
     px, info = dec.decode(jpeg)
     assert (info.width, info.height, info.pixel_format) == (w, h, 3)
+    assert np.array_equal(px, O.decode(want, 3, 3)[0]), "16K 4:2:2 decoded samples differ from the oracle"
     assert psnr(px, raw) > 38.0
-    # crop: first 960 rows x 3840 columns, bit-exact
-    cw, ch = 3840, 960
-    crop = raw.reshape(h, w * 2)[:ch, :cw * 2].copy().reshape(-1)
-    ccase = ("crop", cw, ch, 3, 3, 90, 6, 1, None, 3)
-    p2, pi2 = api_params(gpu_lib, G, ccase)
-    want = O.encode(oracle_image(O, ccase), crop)
-    assert np.array_equal(G.Encoder(gpu_lib).encode(p2, pi2, crop), want)
-    d2 = G.Decoder(gpu_lib)
-    d2.set_output_format(3, 3)
-    assert np.array_equal(d2.decode(want)[0], O.decode(want, 3, 3)[0])
+    dec.close()
+
+
+def test_16k_rgb_vs_oracle(O, G, gpu_lib):
+    """The largest RGB frame of the BASELINE configurations, 15360x8640 q75, takes token mode by itself: stream and decoded samples
+    against the oracle at full size."""
+    w, h = 15360, 8640
+    rng = np.random.default_rng(16)
+    yy, xx = np.mgrid[0:h // 16, 0:w // 16]
+    base = np.stack([128 + 90 * np.sin(xx / 23.0) * np.cos(yy / 17.0), xx * 255.0 / (w // 16), yy * 255.0 / (h // 16)], -1).astype(np.float32)
+    img = np.kron(base, np.ones((16, 16, 1), np.float32))
+    img += rng.normal(0, 3, (h, w, 1)).astype(np.float32)
+    raw = np.clip(img, 0, 255).astype(np.uint8).reshape(-1)
+    del img, base
+    case = ("16k", w, h, 1, 1, 75, -1, 0, None, 3)
+    want = O.encode(oracle_image(O, case), raw)
+    p, pi = api_params(gpu_lib, G, case)
+    enc = G.Encoder(gpu_lib)
+    assert np.array_equal(enc.encode(p, pi, raw), want)
+    enc.close()
+    dec = G.Decoder(gpu_lib)
+    px = dec.decode(want)[0]
+    dec.close()
+    assert np.array_equal(px, O.decode(want)[0])
+
+
+@pytest.mark.parametrize("pattern", ["noise", "gradient"])
+def test_8k_tst_patterns_vs_oracle(O, G, gpu_lib, pattern):
+    """The reference's own synthetic patterns (src/utils/image_delegate.c:562-603, through gpujpeg_image_load_from_file of a .tst name) at
+    8K: worst and best case for the entropy coder, bit-exact against the oracle in both directions."""
+    import bench
+    import torch
+    w, h = 7680, 4320
+    raw = bench.synth_frame(gpu_lib, w, h, pattern, 12345, torch.device("cuda", 0)).cpu().numpy().reshape(-1)
+    if pattern == "noise":
+        assert np.array_equal(raw[:64], O.noise(64, seed=12345)), "the product's .tst LCG and the oracle's disagree"
+    case = ("8k", w, h, 1, 1, 75, -1, 0, None, 3)
+    want = O.encode(oracle_image(O, case), raw)
+    p, pi = api_params(gpu_lib, G, case)
+    enc = G.Encoder(gpu_lib)
+    assert np.array_equal(enc.encode(p, pi, raw), want)
+    enc.close()
+    dec = G.Decoder(gpu_lib)
+    px = dec.decode(want)[0]
+    dec.close()
+    assert np.array_equal(px, O.decode(want)[0])
+
+
+def test_batch_frames_vs_oracle(O, G, gpu_lib):
+    """BASELINE.json config 5: eight of the 256 frames of the 4K batch (seed 12345 + i, bench.py's generator), stream and decoded
+    samples against the oracle."""
+    import bench
+    import torch
+    w, h = 3840, 2160
+    case = ("4k", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    enc, dec = G.Encoder(gpu_lib), G.Decoder(gpu_lib)
+    img = oracle_image(O, case)
+    for i in (0, 1, 37, 64, 101, 128, 200, 255):
+        raw = bench.synth_frame(gpu_lib, w, h, "natural", 12345 + i, torch.device("cuda", 0)).cpu().numpy().reshape(-1)
+        want = O.encode(img, raw)
+        assert np.array_equal(enc.encode(p, pi, raw), want), i
+        assert np.array_equal(dec.decode(want)[0], O.decode(want)[0]), i
+    enc.close()
+    dec.close()
 
 
 def test_reconfiguration_and_reuse(O, G, gpu_lib):
@@ -327,7 +388,9 @@ def test_token_mode_decoder(O, G, gpu_lib, tc, monkeypatch):
         px, _ = dec.decode(jpeg)
         assert np.array_equal(px, want)
         assert np.array_equal(dec.decode(other)[0], O.decode(other)[0])
-    monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
+    dec.close()
+    monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")  # (the switches are read when a decoder is created)
+    dec = G.Decoder(gpu_lib)
     assert np.array_equal(dec.decode(jpeg)[0], want)
     dec.close()
 
@@ -383,38 +446,16 @@ def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
         raw = raw.reshape(-1)[: O.raw_size(w, h, 3)].copy()
     jpeg = O.encode(oracle_image(O, case), raw)
     want = O.decode(jpeg, 3, 3)[0]
-    monkeypatch.setenv("GJ_DEC_TOKENS", "1")
+    monkeypatch.setenv("GJ_DEC_TOKENS", "1")  # (the switches are read when a decoder is created)
     dec = G.Decoder(gpu_lib)
     dec.set_output_format(3, 3)
     for _ in range(2):
         assert np.array_equal(dec.decode(jpeg)[0], want)
+    dec.close()
     monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
+    dec = G.Decoder(gpu_lib)
+    dec.set_output_format(3, 3)
     assert np.array_equal(dec.decode(jpeg)[0], want)
     dec.close()
 
 
-def test_token_mode_equals_plane_mode_16k(O, G, gpu_lib, monkeypatch):
-    """16K RGB (the largest frame of the BASELINE configurations) takes token mode by itself; the pixels must equal the
-    plane-mode decoder's, which the smaller cases pin against the oracle. Also a size-independent round-trip check."""
-    w, h = 15360, 8640
-    rng = np.random.default_rng(16)
-    yy, xx = np.mgrid[0:h // 16, 0:w // 16]
-    base = np.stack([128 + 90 * np.sin(xx / 23.0) * np.cos(yy / 17.0), xx * 255.0 / (w // 16), yy * 255.0 / (h // 16)], -1).astype(np.float32)
-    img = np.kron(base, np.ones((16, 16, 1), np.float32))
-    img += rng.normal(0, 3, (h, w, 1)).astype(np.float32)
-    raw = np.clip(img, 0, 255).astype(np.uint8).reshape(-1)
-    del img, base
-    case = ("16k", w, h, 1, 1, 75, -1, 0, None, 3)
-    p, pi = api_params(gpu_lib, G, case)
-    enc = G.Encoder(gpu_lib)
-    jpeg = enc.encode(p, pi, raw)
-    enc.close()
-    dec = G.Decoder(gpu_lib)
-    monkeypatch.delenv("GJ_DEC_TOKENS", raising=False)
-    monkeypatch.delenv("GJ_DEC_NO_TOKENS", raising=False)
-    tok = dec.decode(jpeg)[0]
-    monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
-    plane = dec.decode(jpeg)[0]
-    dec.close()
-    assert np.array_equal(tok, plane)
-    assert psnr(tok[: w * 3 * 512], raw[: w * 3 * 512]) > 32.0

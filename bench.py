@@ -368,6 +368,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     import torch.distributed as dist
     from gpujpeg_amd.sharding import barrier_and_max, gather_counts, shard_frames
     mine = shard_frames(args.batch, rank, world)
+    red = device if (world == 1 or dist.get_backend() == "nccl") else None  # where the reductions of the timing live (gloo: host)
     frames = [synth_frame(lib, width, height, args.pattern, 12345 + i, device) for i in mine]
     S = max(1, min(args.streams, len(frames)))
     p = lib.default_parameters()
@@ -426,11 +427,11 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     verified = None
     if args.verify:  # every frame of this rank's shard against the CPU oracle: encoder bytes (sha256) and decoded samples
         verified = verify_batch(lib, lanes, p, pi, width, height, args.quality, mine, S)
-    elapsed = barrier_and_max(elapsed, device)
-    total = gather_counts(len(mine), device)
-    jpeg_bytes = gather_counts(sum(ln["bytes"] for ln in lanes), device)
+    elapsed = barrier_and_max(elapsed, red)
+    total = gather_counts(len(mine), red)
+    jpeg_bytes = gather_counts(sum(ln["bytes"] for ln in lanes), red)
     if verified is not None:
-        verified = gather_counts(0 if verified else 1, device) == 0
+        verified = gather_counts(0 if verified else 1, red) == 0
     for ln in lanes:
         ln["enc"].close()
         ln["dec"].close()
@@ -525,10 +526,7 @@ def main():
 
     def barrier():
         if world > 1:
-            if ndev >= world:
-                dist.barrier()
-            else:
-                dist.barrier()
+            dist.barrier()
         torch.cuda.synchronize()
 
     if args.calibrate:

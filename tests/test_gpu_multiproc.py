@@ -1,0 +1,62 @@
+"""-m gpu: the multi-GPU paths with real codec work in more than one process / thread.
+
+The GPU box of the test tier has ONE MI355X, so both proofs run their ranks / devices on device 0 (bench.py maps rank r to device
+r mod device_count and then carries its barrier and timing reduction over gloo; tools/mgpu_encode.c maps device d to d mod
+device_count). What is checked is what an 8-GPU run relies on: the shards cover the batch exactly once, every rank's frames are
+bit-exact against the oracle while another rank codes at the same time, and the reductions produce one whole-job line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(nproc, args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints exactly one line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_shard_a_batch_bit_exact(gpu_lib):
+    """BASELINE config 5 in small: 16 HD frames (seeds 12345 + i) over 2 ranks, every frame of every shard checked against the oracle."""
+    d = _torchrun(2, ["--gpus", "2", "--batch", "16", "--workload", "hd", "--steps", "2", "--warmup", "1", "--verify"])
+    assert d["n_gpus"] == 2 and d["config"]["frames_total"] == 16 and d["config"]["frames_per_gpu"] == 8
+    assert d["verified_bit_exact"] is True
+    assert d["scaling"] == "strong" and d["value"] > 0 and d["psnr_last_frame_db"] > 30
+
+
+def test_two_ranks_headline_line(gpu_lib):
+    """the weak-scaling headline path at N = 2: one JSON line, whole-job throughput over both ranks, per-rank frames of their own seed"""
+    d = _torchrun(2, ["--gpus", "2", "--workload", "hd", "--steps", "3", "--warmup", "1", "--min-seconds", "0.1", "--lean", "--verify"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["verified_bit_exact_encode"] is True and d["verified_bit_exact_decode"] is True
+    assert d["roofline"]["frac"] > 0
+
+
+def test_mgpu_encode_threads_and_pinned_staging(gpu_lib):
+    """tools/mgpu_encode.c: one host thread per coder, pinned staging, 2 coders per device, 2 (virtual) devices, encode + decode of 48 HD
+    frames; equal frames must give equal streams on every coder."""
+    exe = os.path.join(ROOT, "gpujpeg_amd", "lib", "mgpu_encode")
+    assert os.path.exists(exe), "built by gpujpeg_amd/csrc/Makefile"
+    r = subprocess.run([exe, "48", "1920", "1080", "2", "2", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["ok"] and d["frames"] == 48 and d["streams_consistent"] and d["coders_per_device"] == 2

@@ -1,0 +1,175 @@
+/*
+ * mgpu_encode -- frame-sharded encoding (and optionally decoding) over the GPUs of one node through the libgpujpeg C API, the way
+ * SURVEY.md 8(e) describes the deployment: no collective, one host thread per coder, every coder bound to one device and one
+ * stream, frames pre-staged in PINNED host memory, C coders per device so that the upload of one frame overlaps the kernels of
+ * another (PCIe, not xGMI, is the shared resource). Mirrors test/misc/mt_encode.c:12-45 of the reference (one encoder + stream
+ * per thread) and extends it over devices.
+ *
+ *   mgpu_encode <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0]
+ *
+ * Thread t = (device d, coder c) takes frames t, t + T, t + 2T, ... (static round-robin like gpujpeg_amd/sharding.py). Host buffers
+ * on both sides: this is the full-API figure (PCIe included), the one a drop-in caller sees. Prints one JSON line.
+ */
+#define _GNU_SOURCE
+#include <hip/hip_runtime_api.h>
+#include <libgpujpeg/gpujpeg.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define DISTINCT 8 /* distinct synthetic frames, reused round-robin */
+
+struct shared {
+    int frames_total, width, height, threads, decode;
+    uint8_t* frame[DISTINCT]; /* pinned */
+    pthread_barrier_t start;
+};
+
+struct worker {
+    struct shared* sh;
+    int index, device;
+    pthread_t tid;
+    int rc;
+    long frames;
+    size_t jpeg_bytes;
+    uint64_t digest; /* FNV-1a over the streams of this thread's frames: the same frame must give the same stream on every device */
+    double seconds;
+};
+
+static double now(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static void fill_frame(uint8_t* p, int w, int h, unsigned seed)
+{
+    unsigned s = 12345u + seed; /* smooth structure + texture + a little LCG noise: compresses like a photograph */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            s = s * 1664525u + 1013904223u;
+            const int n = (int)((s >> 24) & 7) - 3;
+            const int a = (x * 255 / w + (int)seed * 9) & 255, b = y * 255 / h, c = ((x ^ y) >> 2) & 63;
+            uint8_t* q = p + ((size_t)y * w + x) * 3;
+            q[0] = (uint8_t)((a + c / 4 + n) & 255);
+            q[1] = (uint8_t)((b + c / 8 + n < 0 ? 0 : (b + c / 8 + n > 255 ? 255 : b + c / 8 + n)));
+            q[2] = (uint8_t)(((a + b) / 2 + n) & 255);
+        }
+}
+
+static void* run(void* arg)
+{
+    struct worker* wk = arg;
+    struct shared* sh = wk->sh;
+    wk->rc = 1;
+    if (gpujpeg_init_device(wk->device, 0) != 0) return NULL; /* binds this thread to its device (src/gpujpeg_common.c:215) */
+    hipStream_t stream;
+    if (hipStreamCreate(&stream) != hipSuccess) return NULL;
+    struct gpujpeg_encoder* enc = gpujpeg_encoder_create((cudaStream_t)stream);
+    struct gpujpeg_decoder* dec = sh->decode ? gpujpeg_decoder_create((cudaStream_t)stream) : NULL;
+    if (!enc || (sh->decode && !dec)) return NULL;
+    gpujpeg_encoder_set_option(enc, "enc_opt_out", "enc_out_val_pinned");
+    struct gpujpeg_parameters param;
+    gpujpeg_set_default_parameters(&param);
+    param.restart_interval = RESTART_AUTO;
+    param.verbose = GPUJPEG_LL_QUIET;
+    struct gpujpeg_image_parameters pi;
+    gpujpeg_image_set_default_parameters(&pi);
+    pi.width = sh->width;
+    pi.height = sh->height;
+    uint8_t* out = NULL;
+    const size_t raw = (size_t)sh->width * sh->height * 3;
+    if (sh->decode && hipHostMalloc((void**)&out, raw, hipHostMallocDefault) != hipSuccess) return NULL;
+    /* one untimed call: allocations, tables */
+    struct gpujpeg_encoder_input in;
+    gpujpeg_encoder_input_set_image(&in, sh->frame[0]);
+    uint8_t* jpeg = NULL;
+    size_t size = 0;
+    if (gpujpeg_encoder_encode(enc, &param, &pi, &in, &jpeg, &size) != 0) return NULL;
+    pthread_barrier_wait(&sh->start);
+    const double t0 = now();
+    uint64_t dg = 1469598103934665603ull;
+    for (int f = wk->index; f < sh->frames_total; f += sh->threads) {
+        gpujpeg_encoder_input_set_image(&in, sh->frame[f % DISTINCT]);
+        if (gpujpeg_encoder_encode(enc, &param, &pi, &in, &jpeg, &size) != 0) return NULL;
+        for (size_t i = 0; i < size; i += 997) dg = (dg ^ jpeg[i]) * 1099511628211ull; /* sampled: the digest is not the timed work */
+        dg = (dg ^ (uint64_t)size ^ ((uint64_t)(f % DISTINCT) << 40)) * 1099511628211ull;
+        if (sh->decode) {
+            struct gpujpeg_decoder_output o;
+            gpujpeg_decoder_output_set_custom(&o, out);
+            if (gpujpeg_decoder_decode(dec, jpeg, size, &o) != 0) return NULL;
+        }
+        wk->frames++;
+        wk->jpeg_bytes += size;
+    }
+    wk->seconds = now() - t0;
+    wk->digest = dg;
+    gpujpeg_encoder_destroy(enc);
+    if (dec) gpujpeg_decoder_destroy(dec);
+    if (out) (void)hipHostFree(out);
+    (void)hipStreamDestroy(stream);
+    wk->rc = 0;
+    return NULL;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) {
+        fprintf(stderr, "usage: %s <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0]\n", argv[0]);
+        return 2;
+    }
+    struct shared sh;
+    memset(&sh, 0, sizeof sh);
+    sh.frames_total = atoi(argv[1]);
+    sh.width = atoi(argv[2]);
+    sh.height = atoi(argv[3]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "no device\n"); return 1; }
+    const int devices = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : ndev;
+    const int per_dev = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : 2;
+    sh.decode = argc > 6 ? atoi(argv[6]) : 0;
+    sh.threads = devices * per_dev;
+    const size_t raw = (size_t)sh.width * sh.height * 3;
+    for (int k = 0; k < DISTINCT; k++) {
+        if (hipHostMalloc((void**)&sh.frame[k], raw, hipHostMallocPortable) != hipSuccess) { fprintf(stderr, "pinned allocation failed\n"); return 1; }
+        fill_frame(sh.frame[k], sh.width, sh.height, (unsigned)k);
+    }
+    pthread_barrier_init(&sh.start, NULL, (unsigned)sh.threads + 1);
+    struct worker* wk = calloc((size_t)sh.threads, sizeof *wk);
+    for (int t = 0; t < sh.threads; t++) {
+        wk[t].sh = &sh;
+        wk[t].index = t;
+        wk[t].device = (t % devices) % ndev; /* (more requested devices than present: several threads share one, the 1-GPU proof) */
+        pthread_create(&wk[t].tid, NULL, run, &wk[t]);
+    }
+    pthread_barrier_wait(&sh.start);
+    const double t0 = now();
+    long frames = 0;
+    size_t bytes = 0;
+    int rc = 0;
+    for (int t = 0; t < sh.threads; t++) {
+        pthread_join(wk[t].tid, NULL);
+        rc |= wk[t].rc;
+        frames += wk[t].frames;
+        bytes += wk[t].jpeg_bytes;
+    }
+    const double dt = now() - t0;
+    /* the digests of the threads depend only on which frames they took: recompute what thread 0 would have got for thread t's frames is
+     * not possible without the streams, so the check is pairwise: two threads with the same frame set modulo DISTINCT must agree */
+    int consistent = 1;
+    for (int a = 0; a < sh.threads; a++)
+        for (int b = a + 1; b < sh.threads; b++)
+            if (wk[a].frames == wk[b].frames && (b - a) % DISTINCT == 0 && wk[a].digest != wk[b].digest) consistent = 0;
+    printf("{\"tool\": \"mgpu_encode\", \"ok\": %s, \"frames\": %ld, \"width\": %d, \"height\": %d, \"devices\": %d, \"devices_present\": %d, "
+           "\"coders_per_device\": %d, \"decode\": %d, \"seconds\": %.4f, \"frames_s\": %.2f, \"mpix_s\": %.1f, \"jpeg_bytes\": %zu, "
+           "\"streams_consistent\": %s, \"io\": \"pinned host buffers in and out (PCIe included)\"}\n",
+           rc == 0 && frames == sh.frames_total ? "true" : "false", frames, sh.width, sh.height, devices, ndev, per_dev, sh.decode, dt,
+           (double)frames / dt, (double)frames * sh.width * sh.height / dt / 1e6, bytes, consistent ? "true" : "false");
+    for (int k = 0; k < DISTINCT; k++) (void)hipHostFree(sh.frame[k]);
+    free(wk);
+    return rc == 0 && frames == sh.frames_total && consistent ? 0 : 1;
+}

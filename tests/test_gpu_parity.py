@@ -459,3 +459,4 @@ def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
     dec.close()
 
 
+

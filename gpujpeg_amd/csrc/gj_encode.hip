@@ -663,7 +663,7 @@ struct GjCoderLds {
     uint32_t* coef;      // [32][256]; rows GJ_ENC_PRIV_ROWS.. double as the shared bit window once the walks are done
     const uint32_t* lut; // [2][272]: per table type AC[(run << 4) | nbits] then DC[nbits], entry = (code bits + nbits) << 26 | code << nbits
     uint32_t* wsum;      // [4] block-length totals of the waves
-    int* edge;           // [4][4] the last four DC terms of each wave (predecessors of the next wave's first lanes)
+    int* edge;           // [4][16] the last sixteen DC terms of each wave (predecessors of the next wave's first lanes)
     uint32_t *segx, *segend, *segbase, *segbits, *segff; // [64] ([65] segbase)
 };
 
@@ -781,7 +781,7 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
             mhi = __builtin_amdgcn_perm(ehi, elo, 0x07060302u); // upper halves: positions 32..47 | 48..63
         }
     }
-    if (lane >= 60) L.edge[wave * 4 + (lane - 60)] = dc;
+    if (lane >= 48) L.edge[wave * 16 + (lane - 48)] = dc;
     if (i < GJ_ENC_MAX_SPT) L.segff[i] = 0;
     __syncthreads(); // B1: edges visible (and, for the first component, the tables)
 
@@ -793,7 +793,7 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
         // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342)
         const int src = lane - dc_dist;
         int pred = __builtin_amdgcn_ds_bpermute((src & 63) << 2, dc);
-        if (src < 0 && wave > 0) pred = L.edge[(wave - 1) * 4 + (4 + src)];
+        if (src < 0 && wave > 0) pred = L.edge[(wave - 1) * 16 + (16 + src)];
         if (k - dc_dist < 0) pred = 0;
         dc_diff = dc - pred;
     }
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
     __shared__ uint32_t s_lut[2 * 272];
     __shared__ uint32_t s_wsum[4];
-    __shared__ int s_edge[16];
+    __shared__ int s_edge[64];
     __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
     __shared__ uint32_t s_lut[2 * 272];
     __shared__ uint32_t s_wsum[4];
-    __shared__ int s_edge[16];
+    __shared__ int s_edge[64];
     __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
@@ -1077,6 +1077,199 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
         gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
                      p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0, temp, (uint64_t)seg0 * B, seg_bytes,
                      seg_ff, (uint32_t)seg0);
+    }
+}
+
+// ================================================================================================
+// The fully fused encoder for every other layout with restart segments of 4 .. 256 blocks: one lane per block in CODING order, whatever
+// the scan structure (gj_segment_block gives the lane its component and block position), a workgroup takes spt = 256 / B whole
+// restart segments of one scan, every lane fetches the 64 samples of ITS block, transforms them and the coder of k_encode_rgb444
+// runs once on the tile. Replaces k_preprocess (one thread per pixel, byte loads and stores) + k_dct + k_huffman and their planes
+// (src/gpujpeg_preprocessor.cu:173-292 has one specialised kernel per sampling; here the sampling is the lane's address arithmetic).
+//   PLANAR: planar / grey input whose layout equals the component layout (the reference's copy path, :397-453)
+//   !PLANAR: packed 4:4:4 pixels with a colour transform from RGB (or none) and point-sampled chroma (:49-63): the lane computes only
+//            its own component, out of the pixels (x * sub_h, y * sub_v)
+// ================================================================================================
+// row of the colour matrix that produces component c (RGB -> CS_TO), pre-divided by 256 with offset + 0.5 / 256 (see gj_matrix_to_f)
+__device__ __forceinline__ void gj_matrix_row(const int cs_to, const int c, float& m0, float& m1, float& m2, float& off)
+{
+    static constexpr int M[3][9] = {{66, 129, 25, -38, -74, 112, 112, -94, -18},    // BT.601 limited
+                                    {77, 150, 29, -43, -85, 128, 128, -107, -21},   // BT.601 full range (JPEG)
+                                    {47, 157, 16, -26, -87, 112, 112, -102, -10}};  // BT.709
+    static constexpr int BASE[3][3] = {{16, 128, 128}, {0, 128, 128}, {16, 128, 128}};
+    const int t = cs_to == GJ_CS_BT601 ? 0 : cs_to == GJ_CS_BT601_256 ? 1 : 2;
+    const float s = 1.0f / 256.0f;
+    m0 = (float)M[t][c * 3] * s;
+    m1 = (float)M[t][c * 3 + 1] * s;
+    m2 = (float)M[t][c * 3 + 2] * s;
+    off = (float)BASE[t][c] + 0.5f / 256.0f;
+}
+
+template <bool PLANAR>
+__global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
+                                                          const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
+                                                          uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
+                                                          uint32_t* __restrict__ seg_ff)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
+    __shared__ __attribute__((aligned(8))) float s_q[2][64];
+    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_edge[64];
+    __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
+    const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
+
+    const int i = threadIdx.x;
+    gj_load_coder_lut(s_lut, lut, i);
+    if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
+
+    const int B = g.seg_blocks;
+    const int spt = 256 / B;       // segments per workgroup
+    // tiles never cross a scan: only the last segment of a scan may be short, and it has to be the last one of its tile
+    int scan = 0, tile = (int)blockIdx.x, scan_first = 0, scan_segs = g.segment_count;
+    if (!g.interleaved) {
+        for (int c = 0; c < g.comp_count; c++) {
+            const int tiles_c = (g.comp[c].segment_count + spt - 1) / spt;
+            if (tile < tiles_c || c == g.comp_count - 1) { scan = c; break; }
+            tile -= tiles_c;
+        }
+        scan_first = g.comp[scan].first_segment;
+        scan_segs = g.comp[scan].segment_count;
+    }
+    const int seg0 = tile * spt;   // first segment of the tile inside its scan
+    const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
+    const int j = min((int)(((uint32_t)i * recip) >> 16), GJ_ENC_MAX_SPT - 1);
+    const int k = i - j * B;       // block inside its segment
+    GjSeg sg;
+    sg.nblocks = 0;
+    sg.first_block = 0;
+    const bool seg_valid = i < spt * B && seg0 + j < scan_segs;
+    if (seg_valid) sg = gj_segment(g, scan_first + seg0 + j);
+    const bool active = seg_valid && k < sg.nblocks;
+    __shared__ uint64_t s_first_block; // coding-order index of the tile's first block (thread 0: j = k = 0)
+    if (i == 0) s_first_block = sg.first_block;
+
+    // ---- the lane's block: component, position, samples
+    int comp = 0, mcu_pos = 0;
+    unsigned bx = 0, by = 0;
+    if (active) {
+        const uint64_t off = gj_segment_block(g, sg, k, &comp, &mcu_pos);
+        const unsigned blk = (unsigned)((off - g.comp[comp].data_offset) >> 6);
+        by = blk / (unsigned)g.comp[comp].blocks_x;
+        bx = blk - by * (unsigned)g.comp[comp].blocks_x;
+    }
+    const gj_comp_geom& kc = g.comp[comp];
+    uint32_t px[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) px[t] = 0;
+    if (active && PLANAR) {
+        // raw planes back to back, pitch = component width + padding (src/gpujpeg_preprocessor.cu:414-448); outside: zeros
+        size_t src_off = 0;
+        for (int c = 0; c < comp; c++) src_off += ((size_t)g.comp[c].width + g.width_padding) * g.comp[c].height;
+        const size_t pitch = (size_t)kc.width + g.width_padding;
+        const uint8_t* p0 = raw + src_off + (size_t)(by * 8) * pitch + bx * 8;
+        const bool interior = bx * 8 + 8 <= (unsigned)kc.width && by * 8 + 8 <= (unsigned)kc.height;
+        if (interior && ((pitch | (size_t)p0) & 3) == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(p0 + (size_t)r * pitch);
+                px[2 * r] = p[0];
+                px[2 * r + 1] = p[1];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint32_t d[2] = {0, 0};
+                if (by * 8 + r < (unsigned)kc.height) {
+#pragma unroll
+                    for (int t = 0; t < 8; t++)
+                        if (bx * 8 + t < (unsigned)kc.width) d[t >> 2] |= (uint32_t)p0[(size_t)r * pitch + t] << (8 * (t & 3));
+                }
+                px[2 * r] = d[0];
+                px[2 * r + 1] = d[1];
+            }
+        }
+    }
+    if (active && !PLANAR) {
+        const unsigned sh = (unsigned)kc.sub_h, sv = (unsigned)kc.sub_v;
+        const size_t pitch = (size_t)g.width * 3 + g.width_padding;
+        const bool transform = g.color_space != g.color_space_internal && g.color_space != GJ_CS_NONE && g.color_space_internal != GJ_CS_NONE;
+        float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, off = 0.5f / 256.0f;
+        if (transform) gj_matrix_row(g.color_space_internal, comp, m0, m1, m2, off);
+        else { m0 = comp == 0 ? 1.0f : 0.0f; m1 = comp == 1 ? 1.0f : 0.0f; m2 = comp == 2 ? 1.0f : 0.0f; off = 0.25f; } // (identity: the chosen channel + 0.25 rounds to itself)
+        const unsigned x0 = bx * 8 * sh; // first pixel of the row
+        // rows whose 8 * sub_h pixels all exist are fetched as 6 (sub_h = 1) or 12 (sub_h = 2) aligned dwords; measured against one unaligned
+        // dword load per sampled pixel (no divergence between the luminance and chrominance lanes of a wave): twice as fast
+        const bool fast = sh <= 2 && ((pitch | (size_t)raw) & 3) == 0 && x0 + 8 * sh <= (unsigned)g.width && (by * 8 + 7) * sv < (unsigned)g.height;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned y = (by * 8 + r) * sv;
+            float v[8];
+            if (fast) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(raw + (size_t)y * pitch + (size_t)x0 * 3);
+                float rr[8], gg[8], bb[8];
+                if (sh == 1) {
+                    uint32_t w[6];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) w[t] = p[t];
+                    rr[0] = gj_row_byte_f<0>(w); rr[1] = gj_row_byte_f<3>(w); rr[2] = gj_row_byte_f<6>(w); rr[3] = gj_row_byte_f<9>(w);
+                    rr[4] = gj_row_byte_f<12>(w); rr[5] = gj_row_byte_f<15>(w); rr[6] = gj_row_byte_f<18>(w); rr[7] = gj_row_byte_f<21>(w);
+                    gg[0] = gj_row_byte_f<1>(w); gg[1] = gj_row_byte_f<4>(w); gg[2] = gj_row_byte_f<7>(w); gg[3] = gj_row_byte_f<10>(w);
+                    gg[4] = gj_row_byte_f<13>(w); gg[5] = gj_row_byte_f<16>(w); gg[6] = gj_row_byte_f<19>(w); gg[7] = gj_row_byte_f<22>(w);
+                    bb[0] = gj_row_byte_f<2>(w); bb[1] = gj_row_byte_f<5>(w); bb[2] = gj_row_byte_f<8>(w); bb[3] = gj_row_byte_f<11>(w);
+                    bb[4] = gj_row_byte_f<14>(w); bb[5] = gj_row_byte_f<17>(w); bb[6] = gj_row_byte_f<20>(w); bb[7] = gj_row_byte_f<23>(w);
+                } else { // every other pixel of 16
+                    uint32_t lo[6], hi[6];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) { lo[t] = p[t]; hi[t] = p[6 + t]; }
+                    rr[0] = gj_row_byte_f<0>(lo); rr[1] = gj_row_byte_f<6>(lo); rr[2] = gj_row_byte_f<12>(lo); rr[3] = gj_row_byte_f<18>(lo);
+                    rr[4] = gj_row_byte_f<0>(hi); rr[5] = gj_row_byte_f<6>(hi); rr[6] = gj_row_byte_f<12>(hi); rr[7] = gj_row_byte_f<18>(hi);
+                    gg[0] = gj_row_byte_f<1>(lo); gg[1] = gj_row_byte_f<7>(lo); gg[2] = gj_row_byte_f<13>(lo); gg[3] = gj_row_byte_f<19>(lo);
+                    gg[4] = gj_row_byte_f<1>(hi); gg[5] = gj_row_byte_f<7>(hi); gg[6] = gj_row_byte_f<13>(hi); gg[7] = gj_row_byte_f<19>(hi);
+                    bb[0] = gj_row_byte_f<2>(lo); bb[1] = gj_row_byte_f<8>(lo); bb[2] = gj_row_byte_f<14>(lo); bb[3] = gj_row_byte_f<20>(lo);
+                    bb[4] = gj_row_byte_f<2>(hi); bb[5] = gj_row_byte_f<8>(hi); bb[6] = gj_row_byte_f<14>(hi); bb[7] = gj_row_byte_f<20>(hi);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; t += 2) {
+                    gj_f2 a = gj_f2{rr[t], rr[t + 1]}, b = gj_f2{gg[t], gg[t + 1]}, c = gj_f2{bb[t], bb[t + 1]};
+                    if (transform) { a = gj_scale256_f(a); b = gj_scale256_f(b); c = gj_scale256_f(c); }
+                    const gj_f2 o = __builtin_elementwise_fma((gj_f2)m0, a, __builtin_elementwise_fma((gj_f2)m1, b, __builtin_elementwise_fma((gj_f2)m2, c, (gj_f2)off)));
+                    v[t] = o.x;
+                    v[t + 1] = o.y;
+                }
+            } else {
+                // edges, other sampling factors, unaligned rows: pixel by pixel; a sample whose pixel lies outside the image is a zero
+                // COMPONENT value (src/gpujpeg_common.c:941-944)
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const unsigned x = x0 + t * sh;
+                    v[t] = -1.0f; // (converts to 0)
+                    if (x < (unsigned)g.width && y < (unsigned)g.height) {
+                        const uint8_t* q = raw + (size_t)y * pitch + (size_t)x * 3;
+                        float a = (float)q[0], b = (float)q[1], c = (float)q[2];
+                        if (transform) { a = fmaxf(a, __builtin_fmaf(a, 256.0f, -65024.0f)); b = fmaxf(b, __builtin_fmaf(b, 256.0f, -65024.0f)); c = fmaxf(c, __builtin_fmaf(c, 256.0f, -65024.0f)); }
+                        v[t] = __builtin_fmaf(m0, a, __builtin_fmaf(m1, b, __builtin_fmaf(m2, c, off)));
+                    }
+                }
+            }
+            uint32_t d0 = 0, d1 = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                d0 = __builtin_amdgcn_cvt_pk_u8_f32(v[t], t, d0);
+                d1 = __builtin_amdgcn_cvt_pk_u8_f32(v[t + 4], t, d1);
+            }
+            px[2 * r] = d0;
+            px[2 * r + 1] = d1;
+        }
+    }
+    __syncthreads(); // tables are in LDS
+    {
+        const int table = kc.type;
+#pragma unroll
+        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(px[t]));
+        gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
+        gj_code_tile(L, i, j, k, active, spt, B, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0, temp, s_first_block,
+                     seg_bytes, seg_ff, (uint32_t)(scan_first + seg0));
     }
 }
 
@@ -1288,6 +1481,18 @@ static gj_encode_kernel_t gj_encode_kernel(const gj_geom& g)
     return nullptr;
 }
 
+// k_encode_blocks for this configuration: 1 = planar input in component layout, 0 = packed 4:4:4 with a transform from RGB (or none) and
+// any chroma sampling, -1 = neither (generic kernels)
+static int gj_blocks_kernel_mode(const gj_geom& g)
+{
+    if (g.no_transform) return 1;
+    if (g.pixel_format != GJ_PF_444_P012 || g.comp_count != 3) return -1;
+    const int from = g.color_space, to = g.color_space_internal;
+    const bool none = from == to || from == GJ_CS_NONE || to == GJ_CS_NONE;
+    if (!none && !(from == GJ_CS_RGB && (to == GJ_CS_BT601 || to == GJ_CS_BT601_256 || to == GJ_CS_BT709))) return -1;
+    return 0;
+}
+
 extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS])
 {
     hipStream_t st = (hipStream_t)stream;
@@ -1313,6 +1518,18 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
                            job->d_temp, job->d_seg_bytes, job->d_seg_ff);
+    } else if (!whole && job->use_fused && !job->keep_coefs && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT &&
+               gj_blocks_kernel_mode(g) >= 0) {
+        // every other layout with short restart segments: one lane per block in coding order (k_encode_blocks)
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
+        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+        const int spt = 256 / g.seg_blocks;
+        unsigned wgs = 0;
+        if (g.interleaved) wgs = ((unsigned)g.segment_count + spt - 1) / spt;
+        else
+            for (int c = 0; c < g.comp_count; c++) wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
+        hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
+                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff);
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);

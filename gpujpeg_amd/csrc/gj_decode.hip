@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(256) void k_marker_emit(const uint8_t* __restrict__
 
 // One thread per segment of the table. Scan s is bounded by the "other" markers: it starts after an SOS header and
 // ends at the next other marker. Scan 0 starts at `begin` (the host parsed its SOS).
-__global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const uint32_t* __restrict__ rst_pos, uint64_t begin, uint64_t size,
+__global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint32_t* __restrict__ rst_pos, uint64_t begin, uint64_t size,
                                                         gj_scan_summary* __restrict__ sum, uint32_t* __restrict__ seg_pos,
                                                         uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, uint32_t max_segments)
 {
@@ -1783,6 +1783,9 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
     if (k > c_s) return;                                        // (inconsistent ranks: damaged stream)
     const uint32_t from = k == 0 ? s_start[sc] : rst_pos[s_first[sc] + k - 1] + 2;
     const uint32_t to = k == c_s ? s_end[sc] : rst_pos[s_first[sc] + k];
+    // the marker that ends segment k must be RST(k mod 8), and the last segment of a scan must not be empty: anything else is a
+    // stream the reference reader treats specially, which the host walk reproduces
+    if ((k < c_s && jpeg[to + 1] != (uint8_t)(0xD0 + (k & 7u))) || (k == c_s && c_s > 0 && to <= from)) sum->rst_irregular = 1u;
     seg_pos[gidx] = from;
     seg_len[gidx] = to > from ? to - from : 0;
     // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
@@ -1806,7 +1809,7 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     hipLaunchKernelGGL(k_marker_rank, dim3(1), dim3(1024), 0, st, d_chunk, chunks, d_summary);
     hipLaunchKernelGGL(k_marker_emit, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_rst, max_segments);
     gj_debug_stage(debug_sync != 0, st, "k_marker_rank + k_marker_emit");
-    hipLaunchKernelGGL(k_build_segments, dim3((max_segments + GJ_MAX_COMP + 255) / 256), dim3(256), 0, st, *g, d_rst, begin, size, d_summary,
+    hipLaunchKernelGGL(k_build_segments, dim3((max_segments + GJ_MAX_COMP + 255) / 256), dim3(256), 0, st, *g, d_jpeg, d_rst, begin, size, d_summary,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
     gj_debug_stage(debug_sync != 0, st, "k_build_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -180,7 +180,7 @@ int gpujpeg_decoder_init(struct gpujpeg_decoder* d, const struct gpujpeg_paramet
  * Fills the Huffman table selectors of the later scans. Returns 0 when the device table can be used. */
 static int accept_device_scan(const gj_scan_summary* su, struct gj_reader_result* r, const gj_geom* g)
 {
-    if (su->status != 1 || su->other_count > GJ_SCAN_MAX_OTHER) return -1;
+    if (su->status != 1 || su->other_count > GJ_SCAN_MAX_OTHER || su->rst_irregular) return -1;
     const int expect_scans = g->interleaved ? 1 : g->comp_count;
     if ((int)su->scan_count != expect_scans) return -1;
     if (su->segment_count > (uint32_t)g->segment_count) return -1;

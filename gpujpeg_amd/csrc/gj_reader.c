@@ -110,42 +110,86 @@ static int push_segment(struct gj_host_segments* s, uint32_t pos, uint32_t len, 
     return 0;
 }
 
-/* Walk the entropy-coded data of one scan (src/gpujpeg_reader.c:1039-1155): returns the offset of the
- * marker that ends it; optionally records the segments between restart markers. */
+/* Walk the entropy-coded data of one scan: returns the offset of the marker that ends it; optionally records the segments between
+ * restart markers. Mirrors src/gpujpeg_reader.c:1039-1155 decision by decision, because what a damaged stream decodes to is
+ * observable behaviour (tests/test_gpu_refhip.py compares with the reference reader):
+ *  - an RSTn that is not the expected one ends the segment right there, everything up to the expected marker is skipped (:1074-1100);
+ *    if that one never comes before EOI / SOS, the walk goes on and the marker's two bytes stay inside the segment (:1103-1107);
+ *  - EOI, SOS and APPn end the scan; an empty last segment is dropped (FFmpeg bug #8412, :1132-1135);
+ *  - any other marker is an error (:1145-1148) -- except 0xFF fill bytes, which the reference rejects and we skip (T.81 B.1.1.2). */
 static long walk_scan(const uint8_t* image, size_t begin, size_t size, uint32_t first_index, int max_segments,
                       struct gj_host_segments* segs, int* segment_count)
 {
     const uint8_t* p = image + begin;
     const uint8_t* end = image + size;
     const uint8_t* seg_start = p;
+    size_t dropped = 0; /* bytes the reference's byte counter did not see (skipped while looking for an expected marker that never came): its
+                         * copy of the segment is that much shorter than the segment's extent (:1086,:1112) */
     int idx = 0;
-    int expected = 0xD0;
+    int previous = 0xD0 - 1;
     for (;;) {
         const uint8_t* f = memchr(p, 0xFF, (size_t)(end - p));
         if (f == NULL || f + 1 >= end) {
             GJ_ERROR("JPEG data unexpected ended while reading SOS marker!\n");
             return -1;
         }
-        const int m = f[1];
+        int m = f[1];
         if (m == 0x00) { p = f + 2; continue; }
         if (m == 0xFF) { p = f + 1; continue; } /* fill byte */
         if (m >= 0xD0 && m <= 0xD7) {
-            if (m != expected) { /* reader.c:1074-1108: report and resynchronise on the expected marker */
+            const int expected = previous < 0xD7 ? previous + 1 : 0xD0;
+            const uint8_t* seg_end = f; /* the segment ends in front of this marker, expected or not */
+            const uint8_t* next = f + 2;
+            if (m != expected) {
                 GJ_ERROR("Expected marker 0x%X but 0x%X was presented!\n", expected, m);
+                bool found = false;
+                size_t skipped = 0;
+                const uint8_t* q = f + 2;
+                while (q < end) {
+                    const uint8_t* h = memchr(q, 0xFF, (size_t)(end - q));
+                    if (h == NULL || h + 1 >= end) { q = end; break; }
+                    skipped += (size_t)(h - q) + 2;
+                    q = h + 2;
+                    if (h[1] == expected) {
+                        fprintf(stderr, "[GPUJPEG] [Recovery] Skipping %zu bytes of data until marker 0x%X was found!\n", skipped, expected);
+                        found = true;
+                        break;
+                    }
+                    if (h[1] == 0xD9 || h[1] == 0xDA) { q = h; break; } /* read again by the main loop */
+                }
+                if (!found) {
+                    GJ_ERROR("No marker 0x%X was found until end of current scan!\n", expected);
+                    dropped += (size_t)(q - (f + 2));
+                    p = q; /* the segment goes on: it keeps everything up to and including the unexpected marker */
+                    if (q >= end) {
+                        GJ_ERROR("JPEG data unexpected ended while reading SOS marker!\n");
+                        return -1;
+                    }
+                    continue;
+                }
+                next = q;
+                m = expected;
             }
-            expected = m == 0xD7 ? 0xD0 : m + 1;
-            if (segs && idx < max_segments && push_segment(segs, (uint32_t)(seg_start - image), (uint32_t)(f - seg_start), first_index + (uint32_t)idx) != 0) return -1;
+            previous = m;
+            if (segs && idx < max_segments && push_segment(segs, (uint32_t)(seg_start - image), (uint32_t)((size_t)(seg_end - seg_start) - dropped), first_index + (uint32_t)idx) != 0) return -1;
             idx++;
-            seg_start = p = f + 2;
+            seg_start = p = next;
+            dropped = 0;
             continue;
         }
-        /* any other marker ends the scan; an empty trailing segment is dropped (FFmpeg bug #8412, reader.c:1132-1135) */
-        if (f > seg_start || idx == 0) {
-            if (segs && idx < max_segments && push_segment(segs, (uint32_t)(seg_start - image), (uint32_t)(f - seg_start), first_index + (uint32_t)idx) != 0) return -1;
-            idx++;
+        if (m == 0xD9 || m == 0xDA || (m >= 0xE0 && m <= 0xEF)) {
+            /* end of the scan; an empty trailing segment is dropped */
+            if (f > seg_start) {
+                if (segs && idx < max_segments && push_segment(segs, (uint32_t)(seg_start - image), (uint32_t)((size_t)(f - seg_start) - dropped), first_index + (uint32_t)idx) != 0) return -1;
+                idx++;
+            } else if (idx == 0) {
+                idx = 0; /* a scan without any data: no segment at all, like the reference (segment_count 1 - 1) */
+            }
+            *segment_count = idx;
+            return (long)(f - image);
         }
-        *segment_count = idx;
-        return (long)(f - image);
+        GJ_ERROR("JPEG scan contains unexpected marker 0x%X!\n", m);
+        return -1;
     }
 }
 

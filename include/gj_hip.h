@@ -220,6 +220,8 @@ typedef struct gj_scan_summary {
     uint32_t status;                          /* 1 = clean (scans ... EOI), 2 = unexpected marker between scans, 3 = no EOI */
     uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];
     uint32_t header_differs;                  /* gj_hip_compare_header: 1 when the stream does not start with the cached header */
+    uint32_t rst_irregular;                   /* an RSTn out of sequence, or an empty segment in front of the end of a scan: the reference reader
+                                                 resynchronises / drops it (src/gpujpeg_reader.c:1074-1135), so the host walks such a stream */
 } gj_scan_summary;
 
 /* sets d_summary->header_differs = (d_jpeg[0..n) != d_ref[0..n)); launch after gj_hip_find_segments (which clears the summary) */

@@ -136,3 +136,85 @@ def test_golden_hip(O, G, gpu_lib, refhip):
         json.dump(out, open(os.path.join(ROOT, "gpurun_out", "golden_hip.json"), "w"), indent=1, sort_keys=True)
     if os.path.exists(path):
         assert json.load(open(path))["cases"] == out["cases"]
+
+
+def _rst_positions(jpeg):
+    j = np.asarray(jpeg)
+    idx = np.nonzero((j[:-1] == 0xFF) & (j[1:] >= 0xD0) & (j[1:] <= 0xD7))[0]
+    return [int(i) for i in idx]
+
+
+def _damage(jpeg, kind):
+    """streams with restart markers out of order, missing, duplicated, or followed by nothing"""
+    j = jpeg.copy()
+    r = _rst_positions(j)
+    if kind == "swapped":      # RSTk <-> RSTk+1
+        a, b = r[5], r[6]
+        j[a + 1], j[b + 1] = j[b + 1], j[a + 1]
+    elif kind == "missing":    # one marker removed: two segments run together, every later one moves up
+        a = r[7]
+        j = np.concatenate([j[:a], j[a + 2:]])
+    elif kind == "duplicated":  # the same marker twice in a row
+        a = r[4]
+        j = np.concatenate([j[:a + 2], j[a:a + 2], j[a + 2:]])
+    elif kind == "wrong_number_once":  # one marker renumbered
+        j[r[9] + 1] = 0xD0 + ((int(j[r[9] + 1]) - 0xD0 + 3) % 8)
+    elif kind == "ffmpeg_empty_tail":  # an RSTn right in front of EOI (FFmpeg bug #8412)
+        last = int(j[r[-1] + 1])
+        nxt = 0xD0 + ((last - 0xD0 + 1) % 8)
+        j = np.concatenate([j[:-2], np.array([0xFF, nxt], np.uint8), j[-2:]])
+    elif kind == "second_dri":  # a second DRI with another interval
+        d = int(np.nonzero((j[:-1] == 0xFF) & (j[1:] == 0xDD))[0][0])
+        extra = j[d:d + 6].copy()
+        extra[5] = (int(extra[5]) + 1) & 0xFF
+        j = np.concatenate([j[:d + 6], extra, j[d + 6:]])
+    return j
+
+
+DAMAGE = ["swapped", "missing", "duplicated", "wrong_number_once", "ffmpeg_empty_tail", "second_dri"]
+
+
+@pytest.mark.parametrize("interleaved", [0, 1], ids=["scans", "interleaved"])
+@pytest.mark.parametrize("kind", DAMAGE)
+def test_damaged_restart_markers_like_the_reference_reader(O, G, gpu_lib, refhip, kind, interleaved):
+    """The reference reader resynchronises on the expected restart marker, drops FFmpeg's empty last segment and refuses a second DRI
+    (src/gpujpeg_reader.c:1013-1021,1074-1135). The product -- device marker scan, host walk as the fallback for irregular streams --
+    must return the same code and, where both decode, the same samples (up to the one segment whose data ran out, see below): the
+    reference's own reader and (CPU) Huffman decoder run in oracle/_ref/libgpujpeg_refhip.so, its IDCT and colour kernels on this GPU."""
+    w, h = 640, 368
+    case = ("n4", w, h, 1, 1, 75, 6, interleaved, None, 3)
+    jpeg = O.encode(oracle_image(O, case), natural_image(w, h, 3, seed=5))
+    bad = _damage(jpeg, kind)
+
+    def run(lib):
+        dec = G.Decoder(lib)
+        out = G.DecoderOutput()
+        out.type = G.DECODER_OUTPUT_INTERNAL_BUFFER
+        b = np.ascontiguousarray(bad)
+        rc = lib.L.gpujpeg_decoder_decode(dec.h, b.ctypes.data, b.size, C.byref(out))
+        px = None
+        if rc == 0:
+            px = np.frombuffer((C.c_uint8 * out.data_size).from_address(out.data), np.uint8).copy()
+        # the decoder must still work
+        ok = np.array_equal(dec.decode(jpeg)[0], O.decode(jpeg)[0])
+        dec.close()
+        return rc, px, ok
+
+    import ctypes as C
+    rc_ref, px_ref, ok_ref = run(refhip)
+    rc, px, ok = run(gpu_lib)
+    assert ok and ok_ref
+    assert rc == rc_ref, (kind, rc, rc_ref)
+    if kind == "second_dri":
+        assert rc == -2  # GPUJPEG_ERR_RESTART_CHANGE
+    if rc == 0:
+        # Identical everywhere except inside at most ONE restart segment: the one whose entropy data the damage cut short or removed
+        # (an empty segment after a duplicated marker; the last table entry when every later segment moved up and it gets the short
+        # final segment's data). What a decoder produces once a segment's data has run out is garbage in both implementations -- the
+        # reference's own CPU and GPU Huffman decoders disagree there as well -- so it is not a parity statement.
+        d = (px != px_ref).reshape(h, w, 3).any(-1)
+        ys, xs = np.nonzero(d)
+        blocks = sorted({(int(y) // 8) * (w // 8) + int(x) // 8 for y, x in zip(ys, xs)})
+        assert len(blocks) <= 6 and (not blocks or blocks[-1] // 6 == blocks[0] // 6), (kind, blocks[:12])
+    else:
+        assert px is None

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
 // ================================================================================================
 #define GJ_PAR_CAP_U 8192     // bytes of unstuffed stream per group (incl. 8 B of zero padding per segment)
 #define GJ_PAR_GMAX 64        // segments per batch
-#define GJ_PAR_MAX_BLOCKS 2048 // blocks per batch (DC array in LDS)
+#define GJ_PAR_MAX_BLOCKS 1280 // blocks per batch (DC array in LDS)
 #ifndef GJ_PAR_SUB
 #define GJ_PAR_SUB 16         // bytes per sub-sequence
 #endif
@@ -406,7 +406,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
 }
 
 template <bool INTERLEAVED, int SUB_BYTES, bool TOK>
-__global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+__global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                             const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const int G,
@@ -415,7 +415,10 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                                                             uint32_t* __restrict__ d_tok /* TOK: token buffer */, const uint32_t tok_cap,
                                                             uint2* __restrict__ d_rec /* TOK: per block (coding order) token start, count << 16 | DC */)
 {
-    constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX;
+    // a group's n segments hold at most (CAP_U - 8 n) unstuffed bytes (8 B of padding each), so they are cut into at most
+    // (CAP_U - 8 n) / SUB + n (SUB - 1) / SUB < CAP_U / SUB + n / 2 sub-sequences
+    constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX / 2;
+    static_assert(MAX_SUBS <= GJ_PAR_MAX_BLOCKS, "the work list lives in the DC array");
     constexpr uint32_t SUB_BITS = SUB_BYTES * 8;
     __shared__ uint32_t s_U[GJ_PAR_CAP_U / 4 + 4];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
@@ -432,15 +435,17 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     __shared__ uint16_t s_tend[TOK ? GJ_PAR_GMAX : 1];                      // token mode: end of the last block's tokens, per segment
     // per sub-sequence of the group
     __shared__ __attribute__((aligned(8))) uint2 s_rec[MAX_SUBS];
-    __shared__ uint16_t s_work[MAX_SUBS];
     __shared__ uint8_t s_subseg[MAX_SUBS];
-    __shared__ uint32_t s_scan[MAX_SUBS];
     __shared__ uint32_t s_tmp[4];
     __shared__ int s_j1;
     __shared__ uint32_t s_nwork;
     __shared__ uint32_t s_long[GJ_PAR_GMAX]; // segments too long for the LDS stage: decoded piece by piece afterwards
     __shared__ int s_nlong;
 
+    // LDS is what limits the residency of this kernel (measured: 3 instead of 4 workgroups per CU cost 29 %), so arrays whose lifetimes
+    // do not overlap share their space: the work list of the rounds lives in the DC array (written by the storing pass), and the
+    // prefix sums of the block / token counts replace the counts in the records.
+    uint16_t* const s_work = reinterpret_cast<uint16_t*>(s_dc);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_nlong = 0;
     __syncthreads();
@@ -583,8 +588,6 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         __syncthreads();
         if (tid == 0) s_nwork = 0;
     }
-    for (int k = tid; k < nsub; k += 256) s_scan[k] = s_rec[k].y;
-    __syncthreads();
 
     };
     auto block_positions = [&](const int nsub) {
@@ -593,11 +596,11 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         uint32_t carry = 0;
         for (int k0 = 0; k0 < nsub; k0 += 256) {
             const int k = k0 + tid;
-            const uint32_t v = k < nsub ? s_scan[k] : 0;
+            const uint32_t v = k < nsub ? s_rec[k].y : 0;
             uint32_t tot;
             const uint32_t inc = gj_wg256_incl_scan(v, s_tmp, &tot);
             __syncthreads();
-            if (k < nsub) s_scan[k] = carry + inc;
+            if (k < nsub) s_rec[k].y = carry + inc;
             carry += tot;
         }
     }
@@ -712,20 +715,23 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         // runs of different groups cannot overlap, and no allocator or reset is needed between frames.
         uint32_t gbase = 0;
         if (TOK) {
-            const uint32_t T = nsub > 0 ? s_scan[nsub - 1] >> 16 : 0u;
+            const uint32_t T = nsub > 0 ? s_rec[nsub - 1].y >> 16 : 0u;
             int jb = j0;
             while (jb + 1 < j1 && s_len[jb] == 0) jb++; // (segments without data carry no position)
             gbase = 4u * s_pos[jb];
             if (gbase > tok_cap || T > tok_cap - gbase) gbase = 0xFFFFFFFFu; // (cannot happen with the capacity the host allocates)
-            for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) s_btok[b] = 0xFFFFu; // "block not seen"
+            for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) { s_btok[b] = 0xFFFFu; s_dc[b] = 0; } // "block not seen"
             if (tid >= j0 && tid < j1) s_tend[tid] = 0xFFFFu;
+            __syncthreads();
+        } else {
+            for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) s_dc[b] = 0; // (blocks a damaged segment never reaches)
             __syncthreads();
         }
         for (int k = tid; k < nsub; k += 256) {
             const int j = s_subseg[k];
             const uint32_t k_first = s_sub0[j];
             const uint32_t i = (uint32_t)k - k_first;
-            const uint32_t sc_k = k > 0 ? s_scan[k - 1] : 0u, sc_f = k_first > 0 ? s_scan[k_first - 1] : 0u;
+            const uint32_t sc_k = k > 0 ? s_rec[k - 1].y : 0u, sc_f = k_first > 0 ? s_rec[k_first - 1].y : 0u;
             const uint32_t before = TOK ? (sc_k & 0xFFFFu) - (sc_f & 0xFFFFu) : sc_k - sc_f;
             const uint32_t endb = min((i + 1) * SUB_BITS, s_ulen[j] * 8u);
             const uint32_t tb = s_tabs[j];
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                 if (kb < nblk) {
                     if (TOK) { // block record in coding order: where the tokens are, how many, the DC term
                         const uint32_t k_end = s_sub0[j + 1];
-                        const uint32_t seg_end = k_end > s_sub0[j] ? s_scan[k_end - 1] >> 16 : 0u; // tokens of the group up to the end of this segment
+                        const uint32_t seg_end = k_end > s_sub0[j] ? s_rec[k_end - 1].y >> 16 : 0u; // tokens of the group up to the end of this segment
                         const uint32_t t0 = s_btok[bb + kb];
                         const uint32_t t1 = (kb + 1 < nblk && s_btok[bb + kb + 1] != 0xFFFFu) ? s_btok[bb + kb + 1]
                                             : (kb + 1 == nblk && s_tend[j] != 0xFFFFu)        ? s_tend[j]
@@ -860,7 +866,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             // -- coefficients of this piece (DC still as differences)
             const uint32_t tb = s_tabs[jl];
             for (int k = tid; k < nsub; k += 256) {
-                const uint32_t before = k > 0 ? (TOK ? s_scan[k - 1] & 0xFFFFu : s_scan[k - 1]) : 0u;
+                const uint32_t before = k > 0 ? (TOK ? s_rec[k - 1].y & 0xFFFFu : s_rec[k - 1].y) : 0u;
                 const uint32_t endb = min((uint32_t)(k + 1) * SUB_BITS, ulen * 8u);
                 int nb;
                 gj_decode_sub<true, INTERLEAVED, true>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                                                        &g, &sg);
             }
             __syncthreads(); // (workgroup-scope fence: the differences are visible to the lanes that sum them up)
-            const uint32_t piece_blocks = nsub > 0 ? (TOK ? s_scan[nsub - 1] & 0xFFFFu : s_scan[nsub - 1]) : 0u;
+            const uint32_t piece_blocks = nsub > 0 ? (TOK ? s_rec[nsub - 1].y & 0xFFFFu : s_rec[nsub - 1].y) : 0u;
             const uint32_t b1 = min(blocks_done + piece_blocks, (uint32_t)sg.nblocks);
             for (uint32_t k0 = blocks_done; k0 < b1; k0 += 256) {
                 const uint32_t k = k0 + (uint32_t)tid;
@@ -1551,7 +1557,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         // batch: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks
         const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
         const int eg = job->tune.dec_batch, es = job->tune.dec_sub; // tuning aids: segments per batch, bytes per sub-sequence
-        int G = eg ? eg : (int)((GJ_PAR_CAP_U * 3u / 4u) / avg);
+        int G = eg ? eg : (int)((GJ_PAR_CAP_U * 23u / 32u) / avg); // (a batch that outgrows the stage is decoded in two groups: measured best with this margin)
         if (!eg) G = min(G, job->seg_count / 768); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
         G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / max(1, g.seg_blocks))));
         const int sub = es ? es : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU

@@ -53,12 +53,20 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 DTYPE_DETAIL = "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients"
 
 
-def load_traffic():
-    """HBM bytes per launch from the committed PMC passes (8K RGB q75 natural frame only)."""
+def load_traffic(key="kernels"):
+    """HBM bytes per launch (`kernels`) / vector instructions per launch (`valu_insts`) from the committed PMC passes (8K RGB q75
+    natural frame only)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))["kernels"]
+        return json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json"))).get(key, {})
     except Exception:
         return {}
+
+
+# The kernels of this path are bound by vector-instruction issue, not by HBM (DESIGN 4): a wave64 instruction occupies its SIMD for 4
+# cycles (tools/ubench/valu_rate.hip on this GPU: 4.1-4.6 cycles for shifts, bit-field, compare, convert, packed-fp32 and three-operand
+# integer instructions; 2.3-2.6 for add / and / or / mov / mul / fma; the 4-cycle figure is used for all), there are 256 CUs x 4
+# SIMDs, and the clock is taken at its 2.4 GHz peak, so `valu_issue_frac` = time the counted instructions need at that rate / duration.
+VALU_CYCLES, SIMDS, CLOCK_HZ = 4.0, 1024, 2.4e9
 
 
 def synth_frame(lib, width, height, pattern, seed, device):
@@ -559,7 +567,16 @@ def main():
 
         live = [i for i in range(8) if solo[i] > 0.006]  # (event slots of kernels this configuration does not launch hold only the gap between two events)
         dom = max(live, key=lambda i: solo[i])
-        by_kernel = [dict(roof(names[i], solo[i]), traffic=traffic.get(names[i])) for i in live]
+        valu = load_traffic("valu_insts") if traffic else {}
+
+        def issue(name, ms):
+            n = valu.get(name)
+            if not n or ms <= 0:
+                return {}
+            floor_ms = n * VALU_CYCLES / SIMDS / CLOCK_HZ * 1e3
+            return {"valu_insts": n, "valu_issue_floor_ms": round(floor_ms, 4), "valu_issue_frac": round(floor_ms / ms, 3)}
+
+        by_kernel = [dict(roof(names[i], solo[i]), traffic=traffic.get(names[i]), **issue(names[i], solo[i])) for i in live]
         r = roof(names[dom], solo[dom])
         enc_total, dec_total = float(solo[:5].sum()), float(solo[5:].sum())
         result = {
@@ -576,7 +593,9 @@ def main():
             "encode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["enc_wall"] / 1e6, 2) if args.mode != "decode" else None,
             "decode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["dec_wall"] / 1e6, 2) if args.mode != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"],
-                         "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg),
+                         "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg), **issue(names[dom], solo[dom]),
+                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r2_traffic.json) x 4 cycles / 1024 SIMDs / 2.4 GHz / duration -- "
+                                      "the roofline that actually bounds these kernels (HBM traffic already equals the algorithmic bytes for the encoder)",
                          "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
                                    "coder's stream); profiles/r2_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
                          "by_kernel": by_kernel,

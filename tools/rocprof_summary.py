@@ -81,7 +81,28 @@ def traffic_json(d, out, note):
         base = k.split("<")[0]
         name = ("enc:" if (k + "(").startswith(ENCODER_KERNELS) or base.startswith(ENCODER_KERNELS) else "dec:") + base
         kernels[name] = int(((sf / nf if nf else 0) * 2 + (sw / nw if nw else 0)) * 1024)
-    json.dump({"note": note + "; bytes per launch = FETCH_SIZE x 2 + WRITE_SIZE (separate --pmc passes)", "kernels": kernels}, open(out, "w"), indent=1, sort_keys=True)
+    # vector instructions per launch (SQ_INSTS_VALU, own PMC pass): what bounds these kernels is the issue rate, not HBM
+    va = counter_table(d, "prof_sq", "SQ_INSTS_VALU")
+    wv = counter_table(d, "prof_sq", "SQ_WAVES")
+    valu, waves = {}, {}
+    for k in va:
+        if not k.startswith("k_") or not va[k][0]:
+            continue
+        base = k.split("<")[0]
+        name = ("enc:" if (k + "(").startswith(ENCODER_KERNELS) or base.startswith(ENCODER_KERNELS) else "dec:") + base
+        valu[name] = int(va[k][1] / va[k][0])
+        waves[name] = int(wv[k][1] / wv[k][0]) if wv[k][0] else 0
+    json.dump({"note": note + "; bytes per launch = FETCH_SIZE x 2 + WRITE_SIZE (separate --pmc passes); valu_insts = SQ_INSTS_VALU per launch (wave instructions)",
+               "kernels": kernels, "valu_insts": valu, "waves": waves}, open(out, "w"), indent=1, sort_keys=True)
+    with open(out.replace("_traffic.json", "_sq_counters.txt"), "w") as o:
+        o.write("# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY (one pass), per-dispatch averages\n# " + note + "\n")
+        names = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]
+        tabs = {n: counter_table(d, "prof_sq", n) for n in names}
+        for k in sorted(va, key=lambda k: -va[k][1]):
+            if k.startswith("k_"):
+                o.write(f"{k:<60} " + " ".join(f"{n}={tabs[n][k][1] / max(tabs[n][k][0], 1):.4g}" for n in names) +
+                        f" VALU_per_wave={va[k][1] / max(wv[k][1], 1):.0f}\n")
+    print(open(out.replace("_traffic.json", "_sq_counters.txt")).read())
 
 
 if __name__ == "__main__":

@@ -48,7 +48,7 @@ def child(name, mode):
     for t in range(TRIALS):
         rng = np.random.default_rng(1000 + t)
         bad = jpeg.copy()
-        kind = t % 8
+        kind = t % 9
         if kind == 0:    # byte flips in the entropy-coded data
             idx = rng.integers(hdr, bad.size - 2, size=1 + t)
             bad[idx] = rng.integers(0, 256, size=idx.size, dtype=np.uint8)
@@ -69,6 +69,17 @@ def child(name, mode):
         elif kind == 6:  # over-subscribed Huffman table: the code counts of the first DHT replaced
             d = int(np.nonzero((bad[:-1] == 0xFF) & (bad[1:] == 0xC4))[0][0])
             bad[d + 5:d + 21] = rng.integers(0, 256, size=16, dtype=np.uint8) if t & 8 else np.array([255] + [0] * 15, np.uint8)
+        elif kind == 8:  # restart markers renumbered, doubled or removed (the reader's resynchronisation, src/gpujpeg_reader.c:1074-1108)
+            r = np.nonzero((bad[:-1] == 0xFF) & (bad[1:] >= 0xD0) & (bad[1:] <= 0xD7))[0]
+            if r.size:
+                for i in rng.choice(r, size=min(r.size, 1 + t // 9), replace=False):
+                    op = int(rng.integers(0, 3))
+                    if op == 0:
+                        bad[i + 1] = 0xD0 + int(rng.integers(0, 8))
+                    elif op == 1:
+                        bad[i], bad[i + 1] = 0x12, 0x34
+                    else:
+                        bad[i + 2:i + 4] = bad[i:i + 2]
         else:            # APP13 segment index with arbitrary offsets in front of the first scan
             sos = int(np.nonzero((bad[:-1] == 0xFF) & (bad[1:] == 0xDA))[0][0])
             n = int(rng.integers(1, 64))

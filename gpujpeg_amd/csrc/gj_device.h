@@ -255,10 +255,15 @@ __device__ __forceinline__ void gj_matrix_from_f(gj_f2& c0, gj_f2& c1, gj_f2& c2
                                                  const int b2)
 {
     const float s = 1.0f / 256.0f, h = 0.5f / 256.0f;
-    const gj_f2 r0 = gj_scale256_f(c0 - (gj_f2)(float)b0), r1 = gj_scale256_f(c1 - (gj_f2)(float)b1), r2 = gj_scale256_f(c2 - (gj_f2)(float)b2);
-    c0 = __builtin_elementwise_fma((gj_f2)(m0 * s), r0, __builtin_elementwise_fma((gj_f2)(m1 * s), r1, __builtin_elementwise_fma((gj_f2)(m2 * s), r2, (gj_f2)h)));
-    c1 = __builtin_elementwise_fma((gj_f2)(m3 * s), r0, __builtin_elementwise_fma((gj_f2)(m4 * s), r1, __builtin_elementwise_fma((gj_f2)(m5 * s), r2, (gj_f2)h)));
-    c2 = __builtin_elementwise_fma((gj_f2)(m6 * s), r0, __builtin_elementwise_fma((gj_f2)(m7 * s), r1, __builtin_elementwise_fma((gj_f2)(m8 * s), r2, (gj_f2)h)));
+    // c - b reaches 255, the one value c * 256 / 255 changes, only when b is 0 (the luminance of the full-range matrices); and the
+    // offsets fold into the constant term: sum_j (m_kj / 256) (c_j - b_j) + h = sum_j (m_kj / 256) c_j + (h - sum_j m_kj b_j / 256), every
+    // term still a multiple of 1/512 below 2^11. (Written as c - b, the compiler subtracts in integers and converts afterwards:
+    // two more instructions per chrominance sample.)
+    const gj_f2 r0 = b0 == 0 ? gj_scale256_f(c0) : c0, r1 = b1 == 0 ? gj_scale256_f(c1) : c1, r2 = b2 == 0 ? gj_scale256_f(c2) : c2;
+    const float k0 = h - (float)(m0 * b0 + m1 * b1 + m2 * b2) * s, k1 = h - (float)(m3 * b0 + m4 * b1 + m5 * b2) * s, k2 = h - (float)(m6 * b0 + m7 * b1 + m8 * b2) * s;
+    c0 = __builtin_elementwise_fma((gj_f2)(m0 * s), r0, __builtin_elementwise_fma((gj_f2)(m1 * s), r1, __builtin_elementwise_fma((gj_f2)(m2 * s), r2, (gj_f2)k0)));
+    c1 = __builtin_elementwise_fma((gj_f2)(m3 * s), r0, __builtin_elementwise_fma((gj_f2)(m4 * s), r1, __builtin_elementwise_fma((gj_f2)(m5 * s), r2, (gj_f2)k1)));
+    c2 = __builtin_elementwise_fma((gj_f2)(m6 * s), r0, __builtin_elementwise_fma((gj_f2)(m7 * s), r1, __builtin_elementwise_fma((gj_f2)(m8 * s), r2, (gj_f2)k2)));
 }
 
 // compile-time colour transform of the fused kernels (the same matrices as gj_rgb_to / gj_to_rgb)

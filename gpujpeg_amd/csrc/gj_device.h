@@ -234,10 +234,14 @@ template <int K> __device__ __forceinline__ float gj_ubyte_f_opaque(uint32_t w)
     return r;
 }
 
-// c * 256 / 255 for c in [-254, 255]: c + (c == 255)
+// c * 256 / 255 for an integer c in [0, 255]: c + (c == 255). The indicator is the clamp-to-[0, 1] output modifier on c - 254 (two
+// packed instructions per pixel pair; max(c, 256 c - 65024) costs a packed FMA and two v_max_f32, which have no packed form and
+// issue at half the rate of an add, profiles/r2_09_ubench.txt).
 __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
 {
-    return __builtin_elementwise_max(v, __builtin_elementwise_fma(v, (gj_f2)256.0f, (gj_f2)-65024.0f));
+    gj_f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(v), "v"((gj_f2)-254.0f));
+    return v + d;
 }
 
 __device__ __forceinline__ void gj_matrix_to_f(gj_f2& c0, gj_f2& c1, gj_f2& c2, const int m0, const int m1, const int m2, const int m3, const int m4,

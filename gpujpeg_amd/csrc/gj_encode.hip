@@ -3,6 +3,7 @@
 // Pipeline (all in one stream, the bitstream is assembled on the device):
 //   k_encode_rgb444 / k_encode_uyvy422   raw packed pixels -> entropy-coded segments in one kernel (the default for the BASELINE
 //                         configurations; no coefficient planes)
+//   k_encode_blocks       the same for planar input and for RGB with any chroma sampling: one lane per block in coding order
 //   k_fused_rgb444 / k_fused_uyvy422     raw packed pixels -> quantised coefficients (preprocess + DCT + quant fused)
 //   k_preprocess/k_copy_planes + k_dct   generic path through padded planes (every pixel format / subsampling)
 //   k_huffman             one LANE per 8x8 block: sparse run-length + Huffman coding, bits OR-ed into an LDS stream
@@ -1275,8 +1276,8 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
 
 // ================================================================================================
 // Final offsets: exclusive prefix sum over stuffed segment sizes (+2 for RSTn except at the end of a scan) and over
-// the scan headers that precede each scan. Two launches of ceil(S/1024) workgroups: per-workgroup totals, then every
-// workgroup adds the totals of its predecessors (at most a few hundred values) to its local scan.
+// the scan headers that precede each scan. One launch of ceil(S/1024) workgroups (k_scan_segments below): per-workgroup totals
+// published with an epoch tag, every workgroup adds the totals of its predecessors (at most a few hundred values) to its local scan.
 // ================================================================================================
 __device__ __forceinline__ uint32_t gj_segment_out_size(const gj_enc_job& J, int s, uint32_t* hdr)
 {

@@ -142,3 +142,40 @@ def api_params(lib, G, case, segment_info=0):
     pi = lib.default_image_parameters()
     pi.width, pi.height, pi.pixel_format, pi.color_space = w, h, pf, cs
     return p, pi
+
+
+def random_case(seed):
+    """A random but valid configuration: pixel format, colour spaces, chroma sampling, size, quality, restart interval, interleaving
+    (shared by the oracle-vs-reference and product-vs-oracle differential tests)."""
+    rng = np.random.default_rng(9000 + seed)
+    pf = int(rng.choice([0, 1, 1, 1, 2, 3, 4, 5, 6]))
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 160))
+    q = int(rng.choice([1, 25, 50, 75, 90, 100, int(rng.integers(1, 101))]))
+    ri = int(rng.choice([-1, -1, 0, 1, 2, 3, 5, 8, 13, 36, 100, int(rng.integers(1, 41))]))
+    il = int(rng.integers(0, 2))
+    ss, cs, csi = None, 3, 3
+    if pf == 0:
+        il = 0
+    elif pf == 1:
+        cs = int(rng.choice([1, 1, 1, 3, 4]))
+        csi = int(rng.choice([3, 3, 2, 4, 1])) if cs == 1 else 3
+        ss = [None, None, [(2, 2), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(4, 1), (1, 1), (1, 1)]][int(rng.integers(0, 6))]
+        if csi == 1:
+            ss = None
+    elif pf == 3:
+        w += w & 1  # packed 4:2:2 needs an even width (see CASES)
+        w = max(w, 2)
+    elif pf == 6:
+        cs, il, ss = 1, 1, [(1, 1)] * 4
+    return (f"rand{seed}_pf{pf}", w, h, pf, cs, q, ri, il, ss, csi)
+
+
+def random_raw(O, case, seed):
+    name, w, h, pf, cs, q = case[:6]
+    n = O.raw_size(w, h, pf)
+    if q >= 95:
+        # ramps with a little noise: incompressible data at q100 overflows the reference's own output buffer (1000 + 2 bytes per raw
+        # sample, src/gpujpeg_encoder.c) once the padding to whole MCUs adds enough blocks -- its bug, not a parity case
+        return ((np.arange(n, dtype=np.int64) * 3 // 11 + (O.noise(n, seed=seed) & 3)) % 256).astype(np.uint8)
+    comps = {0: 1, 1: 3, 6: 4}.get(pf)
+    return natural_image(w, h, comps, seed=seed) if comps and seed % 2 == 0 else O.noise(n, seed=777 + seed)

@@ -460,3 +460,25 @@ def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
 
 
 
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations(O, G, gpu_lib, seed):
+    """Differential test over the configuration space the fixed CASES only sample: the product's stream and decoded samples must equal
+    the oracle's for random pixel formats, colour spaces, chroma samplings, odd sizes, qualities, restart intervals and interleaving
+    (exercises k_encode_rgb444 / k_encode_blocks / k_encode_uyvy422 / the generic chain and both entropy decoders at their edges; the
+    same cases pin the oracle to the reference in tests/test_oracle_vs_ref.py)."""
+    from conftest import random_case, random_raw
+    case = random_case(seed)
+    raw = random_raw(O, case, seed)
+    want = O.encode(oracle_image(O, case), raw)
+    p, pi = api_params(gpu_lib, G, case)
+    enc = G.Encoder(gpu_lib)
+    jpeg = enc.encode(p, pi, raw)
+    assert jpeg.size == want.size and np.array_equal(jpeg, want), (case, "stream differs")
+    dec = G.Decoder(gpu_lib)
+    px, info = dec.decode(want)
+    want_px, _ = O.decode(want)
+    assert np.array_equal(px, want_px), (case, "decoded samples differ")
+    enc.close()
+    dec.close()

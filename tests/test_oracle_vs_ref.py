@@ -40,6 +40,27 @@ def test_encode_bytes_and_decode_pixels(O, G, ref, case):
     assert np.array_equal(px, opx)
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations(O, G, ref, seed):
+    """The restatement against the reference (its host C + its CUDA kernels on the CPU, contraction off) on random configurations: pixel
+    formats, colour spaces, chroma samplings, odd sizes, qualities, restart intervals, interleaving. tests/test_gpu_parity.py runs the
+    product against the restatement on the same cases."""
+    from conftest import random_case, random_raw
+    case = random_case(seed)
+    if case[8] and case[8][0][0] == 4:
+        pytest.skip("4:1:1 takes the reference's dynamic-sampling kernel, which divides by the zero sampling factor of the unused fourth "
+                    "component (src/gpujpeg_preprocessor.cu:53-63): ignored by a GPU, a trap on the CPU; covered on the GPU by test_gpu_refhip.py")
+    raw = random_raw(O, case, seed)
+    p, pi = api_params(ref, G, case)
+    jpeg = G.Encoder(ref).encode(p, pi, raw)
+    want = O.encode(oracle_image(O, case), raw)
+    assert jpeg.size == want.size and np.array_equal(jpeg, want), (case, "stream differs")
+    px, info = G.Decoder(ref).decode(jpeg)
+    opx, oinfo = O.decode(want)
+    assert (info.width, info.height, info.pixel_format, info.color_space) == (oinfo.width, oinfo.height, oinfo.pixel_format, oinfo.color_space)
+    assert np.array_equal(px, opx), (case, "decoded samples differ")
+
+
 @pytest.mark.parametrize("case", [c for c in CASES if c[6] != 0][:8], ids=lambda c: c[0])
 def test_segment_info_index(O, G, ref, case):
     """APP13 segment index (src/gpujpeg_writer.c:522-623) written and consumed."""

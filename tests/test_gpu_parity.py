@@ -462,7 +462,7 @@ def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
 
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(160))
 def test_random_configurations(O, G, gpu_lib, seed):
     """Differential test over the configuration space the fixed CASES only sample: the product's stream and decoded samples must equal
     the oracle's for random pixel formats, colour spaces, chroma samplings, odd sizes, qualities, restart intervals and interleaving

@@ -59,7 +59,7 @@ def test_reference_kernels_on_gfx950(O, G, gpu_lib, refhip, case):
     _three_way(O, G, gpu_lib, refhip, case, make_raw(O, case))
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(48))  # (seed 83 = planar 4:2:0, 165 x 36: the reference's own decoder faults on the GPU; not pursued)
 def test_reference_kernels_random_configurations(O, G, gpu_lib, refhip, seed):
     """Random pixel formats / colour spaces / chroma samplings / odd sizes / qualities / restart intervals, three-way."""
     from conftest import random_case, random_raw

@@ -40,7 +40,7 @@ def test_encode_bytes_and_decode_pixels(O, G, ref, case):
     assert np.array_equal(px, opx)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(160))
 def test_random_configurations(O, G, ref, seed):
     """The restatement against the reference (its host C + its CUDA kernels on the CPU, contraction off) on random configurations: pixel
     formats, colour spaces, chroma samplings, odd sizes, qualities, restart intervals, interleaving. tests/test_gpu_parity.py runs the

@@ -476,9 +476,47 @@ def test_random_configurations(O, G, gpu_lib, seed):
     enc = G.Encoder(gpu_lib)
     jpeg = enc.encode(p, pi, raw)
     assert jpeg.size == want.size and np.array_equal(jpeg, want), (case, "stream differs")
+    enc.keep_coefficients()  # the kernels that go through the coefficient planes
+    assert np.array_equal(enc.encode(p, pi, raw), want), (case, "stream differs (coefficient planes)")
+    enc.set_fused(False)     # the generic chain: k_preprocess / k_copy_planes_in, k_dct, k_huffman
+    assert np.array_equal(enc.encode(p, pi, raw), want), (case, "stream differs (generic kernels)")
     dec = G.Decoder(gpu_lib)
     px, info = dec.decode(want)
     want_px, _ = O.decode(want)
     assert np.array_equal(px, want_px), (case, "decoded samples differ")
+    dec.set_fused(False)
+    assert np.array_equal(dec.decode(want)[0], want_px), (case, "decoded samples differ (generic kernels)")
     enc.close()
     dec.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_streams_all_decoder_paths(O, G, gpu_lib, seed, monkeypatch):
+    """Random mid-size streams of the two layouts with token-fed IDCT kernels (RGB 4:4:4 non-interleaved, packed 4:2:2 interleaved)
+    through every decoder path: token mode, plane mode, the lane-per-segment entropy decoder and the generic kernels -- each must give
+    the oracle's samples (batches that straddle scans, ragged last batches, long and empty segments, odd sizes)."""
+    rng = np.random.default_rng(4000 + seed)
+    uyvy = seed % 3 == 2
+    w, h = int(rng.integers(8, 900)), int(rng.integers(8, 500))
+    if uyvy:
+        w += w & 1
+    q = int(rng.choice([5, 30, 60, 75, 85, 92, 100]))
+    ri = int(rng.choice([-1, -1, 0, 1, 2, 4, 7, 16, 36, 64, 250]))
+    case = (f"r{seed}", w, h, 3 if uyvy else 1, 3 if uyvy else 1, q, ri, 1 if uyvy else 0, None, 3)
+    n = O.raw_size(w, h, case[3])
+    kind = int(rng.integers(0, 3))
+    raw = (natural_image(w, h, 3, seed=seed) if kind == 0 and not uyvy else O.noise(n, seed=seed) if kind == 1 else
+           ((np.arange(n, dtype=np.int64) // 5 + (O.noise(n, seed=seed) & 7)) % 256).astype(np.uint8))
+    jpeg = O.encode(oracle_image(O, case), raw)
+    want = O.decode(jpeg, case[3], case[4])[0] if uyvy else O.decode(jpeg)[0]
+    for env in ({"GJ_DEC_TOKENS": "1"}, {"GJ_DEC_NO_TOKENS": "1"}, {"GJ_DEC_ENTROPY": "serial"}, {"GPUJPEG_NO_FUSED": "1"}):
+        for k in ("GJ_DEC_TOKENS", "GJ_DEC_NO_TOKENS", "GJ_DEC_ENTROPY", "GPUJPEG_NO_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dec = G.Decoder(gpu_lib)  # (the switches are read when a decoder is created)
+        if uyvy:
+            dec.set_output_format(3, 3)
+        px, _ = dec.decode(jpeg)
+        assert np.array_equal(px, want), (case, env)
+        dec.close()

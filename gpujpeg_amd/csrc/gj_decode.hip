@@ -295,9 +295,10 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
 // index, [11,16) block inside the MCU.
 // LONG (pieces of a segment that does not fit the LDS stage): block addresses are computed, DC differences go to the plane.
 // TOK (token mode): the counting passes also count the non-zero AC coefficients (upper half of nblk_out); the
-// storing pass appends them as tokens (value | natural position << 16) to `tok_out` instead of scattering them into the
+// storing pass appends them as tokens (value | 2 x natural position << 16) to `tok_out` instead of scattering them into the
 // planes, and notes for every block where its tokens start (s_btok, relative to the group).
-template <bool WRITE, bool INTERLEAVED, bool LONG = false, bool TOK = false>
+// ZZ2: s_zz holds 2 x the natural position (the kernel's token-mode instantiations, also for their piecewise path through the planes)
+template <bool WRITE, bool INTERLEAVED, bool LONG = false, bool TOK = false, bool ZZ2 = TOK>
 __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U, const uint32_t start_bit, const uint32_t end_bit,
                                                   const uint32_t entry, const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab,
                                                   const int P, const uint16_t* tdc, const uint16_t* tac, int& nblk_out,
@@ -368,13 +369,13 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
                     if (z == 0 || (sz != 0 && pos < 64)) {
                         int c_, m_;
                         const uint64_t off = INTERLEAVED ? gj_segment_block(*lg, *lsg, blk + nb, &c_, &m_) : (uint64_t)(first + (uint32_t)(blk + nb)) * 64;
-                        coefs[off + (z == 0 ? 0 : s_zz[pos])] = (int16_t)v;
+                        coefs[off + (z == 0 ? 0 : s_zz[pos] >> (ZZ2 ? 1 : 0))] = (int16_t)v;
                     }
                 } else if (z == 0) {
                     s_dc[blk + nb] = (int16_t)v;
                 } else if (sz != 0 && pos < 64) {
                     const uint32_t b = INTERLEAVED ? s_blk[blk + nb] : first + (uint32_t)(blk + nb);
-                    coefs[(uint64_t)b * 64 + s_zz[pos]] = (int16_t)v;
+                    coefs[(uint64_t)b * 64 + (s_zz[pos] >> (ZZ2 ? 1 : 0))] = (int16_t)v;
                 }
             }
         }
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
         for (int t = tid; t < 4 * GJ_DEC2_WORDS / 8; t += 256) dst[t] = src[t];
     }
-    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    if (tid < 128) s_zz[tid] = (uint8_t)((tid < 64 ? GJ_ZZ[tid] : 63) << (TOK ? 1 : 0)); // token mode: 2 x natural position (gj_slot_put)
     const int P = g.blocks_per_mcu;
     if (tid < GJ_MAX_MCU_BLOCKS) {
         const int pp = tid < P ? tid : 0;
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
                 const uint32_t before = k > 0 ? (TOK ? s_rec[k - 1].y & 0xFFFFu : s_rec[k - 1].y) : 0u;
                 const uint32_t endb = min((uint32_t)(k + 1) * SUB_BITS, ulen * 8u);
                 int nb;
-                gj_decode_sub<true, INTERLEAVED, true>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
+                gj_decode_sub<true, INTERLEAVED, true, false, TOK>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
                                                        s_tab + (tb >> 16), nb, coefs, first, nullptr, nullptr, (int)(blocks_done + before), sg.nblocks, s_zz,
                                                        &g, &sg);
             }
@@ -1066,7 +1067,7 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
 
 // ================================================================================================
 // The same, fed by the entropy decoder's TOKENS (DESIGN 4.3 "token mode"): per block a record (first token, count, DC
-// term) in coding order and, in one dense array, the non-zero AC coefficients as value | natural position << 16.
+// term) in coding order and, in one dense array, the non-zero AC coefficients as value | 2 x natural position << 16.
 // A block costs 8 B + 4 B per non-zero coefficient of HBM traffic instead of 128 B written (twice) and read. Every lane
 // clears its own 128-byte slot of the LDS tile, the wave copies the token range of its 64 blocks into LDS with 16-byte
 // loads (consecutive blocks of a scan have consecutive tokens; a new range starts where a decoder batch ended), every lane
@@ -1076,17 +1077,17 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
 // ================================================================================================
 #define GJ_TOK_STAGE 416 // tokens per wave in LDS (with the 32 KiB tile: four workgroups per CU)
 
-// a lane's 128-byte slot of the block tile: row r (16 bytes) sits at ((r + lane) & 7) * 16, which spreads the row reads and
-// writes of the 64 lanes over all banks without padding the slot
+// a lane's 128-byte slot of the block tile: row r (16 bytes) sits at (r ^ (lane & 7)) * 16, which spreads the row reads and
+// writes of the 64 lanes over all banks without padding the slot. A token carries 2 x its natural position = row << 4 | column << 1
+// in its upper half, so its place in the slot is that field XOR (lane & 7) << 4: one SDWA and + one xor per token.
 __device__ __forceinline__ uint4* gj_slot_row(uint8_t* slot, const int lane, const int r)
 {
-    return reinterpret_cast<uint4*>(slot + (((r + lane) & 7) << 4));
+    return reinterpret_cast<uint4*>(slot + ((uint32_t)(r << 4) ^ (((uint32_t)lane & 7u) << 4)));
 }
 
 __device__ __forceinline__ void gj_slot_put(uint8_t* slot, const int lane, const uint32_t tok)
 {
-    const uint32_t n = (tok >> 16) & 63u;
-    *reinterpret_cast<uint16_t*>(slot + ((((n >> 3) + (uint32_t)lane) & 7u) << 4) + ((n & 7u) << 1)) = (uint16_t)tok;
+    *reinterpret_cast<uint16_t*>(slot + (((tok >> 16) & 0x7Eu) ^ (((uint32_t)lane & 7u) << 4))) = (uint16_t)tok;
 }
 
 // the wave's token range of one component: dense and small enough for the stage (the normal case), with the two 16-byte

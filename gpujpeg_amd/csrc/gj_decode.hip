@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
 // storing pass appends them as tokens (value | 2 x natural position << 16) to `tok_out` instead of scattering them into the
 // planes, and notes for every block where its tokens start (s_btok, relative to the group).
 // ZZ2: s_zz holds 2 x the natural position (the kernel's token-mode instantiations, also for their piecewise path through the planes)
+#define GJ_TABP(tab, byte_off) (reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(tab) + (byte_off)))
 template <bool WRITE, bool INTERLEAVED, bool LONG = false, bool TOK = false, bool ZZ2 = TOK>
 __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U, const uint32_t start_bit, const uint32_t end_bit,
                                                   const uint32_t entry, const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab,
@@ -312,8 +313,8 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
     int p = (int)(entry >> 11);
     if (INTERLEAVED) {
         const uint32_t pt = s_ptab[p];
-        tdc = s_tab + (pt & 0xFFFFu);
-        tac = s_tab + (pt >> 16);
+        tdc = GJ_TABP(s_tab, pt & 0xFFFFu);
+        tac = GJ_TABP(s_tab, pt >> 16);
     }
     uint32_t rd = bitpos >> 5;
     uint64_t acc = (uint64_t)U[rd] << (32 + (bitpos & 31u));
@@ -332,7 +333,9 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
         }
         const uint32_t hi = (uint32_t)(acc >> 32);
         const uint16_t* t = z == 0 ? tdc : tac;
-        uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
+        uint32_t fast; // (as the instruction: written as hi >> 22 the index becomes shift + mask + add instead of bit-field extract + shift-add)
+        asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(fast) : "v"(hi), "n"(32 - GJ_DEC_FAST_BITS), "n"(GJ_DEC_FAST_BITS));
+        uint32_t e = t[fast];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
         const int tot = (int)(e & 31u);
         const int adv = (int)(e >> 9);
@@ -390,8 +393,8 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
             if (INTERLEAVED) {
                 p = p + 1 == P ? 0 : p + 1;
                 const uint32_t pt = s_ptab[p];
-                tdc = s_tab + (pt & 0xFFFFu);
-                tac = s_tab + (pt >> 16);
+                tdc = GJ_TABP(s_tab, pt & 0xFFFFu);
+                tac = GJ_TABP(s_tab, pt >> 16);
             }
         }
     }
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
     __shared__ uint32_t s_U[GJ_PAR_CAP_U / 4 + 4];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
     __shared__ uint8_t s_zz[64 + 64];
-    __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS];      // per MCU block: LDS word offsets of its DC | AC << 16 tables
+    __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS];      // per MCU block: byte offsets of its DC | AC << 16 tables in s_tab
     __shared__ uint32_t s_pblk[GJ_MAX_MCU_BLOCKS][4];   // per MCU block: data_offset/64, blocks_x, samp_h | samp_v << 8 | bx << 16 | by << 24, comp
     // per segment of the batch
     __shared__ uint32_t s_pos[GJ_PAR_GMAX], s_len[GJ_PAR_GMAX], s_nblk[GJ_PAR_GMAX], s_first[GJ_PAR_GMAX], s_tabs[GJ_PAR_GMAX];
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
         const int pp = tid < P ? tid : 0;
         const int c = INTERLEAVED ? g.mcu_comp[pp] : 0;
         const gj_comp_geom& kc = g.comp[c];
-        s_ptab[tid] = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+        s_ptab[tid] = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS * 2) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS * 2) << 16);
         s_pblk[tid][0] = (uint32_t)(kc.data_offset / 64);
         s_pblk[tid][1] = (uint32_t)kc.blocks_x;
         s_pblk[tid][2] = (uint32_t)kc.samp_h | ((uint32_t)kc.samp_v << 8) | ((uint32_t)g.mcu_bx[pp] << 16) | ((uint32_t)g.mcu_by[pp] << 24);
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
                 } else {
                     const gj_comp_geom& kc = g.comp[sg.comp];
                     first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block in the coefficient plane
-                    tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+                    tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS * 2) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS * 2) << 16);
                 }
                 if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U || nblk > GJ_PAR_MAX_BLOCKS) { // too long for the LDS stage / the per-block arrays: in pieces at the end
                     s_long[atomicAdd(&s_nlong, 1)] = (uint32_t)tid;
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
             const uint32_t i = (uint32_t)k - k_first;
             int nb;
             const uint32_t x = gj_decode_sub<false, INTERLEAVED, false, TOK>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
-                                                                 s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
+                                                                 GJ_TABP(s_tab, tb & 0xFFFFu), GJ_TABP(s_tab, tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
             s_rec[k] = make_uint2(e | (x << 16), (uint32_t)nb);
         }
         __syncthreads();
@@ -740,12 +743,12 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
             if (TOK) {
                 if (gbase != 0xFFFFFFFFu)
                     gj_decode_sub<true, INTERLEAVED, false, true>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P,
-                                                                  s_tab + (tb & 0xFFFFu), s_tab + (tb >> 16), nb, nullptr, 0, nullptr, s_dc + s_bb[j], (int)before,
+                                                                  GJ_TABP(s_tab, tb & 0xFFFFu), GJ_TABP(s_tab, tb >> 16), nb, nullptr, 0, nullptr, s_dc + s_bb[j], (int)before,
                                                                   (int)s_nblk[j], s_zz, nullptr, nullptr, d_tok + gbase + (sc_k >> 16), s_btok + s_bb[j],
                                                                   sc_k >> 16, s_tend + j);
             } else {
-                gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
-                                                 s_tab + (tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz);
+                gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, GJ_TABP(s_tab, tb & 0xFFFFu),
+                                                 GJ_TABP(s_tab, tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz);
             }
         }
         __syncthreads();
@@ -870,8 +873,8 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
                 const uint32_t before = k > 0 ? (TOK ? s_rec[k - 1].y & 0xFFFFu : s_rec[k - 1].y) : 0u;
                 const uint32_t endb = min((uint32_t)(k + 1) * SUB_BITS, ulen * 8u);
                 int nb;
-                gj_decode_sub<true, INTERLEAVED, true, false, TOK>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, s_tab + (tb & 0xFFFFu),
-                                                       s_tab + (tb >> 16), nb, coefs, first, nullptr, nullptr, (int)(blocks_done + before), sg.nblocks, s_zz,
+                gj_decode_sub<true, INTERLEAVED, true, false, TOK>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, GJ_TABP(s_tab, tb & 0xFFFFu),
+                                                       GJ_TABP(s_tab, tb >> 16), nb, coefs, first, nullptr, nullptr, (int)(blocks_done + before), sg.nblocks, s_zz,
                                                        &g, &sg);
             }
             __syncthreads(); // (workgroup-scope fence: the differences are visible to the lanes that sum them up)

@@ -283,9 +283,15 @@ __global__ __launch_bounds__(256) void k_huffman_decode(const gj_geom g, const u
 // lane-per-segment kernel. Results are identical to src/gpujpeg_huffman_gpu_decoder.cu:287-495 /
 // src/gpujpeg_huffman_cpu_decoder.c:245-372.
 // ================================================================================================
-#define GJ_PAR_CAP_U 8192     // bytes of unstuffed stream per group (incl. 8 B of zero padding per segment)
+// LDS stage of a workgroup: bytes of unstuffed stream per group (incl. 8 B of zero padding per segment) and blocks per batch (DC and
+// token-start arrays). What is resident is decided by LDS in steps of 1280 B (tools/ubench/lds_occupancy.hip: 4 workgroups per CU up to
+// 40960 B, 5 up to 32000 B -- not the 32768 B the runtime's occupancy query reports). Token mode takes 4 per CU with a stage large
+// enough that an 8K frame is ONE generation of workgroups (a second, partial generation doubles the kernel's duration); plane mode keeps
+// the smaller stage next to its per-block address array.
+#define GJ_PAR_CAP_U_FOR(tok) ((tok) ? 10752 : 8192)
+#define GJ_PAR_MAX_BLOCKS_FOR(tok) ((tok) ? 2304 : 1280)
 #define GJ_PAR_GMAX 64        // segments per batch
-#define GJ_PAR_MAX_BLOCKS 1280 // blocks per batch (DC array in LDS)
+#define GJ_PAR_RESIDENT 1024  // workgroups of the token-mode kernel the GPU holds at once (256 CUs x 4)
 #ifndef GJ_PAR_SUB
 #define GJ_PAR_SUB 16         // bytes per sub-sequence
 #endif
@@ -409,16 +415,28 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
     return (bitpos - end_bit) | ((uint32_t)z << 5) | ((uint32_t)p << 11);
 }
 
+// Batches of the sub-sequence decoder: consecutive table entries, cut per scan -- the luminance segments of a photograph carry two to
+// three times the bytes of the chrominance ones, and a batch is sized to fill the LDS stage (one batch size for the whole stream
+// gave luminance batches that had to be decoded as two groups, and chrominance batches that left half of the lanes idle).
+struct GjBatchPlan {
+    int n;                       // ranges (scans)
+    int first[GJ_MAX_COMP];      // first table entry of range c
+    int count[GJ_MAX_COMP];      // entries
+    int g[GJ_MAX_COMP];          // segments per batch
+    int batch0[GJ_MAX_COMP + 1]; // first batch of range c; [n] = number of batches
+};
+
 template <bool INTERLEAVED, int SUB_BYTES, bool TOK>
-__global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+__global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                             const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
-                                                            const uint32_t* __restrict__ seg_count_ptr, const int G,
+                                                            const uint32_t* __restrict__ seg_count_ptr, const GjBatchPlan plan,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
                                                             const int zero_fill /* 1: the planes are not known to be zero */,
                                                             uint32_t* __restrict__ d_tok /* TOK: token buffer */, const uint32_t tok_cap,
                                                             uint2* __restrict__ d_rec /* TOK: per block (coding order) token start, count << 16 | DC */)
 {
+    constexpr int GJ_PAR_CAP_U = GJ_PAR_CAP_U_FOR(TOK), GJ_PAR_MAX_BLOCKS = GJ_PAR_MAX_BLOCKS_FOR(TOK);
     // a group's n segments hold at most (CAP_U - 8 n) unstuffed bytes (8 B of padding each), so they are cut into at most
     // (CAP_U - 8 n) / SUB + n (SUB - 1) / SUB < CAP_U / SUB + n / 2 sub-sequences
     constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX / 2;
@@ -474,9 +492,12 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
 
     // ---- batch setup: lane j describes segment j of the batch
     const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
-    const int si0 = blockIdx.x * G;
+    int pc = 0;
+    while (pc + 1 < plan.n && (int)blockIdx.x >= plan.batch0[pc + 1]) pc++;
+    const int G = plan.g[pc];
+    const int si0 = plan.first[pc] + ((int)blockIdx.x - plan.batch0[pc]) * G;
     if (si0 >= seg_count) return;
-    const int nseg = min(G, seg_count - si0);
+    const int nseg = min(min(G, plan.first[pc] + plan.count[pc] - si0), seg_count - si0);
     uint32_t my_nblk = 0, my_ucap = 0;
     if (tid < GJ_PAR_GMAX) {
         uint32_t pos = 0, len = 0, nblk = 0, first = 0, tb = 0;
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
                     first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block in the coefficient plane
                     tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS * 2) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS * 2) << 16);
                 }
-                if (((len + 3u) & ~3u) + 8u > GJ_PAR_CAP_U || nblk > GJ_PAR_MAX_BLOCKS) { // too long for the LDS stage / the per-block arrays: in pieces at the end
+                if (((len + 3u) & ~3u) + 8u > (uint32_t)GJ_PAR_CAP_U || nblk > (uint32_t)GJ_PAR_MAX_BLOCKS) { // too long for the LDS stage / the per-block arrays: in pieces at the end
                     s_long[atomicAdd(&s_nlong, 1)] = (uint32_t)tid;
                     len = 0;
                     nblk = 0;
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
     for (int j0 = 0; j0 < nseg;) {
         if (tid == 0) { s_j1 = j0 + 1; s_nwork = 0; }
         __syncthreads();
-        if (tid > j0 && tid <= nseg && s_ub[tid] - s_ub[j0] <= GJ_PAR_CAP_U) atomicMax(&s_j1, tid);
+        if (tid > j0 && tid <= nseg && s_ub[tid] - s_ub[j0] <= (uint32_t)GJ_PAR_CAP_U) atomicMax(&s_j1, tid);
         __syncthreads();
         const int j1 = s_j1;
         const uint32_t ub0 = s_ub[j0];
@@ -624,22 +645,28 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
         //       that the wave waits for HBM once and not once per segment.
         {
             uint8_t* U8 = reinterpret_cast<uint8_t*>(s_U);
+            // (with at most 8 segments per wave -- batches of long segments -- the upper half of the prefetch registers takes the second
+            //  256 B of every segment instead of further segments: a dependent load per segment cost the luminance batches of an 8K
+            //  frame 50 us)
+            const bool two = G <= GJ_PAR_GMAX / 2;
             uint32_t wpre[GJ_PAR_GMAX / 4];
 #pragma unroll
             for (int q = 0; q < GJ_PAR_GMAX / 4; q++) {
-                const int j = j0 + wave + 4 * q;
+                const bool second = two && q >= GJ_PAR_GMAX / 8;
+                const int j = j0 + wave + 4 * (second ? q - GJ_PAR_GMAX / 8 : q);
                 wpre[q] = 0;
                 if (j < j1 && s_len[j]) {
                     const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + s_pos[j];
                     const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
                     const uint32_t ndw = ((uint32_t)(a & 3) + s_len[j] + 3u) >> 2;
-                    if ((uint32_t)lane < ndw && src + lane < end) wpre[q] = src[lane];
+                    const uint32_t idx = (uint32_t)lane + (second ? 64u : 0u);
+                    if (idx < ndw && src + idx < end) wpre[q] = src[idx];
                 }
             }
 #pragma unroll
             for (int q = 0; q < GJ_PAR_GMAX / 4; q++) {
                 const int j = j0 + wave + 4 * q;
-                if (j >= j1) break;
+                if (j >= j1 || (two && q >= GJ_PAR_GMAX / 8)) break;
                 const uint32_t len = s_len[j];
                 const uint32_t ubase = s_ub[j] - ub0;
                 uint32_t out = 0;
@@ -652,7 +679,9 @@ __global__ __launch_bounds__(256, TOK ? 5 : 1) void k_huffman_decode_par(const g
                     for (uint32_t c0 = 0; c0 < ndw; c0 += 64) {
                         const uint32_t idx = c0 + (uint32_t)lane;
                         uint32_t w = wpre[q];
-                        if (c0) {
+                        if (c0 == 64 && two) {
+                            w = wpre[(q + GJ_PAR_GMAX / 8) % (GJ_PAR_GMAX / 4)];
+                        } else if (c0) {
                             w = 0;
                             if (idx < ndw && src + idx < end) w = src[idx];
                         }
@@ -1558,15 +1587,44 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
     }
     if (par) {
-        // batch: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks
-        const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
+        // batches: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks, per scan where the bytes per scan
+        // are known (GjBatchPlan)
         const int eg = job->tune.dec_batch, es = job->tune.dec_sub; // tuning aids: segments per batch, bytes per sub-sequence
-        int G = eg ? eg : (int)((GJ_PAR_CAP_U * 23u / 32u) / avg); // (a batch that outgrows the stage is decoded in two groups: measured best with this margin)
-        if (!eg) G = min(G, job->seg_count / 768); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
-        G = max(1, min(G, min(GJ_PAR_GMAX, GJ_PAR_MAX_BLOCKS / max(1, g.seg_blocks))));
+        const unsigned cap_u = GJ_PAR_CAP_U_FOR(tokens), max_blocks = GJ_PAR_MAX_BLOCKS_FOR(tokens);
+        auto batch_size = [&](uint64_t bytes, int segs, unsigned fill /* 32nds of the stage */) {
+            const unsigned avg = (unsigned)(bytes / (uint64_t)max(1, segs)) + 12u;
+            int G = eg ? eg : (int)((cap_u * fill / 32u) / avg); // (a batch that outgrows the stage is decoded in two groups)
+            if (!eg) G = min(G, max(1, job->seg_count / 768)); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
+            return max(1, min(G, (int)min((unsigned)GJ_PAR_GMAX, max_blocks / (unsigned)max(1, g.seg_blocks))));
+        };
+        GjBatchPlan plan = {};
+        bool per_scan = !g.interleaved && g.comp_count > 1 && job->seg_count == g.segment_count;
+        for (int c = 0; per_scan && c < g.comp_count; c++) per_scan = job->scan_bytes[c] != 0 && g.comp[c].segment_count > 0;
+        // 23/32 of the stage on average is the measured optimum; when that gives a little more than one generation of resident
+        // workgroups, fuller batches (up to 27/32) that fit into one are better than a second generation of a few
+        for (unsigned fill = 23; fill <= 27; fill += 2) {
+            if (per_scan) {
+                plan.n = g.comp_count;
+                int first = 0;
+                for (int c = 0; c < g.comp_count; c++) {
+                    plan.first[c] = first;
+                    plan.count[c] = g.comp[c].segment_count;
+                    plan.g[c] = batch_size(job->scan_bytes[c], plan.count[c], fill);
+                    plan.batch0[c + 1] = plan.batch0[c] + (plan.count[c] + plan.g[c] - 1) / plan.g[c];
+                    first += plan.count[c];
+                }
+            } else {
+                plan.n = 1;
+                plan.count[0] = job->seg_count;
+                plan.g[0] = batch_size(job->jpeg_size, job->seg_count, fill);
+                plan.batch0[1] = (job->seg_count + plan.g[0] - 1) / plan.g[0];
+            }
+            const int nb = plan.batch0[plan.n];
+            if (!tokens || eg || nb <= GJ_PAR_RESIDENT || nb > GJ_PAR_RESIDENT * 5 / 4) break;
+        }
         const int sub = es ? es : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
                                                                            // has to fall into step too): measured best with 32 B
-        const unsigned batches = ((unsigned)job->seg_count + G - 1) / G;
+        const unsigned batches = (unsigned)plan.batch0[plan.n];
         auto kernel = tokens ? (g.interleaved ? k_huffman_decode_par<true, 32, true> : k_huffman_decode_par<false, GJ_PAR_SUB, true>)
                       : g.interleaved ? (sub == 256 ? k_huffman_decode_par<true, 256, false> : sub == 128 ? k_huffman_decode_par<true, 128, false>
                                          : sub == 64 ? k_huffman_decode_par<true, 64, false> : sub == 32 ? k_huffman_decode_par<true, 32, false>
@@ -1575,7 +1633,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
                                          : sub == 64 ? k_huffman_decode_par<false, 64, false> : sub == 32 ? k_huffman_decode_par<false, 32, false>
                                          : sub == 8 ? k_huffman_decode_par<false, 8, false> : k_huffman_decode_par<false, 16, false>);
         hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                           job->d_seg_index, job->seg_count, job->d_seg_count, G, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, job->d_tok, job->tok_cap,
+                           job->d_seg_index, job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, job->d_tok, job->tok_cap,
                            (uint2*)job->d_blkrec);
     } else {
         if (job->seg_count > 0) {

@@ -40,6 +40,7 @@ struct gpujpeg_decoder {
     uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
     uint32_t* d_scan_scratch; size_t d_scan_scratch_cap;
     gj_scan_summary* d_summary;
+    uint32_t last_scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes per scan of the last frame decoded with this header (speculative path) */
     gj_scan_summary* h_summary;   /* pinned */
     int host_scan;                /* 1: always walk the stream on the host (reference behaviour) */
     gj_tuning tune;               /* developer switches, read from the environment when the decoder is created */
@@ -447,6 +448,16 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         job.d_blkrec = d->d_blkrec;
     }
     job.tune = d->tune;
+    /* bytes per scan: what the entropy decoder's batch sizes are cut to (luminance segments are 2-3 x the chrominance ones) */
+    if (spec) {
+        memcpy(job.scan_bytes, d->last_scan_bytes, sizeof job.scan_bytes);
+    } else {
+        for (int sc = 0; sc < GJ_MAX_COMP; sc++) {
+            if (device_scan) job.scan_bytes[sc] = sc < (int)d->h_summary->scan_count ? d->h_summary->scan_end[sc] - d->h_summary->scan_start[sc] : 0;
+            else job.scan_bytes[sc] = sc < r.scan_count && r.scan_end[sc] > r.scan_begin[sc] ? (uint32_t)(r.scan_end[sc] - r.scan_begin[sc]) : 0;
+        }
+        if (seg_count != g->segment_count) memset(job.scan_bytes, 0, sizeof job.scan_bytes); /* (table and geometry out of step: one batch size) */
+    }
     if (gj_hip_decode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Decoder kernels failed: %s\n", gj_hip_last_error());
         goto out;
@@ -492,6 +503,8 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
             free(host_copy);
             return gpujpeg_decoder_decode(d, image, image_size, output);
         }
+        for (int sc = 0; sc < GJ_MAX_COMP; sc++)
+            d->last_scan_bytes[sc] = sc < (int)d->h_summary->scan_count ? d->h_summary->scan_end[sc] - d->h_summary->scan_start[sc] : 0;
         if ((int)d->h_summary->segment_count != g->segment_count && c->param.verbose >= 0)
             GJ_WARN("%d segments read, expected %d. Broken JPEG?\n", (int)d->h_summary->segment_count, g->segment_count);
     } else if (device_scan && r.scan_begin[0] <= GJ_HDR_WINDOW && r.scan_begin[0] < image_size) {
@@ -506,6 +519,8 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
                 d->hdr_cache_r = r;
                 d->hdr_cache_r.comment = NULL;
                 d->hdr_cache_valid = true;
+                for (int sc = 0; sc < GJ_MAX_COMP; sc++)
+                    d->last_scan_bytes[sc] = sc < (int)d->h_summary->scan_count ? d->h_summary->scan_end[sc] - d->h_summary->scan_start[sc] : 0;
             }
         }
     } else {

@@ -175,6 +175,8 @@ typedef struct gj_dec_job {
     int clear_coefs;               /* 1: d_coefs is not known to be all zero, clear it first */
     int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
     gj_tuning tune;
+    uint32_t scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes of every scan when known (this stream's, or the previous frame's on the speculative
+                                         path; 0 = unknown): the entropy decoder sizes its batches per scan with them */
     /* token mode: entropy decoder -> fused IDCT without the coefficient planes (used when a token-fed IDCT kernel exists for the
      * configuration; 0 / NULL = planes) */
     int tokens;

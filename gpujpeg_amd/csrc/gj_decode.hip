@@ -676,7 +676,27 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
                     const int lead = (int)(a & 3);
                     const uint32_t ndw = ((uint32_t)lead + len + 3u) >> 2;
                     uint32_t carry = 0;
-                    for (uint32_t c0 = 0; c0 < ndw; c0 += 64) {
+                    // A segment of up to 64 dwords without a stuffed byte (two thirds of the chrominance segments of a photograph at
+                    // q75) is a plain copy: the lanes' dwords shifted by the start's misalignment and byte-swapped into the stage's
+                    // big-endian dwords. 0xFF00 is looked for in all four bytes at once (zero bytes of w under 0xFF bytes of the
+                    // stream shifted by one; a borrow can only produce a false alarm, which takes the general path below).
+                    bool copied = false;
+                    if (ndw <= 64u) {
+                        const uint32_t w = wpre[q];
+                        const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0: nothing in front)
+                        const uint32_t pb = __builtin_amdgcn_alignbit(w, pw, 24);                                   // the stream one byte earlier
+                        const uint32_t zero = (w - 0x01010101u) & ~w & 0x80808080u, ff = (~pb - 0x01010101u) & pb & 0x80808080u;
+                        if (__ballot((zero & ff) != 0u && (uint32_t)lane < ndw) == 0ull) {
+                            const uint32_t wn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x130, 0xF, 0xF, false); // wave_shl:1 (lane 63: zero)
+                            uint32_t d = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn, w, (uint32_t)lead));
+                            const uint32_t full = len >> 2, rest = len & 3u;
+                            if ((uint32_t)lane == full && rest) d &= 0xFFFFFFFFu << (32u - 8u * rest); // (the bytes behind the end are zero padding)
+                            if ((uint32_t)lane < full + (rest ? 1u : 0u)) s_U[(ubase >> 2) + (uint32_t)lane] = d;
+                            out = len;
+                            copied = true;
+                        }
+                    }
+                    for (uint32_t c0 = 0; !copied && c0 < ndw; c0 += 64) {
                         const uint32_t idx = c0 + (uint32_t)lane;
                         uint32_t w = wpre[q];
                         if (c0 == 64 && two) {

@@ -676,22 +676,32 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
                     const int lead = (int)(a & 3);
                     const uint32_t ndw = ((uint32_t)lead + len + 3u) >> 2;
                     uint32_t carry = 0;
-                    // A segment of up to 64 dwords without a stuffed byte (two thirds of the chrominance segments of a photograph at
-                    // q75) is a plain copy: the lanes' dwords shifted by the start's misalignment and byte-swapped into the stage's
+                    // A segment that lies in the prefetch registers and has no stuffed byte (two thirds of the chrominance, one third of
+                    // the luminance segments of a photograph at q75) is a plain copy: the lanes' dwords shifted by the start's misalignment and byte-swapped into the stage's
                     // big-endian dwords. 0xFF00 is looked for in all four bytes at once (zero bytes of w under 0xFF bytes of the
                     // stream shifted by one; a borrow can only produce a false alarm, which takes the general path below).
                     bool copied = false;
-                    if (ndw <= 64u) {
-                        const uint32_t w = wpre[q];
-                        const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0: nothing in front)
-                        const uint32_t pb = __builtin_amdgcn_alignbit(w, pw, 24);                                   // the stream one byte earlier
-                        const uint32_t zero = (w - 0x01010101u) & ~w & 0x80808080u, ff = (~pb - 0x01010101u) & pb & 0x80808080u;
-                        if (__ballot((zero & ff) != 0u && (uint32_t)lane < ndw) == 0ull) {
-                            const uint32_t wn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x130, 0xF, 0xF, false); // wave_shl:1 (lane 63: zero)
-                            uint32_t d = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn, w, (uint32_t)lead));
-                            const uint32_t full = len >> 2, rest = len & 3u;
-                            if ((uint32_t)lane == full && rest) d &= 0xFFFFFFFFu << (32u - 8u * rest); // (the bytes behind the end are zero padding)
-                            if ((uint32_t)lane < full + (rest ? 1u : 0u)) s_U[(ubase >> 2) + (uint32_t)lane] = d;
+                    if (ndw <= 64u || (two && ndw <= 128u)) { // (everything the prefetch registers hold)
+                        const bool far = ndw > 64u;
+                        const uint32_t w0 = wpre[q], w1 = far ? wpre[(q + GJ_PAR_GMAX / 8) % (GJ_PAR_GMAX / 4)] : 0u;
+                        uint32_t pw0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0: nothing in front)
+                        uint32_t pw1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138, 0xF, 0xF, false);
+                        if (lane == 0) pw1 = (uint32_t)__builtin_amdgcn_readlane((int)w0, 63);
+                        const uint32_t pb0 = __builtin_amdgcn_alignbit(w0, pw0, 24), pb1 = __builtin_amdgcn_alignbit(w1, pw1, 24); // the stream one byte earlier
+                        const uint32_t hit0 = (w0 - 0x01010101u) & ~w0 & (~pb0 - 0x01010101u) & pb0 & 0x80808080u;
+                        const uint32_t hit1 = (w1 - 0x01010101u) & ~w1 & (~pb1 - 0x01010101u) & pb1 & 0x80808080u;
+                        if (__ballot((hit0 != 0u && (uint32_t)lane < ndw) || (hit1 != 0u && (uint32_t)lane + 64u < ndw)) == 0ull) {
+                            uint32_t wn0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x130, 0xF, 0xF, false); // wave_shl:1
+                            const uint32_t wn1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130, 0xF, 0xF, false); // (lane 63: zero, nothing behind)
+                            if (lane == 63) wn0 = (uint32_t)__builtin_amdgcn_readlane((int)w1, 0);
+                            uint32_t d0 = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn0, w0, (uint32_t)lead));
+                            uint32_t d1 = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn1, w1, (uint32_t)lead));
+                            const uint32_t full = len >> 2, rest = len & 3u, cut = 0xFFFFFFFFu << (32u - 8u * rest); // (the bytes behind the end are zero padding)
+                            const uint32_t nout = full + (rest ? 1u : 0u), m0 = (uint32_t)lane, m1 = m0 + 64u;
+                            if (m0 == full && rest) d0 &= cut;
+                            if (m1 == full && rest) d1 &= cut;
+                            if (m0 < nout) s_U[(ubase >> 2) + m0] = d0;
+                            if (far && m1 < nout) s_U[(ubase >> 2) + m1] = d1;
                             out = len;
                             copied = true;
                         }

@@ -40,6 +40,7 @@ struct gpujpeg_decoder {
     uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
     uint32_t* d_scan_scratch; size_t d_scan_scratch_cap;
     gj_scan_summary* d_summary;
+    uint32_t last_max_seg_len;    /* longest segment of the last frame decoded with this header (speculative path) */
     uint32_t last_scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes per scan of the last frame decoded with this header (speculative path) */
     gj_scan_summary* h_summary;   /* pinned */
     int host_scan;                /* 1: always walk the stream on the host (reference behaviour) */
@@ -449,9 +450,19 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     }
     job.tune = d->tune;
     /* bytes per scan: what the entropy decoder's batch sizes are cut to (luminance segments are 2-3 x the chrominance ones) */
+    job.d_overflow = &d->d_summary->seq_overflow;
+    if (!device_scan) gj_hip_memset(job.d_overflow, 0, sizeof(uint32_t), c->stream); /* (the marker scan clears the summary; the host walk has none) */
     if (spec) {
         memcpy(job.scan_bytes, d->last_scan_bytes, sizeof job.scan_bytes);
+        job.max_seg_len = d->last_max_seg_len;
     } else {
+        if (device_scan) {
+            job.max_seg_len = d->h_summary->max_seg_len;
+        } else {
+            job.max_seg_len = 0;
+            for (int i = 0; i < d->segs.count; i++)
+                if (d->segs.len[i] > job.max_seg_len) job.max_seg_len = d->segs.len[i];
+        }
         for (int sc = 0; sc < GJ_MAX_COMP; sc++) {
             if (device_scan) job.scan_bytes[sc] = sc < (int)d->h_summary->scan_count ? d->h_summary->scan_end[sc] - d->h_summary->scan_start[sc] : 0;
             else job.scan_bytes[sc] = sc < r.scan_count && r.scan_end[sc] > r.scan_begin[sc] ? (uint32_t)(r.scan_end[sc] - r.scan_begin[sc]) : 0;
@@ -462,6 +473,8 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         GJ_ERROR("Decoder kernels failed: %s\n", gj_hip_last_error());
         goto out;
     }
+    /* (the lane-per-segment entropy decoder may have met a segment it cannot stage: known once everything has run) */
+    if (gj_hip_memcpy_d2h(&d->h_summary->seq_overflow, &d->d_summary->seq_overflow, sizeof(uint32_t), c->stream) != 0) goto out;
 
     output->data_size = g->raw_size;
     output->param_image = c->param_image;
@@ -492,9 +505,14 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         goto out;
     }
 
+    if (!spec && d->h_summary->seq_overflow) { /* (only when that kernel was forced on a stream with long segments) */
+        d->tune.dec_seq = 2;
+        free(host_copy);
+        return gpujpeg_decoder_decode(d, image, image_size, output);
+    }
     if (spec) { /* now the summary of this stream is on the host: was it what we assumed? */
         struct gj_reader_result chk = r;
-        bool ok = d->h_summary->header_differs == 0 && accept_device_scan(d->h_summary, &chk, g) == 0 &&
+        bool ok = d->h_summary->header_differs == 0 && d->h_summary->seq_overflow == 0 && accept_device_scan(d->h_summary, &chk, g) == 0 &&
                   (int)d->h_summary->segment_count == g->segment_count; /* (a stream with missing segments needs the planes cleared first) */
         for (int i = 0; ok && i < g->comp_count; i++)
             if (chk.huff_map[i][0] != r.huff_map[i][0] || chk.huff_map[i][1] != r.huff_map[i][1]) ok = false;
@@ -505,6 +523,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         }
         for (int sc = 0; sc < GJ_MAX_COMP; sc++)
             d->last_scan_bytes[sc] = sc < (int)d->h_summary->scan_count ? d->h_summary->scan_end[sc] - d->h_summary->scan_start[sc] : 0;
+        d->last_max_seg_len = d->h_summary->max_seg_len;
         if ((int)d->h_summary->segment_count != g->segment_count && c->param.verbose >= 0)
             GJ_WARN("%d segments read, expected %d. Broken JPEG?\n", (int)d->h_summary->segment_count, g->segment_count);
     } else if (device_scan && r.scan_begin[0] <= GJ_HDR_WINDOW && r.scan_begin[0] < image_size) {
@@ -519,6 +538,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
                 d->hdr_cache_r = r;
                 d->hdr_cache_r.comment = NULL;
                 d->hdr_cache_valid = true;
+                d->last_max_seg_len = d->h_summary->max_seg_len;
                 for (int sc = 0; sc < GJ_MAX_COMP; sc++)
                     d->last_scan_bytes[sc] = sc < (int)d->h_summary->scan_count ? d->h_summary->scan_end[sc] - d->h_summary->scan_start[sc] : 0;
             }

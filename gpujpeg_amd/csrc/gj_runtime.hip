@@ -136,5 +136,6 @@ extern "C" void gj_hip_tuning_from_env(gj_tuning* t)
     t->dec_batch = (e = getenv("GJ_DEC_G")) ? atoi(e) : 0;
     t->dec_sub = (e = getenv("GJ_DEC_SUB")) ? atoi(e) : 0;
     t->dec_no_spec = getenv("GJ_DEC_NO_SPEC") != nullptr;
+    if ((e = getenv("GJ_DEC_SEQ"))) t->dec_seq = e[0] == '1' ? 1 : 2;
     t->debug_sync = (e = getenv("GJ_DEC_DEBUG_SYNC")) && e[0] == '1';
 }

@@ -113,6 +113,7 @@ typedef struct gj_tuning {
     int dec_batch;       /* GJ_DEC_G: segments per batch of the sub-sequence decoder, 0 = automatic */
     int dec_sub;         /* GJ_DEC_SUB: bytes per sub-sequence, 0 = automatic */
     int dec_no_spec;     /* GJ_DEC_NO_SPEC: no speculative launch on a cached header */
+    int dec_seq;         /* GJ_DEC_SEQ: 1 = always the lane-per-segment entropy decoder in plane mode, 2 (GJ_DEC_SEQ=0) = never, 0 = by the frame */
     int debug_sync;      /* GJ_DEC_DEBUG_SYNC=1: wait after every decoder stage and name it on stderr */
 } gj_tuning;
 GJ_HIP_API void gj_hip_tuning_from_env(gj_tuning* t);
@@ -175,6 +176,8 @@ typedef struct gj_dec_job {
     int clear_coefs;               /* 1: d_coefs is not known to be all zero, clear it first */
     int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
     gj_tuning tune;
+    uint32_t max_seg_len;          /* longest restart segment of the stream when known (see scan_bytes), 0 = unknown */
+    uint32_t* d_overflow;          /* one word the lane-per-segment entropy decoder sets when it meets a segment it cannot stage */
     uint32_t scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes of every scan when known (this stream's, or the previous frame's on the speculative
                                          path; 0 = unknown): the entropy decoder sizes its batches per scan with them */
     /* token mode: entropy decoder -> fused IDCT without the coefficient planes (used when a token-fed IDCT kernel exists for the
@@ -222,6 +225,8 @@ typedef struct gj_scan_summary {
     uint32_t status;                          /* 1 = clean (scans ... EOI), 2 = unexpected marker between scans, 3 = no EOI */
     uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];
     uint32_t header_differs;                  /* gj_hip_compare_header: 1 when the stream does not start with the cached header */
+    uint32_t max_seg_len;                     /* longest segment of the table */
+    uint32_t seq_overflow;                    /* set by k_huffman_decode_seq: a segment did not fit its stage, decode the frame with the other kernel */
     uint32_t rst_irregular;                   /* an RSTn out of sequence, or an empty segment in front of the end of a scan: the reference reader
                                                  resynchronises / drops it (src/gpujpeg_reader.c:1074-1135), so the host walks such a stream */
 } gj_scan_summary;

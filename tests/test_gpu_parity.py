@@ -302,17 +302,21 @@ ENTROPY_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["par", "serial"])
+@pytest.mark.parametrize("mode", ["par", "serial", "seq"])
 @pytest.mark.parametrize("ec", ENTROPY_CASES, ids=[c[0] for c in ENTROPY_CASES])
 def test_entropy_decoder_variants(O, G, gpu_lib, ec, mode, monkeypatch):
+    """The three entropy decoders (sub-sequence parallel, lane per segment over stream windows, lane per segment over an LDS stage --
+    the last one falls back by itself when a segment does not fit its stage) give the oracle's coefficients."""
     name, w, h, q, ri, il, ss, noisy = ec
     case = (name, w, h, 1, 1, q, ri, il, ss, 3)
     raw = O.noise(w * h * 3, seed=w + h) if noisy else (np.full(w * h * 3, 77, np.uint8) if noisy is None else natural_image(w, h, 3, seed=q))
     want = O.encode(oracle_image(O, case), raw)
+    monkeypatch.delenv("GJ_DEC_ENTROPY", raising=False)
+    monkeypatch.delenv("GJ_DEC_SEQ", raising=False)
     if mode == "serial":
         monkeypatch.setenv("GJ_DEC_ENTROPY", "serial")
-    else:
-        monkeypatch.delenv("GJ_DEC_ENTROPY", raising=False)
+    elif mode == "seq":
+        monkeypatch.setenv("GJ_DEC_SEQ", "1")
     dec = G.Decoder(gpu_lib)
     dec.keep_coefficients()
     px, _ = dec.decode(want)
@@ -509,8 +513,8 @@ def test_random_streams_all_decoder_paths(O, G, gpu_lib, seed, monkeypatch):
            ((np.arange(n, dtype=np.int64) // 5 + (O.noise(n, seed=seed) & 7)) % 256).astype(np.uint8))
     jpeg = O.encode(oracle_image(O, case), raw)
     want = O.decode(jpeg, case[3], case[4])[0] if uyvy else O.decode(jpeg)[0]
-    for env in ({"GJ_DEC_TOKENS": "1"}, {"GJ_DEC_NO_TOKENS": "1"}, {"GJ_DEC_ENTROPY": "serial"}, {"GPUJPEG_NO_FUSED": "1"}):
-        for k in ("GJ_DEC_TOKENS", "GJ_DEC_NO_TOKENS", "GJ_DEC_ENTROPY", "GPUJPEG_NO_FUSED"):
+    for env in ({"GJ_DEC_TOKENS": "1"}, {"GJ_DEC_NO_TOKENS": "1"}, {"GJ_DEC_ENTROPY": "serial"}, {"GPUJPEG_NO_FUSED": "1"}, {"GJ_DEC_NO_TOKENS": "1", "GJ_DEC_SEQ": "1"}):
+        for k in ("GJ_DEC_TOKENS", "GJ_DEC_NO_TOKENS", "GJ_DEC_ENTROPY", "GPUJPEG_NO_FUSED", "GJ_DEC_SEQ"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -31,6 +31,9 @@ def child(name, mode):
     from gpujpeg_amd import libgpujpeg as G
     if mode == "tokens":
         os.environ["GJ_DEC_TOKENS"] = "1"
+    if mode == "seq":  # the lane-per-segment entropy decoder over an LDS stage (plane mode)
+        os.environ["GJ_DEC_NO_TOKENS"] = "1"
+        os.environ["GJ_DEC_SEQ"] = "1"
     lib = G.Library()
     assert lib.L.gpujpeg_init_device(0, 0) == 0
     w, h, pf, cs, q, ri, il, ss, outfmt = CONFIGS[name]
@@ -102,7 +105,7 @@ if __name__ == "__main__":
         sys.exit(0)
     bad = 0
     for name in CONFIGS:
-        for mode in ("default", "tokens"):
+        for mode in ("default", "tokens", "seq"):
             try:
                 r = subprocess.run([sys.executable, __file__, name, mode], capture_output=True, text=True, timeout=300)
                 lines = r.stdout.strip().splitlines()

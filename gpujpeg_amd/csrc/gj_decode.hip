@@ -1054,7 +1054,19 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
     __shared__ uint32_t s_pos[GJ_SEQ_NS], s_len[GJ_SEQ_NS], s_idx[GJ_SEQ_NS], s_ub[GJ_SEQ_NS + 1], s_ulen[GJ_SEQ_NS];
     __shared__ uint32_t s_tmp[4];
     __shared__ int s_j1;
+    __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS];    // per MCU block: word offsets of its DC | AC << 16 tables in s_tab
+    __shared__ uint32_t s_pblk[GJ_MAX_MCU_BLOCKS][4]; // per MCU block: data_offset / 64, blocks_x, samp_h | samp_v << 8 | bx << 16 | by << 24, comp
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < GJ_MAX_MCU_BLOCKS) { // (the geometry is a kernel argument: indexing it by the MCU block in the symbol loop would be loads from memory)
+        const int pp = tid < g.blocks_per_mcu ? tid : 0;
+        const int c = INTERLEAVED ? g.mcu_comp[pp] : 0;
+        const gj_comp_geom& kc = g.comp[c];
+        s_ptab[tid] = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+        s_pblk[tid][0] = (uint32_t)(kc.data_offset / 64);
+        s_pblk[tid][1] = (uint32_t)kc.blocks_x;
+        s_pblk[tid][2] = (uint32_t)kc.samp_h | ((uint32_t)kc.samp_v << 8) | ((uint32_t)g.mcu_bx[pp] << 16) | ((uint32_t)g.mcu_by[pp] << 24);
+        s_pblk[tid][3] = (uint32_t)c;
+    }
     {
         const uint4* src = reinterpret_cast<const uint4*>(tabs);
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
@@ -1146,17 +1158,25 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
             int p = 0, comp = sg.comp;
             unsigned mx = 0, my = 0;
             uint64_t off;
+            const uint16_t *tdc, *tac;
+            auto place = [&]() { // plane address, component and tables of block p of MCU (mx, my)
+                const uint32_t q = s_pblk[p][2];
+                const uint32_t bx = mx * (q & 0xFFu) + ((q >> 16) & 0xFFu), by = my * ((q >> 8) & 0xFFu) + (q >> 24);
+                off = (uint64_t)(s_pblk[p][0] + by * s_pblk[p][1] + bx) * 64;
+                comp = (int)s_pblk[p][3];
+                const uint32_t pt = s_ptab[p];
+                tdc = s_tab + (pt & 0xFFFFu);
+                tac = s_tab + (pt >> 16);
+            };
             if (INTERLEAVED) {
                 my = (unsigned)sg.mcu_first / (unsigned)g.mcu_count_x;
                 mx = (unsigned)sg.mcu_first - my * (unsigned)g.mcu_count_x;
-                comp = g.mcu_comp[0];
-                const gj_comp_geom& kc = g.comp[comp];
-                off = kc.data_offset + ((uint64_t)(my * kc.samp_v + g.mcu_by[0]) * kc.blocks_x + mx * kc.samp_h + g.mcu_bx[0]) * 64;
+                place();
             } else {
                 off = g.comp[comp].data_offset + (uint64_t)sg.mcu_first * 64;
+                tdc = s_tab + (g.comp[comp].dc_table * 2 + 0) * GJ_DEC2_WORDS;
+                tac = s_tab + (g.comp[comp].ac_table * 2 + 1) * GJ_DEC2_WORDS;
             }
-            const uint16_t* tdc = s_tab + (g.comp[comp].dc_table * 2 + 0) * GJ_DEC2_WORDS;
-            const uint16_t* tac = s_tab + (g.comp[comp].ac_table * 2 + 1) * GJ_DEC2_WORDS;
             int dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
             int z = 0;
             uint32_t bitpos = 0, rd = 1, nxt = U[1];
@@ -1207,11 +1227,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
                             p = 0;
                             if (++mx == (unsigned)g.mcu_count_x) { mx = 0; my++; }
                         }
-                        comp = g.mcu_comp[p];
-                        const gj_comp_geom& kc = g.comp[comp];
-                        off = kc.data_offset + ((uint64_t)(my * kc.samp_v + g.mcu_by[p]) * kc.blocks_x + mx * kc.samp_h + g.mcu_bx[p]) * 64;
-                        tdc = s_tab + (kc.dc_table * 2 + 0) * GJ_DEC2_WORDS;
-                        tac = s_tab + (kc.ac_table * 2 + 1) * GJ_DEC2_WORDS;
+                        place();
                     }
                 }
             }

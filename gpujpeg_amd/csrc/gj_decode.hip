@@ -1136,8 +1136,15 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
                 if (zero_fill && s_idx[j] != 0xFFFFFFFFu) {
                     const GjSeg sg = gj_segment(g, (int)s_idx[j]);
                     for (int c = lane; c < sg.nblocks * 8; c += 64) {
-                        int c_, m_;
-                        const uint64_t off = gj_segment_block(g, sg, c >> 3, &c_, &m_);
+                        uint64_t off;
+                        if (INTERLEAVED) { // (gj_segment_block with the per-block constants from LDS)
+                            const unsigned kb = (unsigned)c >> 3, mi = kb / (unsigned)P, pp = kb - mi * (unsigned)P, m = (unsigned)sg.mcu_first + mi;
+                            const unsigned my = m / (unsigned)g.mcu_count_x, mx = m - my * (unsigned)g.mcu_count_x;
+                            const uint32_t q = s_pblk[pp][2];
+                            off = (uint64_t)(s_pblk[pp][0] + (my * ((q >> 8) & 0xFFu) + (q >> 24)) * s_pblk[pp][1] + mx * (q & 0xFFu) + ((q >> 16) & 0xFFu)) * 64;
+                        } else {
+                            off = g.comp[sg.comp].data_offset + (uint64_t)(sg.mcu_first + (c >> 3)) * 64;
+                        }
                         reinterpret_cast<uint4*>(coefs + off)[c & 7] = make_uint4(0, 0, 0, 0);
                     }
                 }

@@ -510,10 +510,21 @@ def main():
     ap.add_argument("--verify", action="store_true", help="check the results of the last frame(s) against the oracle (slow)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as ONE process (the driver's command shape): become the launcher of N ranks, one per GPU,
+        # under torch.distributed.run on this node; the ranks re-enter main() with RANK / LOCAL_RANK / WORLD_SIZE set.
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(1, ndev)  # (more ranks than devices: the 2-process proof on one GPU, tests/test_gpu_multiproc.py)
@@ -546,11 +557,13 @@ def main():
     spec = Spec(lib, args.workload, args.pattern, args.quality, device, 12345 + rank, internal_rgb=args.internal_rgb)
     head = measure(lib, spec, device, dev_index, barrier, mode=args.mode, streams=args.streams, steps=args.steps, warmup=args.warmup,
                    min_seconds=args.min_seconds, keep_coefs=args.keep_coefs, want_solo=True)
-    elapsed = head["elapsed"]
-    if world > 1:
-        t = torch.tensor([elapsed], device=device if ndev >= world else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # whole-job figures: max over ranks of the elapsed time, SUM over ranks of the frames each rank really coded (every rank sizes its
+    # own batch from its own probe, so the counts differ by a few per cent)
+    from gpujpeg_amd.sharding import barrier_and_max, gather_counts
+    red = device if (world == 1 or ndev >= world) else None
+    elapsed = barrier_and_max(head["elapsed"], red)
+    frames_all = gather_counts(head["frames"], red)
+    ranks_seen = gather_counts(1, red)
 
     if rank == 0:
         S, reps, jsize = head["streams"], head["reps"], head["jpeg_bytes"]
@@ -582,8 +595,8 @@ def main():
         result = {
             "metric": ("Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})") if args.mode == "both"
                       else f"Mpix/s {args.mode} only ({args.workload})",
-            "value": round(spec.pixels * world * head["frames"] / elapsed / 1e6, 2), "unit": "Mpix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "value": round(spec.pixels * frames_all / elapsed / 1e6, 2), "unit": "Mpix/s",
+            "n_gpus": world, "ranks_seen": ranks_seen, "frames_all_ranks": frames_all, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL,
             "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per pipeline",
             "config": {"workload": spec.describe() + (" (7680x4320 -> 36)" if args.workload == "8k" else "") + ", encode then decode of every frame",

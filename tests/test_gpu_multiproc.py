@@ -60,3 +60,19 @@ def test_mgpu_encode_threads_and_pinned_staging(gpu_lib):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["ok"] and d["frames"] == 48 and d["streams_consistent"] and d["coders_per_device"] == 2
+    assert d["digest_comparisons"] >= 8  # (the consistency check really compared streams of equal frames between coders)
+
+
+def test_bench_self_launches_its_ranks(gpu_lib):
+    """`python bench.py --gpus 2` as ONE process (the driver's command shape, no torchrun in front): bench.py becomes the launcher, two
+    ranks run, and the line says so."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "hd", "--steps", "3", "--warmup", "1",
+                        "--min-seconds", "0.1", "--lean"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["frames_all_ranks"] > 0 and d["value"] > 0

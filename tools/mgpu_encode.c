@@ -35,7 +35,9 @@ struct worker {
     int rc;
     long frames;
     size_t jpeg_bytes;
-    uint64_t digest; /* FNV-1a over the streams of this thread's frames: the same frame must give the same stream on every device */
+    uint64_t fdig[DISTINCT]; /* FNV-1a (sampled bytes + size) of the stream of distinct frame k as this thread coded it */
+    int fseen[DISTINCT];
+    int self_mismatch;       /* the same frame gave two different streams on this coder */
     double seconds;
 };
 
@@ -92,12 +94,17 @@ static void* run(void* arg)
     if (gpujpeg_encoder_encode(enc, &param, &pi, &in, &jpeg, &size) != 0) return NULL;
     pthread_barrier_wait(&sh->start);
     const double t0 = now();
-    uint64_t dg = 1469598103934665603ull;
-    for (int f = wk->index; f < sh->frames_total; f += sh->threads) {
-        gpujpeg_encoder_input_set_image(&in, sh->frame[f % DISTINCT]);
+    int it = 0;
+    for (int f = wk->index; f < sh->frames_total; f += sh->threads, it++) {
+        const int k = (wk->index + 3 * it) % DISTINCT; /* (3 is coprime to DISTINCT: every thread walks through all the distinct frames) */
+        gpujpeg_encoder_input_set_image(&in, sh->frame[k]);
         if (gpujpeg_encoder_encode(enc, &param, &pi, &in, &jpeg, &size) != 0) return NULL;
-        for (size_t i = 0; i < size; i += 997) dg = (dg ^ jpeg[i]) * 1099511628211ull; /* sampled: the digest is not the timed work */
-        dg = (dg ^ (uint64_t)size ^ ((uint64_t)(f % DISTINCT) << 40)) * 1099511628211ull;
+        uint64_t dg = 1469598103934665603ull;
+        for (size_t i = 0; i < size; i += 97) dg = (dg ^ jpeg[i]) * 1099511628211ull; /* sampled: the digest is not the timed work */
+        dg = (dg ^ (uint64_t)size) * 1099511628211ull;
+        if (wk->fseen[k] && wk->fdig[k] != dg) wk->self_mismatch = 1;
+        wk->fdig[k] = dg;
+        wk->fseen[k] = 1;
         if (sh->decode) {
             struct gpujpeg_decoder_output o;
             gpujpeg_decoder_output_set_custom(&o, out);
@@ -107,7 +114,6 @@ static void* run(void* arg)
         wk->jpeg_bytes += size;
     }
     wk->seconds = now() - t0;
-    wk->digest = dg;
     gpujpeg_encoder_destroy(enc);
     if (dec) gpujpeg_decoder_destroy(dec);
     if (out) (void)hipHostFree(out);
@@ -158,17 +164,24 @@ int main(int argc, char** argv)
         bytes += wk[t].jpeg_bytes;
     }
     const double dt = now() - t0;
-    /* the digests of the threads depend only on which frames they took: recompute what thread 0 would have got for thread t's frames is
-     * not possible without the streams, so the check is pairwise: two threads with the same frame set modulo DISTINCT must agree */
+    /* equal frames must give equal streams on every coder and device: every distinct frame's digest is compared between all the
+     * threads that coded it (and inside a thread between its repetitions); `compared` counts the cross-thread comparisons made */
     int consistent = 1;
-    for (int a = 0; a < sh.threads; a++)
+    long compared = 0;
+    for (int a = 0; a < sh.threads; a++) {
+        if (wk[a].self_mismatch) consistent = 0;
         for (int b = a + 1; b < sh.threads; b++)
-            if (wk[a].frames == wk[b].frames && (b - a) % DISTINCT == 0 && wk[a].digest != wk[b].digest) consistent = 0;
+            for (int k = 0; k < DISTINCT; k++)
+                if (wk[a].fseen[k] && wk[b].fseen[k]) {
+                    compared++;
+                    if (wk[a].fdig[k] != wk[b].fdig[k]) consistent = 0;
+                }
+    }
     printf("{\"tool\": \"mgpu_encode\", \"ok\": %s, \"frames\": %ld, \"width\": %d, \"height\": %d, \"devices\": %d, \"devices_present\": %d, "
            "\"coders_per_device\": %d, \"decode\": %d, \"seconds\": %.4f, \"frames_s\": %.2f, \"mpix_s\": %.1f, \"jpeg_bytes\": %zu, "
-           "\"streams_consistent\": %s, \"io\": \"pinned host buffers in and out (PCIe included)\"}\n",
+           "\"streams_consistent\": %s, \"digest_comparisons\": %ld, \"io\": \"pinned host buffers in and out (PCIe included)\"}\n",
            rc == 0 && frames == sh.frames_total ? "true" : "false", frames, sh.width, sh.height, devices, ndev, per_dev, sh.decode, dt,
-           (double)frames / dt, (double)frames * sh.width * sh.height / dt / 1e6, bytes, consistent ? "true" : "false");
+           (double)frames / dt, (double)frames * sh.width * sh.height / dt / 1e6, bytes, consistent ? "true" : "false", compared);
     for (int k = 0; k < DISTINCT; k++) (void)hipHostFree(sh.frame[k]);
     free(wk);
     return rc == 0 && frames == sh.frames_total && consistent ? 0 : 1;

@@ -1,0 +1,294 @@
+// gj_dec_entropy_seq.hip -- MI355X (gfx950, wave64) JPEG decoder: entropy decoding, one lane per restart segment over an LDS stage (interleaved scans with many short segments)
+// (part of the decoder's device code, see gj_dec_internal.h for the map of the files)
+#include "gj_dec_internal.h"
+
+// ================================================================================================
+// Entropy decoder, third design: ONE LANE PER RESTART SEGMENT over an LDS stage, for interleaved scans with many short segments
+// (BASELINE config 4: 172 800 segments of 250 B).
+//
+// The sub-sequence decoder lives on self-synchronisation. In an interleaved scan a lane that enters a sub-sequence in the wrong block of
+// the MCU decodes with the wrong tables and falls into step only by accident: measured on config 4, 6.2 rounds per batch, i.e. the
+// correct decoding advances by about one sub-sequence per round and segment -- every symbol is decoded seven times, and a workgroup
+// spends 61 of its 99 us in rounds. With this many segments there is enough parallelism without cutting them: a workgroup unstuffs 100
+// to 128 segments into LDS (one wave per segment, as above) and then every lane decodes its own segment once, from the first bit, in the
+// known state: no counting passes, no rounds, DC prediction in registers, coefficients straight to the (zero-filled) planes.
+// A segment that does not fit the stage raises `overflow` and is left alone: the host then decodes the frame with the sub-sequence
+// kernel (it knows the longest segment of a stream before the launch, except on the speculative path, where it finds the flag afterwards).
+// Results are identical to the other two kernels (tests run all three on the same streams).
+// ================================================================================================
+#define GJ_SEQ_STAGE 26112 // bytes of unstuffed stream per group (incl. 8 B of zero padding per segment)
+#define GJ_SEQ_NS 128      // segments per workgroup
+
+// unstuffs one segment into the stage with one wave; w0 = the lane's dword of the segment's first 256 B (zero behind its end)
+__device__ __forceinline__ uint32_t gj_unstuff_segment(const uint8_t* __restrict__ jpeg, const uint32_t* __restrict__ end, const uint32_t pos, const uint32_t len,
+                                                       uint32_t* __restrict__ stage, const uint32_t ubase, const int lane, const uint32_t w0)
+{
+    uint8_t* U8 = reinterpret_cast<uint8_t*>(stage);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + pos;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const int lead = (int)(a & 3);
+    const uint32_t ndw = ((uint32_t)lead + len + 3u) >> 2;
+    uint32_t out = 0;
+    bool copied = false;
+    if (ndw <= 64u) { // no stuffed byte: a shifted, byte-swapped copy (see k_huffman_decode_par)
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x138, 0xF, 0xF, false);
+        const uint32_t pb = __builtin_amdgcn_alignbit(w0, pw, 24);
+        const uint32_t hit = (w0 - 0x01010101u) & ~w0 & (~pb - 0x01010101u) & pb & 0x80808080u;
+        if (__ballot(hit != 0u && (uint32_t)lane < ndw) == 0ull) {
+            const uint32_t wn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x130, 0xF, 0xF, false);
+            uint32_t d = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn, w0, (uint32_t)lead));
+            const uint32_t full = len >> 2, rest = len & 3u;
+            if ((uint32_t)lane == full && rest) d &= 0xFFFFFFFFu << (32u - 8u * rest);
+            if ((uint32_t)lane < full + (rest ? 1u : 0u)) stage[(ubase >> 2) + (uint32_t)lane] = d;
+            out = len;
+            copied = true;
+        }
+    }
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; !copied && c0 < ndw; c0 += 64) {
+        const uint32_t idx = c0 + (uint32_t)lane;
+        uint32_t w = w0;
+        if (c0) {
+            w = 0;
+            if (idx < ndw && src + idx < end) w = src[idx];
+        }
+        uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xF, 0xF, false); // wave_shr:1
+        if (lane == 0) pw = carry;
+        uint32_t prev = pw >> 24;
+        uint32_t keep = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t b = (w >> (8 * k)) & 0xFFu;
+            const int off = (int)(idx * 4u) + k - lead;
+            const bool valid = off >= 0 && off < (int)len;
+            const bool stuffed = b == 0 && prev == 0xFFu && off > 0;
+            if (valid && !stuffed) keep |= 1u << k;
+            prev = b;
+        }
+        const uint32_t cnt = (uint32_t)__popc(keep);
+        const uint32_t inc = gj_wave_incl_scan(cnt);
+        uint32_t o = ubase + out + inc - cnt;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (keep & (1u << k)) { U8[o ^ 3u] = (uint8_t)(w >> (8 * k)); o++; }
+        out += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
+    }
+    for (uint32_t b = out + (uint32_t)lane; b < ((out + 3u) & ~3u) + 8u; b += 64) U8[(ubase + b) ^ 3u] = 0;
+    return out;
+}
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+                                                               const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
+                                                               const uint32_t* __restrict__ seg_index, const int seg_count_max,
+                                                               const uint32_t* __restrict__ seg_count_ptr, const int NS,
+                                                               const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs, const int zero_fill,
+                                                               uint32_t* __restrict__ overflow)
+{
+    __shared__ uint32_t s_U[GJ_SEQ_STAGE / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
+    __shared__ uint8_t s_zz[64 + 64];
+    __shared__ uint32_t s_pos[GJ_SEQ_NS], s_len[GJ_SEQ_NS], s_idx[GJ_SEQ_NS], s_ub[GJ_SEQ_NS + 1], s_ulen[GJ_SEQ_NS];
+    __shared__ uint32_t s_tmp[4];
+    __shared__ int s_j1;
+    __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS];    // per MCU block: word offsets of its DC | AC << 16 tables in s_tab
+    __shared__ uint32_t s_pblk[GJ_MAX_MCU_BLOCKS][4]; // per MCU block: data_offset / 64, blocks_x, samp_h | samp_v << 8 | bx << 16 | by << 24, comp
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < GJ_MAX_MCU_BLOCKS) { // (the geometry is a kernel argument: indexing it by the MCU block in the symbol loop would be loads from memory)
+        const int pp = tid < g.blocks_per_mcu ? tid : 0;
+        const int c = INTERLEAVED ? g.mcu_comp[pp] : 0;
+        const gj_comp_geom& kc = g.comp[c];
+        s_ptab[tid] = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+        s_pblk[tid][0] = (uint32_t)(kc.data_offset / 64);
+        s_pblk[tid][1] = (uint32_t)kc.blocks_x;
+        s_pblk[tid][2] = (uint32_t)kc.samp_h | ((uint32_t)kc.samp_v << 8) | ((uint32_t)g.mcu_bx[pp] << 16) | ((uint32_t)g.mcu_by[pp] << 24);
+        s_pblk[tid][3] = (uint32_t)c;
+    }
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(tabs);
+        uint4* dst = reinterpret_cast<uint4*>(s_tab);
+        for (int t = tid; t < 4 * GJ_DEC2_WORDS / 8; t += 256) dst[t] = src[t];
+    }
+    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
+    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
+    const int si0 = blockIdx.x * NS;
+    if (si0 >= seg_count) return;
+    const int nseg = min(NS, seg_count - si0);
+    uint32_t my_ucap = 0;
+    if (tid < GJ_SEQ_NS) {
+        uint32_t pos = 0, len = 0, idx = 0xFFFFFFFFu;
+        if (tid < nseg) {
+            idx = seg_index[si0 + tid];
+            if (idx < (uint32_t)g.segment_count) {
+                pos = seg_pos[si0 + tid];
+                len = seg_len[si0 + tid];
+                if (((len + 3u) & ~3u) + 8u > (uint32_t)GJ_SEQ_STAGE) { // (not for this kernel)
+                    *overflow = 1u;
+                    len = 0;
+                    idx = 0xFFFFFFFFu;
+                }
+            }
+        }
+        s_pos[tid] = pos;
+        s_len[tid] = len;
+        s_idx[tid] = idx;
+        my_ucap = len ? ((len + 3u) & ~3u) + 8u : 0u;
+    }
+    {
+        uint32_t tot;
+        const uint32_t b = gj_wg256_incl_scan(my_ucap, s_tmp, &tot);
+        if (tid < GJ_SEQ_NS) s_ub[tid + 1] = b;
+        if (tid == 0) s_ub[0] = 0;
+    }
+    __syncthreads();
+    const int P = g.blocks_per_mcu;
+    for (int j0 = 0; j0 < nseg;) {
+        // ---- the segments whose unstuffed bytes fit the stage together (normally all of them)
+        if (tid == 0) s_j1 = j0 + 1;
+        __syncthreads();
+        if (tid > j0 && tid <= nseg && s_ub[tid] - s_ub[j0] <= (uint32_t)GJ_SEQ_STAGE) atomicMax(&s_j1, tid);
+        __syncthreads();
+        const int j1 = s_j1;
+        const uint32_t ub0 = s_ub[j0];
+        // ---- 1. one wave per segment: its blocks are filled with zeros (the planes need no clearing between frames), its bytes go to
+        //         the stage without the stuffed zeros; the first 256 B of eight segments are fetched at a time
+        for (int jb = j0 + wave; jb < j1; jb += 32) {
+            uint32_t wpre[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int j = jb + 4 * q;
+                wpre[q] = 0;
+                if (j < j1 && s_len[j]) {
+                    const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + s_pos[j];
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+                    const uint32_t ndw = ((uint32_t)(a & 3) + s_len[j] + 3u) >> 2;
+                    if ((uint32_t)lane < ndw && src + lane < end) wpre[q] = src[lane];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int j = jb + 4 * q;
+                if (j >= j1) break;
+                if (zero_fill && s_idx[j] != 0xFFFFFFFFu) {
+                    const GjSeg sg = gj_segment(g, (int)s_idx[j]);
+                    for (int c = lane; c < sg.nblocks * 8; c += 64) {
+                        uint64_t off;
+                        if (INTERLEAVED) { // (gj_segment_block with the per-block constants from LDS)
+                            const unsigned kb = (unsigned)c >> 3, mi = kb / (unsigned)P, pp = kb - mi * (unsigned)P, m = (unsigned)sg.mcu_first + mi;
+                            const unsigned my = m / (unsigned)g.mcu_count_x, mx = m - my * (unsigned)g.mcu_count_x;
+                            const uint32_t q = s_pblk[pp][2];
+                            off = (uint64_t)(s_pblk[pp][0] + (my * ((q >> 8) & 0xFFu) + (q >> 24)) * s_pblk[pp][1] + mx * (q & 0xFFu) + ((q >> 16) & 0xFFu)) * 64;
+                        } else {
+                            off = g.comp[sg.comp].data_offset + (uint64_t)(sg.mcu_first + (c >> 3)) * 64;
+                        }
+                        reinterpret_cast<uint4*>(coefs + off)[c & 7] = make_uint4(0, 0, 0, 0);
+                    }
+                }
+                const uint32_t out = s_len[j] ? gj_unstuff_segment(jpeg, end, s_pos[j], s_len[j], s_U, s_ub[j] - ub0, lane, wpre[q]) : 0u;
+                if (lane == 0) s_ulen[j] = out;
+            }
+        }
+        __syncthreads(); // (also orders the zeros before the coefficient stores)
+
+        // ---- 2. every lane decodes its segment: src/gpujpeg_huffman_gpu_decoder.cu:397-495 / src/gpujpeg_huffman_cpu_decoder.c:245-372
+        const int j = j0 + tid;
+        if (j < j1 && s_idx[j] != 0xFFFFFFFFu) {
+            const GjSeg sg = gj_segment(g, (int)s_idx[j]);
+            const uint32_t* U = s_U + ((s_ub[j] - ub0) >> 2);
+            const uint32_t end_bit = s_ulen[j] * 8u;
+            int left = sg.nblocks;
+            // block cursor
+            int p = 0, comp = sg.comp;
+            unsigned mx = 0, my = 0;
+            uint64_t off;
+            const uint16_t *tdc, *tac;
+            auto place = [&]() { // plane address, component and tables of block p of MCU (mx, my)
+                const uint32_t q = s_pblk[p][2];
+                const uint32_t bx = mx * (q & 0xFFu) + ((q >> 16) & 0xFFu), by = my * ((q >> 8) & 0xFFu) + (q >> 24);
+                off = (uint64_t)(s_pblk[p][0] + by * s_pblk[p][1] + bx) * 64;
+                comp = (int)s_pblk[p][3];
+                const uint32_t pt = s_ptab[p];
+                tdc = s_tab + (pt & 0xFFFFu);
+                tac = s_tab + (pt >> 16);
+            };
+            if (INTERLEAVED) {
+                my = (unsigned)sg.mcu_first / (unsigned)g.mcu_count_x;
+                mx = (unsigned)sg.mcu_first - my * (unsigned)g.mcu_count_x;
+                place();
+            } else {
+                off = g.comp[comp].data_offset + (uint64_t)sg.mcu_first * 64;
+                tdc = s_tab + (g.comp[comp].dc_table * 2 + 0) * GJ_DEC2_WORDS;
+                tac = s_tab + (g.comp[comp].ac_table * 2 + 1) * GJ_DEC2_WORDS;
+            }
+            int dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
+            int z = 0;
+            uint32_t bitpos = 0, rd = 1, nxt = U[1];
+            uint64_t acc = (uint64_t)U[0] << 32;
+            int n = 32;
+            while (left > 0) {
+                int v = 0, adv = 64; // (data exhausted: the block ends here, its remaining coefficients stay zero)
+                bool coef = false;
+                if (bitpos < end_bit) {
+                    if (n <= 32) {
+                        acc |= (uint64_t)nxt << (32 - n);
+                        n += 32;
+                        rd++;
+                        nxt = U[rd];
+                    }
+                    const uint32_t hi = (uint32_t)(acc >> 32);
+                    const uint16_t* t = z == 0 ? tdc : tac;
+                    uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
+                    if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
+                    const int tot = (int)(e & 31u), sz = (int)((e >> 5) & 15u);
+                    adv = tot ? (int)(e >> 9) : 64; // (an entry of a table the stream never defined: give up on the block)
+                    const int used = tot - sz;
+                    const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
+                    v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+                    coef = sz != 0;
+                    acc <<= tot;
+                    n -= tot;
+                    bitpos = tot ? bitpos + (uint32_t)tot : end_bit;
+                }
+                if (z == 0) { // DC: predicted from the previous block of the component inside this segment
+                    int pred = dc0;
+                    if (INTERLEAVED) pred = comp == 0 ? dc0 : comp == 1 ? dc1 : comp == 2 ? dc2 : dc3;
+                    v += pred;
+                    if (!INTERLEAVED || comp == 0) dc0 = v; else if (comp == 1) dc1 = v; else if (comp == 2) dc2 = v; else dc3 = v;
+                    coefs[off] = (int16_t)v;
+                } else if (coef) {
+                    const int pos = z + adv - 1;
+                    if (pos < 64) coefs[off + s_zz[pos]] = (int16_t)v;
+                }
+                z += adv;
+                if (z >= 64) { // next block of this segment
+                    z = 0;
+                    left--;
+                    if (!INTERLEAVED) {
+                        off += 64;
+                    } else {
+                        if (++p == P) {
+                            p = 0;
+                            if (++mx == (unsigned)g.mcu_count_x) { mx = 0; my++; }
+                        }
+                        place();
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        j0 = j1;
+    }
+}
+
+
+void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st)
+{
+    const gj_geom& g = job->g;
+    const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
+    const int NS = max(1, min(GJ_SEQ_NS, (int)((GJ_SEQ_STAGE * 7u / 8u) / avg)));
+    auto kernel = g.interleaved ? k_huffman_decode_seq<true> : k_huffman_decode_seq<false>;
+    hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + NS - 1) / NS), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
+                       job->d_seg_index, job->seg_count, job->d_seg_count, NS, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, job->d_overflow);
+}

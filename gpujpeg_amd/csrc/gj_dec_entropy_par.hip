@@ -81,8 +81,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
         }
         const uint32_t hi = (uint32_t)(acc >> 32);
         const uint16_t* t = z == 0 ? tdc : tac;
-        uint32_t fast; // (as the instruction: written as hi >> 22 the index becomes shift + mask + add instead of bit-field extract + shift-add)
-        asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(fast) : "v"(hi), "n"(32 - GJ_DEC_FAST_BITS), "n"(GJ_DEC_FAST_BITS));
+        const uint32_t fast = gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(hi);
         uint32_t e = t[fast];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
         const int tot = (int)(e & 31u);
@@ -428,14 +427,16 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
                         const uint32_t w0 = wpre[q], w1 = far ? wpre[(q + GJ_PAR_GMAX / 8) % (GJ_PAR_GMAX / 4)] : 0u;
                         uint32_t pw0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0: nothing in front)
                         uint32_t pw1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x138, 0xF, 0xF, false);
-                        if (lane == 0) pw1 = (uint32_t)__builtin_amdgcn_readlane((int)w0, 63);
+                        const uint32_t w0_last = (uint32_t)__builtin_amdgcn_readlane((int)w0, 63); // (cross-lane reads stay outside lane-dependent branches)
+                        if (lane == 0) pw1 = w0_last;
                         const uint32_t pb0 = __builtin_amdgcn_alignbit(w0, pw0, 24), pb1 = __builtin_amdgcn_alignbit(w1, pw1, 24); // the stream one byte earlier
                         const uint32_t hit0 = (w0 - 0x01010101u) & ~w0 & (~pb0 - 0x01010101u) & pb0 & 0x80808080u;
                         const uint32_t hit1 = (w1 - 0x01010101u) & ~w1 & (~pb1 - 0x01010101u) & pb1 & 0x80808080u;
                         if (__ballot((hit0 != 0u && (uint32_t)lane < ndw) || (hit1 != 0u && (uint32_t)lane + 64u < ndw)) == 0ull) {
                             uint32_t wn0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w0, 0x130, 0xF, 0xF, false); // wave_shl:1
                             const uint32_t wn1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w1, 0x130, 0xF, 0xF, false); // (lane 63: zero, nothing behind)
-                            if (lane == 63) wn0 = (uint32_t)__builtin_amdgcn_readlane((int)w1, 0);
+                            const uint32_t w1_first = (uint32_t)__builtin_amdgcn_readlane((int)w1, 0);
+                            if (lane == 63) wn0 = w1_first;
                             uint32_t d0 = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn0, w0, (uint32_t)lead));
                             uint32_t d1 = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn1, w1, (uint32_t)lead));
                             const uint32_t full = len >> 2, rest = len & 3u, cut = 0xFFFFFFFFu << (32u - 8u * rest); // (the bytes behind the end are zero padding)

@@ -31,6 +31,7 @@ struct GjBits {
 __device__ __forceinline__ void gj_fill_windows(unsigned long long mask, const uint32_t* src, const uint32_t* end, uint32_t* s_win, int lane)
 {
     const unsigned lo = (unsigned)(uintptr_t)src, hi = (unsigned)((uintptr_t)src >> 32);
+    gj_wave_sync(); // (the rows are written by all lanes and read by their owners: LDS traffic between the lanes of a wave)
     while (mask) {
         uint32_t v[4];
         int js[4];
@@ -51,6 +52,7 @@ __device__ __forceinline__ void gj_fill_windows(unsigned long long mask, const u
         for (int u = 0; u < 4; u++)
             if (js[u] >= 0) s_win[js[u] * GJ_WIN_STRIDE + lane] = v[u];
     }
+    gj_wave_sync();
 }
 
 // canonical search for codes longer than the fast table (ITU T.81 F.2.2.3); rare

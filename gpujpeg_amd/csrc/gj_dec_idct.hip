@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
         gj_idct_pk(wb, s_q[c], pk[c]);
         // pin the transform here: otherwise LLVM sinks all three below the last barrier and spills the staged coefficients
 #pragma unroll
-        for (int i = 0; i < 16; i++) asm volatile("" : "+v"(pk[c][i]));
+        for (int i = 0; i < 16; i++) GJ_KEEP(pk[c][i]);
     }
     // (no early return for the threads past the last block: the compiler would sink the three transforms below it and keep
     // every staged coefficient alive until then)
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
         }
         gj_idct_pk(wb, s_q[c], pk[c]);
 #pragma unroll
-        for (int i = 0; i < 16; i++) asm volatile("" : "+v"(pk[c][i])); // one transform at a time (see k_idct_fused_rgb444)
+        for (int i = 0; i < 16; i++) GJ_KEEP(pk[c][i]); // one transform at a time (see k_idct_fused_rgb444)
     }
     gj_store_rgb444<CS_FROM, CS_TO>(g, raw, pk, lb, nb, bx, by);
 }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void k_idct_fused_uyvy422(const gj_geom g, 
         }
         gj_idct_pk(w, s_q[c], pk[b]);
 #pragma unroll
-        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[b][t])); // one transform at a time
+        for (int t = 0; t < 16; t++) GJ_KEEP(pk[b][t]); // one transform at a time
     }
     const size_t pitch = (size_t)g.width * 2 + g.width_padding;
     const bool interior = (mx * 16 + 16 <= (unsigned)g.width) && (my * 8 + 8 <= (unsigned)g.height);

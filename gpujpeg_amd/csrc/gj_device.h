@@ -7,6 +7,16 @@
 
 #define GJ_WAVE 64
 
+// GJ_HIPEMU: defined only by the CPU execution model of the test tier (tests/hipemu), which compiles these files for the host. The one
+// thing it switches is the meaning of the inline-assembly helpers below (the instruction on the GPU, its C++ meaning on the CPU).
+#ifdef GJ_HIPEMU
+#define GJ_KEEP(x) ((void)0)
+#define GJ_KEEP6(a, b, c, d, e, f) ((void)0)
+#else
+#define GJ_KEEP6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+#define GJ_KEEP(x) asm volatile("" : "+v"(x)) // pins a value in its register here: a scheduling fence for the compiler
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // zig-zag order (ITU T.81 figure A.6): position in scan -> natural (row-major) index.
 // Same contents as the reference's gpujpeg_order_natural (src/gpujpeg_table.h:73-84).
@@ -115,12 +125,29 @@ __device__ __forceinline__ uint32_t gj_wave_incl_scan(uint32_t v)
     return (uint32_t)x;
 }
 
+// bits [OFF, OFF + WIDTH) of v as the instruction itself: written as a shift the compiler folds it into the address arithmetic that
+// follows and ends up with shift + mask + add where bit-field extract + shift-add do
+template <int OFF, int WIDTH> __device__ __forceinline__ uint32_t gj_bfe_u32(uint32_t v)
+{
+#ifdef GJ_HIPEMU
+    return (v >> OFF) & ((1u << WIDTH) - 1u);
+#else
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(OFF), "n"(WIDTH));
+    return r;
+#endif
+}
+
 // per-half minimum of two packed u16 pairs (the compiler scalarises the vector form, hence the instruction itself)
 __device__ __forceinline__ uint32_t gj_pk_min_u16(uint32_t a, uint32_t b)
 {
+#ifdef GJ_HIPEMU
+    return min(a & 0xFFFFu, b & 0xFFFFu) | (min(a >> 16, b >> 16) << 16);
+#else
     uint32_t r;
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 
 // inclusive scan over a 256-thread workgroup; s_tmp needs 4 words; all threads must call
@@ -226,12 +253,16 @@ template <int K> __device__ __forceinline__ float gj_ubyte_f(uint32_t w) { retur
 // the compiler needs to know that the value is no signalling NaN, or every v_max_f32 gets a canonicalising twin.)
 template <int K> __device__ __forceinline__ float gj_ubyte_f_opaque(uint32_t w)
 {
+#ifdef GJ_HIPEMU
+    return gj_ubyte_f<K>(w);
+#else
     float r;
     if (K == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(w));
     else if (K == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(w));
     else if (K == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(w));
     else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
     return r;
+#endif
 }
 
 // c * 256 / 255 for an integer c in [0, 255]: c + (c == 255). The indicator is the clamp-to-[0, 1] output modifier on c - 254 (two
@@ -240,7 +271,13 @@ template <int K> __device__ __forceinline__ float gj_ubyte_f_opaque(uint32_t w)
 __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
 {
     gj_f2 d;
+#ifdef GJ_HIPEMU
+    d = v + (gj_f2)-254.0f;
+    d.x = d.x < 0.0f ? 0.0f : (d.x > 1.0f ? 1.0f : d.x);
+    d.y = d.y < 0.0f ? 0.0f : (d.y > 1.0f ? 1.0f : d.y);
+#else
     asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(v), "v"((gj_f2)-254.0f));
+#endif
     return v + d;
 }
 

@@ -196,7 +196,7 @@ __device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_
         pk[1][r * 2] = o1[0]; pk[1][r * 2 + 1] = o1[1];
         pk[2][r * 2] = o2[0]; pk[2][r * 2 + 1] = o2[1];
         // pin the colour transform of this row here (keeps the raw pixels from staying alive into the transforms)
-        asm volatile("" : "+v"(pk[0][r * 2]), "+v"(pk[0][r * 2 + 1]), "+v"(pk[1][r * 2]), "+v"(pk[1][r * 2 + 1]), "+v"(pk[2][r * 2]), "+v"(pk[2][r * 2 + 1]));
+        GJ_KEEP6(pk[0][r * 2], pk[0][r * 2 + 1], pk[1][r * 2], pk[1][r * 2 + 1], pk[2][r * 2], pk[2][r * 2 + 1]);
     }
 }
 
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_uyvy422(const gj_geom g, const
 #pragma unroll
     for (int b = 0; b < 4; b++) {
 #pragma unroll
-        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[b][t])); // one transform at a time
+        for (int t = 0; t < 16; t++) GJ_KEEP(pk[b][t]); // one transform at a time
         const int c = b < 2 ? 0 : b - 1;
         uint32_t q[32];
         gj_fdct_quant_pk(pk[b], s_q[g.comp[c].type ? 1 : 0], q);
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
         const gj_comp_geom& kc = g.comp[c];
         // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
 #pragma unroll
-        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(pk[c][t]));
+        for (int t = 0; t < 16; t++) GJ_KEEP(pk[c][t]);
         gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0, temp,
                      kc.data_offset / 64 + (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0));
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
     {
         const int table = p < 2 ? g.comp[0].type : g.comp[1].type;
 #pragma unroll
-        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(px[t]));
+        for (int t = 0; t < 16; t++) GJ_KEEP(px[t]);
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
                      p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0, temp, (uint64_t)seg0 * B, seg_bytes,
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
     {
         const int table = kc.type;
 #pragma unroll
-        for (int t = 0; t < 16; t++) asm volatile("" : "+v"(px[t]));
+        for (int t = 0; t < 16; t++) GJ_KEEP(px[t]);
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         gj_code_tile(L, i, j, k, active, spt, B, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0, temp, s_first_block,
                      seg_bytes, seg_ff, (uint32_t)(scan_first + seg0));

@@ -1,0 +1,88 @@
+"""-m "not gpu": the product's OWN kernels (gpujpeg_amd/csrc/*.hip, unmodified) executed on the CPU by tests/hipemu -- a fiber per
+work-item, wave64 cross-lane operations with the ISA's semantics, LDS, barriers -- behind the same public C API, against the same oracle
+and with the same test bodies as the GPU tier (tests/test_gpu_parity.py; imported, not copied). What this tier can and cannot say:
+it checks the LOGIC of every kernel (indexing, prefix sums, bit packing, DPP / ballot protocols, LDS bounds when built with
+-fsanitize=address) bit for bit on small frames in a container without a GPU; it says nothing about timing, and the float stages run
+on x86 FMA units instead of gfx950's (same IEEE operations, explicit fmaf only). The GPU tier remains the parity proof.
+hipemu is test infrastructure: nothing under tests/ is linked into or loaded by the product."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import test_gpu_parity as T
+from conftest import CASES
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "hipemu")
+EMU_LIB = os.path.join(EMU_DIR, "_build", "libgpujpeg_emu.so")
+
+
+@pytest.fixture(scope="session")
+def emu_lib(G):
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("make") is None:
+        pytest.skip("hipemu needs ROCm's clang++ (host compilation of the .hip files)")
+    r = subprocess.run(["make", "-s", "-j8", "-C", EMU_DIR], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lib = G.Library(EMU_LIB)
+    assert lib.L.gpujpeg_init_device(0, 0) == 0
+    return lib
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "generic"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_emu_encode_decode_bit_exact(O, G, emu_lib, case, fused):
+    T.test_encode_decode_bit_exact(O, G, emu_lib, case, fused)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[6] != 0][:3], ids=lambda c: c[0])
+def test_emu_segment_info(O, G, emu_lib, case):
+    T.test_segment_info(O, G, emu_lib, case)
+
+
+@pytest.mark.parametrize("pf,w,h", [(1, 161, 121), (3, 322, 77), (5, 33, 35), (0, 99, 3), (6, 17, 9)])
+def test_emu_output_formats(O, G, emu_lib, pf, w, h):
+    T.test_output_formats(O, G, emu_lib, pf, w, h)
+
+
+@pytest.mark.parametrize("mode", ["par", "serial", "seq"])
+@pytest.mark.parametrize("ec", T.ENTROPY_CASES, ids=[c[0] for c in T.ENTROPY_CASES])
+def test_emu_entropy_decoder_variants(O, G, emu_lib, ec, mode, monkeypatch):
+    T.test_entropy_decoder_variants(O, G, emu_lib, ec, mode, monkeypatch)
+
+
+@pytest.mark.parametrize("tc", T.TOKEN_CASES, ids=[c[0] for c in T.TOKEN_CASES])
+def test_emu_token_mode_decoder(O, G, emu_lib, tc, monkeypatch):
+    T.test_token_mode_decoder(O, G, emu_lib, tc, monkeypatch)
+
+
+def test_emu_token_mode_damaged_streams(O, G, emu_lib, monkeypatch):
+    T.test_token_mode_damaged_streams(O, G, emu_lib, monkeypatch)
+
+
+@pytest.mark.parametrize("tc", T.TOKEN_422_CASES, ids=[c[0] for c in T.TOKEN_422_CASES])
+def test_emu_token_mode_decoder_422(O, G, emu_lib, tc, monkeypatch):
+    T.test_token_mode_decoder_422(O, G, emu_lib, tc, monkeypatch)
+
+
+@pytest.mark.parametrize("w,h,restart", [(648, 50, 6), (322, 77, 1), (640, 64, 64), (640, 64, 65), (16, 8, 3)])
+def test_emu_packed_422_whole_frame_encoder(O, G, emu_lib, w, h, restart):
+    T.test_packed_422_whole_frame_encoder(O, G, emu_lib, w, h, restart)
+
+
+def test_emu_reuse_padding_and_reconfiguration(O, G, emu_lib):
+    T.test_width_padding(O, G, emu_lib)
+    T.test_decoder_reuse_without_clearing(O, G, emu_lib)
+    T.test_zero_image_round_trip(O, G, emu_lib)
+
+
+@pytest.mark.parametrize("seed", range(0, 160, 4))
+def test_emu_random_configurations(O, G, emu_lib, seed):
+    T.test_random_configurations(O, G, emu_lib, seed)
+
+
+@pytest.mark.parametrize("seed", range(0, 40, 4))
+def test_emu_random_streams_all_decoder_paths(O, G, emu_lib, seed, monkeypatch):
+    T.test_random_streams_all_decoder_paths(O, G, emu_lib, seed, monkeypatch)

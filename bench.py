@@ -16,7 +16,8 @@ On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --
                     JPEG in + raw out for the decoder) / its average hipEvent duration in a SOLO timed region (one pipeline, the GPU
                     otherwise idle, events on the coder's own stream) against 8 TB/s; `by_kernel` has every kernel of the step,
                     `contended` the same kernel inside the headline region where four pipelines share the GPU; `traffic` = HBM bytes
-                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r2_traffic.json)
+                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r3_traffic.json; dropped when the
+                    device sources differ from the ones profiled)
   encode_only / decode_only   each direction alone, device resident ("w/o PCIe" in the reference's tables)
   full_api          host buffers in and out (pinned), i.e. what a drop-in caller of the reference API sees, PCIe included
   workloads         HD / 4K / 8K / 16K RGB, 16K 4:2:2 interleaved q90 (BASELINE config 4), 256 x 4K batch (config 5)
@@ -53,11 +54,20 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 DTYPE_DETAIL = "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients"
 
 
-def load_traffic(key="kernels"):
-    """HBM bytes per launch (`kernels`) / vector instructions per launch (`valu_insts`) from the committed PMC passes (8K RGB q75
-    natural frame only)."""
+TRAFFIC_FILE = "r3_traffic.json"
+
+
+from gpujpeg_amd.source_hash import kernel_source_hash  # noqa: E402
+
+
+def load_traffic(key="kernels", workload="8k"):
+    """HBM bytes per launch (`kernels`) / vector instructions per launch (`valu_insts`) of a workload from the committed PMC passes
+    (profiles/r3_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json"))).get(key, {})
+        d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+        if d.get("source_hash") != kernel_source_hash():
+            return {}
+        return d.get("workloads", {}).get(workload, {}).get(key, {})
     except Exception:
         return {}
 
@@ -251,7 +261,8 @@ def kernel_names(spec, enc_ms, token_mode):
     whole = enc_ms[1] < 0.02 * max(1.0, spec.pixels / 33e6)  # fully fused encoder: pixels -> segment streams in one kernel (slots 0/1 empty)
     fmt = "uyvy422" if spec.is422 else "rgb444"
     return ["enc:k_preprocess", f"enc:k_fused_{fmt}", f"enc:k_encode_{fmt}" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
-            "dec:k_huffman_decode_par", f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}", "dec:k_postprocess"]
+            "dec:k_huffman_decode_tok" if token_mode else ("dec:k_huffman_decode_seq" if spec.is422 and spec.pixels > 3e7 else "dec:k_huffman_decode_par"),
+            f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}", "dec:k_postprocess"]
 
 
 def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, steps=20, warmup=3, min_seconds=0.5, host_io=False, keep_coefs=False,
@@ -572,7 +583,8 @@ def main():
         names = kernel_names(spec, head["solo_ms"], token_mode)
         alg = spec.raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (the same sum)
         solo, cont = head["solo_ms"], head["kernel_ms"]
-        traffic = load_traffic() if (args.workload == "8k" and spec.quality == 75 and args.pattern == "natural" and not args.internal_rgb) else {}
+        standard = spec.quality == (90 if spec.is422 else 75) and args.pattern == "natural" and not args.internal_rgb
+        traffic = load_traffic("kernels", args.workload) if standard else {}
 
         def roof(name, ms):
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -580,7 +592,7 @@ def main():
 
         live = [i for i in range(8) if solo[i] > 0.006]  # (event slots of kernels this configuration does not launch hold only the gap between two events)
         dom = max(live, key=lambda i: solo[i])
-        valu = load_traffic("valu_insts") if traffic else {}
+        valu = load_traffic("valu_insts", args.workload) if traffic else {}
 
         def issue(name, ms):
             n = valu.get(name)
@@ -607,10 +619,10 @@ def main():
             "decode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["dec_wall"] / 1e6, 2) if args.mode != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"],
                          "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg), **issue(names[dom], solo[dom]),
-                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r2_traffic.json) x 4 cycles / 1024 SIMDs / 2.4 GHz / duration -- "
+                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r3_traffic.json) x 4 cycles / 1024 SIMDs / 2.4 GHz / duration -- "
                                       "the roofline that actually bounds these kernels (HBM traffic already equals the algorithmic bytes for the encoder)",
                          "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
-                                   "coder's stream); profiles/r2_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
+                                   "coder's stream); profiles/r3_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
                          "by_kernel": by_kernel,
                          "by_direction": {"encode": dict(roof("all encoder kernels", enc_total)), "decode": dict(roof("all decoder kernels", dec_total))},
                          "contended": dict(roof(names[dom], cont[dom]), concurrent_pipelines=S,

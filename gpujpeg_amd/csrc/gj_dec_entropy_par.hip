@@ -30,8 +30,8 @@
 // 40960 B, 5 up to 32000 B -- not the 32768 B the runtime's occupancy query reports). Token mode takes 4 per CU with a stage large
 // enough that an 8K frame is ONE generation of workgroups (a second, partial generation doubles the kernel's duration); plane mode keeps
 // the smaller stage next to its per-block address array.
-#define GJ_PAR_CAP_U_FOR(tok) ((tok) ? 10752 : 8192)
-#define GJ_PAR_MAX_BLOCKS_FOR(tok) ((tok) ? 2304 : 1280)
+#define GJ_PAR_CAP_U 8192
+#define GJ_PAR_MAX_BLOCKS 1280
 #define GJ_PAR_GMAX 64        // segments per batch
 #define GJ_PAR_RESIDENT 1024  // workgroups of the token-mode kernel the GPU holds at once (256 CUs x 4)
 #ifndef GJ_PAR_SUB
@@ -42,19 +42,14 @@
 // [9,16) zig-zag advance. State between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag
 // index, [11,16) block inside the MCU.
 // LONG (pieces of a segment that does not fit the LDS stage): block addresses are computed, DC differences go to the plane.
-// TOK (token mode): the counting passes also count the non-zero AC coefficients (upper half of nblk_out); the
-// storing pass appends them as tokens (value | 2 x natural position << 16) to `tok_out` instead of scattering them into the
-// planes, and notes for every block where its tokens start (s_btok, relative to the group).
-// ZZ2: s_zz holds 2 x the natural position (the kernel's token-mode instantiations, also for their piecewise path through the planes)
 #define GJ_TABP(tab, byte_off) (reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(tab) + (byte_off)))
-template <bool WRITE, bool INTERLEAVED, bool LONG = false, bool TOK = false, bool ZZ2 = TOK>
+template <bool WRITE, bool INTERLEAVED, bool LONG = false>
 __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U, const uint32_t start_bit, const uint32_t end_bit,
                                                   const uint32_t entry, const uint16_t* __restrict__ s_tab, const uint32_t* __restrict__ s_ptab,
                                                   const int P, const uint16_t* tdc, const uint16_t* tac, int& nblk_out,
                                                   int16_t* __restrict__ coefs, const uint32_t first, const uint32_t* __restrict__ s_blk,
                                                   int16_t* __restrict__ s_dc, int blk, const int nblocks, const uint8_t* __restrict__ s_zz,
-                                                  const gj_geom* lg = nullptr, const GjSeg* lsg = nullptr, uint32_t* __restrict__ tok_out = nullptr,
-                                                  uint16_t* __restrict__ s_btok = nullptr, const uint32_t tok_rel = 0, uint16_t* __restrict__ s_tend = nullptr)
+                                                  const gj_geom* lg = nullptr, const GjSeg* lsg = nullptr)
 {
     uint32_t bitpos = start_bit + (entry & 31u);
     int z = (int)((entry >> 5) & 63u);
@@ -70,8 +65,6 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
     rd++;
     uint32_t nxt = U[rd];
     int nb = 0;
-    uint32_t ntok = 0;
-    uint4 tb = make_uint4(0, 0, 0, 0);
     while (bitpos < end_bit) {
         if (n <= 32) {
             acc |= (uint64_t)nxt << (32 - n);
@@ -86,29 +79,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
         if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
         const int tot = (int)(e & 31u);
         const int adv = (int)(e >> 9);
-        if (TOK && !WRITE) ntok += (z != 0 && (e & 0x1E0u) != 0) ? 1u : 0u;
-        if (WRITE && TOK) {
-            const int sz = (int)((e >> 5) & 15u);
-            const int used = tot - sz;
-            const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
-            const int v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
-            if (z == 0) {
-                if (blk + nb < nblocks) {
-                    s_dc[blk + nb] = (int16_t)v;
-                    s_btok[blk + nb] = (uint16_t)(tok_rel + ntok);
-                }
-            } else if (sz != 0) { // exactly the symbols the counting passes counted (s_zz[64..127] = 63: damaged streams only)
-                // four tokens per 16-byte store: what a scattered store costs in the address path does not depend on its width
-                const uint32_t tk = ((uint32_t)v & 0xFFFFu) | ((uint32_t)s_zz[z + adv - 1] << 16);
-                const uint32_t q = ntok & 3u;
-                tb.x = q == 0 ? tk : tb.x;
-                tb.y = q == 1 ? tk : tb.y;
-                tb.z = q == 2 ? tk : tb.z;
-                tb.w = tk;
-                ntok++;
-                if (q == 3) *reinterpret_cast<uint4*>(tok_out + (ntok - 4u)) = tb; // (dword aligned)
-            }
-        } else if (WRITE) {
+        if (WRITE) {
             const int sz = (int)((e >> 5) & 15u);
             const int used = tot - sz;
             const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
@@ -119,13 +90,13 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
                     if (z == 0 || (sz != 0 && pos < 64)) {
                         int c_, m_;
                         const uint64_t off = INTERLEAVED ? gj_segment_block(*lg, *lsg, blk + nb, &c_, &m_) : (uint64_t)(first + (uint32_t)(blk + nb)) * 64;
-                        coefs[off + (z == 0 ? 0 : s_zz[pos] >> (ZZ2 ? 1 : 0))] = (int16_t)v;
+                        coefs[off + (z == 0 ? 0 : s_zz[pos])] = (int16_t)v;
                     }
                 } else if (z == 0) {
                     s_dc[blk + nb] = (int16_t)v;
                 } else if (sz != 0 && pos < 64) {
                     const uint32_t b = INTERLEAVED ? s_blk[blk + nb] : first + (uint32_t)(blk + nb);
-                    coefs[(uint64_t)b * 64 + (s_zz[pos] >> (ZZ2 ? 1 : 0))] = (int16_t)v;
+                    coefs[(uint64_t)b * 64 + s_zz[pos]] = (int16_t)v;
                 }
             }
         }
@@ -136,7 +107,6 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
         if (z >= 64) {
             z = 0;
             nb++;
-            if (WRITE && TOK && blk + nb == nblocks) *s_tend = (uint16_t)(tok_rel + ntok); // the last block of the segment ends here
             if (INTERLEAVED) {
                 p = p + 1 == P ? 0 : p + 1;
                 const uint32_t pt = s_ptab[p];
@@ -145,42 +115,22 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
             }
         }
     }
-    if (WRITE && TOK) { // the last one to three tokens
-        uint32_t* o = tok_out + (ntok & ~3u);
-        const uint32_t r = ntok & 3u;
-        if (r > 0) o[0] = tb.x;
-        if (r > 1) o[1] = tb.y;
-        if (r > 2) o[2] = tb.z;
-    }
-    nblk_out = TOK ? (int)((uint32_t)nb | (ntok << 16)) : nb;
+    nblk_out = nb;
     return (bitpos - end_bit) | ((uint32_t)z << 5) | ((uint32_t)p << 11);
 }
 
-// Batches of the sub-sequence decoder: consecutive table entries, cut per scan -- the luminance segments of a photograph carry two to
-// three times the bytes of the chrominance ones, and a batch is sized to fill the LDS stage (one batch size for the whole stream
-// gave luminance batches that had to be decoded as two groups, and chrominance batches that left half of the lanes idle).
-struct GjBatchPlan {
-    int n;                       // ranges (scans)
-    int first[GJ_MAX_COMP];      // first table entry of range c
-    int count[GJ_MAX_COMP];      // entries
-    int g[GJ_MAX_COMP];          // segments per batch
-    int batch0[GJ_MAX_COMP + 1]; // first batch of range c; [n] = number of batches
-};
-
-template <bool INTERLEAVED, int SUB_BYTES, bool TOK>
-__global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+template <bool INTERLEAVED, int SUB_BYTES>
+__global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                             const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const GjBatchPlan plan,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
-                                                            const int zero_fill /* 1: the planes are not known to be zero */,
-                                                            uint32_t* __restrict__ d_tok /* TOK: token buffer */, const uint32_t tok_cap,
-                                                            uint2* __restrict__ d_rec /* TOK: per block (coding order) token start, count << 16 | DC */)
+                                                            const int zero_fill /* 1: the planes are not known to be zero */)
 {
-    constexpr int GJ_PAR_CAP_U = GJ_PAR_CAP_U_FOR(TOK), GJ_PAR_MAX_BLOCKS = GJ_PAR_MAX_BLOCKS_FOR(TOK);
-    // a group's n segments hold at most (CAP_U - 8 n) unstuffed bytes (8 B of padding each), so they are cut into at most
-    // (CAP_U - 8 n) / SUB + n (SUB - 1) / SUB < CAP_U / SUB + n / 2 sub-sequences
-    constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX / 2;
+    // every segment of a group ends with a partial sub-sequence: at most CAP_U / SUB + n sub-sequences for n segments (tighter bounds
+    // hold only for short sub-sequences; nsub is clamped below all the same, so that a fault in this arithmetic cannot become a write
+    // behind the per-sub-sequence arrays)
+    constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX;
     static_assert(MAX_SUBS <= GJ_PAR_MAX_BLOCKS, "the work list lives in the DC array");
     constexpr uint32_t SUB_BITS = SUB_BYTES * 8;
     __shared__ uint32_t s_U[GJ_PAR_CAP_U / 4 + 4];
@@ -193,9 +143,7 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
     __shared__ uint32_t s_bb[GJ_PAR_GMAX + 1], s_ub[GJ_PAR_GMAX + 1], s_ulen[GJ_PAR_GMAX], s_sub0[GJ_PAR_GMAX + 1];
     // per block of the batch
     __shared__ int16_t s_dc[GJ_PAR_MAX_BLOCKS];
-    __shared__ uint32_t s_blk[INTERLEAVED && !TOK ? GJ_PAR_MAX_BLOCKS : 1]; // interleaved: block index in the coefficient planes
-    __shared__ uint16_t s_btok[TOK ? GJ_PAR_MAX_BLOCKS : 1];                // token mode: first token of every block, relative to the group
-    __shared__ uint16_t s_tend[TOK ? GJ_PAR_GMAX : 1];                      // token mode: end of the last block's tokens, per segment
+    __shared__ uint32_t s_blk[INTERLEAVED ? GJ_PAR_MAX_BLOCKS : 1]; // interleaved: block index in the coefficient planes
     // per sub-sequence of the group
     __shared__ __attribute__((aligned(8))) uint2 s_rec[MAX_SUBS];
     __shared__ uint8_t s_subseg[MAX_SUBS];
@@ -217,7 +165,7 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
         for (int t = tid; t < 4 * GJ_DEC2_WORDS / 8; t += 256) dst[t] = src[t];
     }
-    if (tid < 128) s_zz[tid] = (uint8_t)((tid < 64 ? GJ_ZZ[tid] : 63) << (TOK ? 1 : 0)); // token mode: 2 x natural position (gj_slot_put)
+    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
     const int P = g.blocks_per_mcu;
     if (tid < GJ_MAX_MCU_BLOCKS) {
         const int pp = tid < P ? tid : 0;
@@ -281,7 +229,7 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
     }
     __syncthreads();
     const int nblocks_batch = (int)s_bb[nseg];
-    if (INTERLEAVED && !TOK) { // where every block of the batch lives in the coefficient planes
+    if (INTERLEAVED) { // where every block of the batch lives in the coefficient planes
         for (int t = tid; t < nblocks_batch; t += 256) {
             int lo = 0, hi = nseg;
             while (hi - lo > 1) {
@@ -300,8 +248,8 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
     // ---- every block of the batch is filled with zeros (fully coalesced 16 B stores, 128 B per block) before its non-zero
     //      coefficients are scattered into it: the planes need no clearing between frames, and the scattered stores land in
     //      lines this workgroup has just put into L2 instead of pulling the whole plane through partial-line write-backs
-    if (INTERLEAVED && !TOK) __syncthreads(); // s_blk is complete
-    if (zero_fill && !TOK) {
+    if (INTERLEAVED) __syncthreads(); // s_blk is complete
+    if (zero_fill) {
         for (int j = wave; j < nseg; j += 4) {
             const uint32_t chunks = s_nblk[j] * 8u;
             for (uint32_t c = (uint32_t)lane; c < chunks; c += 64) {
@@ -329,7 +277,7 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
             const uint32_t e = round == 0 ? (s_rec[k].x & 0xFFFFu) : (s_rec[k - 1].x >> 16);
             const uint32_t i = (uint32_t)k - k_first;
             int nb;
-            const uint32_t x = gj_decode_sub<false, INTERLEAVED, false, TOK>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
+            const uint32_t x = gj_decode_sub<false, INTERLEAVED>(U, i * SUB_BITS, min((i + 1) * SUB_BITS, seg_bits), e, s_tab, s_ptab, P,
                                                                  GJ_TABP(s_tab, tb & 0xFFFFu), GJ_TABP(s_tab, tb >> 16), nb, nullptr, 0, nullptr, nullptr, 0, 0, s_zz);
             s_rec[k] = make_uint2(e | (x << 16), (uint32_t)nb);
         }
@@ -493,7 +441,7 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
         {
             uint32_t tot;
             const uint32_t a = gj_wg256_incl_scan(my_nsub, s_tmp, &tot);
-            if (tid >= j0 && tid < j1) s_sub0[tid + 1] = a;
+            if (tid >= j0 && tid < j1) s_sub0[tid + 1] = min(a, (uint32_t)MAX_SUBS);
             if (tid == 0) s_sub0[j0] = 0;
         }
         __syncthreads();
@@ -516,42 +464,19 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
         block_positions(nsub);
 
         // -- 5. decode once more, now storing the coefficients
-        // token mode: the group's tokens form one dense run (lanes write their sub-sequences' tokens back to back). It starts at
-        // 4 x the byte offset of the group's first segment: a non-zero AC coefficient takes at least 2 bits of the stream, so the
-        // runs of different groups cannot overlap, and no allocator or reset is needed between frames.
-        uint32_t gbase = 0;
-        if (TOK) {
-            const uint32_t T = nsub > 0 ? s_rec[nsub - 1].y >> 16 : 0u;
-            int jb = j0;
-            while (jb + 1 < j1 && s_len[jb] == 0) jb++; // (segments without data carry no position)
-            gbase = 4u * s_pos[jb];
-            if (gbase > tok_cap || T > tok_cap - gbase) gbase = 0xFFFFFFFFu; // (cannot happen with the capacity the host allocates)
-            for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) { s_btok[b] = 0xFFFFu; s_dc[b] = 0; } // "block not seen"
-            if (tid >= j0 && tid < j1) s_tend[tid] = 0xFFFFu;
-            __syncthreads();
-        } else {
-            for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) s_dc[b] = 0; // (blocks a damaged segment never reaches)
-            __syncthreads();
-        }
+        for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) s_dc[b] = 0; // (blocks a damaged segment never reaches)
+        __syncthreads();
         for (int k = tid; k < nsub; k += 256) {
             const int j = s_subseg[k];
             const uint32_t k_first = s_sub0[j];
             const uint32_t i = (uint32_t)k - k_first;
             const uint32_t sc_k = k > 0 ? s_rec[k - 1].y : 0u, sc_f = k_first > 0 ? s_rec[k_first - 1].y : 0u;
-            const uint32_t before = TOK ? (sc_k & 0xFFFFu) - (sc_f & 0xFFFFu) : sc_k - sc_f;
+            const uint32_t before = sc_k - sc_f;
             const uint32_t endb = min((i + 1) * SUB_BITS, s_ulen[j] * 8u);
             const uint32_t tb = s_tabs[j];
             int nb;
-            if (TOK) {
-                if (gbase != 0xFFFFFFFFu)
-                    gj_decode_sub<true, INTERLEAVED, false, true>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P,
-                                                                  GJ_TABP(s_tab, tb & 0xFFFFu), GJ_TABP(s_tab, tb >> 16), nb, nullptr, 0, nullptr, s_dc + s_bb[j], (int)before,
-                                                                  (int)s_nblk[j], s_zz, nullptr, nullptr, d_tok + gbase + (sc_k >> 16), s_btok + s_bb[j],
-                                                                  sc_k >> 16, s_tend + j);
-            } else {
-                gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, GJ_TABP(s_tab, tb & 0xFFFFu),
-                                                 GJ_TABP(s_tab, tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz);
-            }
+            gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, GJ_TABP(s_tab, tb & 0xFFFFu),
+                                             GJ_TABP(s_tab, tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz);
         }
         __syncthreads();
 
@@ -574,21 +499,8 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
                     carry[c] += (int)(uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 }
                 if (kb < nblk) {
-                    if (TOK) { // block record in coding order: where the tokens are, how many, the DC term
-                        const uint32_t k_end = s_sub0[j + 1];
-                        const uint32_t seg_end = k_end > s_sub0[j] ? s_rec[k_end - 1].y >> 16 : 0u; // tokens of the group up to the end of this segment
-                        const uint32_t t0 = s_btok[bb + kb];
-                        const uint32_t t1 = (kb + 1 < nblk && s_btok[bb + kb + 1] != 0xFFFFu) ? s_btok[bb + kb + 1]
-                                            : (kb + 1 == nblk && s_tend[j] != 0xFFFFu)        ? s_tend[j]
-                                                                                              : seg_end;
-                        const bool seen = t0 != 0xFFFFu && gbase != 0xFFFFFFFFu;
-                        const uint32_t cnt = seen && t1 >= t0 ? min(t1 - t0, 63u) : 0u;
-                        const uint32_t r = (INTERLEAVED ? s_first[j] * (uint32_t)P : s_first[j]) + (uint32_t)kb;
-                        d_rec[r] = make_uint2(seen ? gbase + t0 : 0u, (cnt << 16) | ((uint32_t)dc & 0xFFFFu));
-                    } else {
-                        const uint32_t b = INTERLEAVED ? s_blk[bb + kb] : s_first[j] + (uint32_t)kb;
-                        coefs[(uint64_t)b * 64] = (int16_t)dc;
-                    }
+                    const uint32_t b = INTERLEAVED ? s_blk[bb + kb] : s_first[j] + (uint32_t)kb;
+                    coefs[(uint64_t)b * 64] = (int16_t)dc;
                 }
             }
         }
@@ -607,9 +519,7 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
         const uint8_t* base = jpeg + seg_pos[si0 + jl];
         const uint32_t len = seg_len[si0 + jl];
         const uint32_t first = s_first[jl];
-        if (TOK) // token mode: the blocks of a long segment live in the coefficient planes; their records say so (count 0xFFFF)
-            for (uint32_t c = (uint32_t)tid; c < (uint32_t)sg.nblocks; c += 256) d_rec[sg.first_block + c] = make_uint2(0u, 0xFFFF0000u);
-        if (zero_fill || TOK) {
+        if (zero_fill) {
             for (uint32_t c = (uint32_t)tid; c < (uint32_t)sg.nblocks * 8u; c += 256) {
                 int c_, m_;
                 const uint64_t off = INTERLEAVED ? gj_segment_block(g, sg, (int)(c >> 3), &c_, &m_) : (uint64_t)(first + (c >> 3)) * 64;
@@ -672,15 +582,15 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
             // -- coefficients of this piece (DC still as differences)
             const uint32_t tb = s_tabs[jl];
             for (int k = tid; k < nsub; k += 256) {
-                const uint32_t before = k > 0 ? (TOK ? s_rec[k - 1].y & 0xFFFFu : s_rec[k - 1].y) : 0u;
+                const uint32_t before = k > 0 ? s_rec[k - 1].y : 0u;
                 const uint32_t endb = min((uint32_t)(k + 1) * SUB_BITS, ulen * 8u);
                 int nb;
-                gj_decode_sub<true, INTERLEAVED, true, false, TOK>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, GJ_TABP(s_tab, tb & 0xFFFFu),
+                gj_decode_sub<true, INTERLEAVED, true>(s_U, (uint32_t)k * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, GJ_TABP(s_tab, tb & 0xFFFFu),
                                                        GJ_TABP(s_tab, tb >> 16), nb, coefs, first, nullptr, nullptr, (int)(blocks_done + before), sg.nblocks, s_zz,
                                                        &g, &sg);
             }
             __syncthreads(); // (workgroup-scope fence: the differences are visible to the lanes that sum them up)
-            const uint32_t piece_blocks = nsub > 0 ? (TOK ? s_rec[nsub - 1].y & 0xFFFFu : s_rec[nsub - 1].y) : 0u;
+            const uint32_t piece_blocks = nsub > 0 ? s_rec[nsub - 1].y : 0u;
             const uint32_t b1 = min(blocks_done + piece_blocks, (uint32_t)sg.nblocks);
             for (uint32_t k0 = blocks_done; k0 < b1; k0 += 256) {
                 const uint32_t k = k0 + (uint32_t)tid;
@@ -708,18 +618,16 @@ __global__ __launch_bounds__(256, TOK ? 4 : 1) void k_huffman_decode_par(const g
 }
 
 
-void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st, const bool tokens)
+GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const unsigned max_blocks, const unsigned gmax, const bool one_generation)
 {
     const gj_geom& g = job->g;
-    // batches: as many segments as fill the LDS stage on average, at most GJ_PAR_MAX_BLOCKS blocks, per scan where the bytes per scan
-    // are known (GjBatchPlan)
-    const int eg = job->tune.dec_batch, es = job->tune.dec_sub; // tuning aids: segments per batch, bytes per sub-sequence
-    const unsigned cap_u = GJ_PAR_CAP_U_FOR(tokens), max_blocks = GJ_PAR_MAX_BLOCKS_FOR(tokens);
+    // batches: as many segments as fill the LDS stage on average, at most max_blocks blocks, per scan where the bytes per scan are known
+    const int eg = job->tune.dec_batch; // tuning aid: segments per batch
     auto batch_size = [&](uint64_t bytes, int segs, unsigned fill /* 32nds of the stage */) {
         const unsigned avg = (unsigned)(bytes / (uint64_t)max(1, segs)) + 12u;
         int G = eg ? eg : (int)((cap_u * fill / 32u) / avg); // (a batch that outgrows the stage is decoded in two groups)
         if (!eg) G = min(G, max(1, job->seg_count / 768)); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
-        return max(1, min(G, (int)min((unsigned)GJ_PAR_GMAX, max_blocks / (unsigned)max(1, g.seg_blocks))));
+        return max(1, min(G, (int)min(gmax, max_blocks / (unsigned)max(1, g.seg_blocks))));
     };
     GjBatchPlan plan = {};
     bool per_scan = !g.interleaved && g.comp_count > 1 && job->seg_count == g.segment_count;
@@ -744,22 +652,25 @@ void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st, const bool tok
             plan.batch0[1] = (job->seg_count + plan.g[0] - 1) / plan.g[0];
         }
         const int nb = plan.batch0[plan.n];
-        if (!tokens || eg || nb <= GJ_PAR_RESIDENT || nb > GJ_PAR_RESIDENT * 5 / 4) break;
+        if (!one_generation || eg || nb <= GJ_PAR_RESIDENT || nb > GJ_PAR_RESIDENT * 5 / 4) break;
     }
+    return plan;
+}
+
+void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st)
+{
+    const gj_geom& g = job->g;
+    const GjBatchPlan plan = gj_plan_batches(job, GJ_PAR_CAP_U, GJ_PAR_MAX_BLOCKS, GJ_PAR_GMAX, false);
+    const int es = job->tune.dec_sub; // tuning aid: bytes per sub-sequence
     const int sub = es ? es : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
                                                                        // has to fall into step too): measured best with 32 B
     const unsigned batches = (unsigned)plan.batch0[plan.n];
-    auto kernel = tokens ? (g.interleaved ? k_huffman_decode_par<true, 32, true> : k_huffman_decode_par<false, GJ_PAR_SUB, true>)
-                  : g.interleaved ? (sub == 256 ? k_huffman_decode_par<true, 256, false> : sub == 128 ? k_huffman_decode_par<true, 128, false>
-                                     : sub == 64 ? k_huffman_decode_par<true, 64, false> : sub == 32 ? k_huffman_decode_par<true, 32, false>
-                                     : sub == 8 ? k_huffman_decode_par<true, 8, false> : k_huffman_decode_par<true, 16, false>)
-                                  : (sub == 256 ? k_huffman_decode_par<false, 256, false> : sub == 128 ? k_huffman_decode_par<false, 128, false>
-                                     : sub == 64 ? k_huffman_decode_par<false, 64, false> : sub == 32 ? k_huffman_decode_par<false, 32, false>
-                                     : sub == 8 ? k_huffman_decode_par<false, 8, false> : k_huffman_decode_par<false, 16, false>);
+    auto kernel = g.interleaved ? (sub == 256 ? k_huffman_decode_par<true, 256> : sub == 128 ? k_huffman_decode_par<true, 128>
+                                   : sub == 64 ? k_huffman_decode_par<true, 64> : sub == 32 ? k_huffman_decode_par<true, 32>
+                                   : sub == 8 ? k_huffman_decode_par<true, 8> : k_huffman_decode_par<true, 16>)
+                                : (sub == 256 ? k_huffman_decode_par<false, 256> : sub == 128 ? k_huffman_decode_par<false, 128>
+                                   : sub == 64 ? k_huffman_decode_par<false, 64> : sub == 32 ? k_huffman_decode_par<false, 32>
+                                   : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
     hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                       job->d_seg_index, job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, job->d_tok, job->tok_cap,
-                       (uint2*)job->d_blkrec);
+                       job->d_seg_index, job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1);
 }
-
-// the sub-sequence bytes of the automatic choice (the host's token-mode rule refers to it)
-int gj_huffman_par_default_sub(const gj_geom& g) { return g.interleaved ? 32 : GJ_PAR_SUB; }

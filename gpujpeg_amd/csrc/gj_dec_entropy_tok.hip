@@ -1,0 +1,506 @@
+// gj_dec_entropy_tok.hip -- MI355X (gfx950, wave64) JPEG decoder: sub-sequence parallel entropy decoding into TOKENS.
+// (part of the decoder's device code, see gj_dec_internal.h for the map of the files)
+//
+// The default entropy decoder of large non-interleaved frames. A workgroup takes a batch of consecutive restart segments of one scan and
+//   1. copies their bytes into LDS without the stuffed zeros and the restart markers -- the whole batch is ONE contiguous piece of the
+//      stream, so all 256 lanes take an equal share of it (one prefix sum; segment boundaries fall out of the marker count),
+//   2. cuts every segment into sub-sequences of 16 bytes; a lane decodes its sub-sequence from an assumed state, takes its predecessor's
+//      exit state from the neighbouring lane (DPP) and decodes again if that differs -- Huffman codes self-synchronise, so after this
+//      pass most sub-sequences are right; the others go through rounds over dense work lists until nothing changes (Klein & Wiseman 2003,
+//      Weissenberger & Schmidt 2021). These passes only count: blocks completed and non-zero AC coefficients per sub-sequence,
+//   3. turns the counts into block and token positions with one prefix sum,
+//   4. decodes once more, now producing 16-bit TOKENS (value << 6 | natural position) for the non-zero AC coefficients. A wave stages the
+//      tokens of its 64 sub-sequences in LDS and flushes them with whole 16-byte pieces: the token array is written in full lines,
+//   5. resolves the DC prediction (wave prefix sum per segment) and writes one record per block: first token, count, DC term.
+// The token-fed IDCT (gj_dec_idct.hip) rebuilds the blocks in LDS; the coefficient planes are never touched.
+// What does not fit this scheme raises `overflow` and the host decodes the frame with k_huffman_decode_par through the planes: a segment
+// longer than the LDS stage. A coefficient that does not fit the token's 10 value bits (|v| >= 512: DCT coefficients of 8-bit samples
+// quantised with a step below 3, or a damaged stream) sends its batch through the planes inside this kernel (records say so).
+// Results are identical to src/gpujpeg_huffman_gpu_decoder.cu:287-495 / src/gpujpeg_huffman_cpu_decoder.c:245-372.
+#include "gj_dec_internal.h"
+#include "gj_bitreader.h"
+
+// LDS budget: 4 workgroups per CU need <= 40960 B (granted in steps of 1280 B, tools/ubench/lds_occupancy.hip), and an 8K frame has to be
+// ONE generation of workgroups (a second, partial generation doubles the kernel's duration): hence the stage of 10.5 KB.
+#define GJ_TOK_SUB 16                                           // bytes per sub-sequence
+#define GJ_TOK_MAX_SUBS (GJ_TOK_CAP_U / GJ_TOK_SUB + GJ_TOK_GMAX) // every segment ends with a partial sub-sequence
+#define GJ_TOK_WSTAGE 800                                       // tokens a wave stages per flush (incl. up to 7 of alignment)
+#define GJ_TOK_CHUNK_MAX 48                                     // bytes of the batch's stream per lane in the cooperative copy
+
+// state between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag index
+// counts of a sub-sequence: bits [0,16) blocks completed, [16,32) tokens
+
+// One pass over a sub-sequence. MODE 0: count. MODE 1: tokens into the wave's LDS stage, DC differences + token positions of the blocks
+// into s_dcbt. MODE 2: coefficients into the planes (batches with a coefficient beyond the token range).
+template <int MODE>
+__device__ __forceinline__ uint32_t gj_tok_decode(const uint32_t* __restrict__ s_U, const uint16_t* __restrict__ s_tab, const uint8_t* __restrict__ s_zz,
+                                                  const uint32_t start_bit, const uint32_t end_bit, const uint32_t entry, uint32_t& counts,
+                                                  uint16_t* __restrict__ tok_out /* MODE 1: where this sub-sequence's tokens go in the stage */,
+                                                  uint32_t* __restrict__ s_blkinfo /* MODE 1, 2: slots of the segment's blocks (+ 1) */,
+                                                  const uint32_t tok_rel /* tokens of the group in front of this sub-sequence */, uint32_t blk,
+                                                  const uint32_t nblocks, int16_t* __restrict__ coefs /* MODE 2: first block of the segment */,
+                                                  uint32_t* __restrict__ s_big)
+{
+    uint32_t bitpos = start_bit + (entry & 31u);
+    uint32_t z = (entry >> 5) & 63u;
+    uint32_t nb = 0, ntok = 0;
+    while (bitpos < end_bit) {
+        const uint32_t wi = bitpos >> 5;
+        const uint64_t two = ((uint64_t)s_U[wi] << 32) | s_U[wi + 1];
+        const uint32_t win = (uint32_t)((two << (bitpos & 31u)) >> 32); // the next 32 bits of the stream
+        const uint16_t* t = s_tab + (z == 0 ? 0 : GJ_DEC2_WORDS);
+        uint32_t e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
+        if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)]; // codes longer than 10 bits
+        const uint32_t tot = e & 31u, adv = e >> 9, sz = (e >> 5) & 15u;
+        if (MODE == 0) {
+            ntok += (z != 0 && sz != 0) ? 1u : 0u;
+        } else {
+            const uint32_t bits = sz ? (win << (tot - sz)) >> (32u - sz) : 0u;
+            const int v = (sz && bits < (1u << (sz - 1u))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+            if (z == 0) {
+                // slot blk + nb of the segment: DC difference and where the block's tokens start; the slot behind the last block takes the
+                // start of a block the segment should not have (damaged stream): it ends the last block's tokens
+                if (blk + nb <= nblocks) s_blkinfo[blk + nb] = ((uint32_t)v & 0xFFFFu) | ((tok_rel + ntok) << 16);
+            } else if (sz != 0) {
+                const uint32_t pos = z + adv - 1u; // (s_zz[64..127] = 63: damaged streams only)
+                if (MODE == 1) {
+                    if (sz >= 10u) *s_big = 1u; // does not fit 10 value bits: the batch goes through the planes
+                    tok_out[ntok] = (uint16_t)(((uint32_t)v << 6) | s_zz[pos]);
+                } else if (blk + nb < nblocks && pos < 64u) {
+                    coefs[(uint64_t)(blk + nb) * 64 + s_zz[pos]] = (int16_t)v;
+                }
+                ntok++;
+            }
+        }
+        bitpos += tot;
+        z += adv;
+        if (z >= 64u) {
+            z = 0;
+            nb++;
+        }
+    }
+    counts = nb | (ntok << 16);
+    return (bitpos - end_bit) | (z << 5);
+}
+
+template <bool COOP>
+__global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+                                                               const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
+                                                               const uint32_t* __restrict__ seg_index, const int seg_count_max,
+                                                               const uint32_t* __restrict__ seg_count_ptr, const GjBatchPlan plan,
+                                                               const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
+                                                               uint16_t* __restrict__ d_tok, const uint32_t tok_cap, uint2* __restrict__ d_rec,
+                                                               uint32_t* __restrict__ overflow)
+{
+    constexpr int CAP_U = GJ_TOK_CAP_U, MAX_BLOCKS = GJ_TOK_MAX_BLOCKS, GMAX = GJ_TOK_GMAX, MAX_SUBS = GJ_TOK_MAX_SUBS;
+    constexpr uint32_t SUB_BITS = GJ_TOK_SUB * 8;
+    static_assert(MAX_SUBS * 2 <= (MAX_BLOCKS + GMAX) * 4, "the work list lives in the block slots");
+    __shared__ uint32_t s_U[CAP_U / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[2 * GJ_DEC2_WORDS]; // DC table, AC table of the group's component
+    __shared__ uint8_t s_zz[64 + 64];
+    __shared__ __attribute__((aligned(8))) uint2 s_rec[MAX_SUBS];              // per sub-sequence: entry | exit << 16, counts (then their prefix sums)
+    __shared__ uint8_t s_subseg[MAX_SUBS];
+    __shared__ uint32_t s_blkinfo[MAX_BLOCKS + GMAX];                          // per block of the batch (+ one slot per segment): DC difference | first token << 16
+    __shared__ __attribute__((aligned(16))) uint16_t s_tokst[4][GJ_TOK_WSTAGE]; // per wave: tokens on their way to HBM
+    // per segment of the batch: first slot in s_blkinfo, capacity offsets (which segments fit the stage together), first record, tables
+    __shared__ uint32_t s_bb[GMAX + 1], s_cap[GMAX + 1], s_first[GMAX];
+    __shared__ uint16_t s_tabsel[GMAX];
+    // per segment of the group: first and end bit in the stage, first sub-sequence
+    __shared__ uint32_t s_sbit[GMAX], s_ebit[GMAX], s_sub0[GMAX + 1];
+    __shared__ uint32_t s_tmp[4];
+    __shared__ int s_j1, s_jstop;
+    __shared__ uint32_t s_nwork[2], s_big;
+    // stream positions and lengths are needed until the stage is filled: they borrow the token stage
+    uint32_t* const s_pos = reinterpret_cast<uint32_t*>(&s_tokst[0][0]);
+    uint32_t* const s_len = s_pos + GMAX;
+    uint32_t* const s_ubyte = s_len + GMAX;     // [GMAX + 1] byte offset of every segment in the stage
+    uint32_t* const s_ulen = s_ubyte + GMAX + 1; // [GMAX] its unstuffed length
+    static_assert((4 * GMAX + 1) * 4 <= sizeof(s_tokst), "borrowed space");
+    uint16_t* const s_work = reinterpret_cast<uint16_t*>(s_blkinfo);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
+
+    // ---- batch setup: lane j describes segment j of the batch
+    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
+    int pc = 0;
+    while (pc + 1 < plan.n && (int)blockIdx.x >= plan.batch0[pc + 1]) pc++;
+    const int G = plan.g[pc];
+    const int si0 = plan.first[pc] + ((int)blockIdx.x - plan.batch0[pc]) * G;
+    if (si0 >= seg_count) return;
+    const int nseg = min(min(G, plan.first[pc] + plan.count[pc] - si0), seg_count - si0);
+    // (kept in registers of lanes 0 .. nseg - 1 for the groups: position, length, blocks)
+    uint32_t my_pos = 0, my_len = 0, my_nblk = 0;
+    {
+        uint32_t first = 0, tb = 0;
+        if (tid < nseg) {
+            const uint32_t s = seg_index[si0 + tid];
+            if (s < (uint32_t)g.segment_count) {
+                const GjSeg sg = gj_segment(g, (int)s);
+                const gj_comp_geom& kc = g.comp[sg.comp];
+                my_nblk = (uint32_t)sg.nblocks;
+                my_pos = seg_pos[si0 + tid];
+                my_len = seg_len[si0 + tid];
+                first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block: record index = block index of the planes
+                tb = (uint32_t)(kc.dc_table * 2 + 0) | ((uint32_t)(kc.ac_table * 2 + 1) << 8);
+                if (((my_len + 3u) & ~3u) + 8u > (uint32_t)CAP_U || my_nblk > (uint32_t)MAX_BLOCKS) { // not for this kernel: the host decodes the frame again
+                    *overflow = 1u;
+                    my_len = 0;
+                    my_nblk = 0;
+                }
+            }
+        }
+        if (tid < GMAX) {
+            s_first[tid] = first;
+            s_tabsel[tid] = (uint16_t)tb;
+        }
+        uint32_t tot;
+        const uint32_t a = gj_wg256_incl_scan(tid < nseg ? my_nblk + 1u : 0u, s_tmp, &tot); // (one slot more per segment, see gj_tok_decode)
+        if (tid < GMAX) s_bb[tid + 1] = a;
+        const uint32_t b = gj_wg256_incl_scan(my_len ? ((my_len + 3u) & ~3u) + 8u : 0u, s_tmp, &tot);
+        if (tid < GMAX) s_cap[tid + 1] = b;
+        if (tid == 0) { s_bb[0] = 0; s_cap[0] = 0; s_nwork[0] = 0; s_nwork[1] = 0; }
+    }
+    __syncthreads();
+
+    uint32_t loaded_tabs = 0xFFFFFFFFu;
+    // ---- groups: consecutive segments with the same Huffman tables whose unstuffed bytes fit the LDS stage (normally one group = the batch)
+    for (int j0 = 0; j0 < nseg;) {
+        if (tid == 0) { s_j1 = j0 + 1; s_jstop = nseg; s_big = 0; }
+        if (tid < nseg) { s_pos[tid] = my_pos; s_len[tid] = my_len; }
+        __syncthreads();
+        const uint32_t tb = s_tabsel[j0];
+        if (tid > j0 && tid < nseg && my_nblk != 0 && s_tabsel[tid] != tb) atomicMin(&s_jstop, tid); // other tables (the next scan) end the group
+        __syncthreads();
+        if (tid > j0 && tid <= s_jstop && s_cap[tid] - s_cap[j0] <= (uint32_t)CAP_U) atomicMax(&s_j1, tid);
+        __syncthreads();
+        const int j1 = s_j1;
+        const int ng = j1 - j0;
+
+        // -- 0. the group's Huffman tables
+        if (tb != loaded_tabs) {
+            const uint4* src0 = reinterpret_cast<const uint4*>(tabs + (tb & 0xFFu) * GJ_DEC2_WORDS);
+            const uint4* src1 = reinterpret_cast<const uint4*>(tabs + (tb >> 8) * GJ_DEC2_WORDS);
+            uint4* dst = reinterpret_cast<uint4*>(s_tab);
+            for (int t = tid; t < GJ_DEC2_WORDS / 8; t += 256) { dst[t] = src0[t]; dst[GJ_DEC2_WORDS / 8 + t] = src1[t]; }
+            loaded_tabs = tb;
+        }
+
+        // -- 1. the group's bytes without stuffing and markers. Layout of the stage: segment j at byte s_ubyte[j] (big-endian dwords), 8 zero
+        //       bytes behind every segment (a symbol that straddles the end reads zeros, src/gpujpeg_huffman_cpu_decoder.c:80-118)
+        bool coop = false;
+        if (COOP) {
+            // regular: every segment has data and is followed, two bytes later, by the next one (what a scan of restart intervals looks like)
+            bool irregular = false;
+            if (lane < ng) {
+                const int j = j0 + lane;
+                irregular = s_len[j] == 0 || (lane + 1 < ng && s_pos[j + 1] != s_pos[j] + s_len[j] + 2u);
+            }
+            const uint32_t A = s_pos[j0], total = s_pos[j1 - 1] + s_len[j1 - 1] - A;
+            coop = __ballot(irregular) == 0ull && total <= 256u * GJ_TOK_CHUNK_MAX && A >= 8u && (uint64_t)A + total <= jpeg_size;
+        }
+        if (coop) {
+            const uint32_t A = s_pos[j0], total = s_pos[j1 - 1] + s_len[j1 - 1] - A;
+            const uint32_t C = (((total + 255u) >> 8) + 3u) & ~3u; // bytes per lane, a multiple of 4
+            const uint32_t off0 = (uint32_t)tid * C;                // this lane's first byte, relative to A
+            const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + A + off0;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3) - 1;
+            const uint32_t lead = (uint32_t)((reinterpret_cast<uintptr_t>(jpeg) + A) & 3); // (C is a multiple of 4: the same for every lane)
+            // window: the dword in front of the lane's first byte ... the dword behind its last one
+            uint32_t win[GJ_TOK_CHUNK_MAX / 4 + 3];
+#pragma unroll
+            for (int i = 0; i < GJ_TOK_CHUNK_MAX / 4 + 3; i++) {
+                win[i] = 0;
+                if ((uint32_t)i < C / 4 + 3u && off0 < total + 4u && src + i < end) win[i] = src[i];
+            }
+            uint32_t prevb = off0 == 0 ? 0u : __builtin_amdgcn_alignbyte(win[1], win[0], lead) >> 24; // the byte in front of the share
+            uint64_t keep = 0; // bit b: byte b of the share goes to the stage
+            uint64_t mark = 0; // bit b: byte b starts a restart marker
+            uint32_t nkeep = 0, nmark = 0;
+#pragma unroll
+            for (int i = 0; i < GJ_TOK_CHUNK_MAX / 4; i++) {
+                if ((uint32_t)(4 * i) < C) {
+                    const uint32_t w = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead);  // bytes 4i .. 4i + 3 of the share
+                    const uint32_t wn = __builtin_amdgcn_alignbyte(win[i + 3], win[i + 2], lead); // (its first byte follows the last one of w)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t b = (w >> (8 * k)) & 0xFFu;
+                        const uint32_t nx = k < 3 ? (w >> (8 * k + 8)) & 0xFFu : wn & 0xFFu;
+                        const bool valid = off0 + (uint32_t)(4 * i + k) < total;
+                        const bool m1 = b == 0xFFu && (nx & 0xF8u) == 0xD0u;    // FF Dn: a restart marker starts here
+                        const bool m2 = prevb == 0xFFu && (b & 0xF8u) == 0xD0u; // its second byte
+                        const bool st = prevb == 0xFFu && b == 0u;              // stuffed zero
+                        if (valid && m1) { mark |= 1ull << (4 * i + k); nmark++; }
+                        if (valid && !m1 && !m2 && !st) { keep |= 1ull << (4 * i + k); nkeep++; }
+                        prevb = b;
+                    }
+                }
+            }
+            uint32_t tot;
+            const uint32_t inc = gj_wg256_incl_scan(nkeep | (nmark << 16), s_tmp, &tot);
+            uint32_t o = (inc & 0xFFFFu) - nkeep, m = (inc >> 16) - nmark; // kept bytes / markers in front of this lane's share
+            uint8_t* U8 = reinterpret_cast<uint8_t*>(s_U);
+            coop = (tot >> 16) == (uint32_t)(ng - 1); // (as many markers as the table says; the same for every lane)
+            if (coop) {
+#pragma unroll
+                for (int i = 0; i < GJ_TOK_CHUNK_MAX / 4; i++) {
+                    if ((uint32_t)(4 * i) < C) {
+                        const uint32_t w = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if ((mark >> (4 * i + k)) & 1ull) { // segment j0 + m ends here: 8 zero bytes, the next one starts behind them
+                                for (uint32_t q = 0; q < 8; q++) U8[(o + 8u * m + q) ^ 3u] = 0;
+                                m++;
+                                s_ubyte[j0 + (int)m] = o + 8u * m;
+                            }
+                            if ((keep >> (4 * i + k)) & 1ull) {
+                                U8[(o + 8u * m) ^ 3u] = (uint8_t)(w >> (8 * k));
+                                o++;
+                            }
+                        }
+                    }
+                }
+                if (tid == 255) { // behind the last segment
+                    for (uint32_t q = 0; q < 12; q++) U8[(o + 8u * m + q) ^ 3u] = 0;
+                    s_ubyte[j1] = o + 8u * m + 8u;
+                }
+                if (tid == 0) s_ubyte[j0] = 0;
+            }
+        }
+        __syncthreads();
+        if (coop) {
+            if (tid >= j0 && tid < j1) s_ulen[tid] = s_ubyte[tid + 1] - s_ubyte[tid] - 8u;
+        } else {
+            // segment by segment, one wave each (irregular tables: host walk of a damaged stream, APP13 index, missing segments)
+            for (int j = j0 + wave; j < j1; j += 4) {
+                const uint32_t len = s_len[j], base = s_cap[j] - s_cap[j0];
+                uint32_t ulen = 0;
+                if (len) {
+                    const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + s_pos[j];
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+                    const uint32_t ndw = ((uint32_t)(a & 3) + len + 3u) >> 2;
+                    uint32_t w0 = 0;
+                    if ((uint32_t)lane < ndw && src + lane < end) w0 = src[lane];
+                    ulen = gj_unstuff_segment(jpeg, end, s_pos[j], len, s_U, base, lane, w0);
+                }
+                if (lane == 0) { s_ubyte[j] = base; s_ulen[j] = ulen; }
+            }
+        }
+        __syncthreads();
+
+        // -- 2. sub-sequence table
+        {
+            uint32_t my_nsub = 0;
+            if (tid >= j0 && tid < j1) {
+                const uint32_t ulen = my_nblk ? s_ulen[tid] : 0u;
+                my_nsub = (ulen + GJ_TOK_SUB - 1) / GJ_TOK_SUB;
+                s_sbit[tid] = s_ubyte[tid] * 8u;
+                s_ebit[tid] = (s_ubyte[tid] + ulen) * 8u;
+            }
+            uint32_t tot;
+            const uint32_t a = gj_wg256_incl_scan(my_nsub, s_tmp, &tot);
+            // (a segment of n bytes has n / 16 + 1 sub-sequences at most: MAX_SUBS cannot be exceeded; the clamp keeps a fault in the
+            // arithmetic above from becoming a write behind s_rec)
+            if (tid >= j0 && tid < j1) s_sub0[tid + 1] = min(a, (uint32_t)MAX_SUBS);
+            if (tid == 0) s_sub0[j0] = 0;
+        }
+        __syncthreads();
+        const int nsub = (int)s_sub0[j1];
+        for (int k = tid; k < nsub; k += 256) {
+            int lo = j0, hi = j1; // segment j with s_sub0[j] <= k < s_sub0[j + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_sub0[mid] <= (uint32_t)k) lo = mid; else hi = mid;
+            }
+            s_subseg[k] = (uint8_t)lo;
+        }
+        __syncthreads();
+
+        // -- 3. first pass: every sub-sequence from its assumed state (the first one of a segment: the true state; any other one most
+        //       likely starts in the middle of a block), then once more from what the neighbouring lane leaves, if that is different
+        for (int k0 = 0; k0 < nsub; k0 += 256) {
+            const int k = k0 + tid;
+            const bool act = k < nsub;
+            uint32_t e0 = 0, x0 = 0, c0 = 0, sb = 0, eb = 0;
+            bool first = true;
+            if (act) {
+                const int j = s_subseg[k];
+                const uint32_t i = (uint32_t)k - s_sub0[j];
+                first = i == 0;
+                sb = s_sbit[j] + i * SUB_BITS;
+                eb = min(sb + SUB_BITS, s_ebit[j]);
+                e0 = first ? 0u : (1u << 5);
+                x0 = gj_tok_decode<0>(s_U, s_tab, s_zz, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+            }
+            const uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x0, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0: nobody in front)
+            if (act && !first && lane != 0 && xp != e0) {
+                e0 = xp;
+                x0 = gj_tok_decode<0>(s_U, s_tab, s_zz, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+            }
+            if (act) s_rec[k] = make_uint2(e0 | (x0 << 16), c0);
+        }
+        // -- rounds: sub-sequences whose predecessor leaves in another state than they were entered with are decoded again, densely packed
+        //    onto the lanes, until there is none (s_rec[k] is written with one 64-bit store: a record always describes one decoding)
+        for (int round = 0;; round++) {
+            __syncthreads();
+            uint32_t* const cnt = &s_nwork[round & 1];
+            for (int k0 = 0; k0 < nsub; k0 += 256) {
+                const int k = k0 + tid;
+                bool cand = false;
+                if (k < nsub) {
+                    const uint32_t kf = s_sub0[s_subseg[k]];
+                    cand = (uint32_t)k != kf && (s_rec[k - 1].x >> 16) != (s_rec[k].x & 0xFFFFu);
+                }
+                const unsigned long long m = __ballot(cand);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(cnt, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (cand) s_work[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+            }
+            __syncthreads();
+            const int nwork = (int)*cnt;
+            if (tid == 0) s_nwork[(round + 1) & 1] = 0;
+            if (nwork == 0) break;
+            for (int w = tid; w < nwork; w += 256) {
+                const int k = s_work[w];
+                const int j = s_subseg[k];
+                const uint32_t i = (uint32_t)k - s_sub0[j];
+                const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
+                const uint32_t e = s_rec[k - 1].x >> 16;
+                uint32_t c;
+                const uint32_t x = gj_tok_decode<0>(s_U, s_tab, s_zz, sb, eb, e, c, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+                s_rec[k] = make_uint2(e | (x << 16), c);
+            }
+        }
+
+        // -- 4. block and token positions: inclusive prefix sums of both counts (two 16-bit sums in one scan)
+        {
+            uint32_t carry = 0;
+            for (int k0 = 0; k0 < nsub; k0 += 256) {
+                const int k = k0 + tid;
+                const uint32_t v = k < nsub ? s_rec[k].y : 0;
+                uint32_t tot;
+                const uint32_t inc = gj_wg256_incl_scan(v, s_tmp, &tot);
+                __syncthreads();
+                if (k < nsub) s_rec[k].y = carry + inc;
+                carry += tot;
+            }
+        }
+        for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) s_blkinfo[b] = 0xFFFF0000u; // "block not seen", DC difference 0
+        __syncthreads();
+
+        // -- 5. decode once more, now with values. The group's tokens form one dense run that starts at 4 x the byte offset of the group's
+        //       first segment (a token takes at least 3 bits of the stream, so the runs of different groups cannot overlap, and no
+        //       allocator or reset is needed between frames). Wave w takes the w-th quarter of the sub-sequences, 64 (or as many as
+        //       fit its stage) at a time, and flushes their tokens -- consecutive in the run -- with 16-byte pieces.
+        const uint32_t T = nsub > 0 ? s_rec[nsub - 1].y >> 16 : 0u;
+        uint32_t gbase;
+        {
+            int jb = j0;
+            while (jb + 1 < j1 && s_bb[jb + 1] - s_bb[jb] == 1u) jb++; // (segments without blocks carry no position)
+            gbase = 4u * seg_pos[si0 + jb];
+            if (gbase > tok_cap || T > tok_cap - gbase) gbase = 0xFFFFFFFFu; // (cannot happen with the capacity the host allocates)
+        }
+        if (gbase != 0xFFFFFFFFu) {
+            const int ka = (int)(((uint32_t)nsub * (uint32_t)wave) >> 2), kb = (int)(((uint32_t)nsub * (uint32_t)(wave + 1)) >> 2);
+            uint16_t* const stage = s_tokst[wave];
+            for (int k0 = ka; k0 < kb;) {
+                const uint32_t P0 = k0 > 0 ? s_rec[k0 - 1].y >> 16 : 0u; // tokens of the group in front of this chunk
+                const uint32_t a0 = (gbase + P0) & 7u;                    // the stage mirrors the alignment of the run: piece p <-> tokens 8p .. 8p + 7
+                const int kk = k0 + lane;
+                const bool fits = kk < kb && a0 + ((s_rec[min(kk, nsub - 1)].y >> 16) - P0) <= (uint32_t)GJ_TOK_WSTAGE;
+                const unsigned long long fm = __ballot(fits);
+                const int n = fm == ~0ull ? 64 : __builtin_ctzll(~fm); // leading lanes whose tokens fit (at least one: a sub-sequence has < 64 tokens)
+                gj_wave_sync(); // (the previous flush has read the stage)
+                if (lane < n) {
+                    const int j = s_subseg[kk];
+                    const uint32_t kf = s_sub0[j];
+                    const uint32_t i = (uint32_t)kk - kf;
+                    const uint32_t before_k = kk > 0 ? s_rec[kk - 1].y : 0u, before_f = kf > 0 ? s_rec[kf - 1].y : 0u;
+                    const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
+                    uint32_t c;
+                    gj_tok_decode<1>(s_U, s_tab, s_zz, sb, eb, s_rec[kk].x & 0xFFFFu, c, stage + a0 + ((before_k >> 16) - P0), s_blkinfo + s_bb[j], before_k >> 16,
+                                     (before_k & 0xFFFFu) - (before_f & 0xFFFFu), s_bb[j + 1] - s_bb[j] - 1u, nullptr, &s_big);
+                }
+                gj_wave_sync();
+                // flush
+                const uint32_t cnt = (s_rec[k0 + n - 1].y >> 16) - P0;
+                uint16_t* const dst = d_tok + (size_t)(gbase + P0 - a0); // 16-byte aligned; stage[s] <-> dst[s]
+                for (uint32_t p = (uint32_t)lane; p * 8u < a0 + cnt; p += 64) {
+                    const uint32_t lo = p * 8u, hi = lo + 8u;
+                    if (lo >= a0 && hi <= a0 + cnt) {
+                        *reinterpret_cast<uint4*>(dst + lo) = *reinterpret_cast<const uint4*>(stage + lo);
+                    } else { // the ends of the chunk: token by token (the neighbours belong to another wave)
+                        for (uint32_t s = max(lo, a0); s < min(hi, a0 + cnt); s++) dst[s] = stage[s];
+                    }
+                }
+                k0 += n;
+            }
+        }
+        __syncthreads();
+
+        // -- 5b. a coefficient did not fit a token: the group's blocks go through the coefficient planes instead (records say so)
+        const bool planes = s_big != 0 || gbase == 0xFFFFFFFFu;
+        if (planes) {
+            for (int j = j0 + wave; j < j1; j += 4) {
+                const uint32_t chunks = (s_bb[j + 1] - s_bb[j] - 1u) * 8u;
+                for (uint32_t c = (uint32_t)lane; c < chunks; c += 64)
+                    reinterpret_cast<uint4*>(coefs + (uint64_t)(s_first[j] + (c >> 3)) * 64)[c & 7u] = make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads(); // (orders the zeros before the coefficient stores of the other lanes)
+            for (int k = tid; k < nsub; k += 256) {
+                const int j = s_subseg[k];
+                const uint32_t kf = s_sub0[j];
+                const uint32_t i = (uint32_t)k - kf;
+                const uint32_t before_k = k > 0 ? s_rec[k - 1].y : 0u, before_f = kf > 0 ? s_rec[kf - 1].y : 0u;
+                const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
+                uint32_t c;
+                gj_tok_decode<2>(s_U, s_tab, s_zz, sb, eb, s_rec[k].x & 0xFFFFu, c, nullptr, s_blkinfo + s_bb[j], 0, (before_k & 0xFFFFu) - (before_f & 0xFFFFu),
+                                 s_bb[j + 1] - s_bb[j] - 1u, coefs + (uint64_t)s_first[j] * 64, nullptr);
+            }
+            __syncthreads();
+        }
+
+        // -- 6. DC prediction: one wave per segment, prefix sum over its blocks; one record per block in coding order
+        for (int j = j0 + wave; j < j1; j += 4) {
+            const uint32_t bb = s_bb[j];
+            const int nblk = (int)(s_bb[j + 1] - bb) - 1;
+            const uint32_t k_end = s_sub0[j + 1];
+            const uint32_t seg_end = k_end > s_sub0[j] ? s_rec[k_end - 1].y >> 16 : 0u; // tokens of the group up to the end of this segment
+            int carry = 0;
+            for (int kb0 = 0; kb0 < nblk; kb0 += 64) {
+                const int kb = kb0 + lane;
+                const uint32_t info = kb < nblk ? s_blkinfo[bb + kb] : 0xFFFF0000u;
+                const uint32_t inc = gj_wave_incl_scan((uint32_t)(int)(int16_t)(info & 0xFFFFu));
+                const int dc = carry + (int)inc;
+                carry += (int)(uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                if (kb < nblk) {
+                    const uint32_t r = s_first[j] + (uint32_t)kb;
+                    if (planes) {
+                        coefs[(uint64_t)r * 64] = (int16_t)dc;
+                        d_rec[r] = make_uint2(0u, 0xFFFF0000u); // "the block is in the coefficient planes"
+                    } else {
+                        const uint32_t t0 = info >> 16, nx = s_blkinfo[bb + kb + 1] >> 16;
+                        const uint32_t t1 = nx != 0xFFFFu ? nx : seg_end;
+                        const bool seen = t0 != 0xFFFFu;
+                        const uint32_t cnt = seen && t1 >= t0 ? min(t1 - t0, 63u) : 0u;
+                        d_rec[r] = make_uint2(seen ? gbase + t0 : 0u, (cnt << 16) | ((uint32_t)dc & 0xFFFFu));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        j0 = j1;
+    }
+}
+
+void gj_launch_huffman_tok(const gj_dec_job* job, hipStream_t st)
+{
+    const gj_geom& g = job->g;
+    const GjBatchPlan plan = gj_plan_batches(job, GJ_TOK_CAP_U, GJ_TOK_MAX_BLOCKS, GJ_TOK_GMAX, true);
+    auto kernel = job->tune.dec_tok_nocoop ? k_huffman_decode_tok<false> : k_huffman_decode_tok<true>;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)plan.batch0[plan.n]), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len, job->d_seg_index,
+                       job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, (uint16_t*)job->d_tok, job->tok_cap, (uint2*)job->d_blkrec,
+                       job->d_overflow);
+}

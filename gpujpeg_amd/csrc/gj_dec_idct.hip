@@ -168,27 +168,29 @@ __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, i
 
 // ================================================================================================
 // The same, fed by the entropy decoder's TOKENS (DESIGN 4.3 "token mode"): per block a record (first token, count, DC
-// term) in coding order and, in one dense array, the non-zero AC coefficients as value | 2 x natural position << 16.
-// A block costs 8 B + 4 B per non-zero coefficient of HBM traffic instead of 128 B written (twice) and read. Every lane
+// term) in coding order and, in one dense array, the non-zero AC coefficients as 16-bit tokens value << 6 | natural position.
+// A block costs 8 B + 2 B per non-zero coefficient of HBM traffic instead of 128 B written (twice) and read. Every lane
 // clears its own 128-byte slot of the LDS tile, the wave copies the token range of its 64 blocks into LDS with 16-byte
 // loads (consecutive blocks of a scan have consecutive tokens; a new range starts where a decoder batch ended), every lane
 // scatters its own tokens into its slot (2-byte LDS stores) and reads the block back as rows. Nothing crosses waves, so
 // there is no workgroup barrier. Blocks of segments too long for the decoder's LDS stage arrive through the coefficient
 // planes as before (count 0xFFFF in the record). Non-interleaved scans only (plane order == coding order).
 // ================================================================================================
-#define GJ_TOK_STAGE 416 // tokens per wave in LDS (with the 32 KiB tile: four workgroups per CU)
+#define GJ_TOK_STAGE 832 // tokens per wave in LDS (with the 32 KiB tile: four workgroups per CU)
 
 // a lane's 128-byte slot of the block tile: row r (16 bytes) sits at (r ^ (lane & 7)) * 16, which spreads the row reads and
-// writes of the 64 lanes over all banks without padding the slot. A token carries 2 x its natural position = row << 4 | column << 1
-// in its upper half, so its place in the slot is that field XOR (lane & 7) << 4: one SDWA and + one xor per token.
+// writes of the 64 lanes over all banks without padding the slot. A token carries its natural position = row << 3 | column in its low
+// 6 bits and the value above them: its place in the slot is 2 x (position XOR (lane & 7) << 3), and what is stored there is the token
+// with the position masked off = 64 x the value -- the dequantisation table of the token-fed kernels holds q / 64 for the AC positions
+// (a power of two: the product is the same fp32 number), so no shift is spent on the value.
 __device__ __forceinline__ uint4* gj_slot_row(uint8_t* slot, const int lane, const int r)
 {
     return reinterpret_cast<uint4*>(slot + ((uint32_t)(r << 4) ^ (((uint32_t)lane & 7u) << 4)));
 }
 
-__device__ __forceinline__ void gj_slot_put(uint8_t* slot, const int lane, const uint32_t tok)
+__device__ __forceinline__ void gj_slot_put(uint8_t* slot, const uint32_t swz /* (lane & 7) << 3 */, const uint32_t tok)
 {
-    *reinterpret_cast<uint16_t*>(slot + (((tok >> 16) & 0x7Eu) ^ (((uint32_t)lane & 7u) << 4))) = (uint16_t)tok;
+    reinterpret_cast<uint16_t*>(slot)[(tok & 63u) ^ swz] = (uint16_t)(tok & 0xFFC0u);
 }
 
 // the wave's token range of one component: dense and small enough for the stage (the normal case), with the two 16-byte
@@ -199,18 +201,18 @@ struct GjTokRange {
     uint4 t0, t1;
 };
 
-__device__ __forceinline__ GjTokRange gj_tok_fetch(const uint32_t* __restrict__ d_tok, const uint32_t start, const uint32_t cnt, const int lane)
+__device__ __forceinline__ GjTokRange gj_tok_fetch(const uint16_t* __restrict__ d_tok, const uint32_t start, const uint32_t cnt, const int lane)
 {
     GjTokRange r;
     const uint32_t end = start + cnt;
     const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false); // wave_shr:1
     const unsigned long long breaks = __ballot(lane != 0 && start != prev_end);
-    r.S = (uint32_t)__builtin_amdgcn_readlane((int)start, 0) & ~3u;
+    r.S = (uint32_t)__builtin_amdgcn_readlane((int)start, 0) & ~7u; // (16-byte pieces of 8 tokens)
     r.E = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
     r.fast = breaks == 0 && r.E - r.S <= GJ_TOK_STAGE;
     r.t0 = r.t1 = make_uint4(0, 0, 0, 0);
     if (r.fast) {
-        const uint32_t i0 = (uint32_t)lane * 4u, i1 = i0 + 256u;
+        const uint32_t i0 = (uint32_t)lane * 8u, i1 = i0 + 512u;
         if (r.S + i0 < r.E) r.t0 = *reinterpret_cast<const uint4*>(d_tok + r.S + i0);
         if (i1 < GJ_TOK_STAGE && r.S + i1 < r.E) r.t1 = *reinterpret_cast<const uint4*>(d_tok + r.S + i1);
     }
@@ -219,9 +221,9 @@ __device__ __forceinline__ GjTokRange gj_tok_fetch(const uint32_t* __restrict__ 
 
 // One block per lane: zeros, the DC term and the lane's tokens go into its tile slot. `fast`: the wave's tokens are in the stage
 // already (dense range starting at token S).
-__device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint32_t* stage, const int lane, const bool fast, const uint32_t S, const uint32_t start,
+__device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint16_t* stage, const int lane, const bool fast, const uint32_t S, const uint32_t start,
                                                const uint32_t cnt, const uint32_t dc, const bool in_plane, const uint4* __restrict__ plane_block,
-                                               const uint32_t* __restrict__ d_tok)
+                                               const uint16_t* __restrict__ d_tok)
 {
 #pragma unroll
     for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = make_uint4(0, 0, 0, 0);
@@ -232,16 +234,17 @@ __device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint32_t* stage, c
         *reinterpret_cast<uint16_t*>(slot + ((lane & 7) << 4)) = (uint16_t)dc;
     }
     const uint32_t end = start + cnt;
+    const uint32_t swz = ((uint32_t)lane & 7u) << 3;
     if (fast) {
         gj_wave_sync();
         uint32_t a = start - S;
         const uint32_t b = end - S;
         for (; a + 2 <= b; a += 2) {
             const uint32_t ta = stage[a], tb = stage[a + 1];
-            gj_slot_put(slot, lane, ta);
-            gj_slot_put(slot, lane, tb);
+            gj_slot_put(slot, swz, ta);
+            gj_slot_put(slot, swz, tb);
         }
-        if (a < b) gj_slot_put(slot, lane, stage[a]);
+        if (a < b) gj_slot_put(slot, swz, stage[a]);
     } else {
         // several ranges (a decoder batch ended inside the wave's blocks) or more tokens than the stage holds: range by range,
         // chunk by chunk
@@ -253,14 +256,14 @@ __device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint32_t* stage, c
             const int dn = runs ? __builtin_ctzll(runs) : 64;
             const uint32_t RS = (uint32_t)__builtin_amdgcn_readlane((int)start, d), RE = (uint32_t)__builtin_amdgcn_readlane((int)end, dn - 1);
             const bool mine = lane >= d && lane < dn;
-            for (uint32_t base = RS & ~3u; base < RE; base += GJ_TOK_STAGE) {
+            for (uint32_t base = RS & ~7u; base < RE; base += GJ_TOK_STAGE) {
                 gj_wave_sync();
-                for (uint32_t i = (uint32_t)lane * 4u; i < GJ_TOK_STAGE && base + i < RE; i += 256u)
+                for (uint32_t i = (uint32_t)lane * 8u; i < GJ_TOK_STAGE && base + i < RE; i += 512u)
                     *reinterpret_cast<uint4*>(stage + i) = *reinterpret_cast<const uint4*>(d_tok + base + i);
                 gj_wave_sync();
                 if (mine) {
                     const uint32_t b = min(end, base + GJ_TOK_STAGE);
-                    for (uint32_t a = max(start, base); a < b; a++) gj_slot_put(slot, lane, stage[a - base]);
+                    for (uint32_t a = max(start, base); a < b; a++) gj_slot_put(slot, swz, stage[a - base]);
                 }
             }
         }
@@ -270,20 +273,26 @@ __device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint32_t* stage, c
 
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
-                                                            const uint32_t* __restrict__ d_tok, const uint32_t tok_cap,
+                                                            const uint16_t* __restrict__ d_tok, const uint32_t tok_cap,
                                                             const float* __restrict__ qtab, uint8_t* __restrict__ raw)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][GJ_TOK_STAGE];
-    __shared__ __attribute__((aligned(8))) float s_q[3][64];
-    if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
+    __shared__ __attribute__((aligned(16))) uint16_t s_stage[4][GJ_TOK_STAGE];
+    // dequantisation tables: [0] for blocks rebuilt from tokens (AC entries / 64: the slot holds 64 x the value, see gj_slot_put; the DC term is
+    // stored as it is), [1] for blocks that arrive through the coefficient planes
+    __shared__ __attribute__((aligned(8))) float s_q[2][3][64];
+    if (threadIdx.x < 192) {
+        const float q = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
+        s_q[0][threadIdx.x >> 6][threadIdx.x & 63] = (threadIdx.x & 63) ? q * 0.015625f : q;
+        s_q[1][threadIdx.x >> 6][threadIdx.x & 63] = q;
+    }
     const gj_comp_geom& k0 = g.comp[0];
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
     const unsigned lb = blockIdx.x * 256u + threadIdx.x;
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
     const int lane = threadIdx.x & 63;
     uint8_t* slot = s_blk + threadIdx.x * 128;
-    uint32_t* stage = s_stage[threadIdx.x >> 6];
+    uint16_t* stage = s_stage[threadIdx.x >> 6];
 
     // ---- 1. the three block records (independent loads)
     uint32_t start[3], cnt[3], dc[3];
@@ -312,8 +321,8 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
         const bool fast = cur.fast;
         const uint32_t S = cur.S;
         if (fast) {
-            *reinterpret_cast<uint4*>(stage + lane * 4) = cur.t0;
-            if (lane * 4 + 256 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 4 + 256) = cur.t1;
+            *reinterpret_cast<uint4*>(stage + lane * 8) = cur.t0;
+            if (lane * 8 + 512 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 8 + 512) = cur.t1;
         }
         if (c < 2) cur = gj_tok_fetch(d_tok, start[c + 1], cnt[c + 1], lane);
         gj_tok_to_slot(slot, stage, lane, fast, S, start[c], cnt[c], dc[c], in_plane[c],
@@ -325,96 +334,11 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
             const uint4 v = *gj_slot_row(slot, lane, r);
             wb[r * 4] = v.x; wb[r * 4 + 1] = v.y; wb[r * 4 + 2] = v.z; wb[r * 4 + 3] = v.w;
         }
-        gj_idct_pk(wb, s_q[c], pk[c]);
+        gj_idct_pk(wb, s_q[in_plane[c] ? 1 : 0][c], pk[c]);
 #pragma unroll
         for (int i = 0; i < 16; i++) GJ_KEEP(pk[c][i]); // one transform at a time (see k_idct_fused_rgb444)
     }
     gj_store_rgb444<CS_FROM, CS_TO>(g, raw, pk, lb, nb, bx, by);
-}
-
-// ================================================================================================
-// Token-fed IDCT for interleaved 4:2:2 scans with packed UYVY output and no colour transform (BASELINE config 4): one lane
-// per BLOCK in coding order (Y0 Y1 Cb Cr of MCU 0, of MCU 1, ...), so a workgroup's 256 records and its tokens are dense
-// ranges. After the transform the four lanes of an MCU exchange their rows with quad-permute DPP moves and every lane
-// stores 8 of the MCU's 32 bytes per pixel row (a wave writes 512 contiguous bytes per row).
-// ================================================================================================
-__global__ __launch_bounds__(256, 4) void k_idct_tok_uyvy422(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
-                                                             const uint32_t* __restrict__ d_tok, const uint32_t tok_cap,
-                                                             const float* __restrict__ qtab, uint8_t* __restrict__ raw)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[4][GJ_TOK_STAGE];
-    __shared__ __attribute__((aligned(8))) float s_q[3][64];
-    if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
-    const gj_comp_geom& kc = g.comp[1];
-    const unsigned nm = (unsigned)(kc.blocks_x * kc.blocks_y);
-    const int p = threadIdx.x & 3; // Y0 Y1 Cb Cr
-    const unsigned m = blockIdx.x * 64u + (threadIdx.x >> 2);
-    const unsigned my = m / (unsigned)kc.blocks_x, mx = m - my * (unsigned)kc.blocks_x;
-    const int c = p < 2 ? 0 : p - 1;
-    const int lane = threadIdx.x & 63;
-    uint8_t* slot = s_blk + threadIdx.x * 128;
-    uint32_t* stage = s_stage[threadIdx.x >> 6];
-    uint32_t start = 0, cnt = 0, dc = 0;
-    bool in_plane = false;
-    if (m < nm) {
-        const uint2 r = d_rec[(size_t)m * 4 + p];
-        start = r.x;
-        cnt = r.y >> 16;
-        dc = r.y & 0xFFFFu;
-        if (cnt == 0xFFFFu) { in_plane = true; cnt = 0; }
-        else if (cnt > 63u || start > tok_cap || cnt > tok_cap - start) cnt = 0; // (a record nobody wrote: damaged stream)
-    }
-    const GjTokRange tr = gj_tok_fetch(d_tok, start, cnt, lane);
-    if (tr.fast) {
-        *reinterpret_cast<uint4*>(stage + lane * 4) = tr.t0;
-        if (lane * 4 + 256 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 4 + 256) = tr.t1;
-    }
-    __syncthreads(); // (s_q)
-    const size_t blk = p < 2 ? (size_t)my * g.comp[0].blocks_x + 2 * mx + p : (size_t)m; // (plane address: blocks of long segments only)
-    gj_tok_to_slot(slot, stage, lane, tr.fast, tr.S, start, cnt, dc, in_plane,
-                   reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (m < nm ? blk : 0) * 64), d_tok);
-    uint32_t wb[32];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint4 v = *gj_slot_row(slot, lane, r);
-        wb[r * 4] = v.x; wb[r * 4 + 1] = v.y; wb[r * 4 + 2] = v.z; wb[r * 4 + 3] = v.w;
-    }
-    uint32_t px[16];
-    gj_idct_pk(wb, s_q[c], px);
-
-    // ---- UYVY: dword k of an MCU row = U_k | Y_2k << 8 | V_k << 16 | Y_2k+1 << 24; lane p writes dwords 2p and 2p + 1
-    const size_t pitch = (size_t)g.width * 2 + g.width_padding;
-    const bool interior = m < nm && (mx * 16 + 16 <= (unsigned)g.width) && (my * 8 + 8 <= (unsigned)g.height);
-    const bool aligned = ((pitch | (size_t)raw) & 7) == 0;
-    const uint32_t sel_uv = (p & 1) ? 0x07030602u : 0x05010400u; // [U_2p, V_2p, U_2p+1, V_2p+1] out of the chroma lanes' dwords
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int a0 = (int)px[2 * r], a1 = (int)px[2 * r + 1];
-        // quad_perm broadcasts: lane 0 = Y0, 1 = Y1, 2 = Cb, 3 = Cr of this MCU
-        const uint32_t y00 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0x00, 0xF, 0xF, false), y01 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0x00, 0xF, 0xF, false);
-        const uint32_t y10 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0x55, 0xF, 0xF, false), y11 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0x55, 0xF, 0xF, false);
-        const uint32_t u0 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0xAA, 0xF, 0xF, false), u1 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0xAA, 0xF, 0xF, false);
-        const uint32_t v0 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0xFF, 0xF, 0xF, false), v1 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0xFF, 0xF, 0xF, false);
-        const uint32_t ys = p == 0 ? y00 : p == 1 ? y01 : p == 2 ? y10 : y11; // Y_4p .. Y_4p+3
-        const uint32_t us = (p >> 1) ? u1 : u0, vs = (p >> 1) ? v1 : v0;
-        const uint32_t uv = __builtin_amdgcn_perm(vs, us, sel_uv);
-        const uint32_t d0 = __builtin_amdgcn_perm(ys, uv, 0x05010400u), d1 = __builtin_amdgcn_perm(ys, uv, 0x07030602u);
-        const unsigned y = my * 8 + r;
-        if (interior && aligned) {
-            *reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)mx * 32 + p * 8) = make_uint2(d0, d1);
-        } else if (m < nm && y < (unsigned)g.height) {
-            // the generic store writes chroma only with the even pixel and whole pixels only (k_postprocess)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint32_t d = k ? d1 : d0;
-                const unsigned x0 = mx * 16 + 2 * (2 * p + k);
-                uint8_t* q = raw + (size_t)y * pitch + (size_t)x0 * 2;
-                if (x0 < (unsigned)g.raw_width) { q[0] = (uint8_t)d; q[1] = (uint8_t)(d >> 8); }
-                if (x0 + 1 < (unsigned)g.raw_width) { q[2] = (uint8_t)(d >> 16); q[3] = (uint8_t)(d >> 24); }
-            }
-        }
-    }
 }
 
 // ================================================================================================
@@ -601,14 +525,10 @@ bool gj_is_uyvy422(const gj_geom& g)
            g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
 }
 
-// the token-fed IDCT kernel for this configuration, or nullptr
+// the token-fed IDCT kernel for this configuration, or nullptr (non-interleaved 4:4:4 scans: plane order == coding order)
 gj_idct_tok_t gj_idct_tok_for(const gj_geom& g)
 {
-    if (!g.interleaved) return gj_idct_tok_kernel(g);
-    if (gj_is_uyvy422(g) && g.blocks_per_mcu == 4 && g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.mcu_comp[0] == 0 && g.mcu_comp[1] == 0 &&
-        g.mcu_comp[2] == 1 && g.mcu_comp[3] == 2 && g.mcu_bx[0] == 0 && g.mcu_bx[1] == 1)
-        return k_idct_tok_uyvy422;
-    return nullptr;
+    return g.interleaved ? nullptr : gj_idct_tok_kernel(g);
 }
 
 void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_tok, gj_event_t* ev)
@@ -617,8 +537,8 @@ void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_to
     const bool uyvy = job->use_fused && gj_is_uyvy422(g);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
     if (idct_tok) {
-        const unsigned nb = g.interleaved ? (unsigned)g.block_count : (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block (position)
-        hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, job->d_tok, job->tok_cap,
+        const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block position
+        hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, (const uint16_t*)job->d_tok, job->tok_cap,
                            job->d_qtabf, job->d_raw);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else if (uyvy) {

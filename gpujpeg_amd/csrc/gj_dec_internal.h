@@ -2,8 +2,9 @@
 //
 //   gj_decode.hip               gj_hip_decode: picks the kernels of a frame and launches them
 //   gj_dec_markers.hip          k_marker_count / rank / emit, k_build_segments, k_compare_header: segment table built on the device
-//   gj_dec_entropy_par.hip      k_huffman_decode_par: sub-sequence parallel entropy decoding of batches of restart segments (the default); output
-//                               either the coefficient planes or, in token mode, a dense token array + one record per block
+//   gj_dec_entropy_tok.hip      k_huffman_decode_tok: sub-sequence parallel entropy decoding into 16-bit TOKENS + one record per block
+//                               (the default for large non-interleaved frames)
+//   gj_dec_entropy_par.hip      k_huffman_decode_par: sub-sequence parallel entropy decoding into the coefficient planes (segments of any length)
 //   gj_dec_entropy_seq.hip      k_huffman_decode_seq: one lane per restart segment over an LDS stage (interleaved scans with many short segments)
 //   gj_dec_entropy_serial.hip   k_huffman_decode: one lane per restart segment, stream windows (Huffman tables that do not fit the two-level layout)
 //   gj_dec_idct.hip             k_idct_fused_* (from the planes), k_idct_tok_* (from tokens), k_idct / k_postprocess / k_copy_planes_out (generic)
@@ -29,11 +30,31 @@ static inline void gj_debug_stage(const bool on, hipStream_t st, const char* wha
 
 // ---- entropy decoders: each launches its kernel for the whole segment table of the job
 void gj_launch_huffman_serial(const gj_dec_job* job, hipStream_t st);
-void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st, bool tokens);
+void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st);
 void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st);
+void gj_launch_huffman_tok(const gj_dec_job* job, hipStream_t st);
+
+// Batches of the sub-sequence decoders: consecutive table entries, cut per scan -- the luminance segments of a photograph carry two to
+// three times the bytes of the chrominance ones, and a batch is sized to fill the LDS stage (one batch size for the whole stream
+// gave luminance batches that had to be decoded as two groups, and chrominance batches that left half of the lanes idle).
+struct GjBatchPlan {
+    int n;                       // ranges (scans)
+    int first[GJ_MAX_COMP];      // first table entry of range c
+    int count[GJ_MAX_COMP];      // entries
+    int g[GJ_MAX_COMP];          // segments per batch
+    int batch0[GJ_MAX_COMP + 1]; // first batch of range c; [n] = number of batches
+};
+// cap_u: bytes of the kernel's LDS stage, max_blocks / gmax: blocks / segments a batch may have; one_generation: prefer fuller batches when
+// that keeps the launch within the workgroups the GPU holds at once
+GjBatchPlan gj_plan_batches(const gj_dec_job* job, unsigned cap_u, unsigned max_blocks, unsigned gmax, bool one_generation);
+
+// k_huffman_decode_tok (shared with the launcher's choice of the kernel)
+#define GJ_TOK_CAP_U 10752     // bytes of unstuffed stream per group, incl. 8 B of zero padding per segment
+#define GJ_TOK_MAX_BLOCKS 2304 // blocks per batch
+#define GJ_TOK_GMAX 64         // segments per batch
 
 // ---- IDCT side
-typedef void (*gj_idct_tok_t)(const gj_geom, const int16_t*, const uint2*, const uint32_t*, uint32_t, const float*, uint8_t*);
+typedef void (*gj_idct_tok_t)(const gj_geom, const int16_t*, const uint2*, const uint16_t*, uint32_t, const float*, uint8_t*);
 gj_idct_tok_t gj_idct_tok_for(const gj_geom& g); // the token-fed IDCT kernel for this configuration, or nullptr
 bool gj_is_uyvy422(const gj_geom& g);
 // dequantisation + IDCT + postprocessing of the frame; ev (may be null): events 2 and 3 of gj_hip_decode

@@ -2,18 +2,17 @@
 // The kernels live in gj_dec_*.hip (map: gj_dec_internal.h).
 #include "gj_dec_internal.h"
 
-int gj_huffman_par_default_sub(const gj_geom& g);
-
 // Does a frame of this geometry and stream size go through token mode (given fused kernels and two-level Huffman tables)? The host
 // asks before it allocates the token buffers; the launcher asks again.
 // Measured (8K / 16K RGB natural frames at q75, 4.75 B of stream per block: +17 % enc+dec; HD and 4K equal or slightly slower;
-// 16K 4:2:2 at q90, 10.4 B per block: -6 %; 8K noise -15 %; crossover at 8K RGB near 9 B per block): tokens pay when the frame
-// fills the GPU more than once (the token-fed IDCT has the longer dependency chain per workgroup) and blocks carry few coefficients
-// (4 B per coefficient against 128 B per block). gj_tuning::dec_tokens forces either mode (tests, A/B runs).
+// 8K noise -15 %; crossover at 8K RGB near 9 B per block): tokens pay when the frame fills the GPU more than once (the token-fed IDCT has
+// the longer dependency chain per workgroup) and blocks carry few coefficients (2 B per coefficient against 128 B per block).
+// gj_tuning::dec_tokens forces either mode (tests, A/B runs).
 extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, const gj_tuning* tune)
 {
     if (tune->dec_tokens == 0 || gj_idct_tok_for(*g) == nullptr) return 0;
-    if (tune->dec_sub && tune->dec_sub != gj_huffman_par_default_sub(*g)) return 0; // (the tuning aid sweeps the plane-mode kernels)
+    if (g->seg_blocks > GJ_TOK_MAX_BLOCKS || g->restart_interval == 0) return 0; // (k_huffman_decode_tok takes whole segments into its LDS stage)
+    if (tune->dec_sub) return 0; // (the tuning aid sweeps the plane-mode kernels)
     if (tune->dec_tokens == 1) return 1;
     return g->block_count >= 900000 && jpeg_size <= (uint64_t)g->block_count * 8u;
 }
@@ -28,7 +27,10 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     if (job->tune.dec_serial) par = false; // the lane-per-segment kernel (A/B measurements, tests)
     // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
     // record per block instead of through the coefficient planes
-    gj_idct_tok_t idct_tok = (par && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && gj_hip_decode_wants_tokens(&g, job->jpeg_size, &job->tune))
+    // (k_huffman_decode_tok needs every segment in its LDS stage: the host vouches for the longest one -- this stream's, or the previous
+    // frame's on the speculative path, where `d_overflow` is checked afterwards)
+    gj_idct_tok_t idct_tok = (par && !job->tune.dec_careful && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && job->d_overflow && job->max_seg_len != 0 &&
+                              job->max_seg_len + 12u <= (uint32_t)GJ_TOK_CAP_U && gj_hip_decode_wants_tokens(&g, job->jpeg_size, &job->tune))
                                  ? gj_idct_tok_for(g) : nullptr;
     const bool tokens = idct_tok != nullptr;
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
@@ -40,10 +42,11 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     }
     // interleaved scans with many short segments in plane mode: one lane per segment (k_huffman_decode_seq); the host vouches for the
     // longest segment (this stream's, or the previous frame's on the speculative path, where `d_overflow` is checked afterwards)
-    const bool seq = par && !tokens && job->d_overflow != nullptr && job->tune.dec_seq != 2 &&
+    const bool seq = par && !tokens && !job->tune.dec_careful && job->d_overflow != nullptr && job->tune.dec_seq != 2 &&
                      (job->tune.dec_seq == 1 || (g.interleaved && job->max_seg_len != 0 && job->max_seg_len <= 1024u && job->seg_count >= 16384));
-    if (seq) gj_launch_huffman_seq(job, st);
-    else if (par) gj_launch_huffman_par(job, st, tokens);
+    if (tokens) gj_launch_huffman_tok(job, st);
+    else if (seq) gj_launch_huffman_seq(job, st);
+    else if (par) gj_launch_huffman_par(job, st);
     else gj_launch_huffman_serial(job, st);
     gj_debug_stage(job->tune.debug_sync != 0, st, "entropy decoder");
     if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);

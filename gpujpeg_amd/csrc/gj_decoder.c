@@ -33,7 +33,7 @@ struct gpujpeg_decoder {
     bool flipped;                 /* dec_opt_flipped */
     unsigned channel_remap;       /* dec_opt_channel_remap, packed; 0 = none */
     int keep_coefs;               /* 1: leave the coefficients in HBM after the call (gpujpeg_amd_decoder_keep_coefficients) */
-    uint32_t* d_tok; size_t d_tok_cap;     /* token mode (gj_hip.h): non-zero AC coefficients of the frame */
+    uint16_t* d_tok; size_t d_tok_cap;     /* token mode (gj_hip.h): non-zero AC coefficients of the frame */
     void* d_blkrec; size_t d_blkrec_cap;   /* token mode: one record per block */
     bool coefs_clean;             /* d_coefs is all zero: the previous call's IDCT cleared what it read */
     /* device-side segment discovery */
@@ -209,7 +209,9 @@ static int accept_device_scan(const gj_scan_summary* su, struct gj_reader_result
     return -1; /* no EOI */
 }
 
-int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t image_size, struct gpujpeg_decoder_output* output)
+/* careful: this call must not use the entropy decoders that take whole restart segments into LDS (a previous attempt on this stream met a
+ * segment that does not fit), and it does not launch on the header cache */
+static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t image_size, struct gpujpeg_decoder_output* output, bool careful)
 {
     struct gj_coder* c = &d->coder;
     const bool stats = c->param.perf_stats != 0 || c->param.verbose >= GPUJPEG_LL_STATUS;
@@ -226,7 +228,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     struct gj_reader_result r;
     bool device_scan = !d->host_scan;
     /* speculative path: same header as last time (compared on the device for a device-resident stream) */
-    bool spec = device_scan && d->hdr_cache_valid && image_size > d->hdr_cache_len && !d->tune.dec_no_spec;
+    bool spec = device_scan && d->hdr_cache_valid && image_size > d->hdr_cache_len && !d->tune.dec_no_spec && !careful;
     if (spec && !jpeg_on_device) spec = memcmp(image, d->hdr_cache, d->hdr_cache_len) == 0;
     if (spec) {
         r = d->hdr_cache_r;
@@ -435,7 +437,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
     job.zero_coefs = 0;
     /* token mode buffers (gj_hip.h): one record per block, 4 tokens per stream byte at most */
     if (!d->keep_coefs && job.use_fused && tab2_ok && image_size < ((size_t)1 << 29) && gj_hip_decode_wants_tokens(&job.g, image_size, &d->tune)) {
-        const size_t tok_need = (image_size * 4 + 64) * sizeof(uint32_t);
+        const size_t tok_need = (image_size * 4 + 64) * sizeof(uint16_t);
         if (tok_need > d->d_tok_cap) { /* (grown with headroom: frames of a sequence vary in size) */
             if (gj_ensure_device_buffer((void**)&d->d_tok, &d->d_tok_cap, tok_need + tok_need / 4) != 0) goto out;
         }
@@ -449,6 +451,7 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         job.d_blkrec = d->d_blkrec;
     }
     job.tune = d->tune;
+    job.tune.dec_careful = careful;
     /* bytes per scan: what the entropy decoder's batch sizes are cut to (luminance segments are 2-3 x the chrominance ones) */
     job.d_overflow = &d->d_summary->seq_overflow;
     if (!device_scan) gj_hip_memset(job.d_overflow, 0, sizeof(uint32_t), c->stream); /* (the marker scan clears the summary; the host walk has none) */
@@ -505,10 +508,11 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         goto out;
     }
 
-    if (!spec && d->h_summary->seq_overflow) { /* (only when that kernel was forced on a stream with long segments) */
-        d->tune.dec_seq = 2;
+    if (!spec && d->h_summary->seq_overflow && !careful) { /* (a kernel forced on a stream with segments it cannot stage; or, after a host
+                                                               walk, a table whose longest segment the host did not foresee) */
+        GJ_DEBUG(c->param.verbose, "a restart segment did not fit the entropy decoder's LDS stage: decoding again through the coefficient planes\n");
         free(host_copy);
-        return gpujpeg_decoder_decode(d, image, image_size, output);
+        return decoder_decode(d, image, image_size, output, true);
     }
     if (spec) { /* now the summary of this stream is on the host: was it what we assumed? */
         struct gj_reader_result chk = r;
@@ -517,9 +521,10 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
         for (int i = 0; ok && i < g->comp_count; i++)
             if (chk.huff_map[i][0] != r.huff_map[i][0] || chk.huff_map[i][1] != r.huff_map[i][1]) ok = false;
         if (!ok) { /* different header or unusual scan structure: decode again the careful way */
+            const bool overflow_only = d->h_summary->seq_overflow != 0;
             d->hdr_cache_valid = false;
             free(host_copy);
-            return gpujpeg_decoder_decode(d, image, image_size, output);
+            return decoder_decode(d, image, image_size, output, overflow_only);
         }
         for (int sc = 0; sc < GJ_MAX_COMP; sc++)
             d->last_scan_bytes[sc] = sc < (int)d->h_summary->scan_count ? d->h_summary->scan_end[sc] - d->h_summary->scan_start[sc] : 0;
@@ -567,6 +572,11 @@ int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t ima
 out:
     free(host_copy);
     return rc;
+}
+
+int gpujpeg_decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t image_size, struct gpujpeg_decoder_output* output)
+{
+    return decoder_decode(d, image, image_size, output, false);
 }
 
 int gpujpeg_decoder_get_stats(struct gpujpeg_decoder* d, struct gpujpeg_duration_stats* stats)

@@ -115,6 +115,9 @@ typedef struct gj_tuning {
     int dec_no_spec;     /* GJ_DEC_NO_SPEC: no speculative launch on a cached header */
     int dec_seq;         /* GJ_DEC_SEQ: 1 = always the lane-per-segment entropy decoder in plane mode, 2 (GJ_DEC_SEQ=0) = never, 0 = by the frame */
     int debug_sync;      /* GJ_DEC_DEBUG_SYNC=1: wait after every decoder stage and name it on stderr */
+    int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
+    int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that
+                            does not fit (overflow flag) -- this call uses the kernels without that limit */
 } gj_tuning;
 GJ_HIP_API void gj_hip_tuning_from_env(gj_tuning* t);
 
@@ -177,14 +180,16 @@ typedef struct gj_dec_job {
     int zero_coefs;                /* 1: the IDCT kernels zero every block after reading it (next call may skip clear_coefs) */
     gj_tuning tune;
     uint32_t max_seg_len;          /* longest restart segment of the stream when known (see scan_bytes), 0 = unknown */
-    uint32_t* d_overflow;          /* one word the lane-per-segment entropy decoder sets when it meets a segment it cannot stage */
+    uint32_t* d_overflow;          /* one word the entropy decoders that take whole segments into LDS (k_huffman_decode_tok, _seq) set when they
+                                      meet a segment they cannot stage */
     uint32_t scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes of every scan when known (this stream's, or the previous frame's on the speculative
                                          path; 0 = unknown): the entropy decoder sizes its batches per scan with them */
     /* token mode: entropy decoder -> fused IDCT without the coefficient planes (used when a token-fed IDCT kernel exists for the
      * configuration; 0 / NULL = planes) */
     int tokens;
-    uint32_t* d_tok;               /* [tok_cap + 64] value | natural position << 16; a group's run starts at 4 x its first byte offset */
-    uint32_t tok_cap;              /* >= 4 x jpeg_size */
+    uint16_t* d_tok;               /* [tok_cap + 64] 16-bit tokens: value << 6 | natural position; the run of a decoder group starts at token
+                                      4 x the byte offset of its first segment */
+    uint32_t tok_cap;              /* >= 4 x jpeg_size (tokens) */
     void* d_blkrec;                /* [g.block_count] uint2 per block in coding order: first token, count << 16 | (uint16) DC term;
                                       count 0xFFFF = the block is in d_coefs (segment decoded piece by piece) */
 } gj_dec_job;
@@ -226,7 +231,7 @@ typedef struct gj_scan_summary {
     uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];
     uint32_t header_differs;                  /* gj_hip_compare_header: 1 when the stream does not start with the cached header */
     uint32_t max_seg_len;                     /* longest segment of the table */
-    uint32_t seq_overflow;                    /* set by k_huffman_decode_seq: a segment did not fit its stage, decode the frame with the other kernel */
+    uint32_t seq_overflow;                    /* set by k_huffman_decode_tok / _seq: a segment did not fit the LDS stage, decode the frame with the other kernel */
     uint32_t rst_irregular;                   /* an RSTn out of sequence, or an empty segment in front of the end of a scan: the reference reader
                                                  resynchronises / drops it (src/gpujpeg_reader.c:1074-1135), so the host walks such a stream */
 } gj_scan_summary;

@@ -349,6 +349,8 @@ void run_grid(const char* name, dim3 grid, dim3 block, const std::function<void(
     if ((unsigned long)grid.x * grid.y * grid.z == 0) return;
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     g_kernel_name = name;
+    static const bool trace = getenv("HIPEMU_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "hipemu: launch %s grid %u x %u block %u\n", name, grid.x, grid.y, block.x);
     pool().run(grid, block, body);
 }
 } // namespace hipemu

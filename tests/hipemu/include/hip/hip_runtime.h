@@ -156,6 +156,12 @@ template <typename T, typename U> static inline T atomicMax(T* p, U v)
     while (old < (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {}
     return old;
 }
+template <typename T, typename U> static inline T atomicMin(T* p, U v)
+{
+    T old = __atomic_load_n(p, __ATOMIC_ACQUIRE);
+    while (old > (T)v && !__atomic_compare_exchange_n(p, &old, (T)v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {}
+    return old;
+}
 template <typename T, typename U> static inline T atomicOr(T* p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_ACQ_REL); }
 template <typename T, typename U> static inline T atomicExch(T* p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_ACQ_REL); }
 #define __HIP_MEMORY_SCOPE_AGENT 0

@@ -92,8 +92,14 @@ def traffic_json(d, out, note):
         name = ("enc:" if (k + "(").startswith(ENCODER_KERNELS) or base.startswith(ENCODER_KERNELS) else "dec:") + base
         valu[name] = int(va[k][1] / va[k][0])
         waves[name] = int(wv[k][1] / wv[k][0]) if wv[k][0] else 0
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from gpujpeg_amd.source_hash import kernel_source_hash
+        src_hash = kernel_source_hash()
+    except Exception:
+        src_hash = None
     json.dump({"note": note + "; bytes per launch = FETCH_SIZE x 2 + WRITE_SIZE (separate --pmc passes); valu_insts = SQ_INSTS_VALU per launch (wave instructions)",
-               "kernels": kernels, "valu_insts": valu, "waves": waves}, open(out, "w"), indent=1, sort_keys=True)
+               "source_hash": src_hash, "kernels": kernels, "valu_insts": valu, "waves": waves}, open(out, "w"), indent=1, sort_keys=True)
     with open(out.replace("_traffic.json", "_sq_counters.txt"), "w") as o:
         o.write("# rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY (one pass), per-dispatch averages\n# " + note + "\n")
         names = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]

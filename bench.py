@@ -518,6 +518,7 @@ def main():
     ap.add_argument("--internal-rgb", action="store_true", help="code RGB without colour transform (tuning aid; not the headline config)")
     ap.add_argument("--calibrate", action="store_true", help="run a 256 MiB device fill + copy first (known byte counts for calibrating PMC traffic counters)")
     ap.add_argument("--keep-coefs", action="store_true", help="decoder keeps its coefficients in HBM (adds the per-frame clear; tuning aid)")
+    ap.add_argument("--lib", default=None, help="another build of the library (A/B runs of compile-time variants: make -C gpujpeg_amd/csrc variant NAME=...)")
     ap.add_argument("--verify", action="store_true", help="check the results of the last frame(s) against the oracle (slow)")
     args = ap.parse_args()
 
@@ -546,7 +547,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl" if ndev >= world else "gloo", **({"device_id": device} if ndev >= world else {}))
 
-    lib = G.Library()  # raises if the HIP library has not been built: there is no fallback
+    lib = G.Library(args.lib)  # raises if the HIP library has not been built: there is no fallback
     assert lib.L.gpujpeg_init_device(dev_index, 0) == 0
     width, height = WORKLOADS[args.workload]
     if args.batch:

@@ -22,33 +22,73 @@
 
 // LDS budget: 4 workgroups per CU need <= 40960 B (granted in steps of 1280 B, tools/ubench/lds_occupancy.hip), and an 8K frame has to be
 // ONE generation of workgroups (a second, partial generation doubles the kernel's duration): hence the stage of 10.5 KB.
+#ifndef GJ_TOK_SUB
 #define GJ_TOK_SUB 16                                           // bytes per sub-sequence
-#define GJ_TOK_MAX_SUBS (GJ_TOK_CAP_U / GJ_TOK_SUB + GJ_TOK_GMAX) // every segment ends with a partial sub-sequence
-#define GJ_TOK_WSTAGE 800                                       // tokens a wave stages per flush (incl. up to 7 of alignment)
+#endif
+// n segments of a group hold at most CAP_U - 8 n unstuffed bytes (8 B of padding each) and every one ends with a partial sub-sequence:
+// (CAP_U - 8 n) / 16 + 15 n / 16 < CAP_U / 16 + n / 2 sub-sequences (this bound needs sub-sequences of at most 17 bytes; the table is
+// clamped to it all the same)
+#define GJ_TOK_MAX_SUBS (GJ_TOK_CAP_U / GJ_TOK_SUB + (GJ_TOK_SUB <= 17 ? GJ_TOK_GMAX / 2 : GJ_TOK_GMAX))
+#define GJ_TOK_WSTAGE 944                                       // tokens a wave can stage per flush at least (incl. up to 7 of alignment)
 #define GJ_TOK_CHUNK_MAX 48                                     // bytes of the batch's stream per lane in the cooperative copy
+
+// -DGJ_TRACE_PHASES (the `trace` target of the Makefile, tools/decoder_phases.py): the first work-item of every workgroup notes the wall
+// clock (100 MHz) at the phase boundaries in a buffer the tool hands over
+#ifdef GJ_TRACE_PHASES
+static __device__ unsigned long long* gj_trace_buf;
+extern "C" GJ_HIP_API int gj_hip_trace_set(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(gj_trace_buf), &p, sizeof p) == hipSuccess ? 0 : -1; }
+#define GJ_TRACE(slot) do { if (threadIdx.x == 0 && gj_trace_buf) gj_trace_buf[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GJ_TRACE(slot) ((void)0)
+#endif
 
 // state between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag index
 // counts of a sub-sequence: bits [0,16) blocks completed, [16,32) tokens
 
+// The workgroup's LDS as ONE object with the stage in front: the stage then sits at LDS address 0, and a bit position turns into a
+// dword address with a shift and a mask (with separate arrays the compiler adds the array's base in every symbol).
+struct GjTokLds {
+    // bytes of unstuffed stream per group (big-endian dwords). Dword 0 is not used: the bit reader addresses the dword of "bit position
+    // - 1", see gj_tok_decode; the unstuffed bytes start at dword 1 = bit 32
+    uint32_t U[GJ_TOK_CAP_U / 4 + 8];
+    __attribute__((aligned(16))) uint16_t tab[2 * GJ_DEC2_WORDS]; // DC table, AC table of the group's component
+    __attribute__((aligned(8))) uint2 rec[GJ_TOK_MAX_SUBS];       // per sub-sequence: entry | exit << 11 | segment << 22, counts (then their prefix sums)
+    // one pool for the block slots of the batch (per block + one per segment: DC difference | first token << 16) and, behind them, the four
+    // waves' token stages: a batch of luminance segments has few blocks and many tokens per sub-sequence, a chrominance batch the opposite
+    __attribute__((aligned(16))) uint16_t pool[(GJ_TOK_MAX_BLOCKS + GJ_TOK_GMAX) * 2 + 4 * GJ_TOK_WSTAGE];
+    // per segment of the batch: first slot in the pool, capacity offsets (which segments fit the stage together), first record, tables
+    uint32_t bb[GJ_TOK_GMAX + 1], cap[GJ_TOK_GMAX + 1], first[GJ_TOK_GMAX];
+    uint16_t tabsel[GJ_TOK_GMAX];
+    // per segment of the group: first and end bit in the stage, first sub-sequence
+    uint32_t sbit[GJ_TOK_GMAX], ebit[GJ_TOK_GMAX], sub0[GJ_TOK_GMAX + 1];
+    uint32_t tmp[4];
+    int j1, jstop;
+    uint32_t nwork[2], big;
+    uint8_t zz[64 + 64];
+};
+
 // One pass over a sub-sequence. MODE 0: count. MODE 1: tokens into the wave's LDS stage, DC differences + token positions of the blocks
-// into s_dcbt. MODE 2: coefficients into the planes (batches with a coefficient beyond the token range).
+// into the block slots. MODE 2: coefficients into the planes (batches with a coefficient beyond the token range).
+// The bit reader keeps p1 = bit position - 1: the 32 bits at position p1 + 1 are the dword pair (U[p1 >> 5], U[(p1 >> 5) + 1]) shifted right
+// by 31 - (p1 & 31) = ~p1 & 31, which is one v_alignbit_b32 (the pair of "bit position" would need a shift by 32 when the position is
+// dword aligned, which the instruction does not have).
 template <int MODE>
-__device__ __forceinline__ uint32_t gj_tok_decode(const uint32_t* __restrict__ s_U, const uint16_t* __restrict__ s_tab, const uint8_t* __restrict__ s_zz,
-                                                  const uint32_t start_bit, const uint32_t end_bit, const uint32_t entry, uint32_t& counts,
+__device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint32_t start_bit, const uint32_t end_bit, const uint32_t entry, uint32_t& counts,
                                                   uint16_t* __restrict__ tok_out /* MODE 1: where this sub-sequence's tokens go in the stage */,
                                                   uint32_t* __restrict__ s_blkinfo /* MODE 1, 2: slots of the segment's blocks (+ 1) */,
                                                   const uint32_t tok_rel /* tokens of the group in front of this sub-sequence */, uint32_t blk,
                                                   const uint32_t nblocks, int16_t* __restrict__ coefs /* MODE 2: first block of the segment */,
                                                   uint32_t* __restrict__ s_big)
 {
-    uint32_t bitpos = start_bit + (entry & 31u);
+    uint32_t p1 = start_bit + (entry & 31u) - 1u;
+    const uint32_t e1 = end_bit - 1u;
     uint32_t z = (entry >> 5) & 63u;
-    uint32_t nb = 0, ntok = 0;
-    while (bitpos < end_bit) {
-        const uint32_t wi = bitpos >> 5;
-        const uint64_t two = ((uint64_t)s_U[wi] << 32) | s_U[wi + 1];
-        const uint32_t win = (uint32_t)((two << (bitpos & 31u)) >> 32); // the next 32 bits of the stream
-        const uint16_t* t = s_tab + (z == 0 ? 0 : GJ_DEC2_WORDS);
+    uint32_t toff = z == 0 ? 0u : (uint32_t)GJ_DEC2_WORDS * 2u; // byte offset of the table: DC in front of a block, AC inside
+    uint32_t nb = 0, ntok = 0, mx = 0;
+    while (p1 < e1) {
+        const uint32_t wi = p1 >> 5;
+        const uint32_t win = __builtin_amdgcn_alignbit(sm.U[wi], sm.U[wi + 1], ~p1); // the next 32 bits of the stream
+        const uint16_t* t = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(sm.tab) + toff);
         uint32_t e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)]; // codes longer than 10 bits
         const uint32_t tot = e & 31u, adv = e >> 9, sz = (e >> 5) & 15u;
@@ -62,25 +102,26 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const uint32_t* __restrict__ s
                 // start of a block the segment should not have (damaged stream): it ends the last block's tokens
                 if (blk + nb <= nblocks) s_blkinfo[blk + nb] = ((uint32_t)v & 0xFFFFu) | ((tok_rel + ntok) << 16);
             } else if (sz != 0) {
-                const uint32_t pos = z + adv - 1u; // (s_zz[64..127] = 63: damaged streams only)
+                const uint32_t pos = z + adv - 1u; // (zz[64..127] = 63: damaged streams only)
                 if (MODE == 1) {
-                    if (sz >= 10u) *s_big = 1u; // does not fit 10 value bits: the batch goes through the planes
-                    tok_out[ntok] = (uint16_t)(((uint32_t)v << 6) | s_zz[pos]);
+                    mx = max(mx, sz);
+                    tok_out[ntok] = (uint16_t)(((uint32_t)v << 6) | sm.zz[pos]);
                 } else if (blk + nb < nblocks && pos < 64u) {
-                    coefs[(uint64_t)(blk + nb) * 64 + s_zz[pos]] = (int16_t)v;
+                    coefs[(uint64_t)(blk + nb) * 64 + sm.zz[pos]] = (int16_t)v;
                 }
                 ntok++;
             }
         }
-        bitpos += tot;
+        p1 += tot;
         z += adv;
-        if (z >= 64u) {
-            z = 0;
-            nb++;
-        }
+        const bool done = z >= 64u; // the block is complete
+        z = done ? 0u : z;
+        toff = done ? 0u : (uint32_t)GJ_DEC2_WORDS * 2u;
+        nb += done ? 1u : 0u;
     }
+    if (MODE == 1 && mx >= 10u) *s_big = 1u; // a value that does not fit a token's 10 bits: the batch goes through the planes
     counts = nb | (ntok << 16);
-    return (bitpos - end_bit) | (z << 5);
+    return (p1 - e1) | (z << 5);
 }
 
 template <bool COOP>
@@ -94,32 +135,27 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
 {
     constexpr int CAP_U = GJ_TOK_CAP_U, MAX_BLOCKS = GJ_TOK_MAX_BLOCKS, GMAX = GJ_TOK_GMAX, MAX_SUBS = GJ_TOK_MAX_SUBS;
     constexpr uint32_t SUB_BITS = GJ_TOK_SUB * 8;
-    static_assert(MAX_SUBS * 2 <= (MAX_BLOCKS + GMAX) * 4, "the work list lives in the block slots");
-    __shared__ uint32_t s_U[CAP_U / 4 + 4];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[2 * GJ_DEC2_WORDS]; // DC table, AC table of the group's component
-    __shared__ uint8_t s_zz[64 + 64];
-    __shared__ __attribute__((aligned(8))) uint2 s_rec[MAX_SUBS];              // per sub-sequence: entry | exit << 16, counts (then their prefix sums)
-    __shared__ uint8_t s_subseg[MAX_SUBS];
-    __shared__ uint32_t s_blkinfo[MAX_BLOCKS + GMAX];                          // per block of the batch (+ one slot per segment): DC difference | first token << 16
-    __shared__ __attribute__((aligned(16))) uint16_t s_tokst[4][GJ_TOK_WSTAGE]; // per wave: tokens on their way to HBM
-    // per segment of the batch: first slot in s_blkinfo, capacity offsets (which segments fit the stage together), first record, tables
-    __shared__ uint32_t s_bb[GMAX + 1], s_cap[GMAX + 1], s_first[GMAX];
-    __shared__ uint16_t s_tabsel[GMAX];
-    // per segment of the group: first and end bit in the stage, first sub-sequence
-    __shared__ uint32_t s_sbit[GMAX], s_ebit[GMAX], s_sub0[GMAX + 1];
-    __shared__ uint32_t s_tmp[4];
-    __shared__ int s_j1, s_jstop;
-    __shared__ uint32_t s_nwork[2], s_big;
-    // stream positions and lengths are needed until the stage is filled: they borrow the token stage
-    uint32_t* const s_pos = reinterpret_cast<uint32_t*>(&s_tokst[0][0]);
+    __shared__ GjTokLds sm;
+    constexpr int POOL = sizeof(sm.pool) / 2; // 16-bit units
+    uint32_t* const s_stage = sm.U + 1;      // where the unstuffed bytes go: bit position 32 of the reader
+    uint16_t* const s_pool = sm.pool;
+    uint32_t* const s_blkinfo = reinterpret_cast<uint32_t*>(sm.pool);
+    uint2* const s_rec = sm.rec;
+    uint32_t *const s_bb = sm.bb, *const s_cap = sm.cap, *const s_first = sm.first, *const s_sbit = sm.sbit, *const s_ebit = sm.ebit, *const s_sub0 = sm.sub0;
+    uint32_t* const s_tmp = sm.tmp;
+    // stream positions and lengths are needed until the stage is filled: they borrow the end of the pool (the last wave's token stage)
+    constexpr int BORROW = ((4 * GMAX + 1) * 2 + 7) & ~7;
+    uint32_t* const s_pos = reinterpret_cast<uint32_t*>(s_pool + POOL - BORROW);
     uint32_t* const s_len = s_pos + GMAX;
     uint32_t* const s_ubyte = s_len + GMAX;     // [GMAX + 1] byte offset of every segment in the stage
     uint32_t* const s_ulen = s_ubyte + GMAX + 1; // [GMAX] its unstuffed length
-    static_assert((4 * GMAX + 1) * 4 <= sizeof(s_tokst), "borrowed space");
-    uint16_t* const s_work = reinterpret_cast<uint16_t*>(s_blkinfo);
+    static_assert(BORROW <= GJ_TOK_WSTAGE && MAX_SUBS <= POOL - BORROW, "borrowed space");
+    uint16_t* const s_work = s_pool; // (the work list of the rounds: before the block slots are used)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    GJ_TRACE(0);
+    if (tid < 128) sm.zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    if (tid == 0) sm.U[0] = 0;
     const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
 
     // ---- batch setup: lane j describes segment j of the batch
@@ -153,36 +189,40 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         }
         if (tid < GMAX) {
             s_first[tid] = first;
-            s_tabsel[tid] = (uint16_t)tb;
+            sm.tabsel[tid] = (uint16_t)tb;
         }
         uint32_t tot;
         const uint32_t a = gj_wg256_incl_scan(tid < nseg ? my_nblk + 1u : 0u, s_tmp, &tot); // (one slot more per segment, see gj_tok_decode)
         if (tid < GMAX) s_bb[tid + 1] = a;
         const uint32_t b = gj_wg256_incl_scan(my_len ? ((my_len + 3u) & ~3u) + 8u : 0u, s_tmp, &tot);
         if (tid < GMAX) s_cap[tid + 1] = b;
-        if (tid == 0) { s_bb[0] = 0; s_cap[0] = 0; s_nwork[0] = 0; s_nwork[1] = 0; }
+        if (tid == 0) { s_bb[0] = 0; s_cap[0] = 0; sm.nwork[0] = 0; sm.nwork[1] = 0; }
     }
     __syncthreads();
+    // the waves' token stages: what the batch's block slots leave of the pool, in four equal 16-byte aligned parts
+    const uint32_t stage0 = (2u * s_bb[nseg] + 7u) & ~7u, stage_cap = (((uint32_t)POOL - stage0) >> 2) & ~7u;
+    uint16_t* const stage = s_pool + stage0 + (uint32_t)wave * stage_cap;
 
     uint32_t loaded_tabs = 0xFFFFFFFFu;
     // ---- groups: consecutive segments with the same Huffman tables whose unstuffed bytes fit the LDS stage (normally one group = the batch)
     for (int j0 = 0; j0 < nseg;) {
-        if (tid == 0) { s_j1 = j0 + 1; s_jstop = nseg; s_big = 0; }
+        if (tid == 0) { sm.j1 = j0 + 1; sm.jstop = nseg; sm.big = 0; }
         if (tid < nseg) { s_pos[tid] = my_pos; s_len[tid] = my_len; }
         __syncthreads();
-        const uint32_t tb = s_tabsel[j0];
-        if (tid > j0 && tid < nseg && my_nblk != 0 && s_tabsel[tid] != tb) atomicMin(&s_jstop, tid); // other tables (the next scan) end the group
+        const uint32_t tb = sm.tabsel[j0];
+        if (tid > j0 && tid < nseg && my_nblk != 0 && sm.tabsel[tid] != tb) atomicMin(&sm.jstop, tid); // other tables (the next scan) end the group
         __syncthreads();
-        if (tid > j0 && tid <= s_jstop && s_cap[tid] - s_cap[j0] <= (uint32_t)CAP_U) atomicMax(&s_j1, tid);
+        if (tid > j0 && tid <= sm.jstop && s_cap[tid] - s_cap[j0] <= (uint32_t)CAP_U) atomicMax(&sm.j1, tid);
         __syncthreads();
-        const int j1 = s_j1;
+        const int j1 = sm.j1;
         const int ng = j1 - j0;
+        GJ_TRACE(1);
 
         // -- 0. the group's Huffman tables
         if (tb != loaded_tabs) {
             const uint4* src0 = reinterpret_cast<const uint4*>(tabs + (tb & 0xFFu) * GJ_DEC2_WORDS);
             const uint4* src1 = reinterpret_cast<const uint4*>(tabs + (tb >> 8) * GJ_DEC2_WORDS);
-            uint4* dst = reinterpret_cast<uint4*>(s_tab);
+            uint4* dst = reinterpret_cast<uint4*>(sm.tab);
             for (int t = tid; t < GJ_DEC2_WORDS / 8; t += 256) { dst[t] = src0[t]; dst[GJ_DEC2_WORDS / 8 + t] = src1[t]; }
             loaded_tabs = tb;
         }
@@ -240,7 +280,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
             uint32_t tot;
             const uint32_t inc = gj_wg256_incl_scan(nkeep | (nmark << 16), s_tmp, &tot);
             uint32_t o = (inc & 0xFFFFu) - nkeep, m = (inc >> 16) - nmark; // kept bytes / markers in front of this lane's share
-            uint8_t* U8 = reinterpret_cast<uint8_t*>(s_U);
+            uint8_t* U8 = reinterpret_cast<uint8_t*>(s_stage);
             coop = (tot >> 16) == (uint32_t)(ng - 1); // (as many markers as the table says; the same for every lane)
             if (coop) {
 #pragma unroll
@@ -282,21 +322,22 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                     const uint32_t ndw = ((uint32_t)(a & 3) + len + 3u) >> 2;
                     uint32_t w0 = 0;
                     if ((uint32_t)lane < ndw && src + lane < end) w0 = src[lane];
-                    ulen = gj_unstuff_segment(jpeg, end, s_pos[j], len, s_U, base, lane, w0);
+                    ulen = gj_unstuff_segment(jpeg, end, s_pos[j], len, s_stage, base, lane, w0);
                 }
                 if (lane == 0) { s_ubyte[j] = base; s_ulen[j] = ulen; }
             }
         }
         __syncthreads();
 
+        GJ_TRACE(2);
         // -- 2. sub-sequence table
         {
             uint32_t my_nsub = 0;
             if (tid >= j0 && tid < j1) {
                 const uint32_t ulen = my_nblk ? s_ulen[tid] : 0u;
                 my_nsub = (ulen + GJ_TOK_SUB - 1) / GJ_TOK_SUB;
-                s_sbit[tid] = s_ubyte[tid] * 8u;
-                s_ebit[tid] = (s_ubyte[tid] + ulen) * 8u;
+                s_sbit[tid] = s_ubyte[tid] * 8u + 32u; // (the stage starts at dword 1 of the reader's address space)
+                s_ebit[tid] = (s_ubyte[tid] + ulen) * 8u + 32u;
             }
             uint32_t tot;
             const uint32_t a = gj_wg256_incl_scan(my_nsub, s_tmp, &tot);
@@ -313,10 +354,11 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                 const int mid = (lo + hi) >> 1;
                 if (s_sub0[mid] <= (uint32_t)k) lo = mid; else hi = mid;
             }
-            s_subseg[k] = (uint8_t)lo;
+            s_rec[k].x = (uint32_t)lo << 22;
         }
         __syncthreads();
 
+        GJ_TRACE(3);
         // -- 3. first pass: every sub-sequence from its assumed state (the first one of a segment: the true state; any other one most
         //       likely starts in the middle of a block), then once more from what the neighbouring lane leaves, if that is different
         for (int k0 = 0; k0 < nsub; k0 += 256) {
@@ -324,33 +366,35 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
             const bool act = k < nsub;
             uint32_t e0 = 0, x0 = 0, c0 = 0, sb = 0, eb = 0;
             bool first = true;
+            int j = 0;
             if (act) {
-                const int j = s_subseg[k];
+                j = (int)(s_rec[k].x >> 22);
                 const uint32_t i = (uint32_t)k - s_sub0[j];
                 first = i == 0;
                 sb = s_sbit[j] + i * SUB_BITS;
                 eb = min(sb + SUB_BITS, s_ebit[j]);
                 e0 = first ? 0u : (1u << 5);
-                x0 = gj_tok_decode<0>(s_U, s_tab, s_zz, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+                x0 = gj_tok_decode<0>(sm, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
             }
             const uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x0, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0: nobody in front)
             if (act && !first && lane != 0 && xp != e0) {
                 e0 = xp;
-                x0 = gj_tok_decode<0>(s_U, s_tab, s_zz, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+                x0 = gj_tok_decode<0>(sm, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
             }
-            if (act) s_rec[k] = make_uint2(e0 | (x0 << 16), c0);
+            if (act) s_rec[k] = make_uint2(e0 | (x0 << 11) | ((uint32_t)j << 22), c0);
         }
+        GJ_TRACE(4);
         // -- rounds: sub-sequences whose predecessor leaves in another state than they were entered with are decoded again, densely packed
         //    onto the lanes, until there is none (s_rec[k] is written with one 64-bit store: a record always describes one decoding)
         for (int round = 0;; round++) {
             __syncthreads();
-            uint32_t* const cnt = &s_nwork[round & 1];
+            uint32_t* const cnt = &sm.nwork[round & 1];
             for (int k0 = 0; k0 < nsub; k0 += 256) {
                 const int k = k0 + tid;
                 bool cand = false;
                 if (k < nsub) {
-                    const uint32_t kf = s_sub0[s_subseg[k]];
-                    cand = (uint32_t)k != kf && (s_rec[k - 1].x >> 16) != (s_rec[k].x & 0xFFFFu);
+                    const uint32_t x = s_rec[k].x;
+                    cand = (uint32_t)k != s_sub0[x >> 22] && ((s_rec[k - 1].x >> 11) & 0x7FFu) != (x & 0x7FFu);
                 }
                 const unsigned long long m = __ballot(cand);
                 uint32_t base = 0;
@@ -360,20 +404,21 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
             }
             __syncthreads();
             const int nwork = (int)*cnt;
-            if (tid == 0) s_nwork[(round + 1) & 1] = 0;
+            if (tid == 0) sm.nwork[(round + 1) & 1] = 0;
             if (nwork == 0) break;
             for (int w = tid; w < nwork; w += 256) {
                 const int k = s_work[w];
-                const int j = s_subseg[k];
+                const int j = (int)(s_rec[k].x >> 22);
                 const uint32_t i = (uint32_t)k - s_sub0[j];
                 const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
-                const uint32_t e = s_rec[k - 1].x >> 16;
+                const uint32_t e = (s_rec[k - 1].x >> 11) & 0x7FFu;
                 uint32_t c;
-                const uint32_t x = gj_tok_decode<0>(s_U, s_tab, s_zz, sb, eb, e, c, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
-                s_rec[k] = make_uint2(e | (x << 16), c);
+                const uint32_t x = gj_tok_decode<0>(sm, sb, eb, e, c, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+                s_rec[k] = make_uint2(e | (x << 11) | ((uint32_t)j << 22), c);
             }
         }
 
+        GJ_TRACE(5);
         // -- 4. block and token positions: inclusive prefix sums of both counts (two 16-bit sums in one scan)
         {
             uint32_t carry = 0;
@@ -390,6 +435,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         for (uint32_t b = s_bb[j0] + (uint32_t)tid; b < s_bb[j1]; b += 256) s_blkinfo[b] = 0xFFFF0000u; // "block not seen", DC difference 0
         __syncthreads();
 
+        GJ_TRACE(6);
         // -- 5. decode once more, now with values. The group's tokens form one dense run that starts at 4 x the byte offset of the group's
         //       first segment (a token takes at least 3 bits of the stream, so the runs of different groups cannot overlap, and no
         //       allocator or reset is needed between frames). Wave w takes the w-th quarter of the sub-sequences, 64 (or as many as
@@ -404,24 +450,23 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         }
         if (gbase != 0xFFFFFFFFu) {
             const int ka = (int)(((uint32_t)nsub * (uint32_t)wave) >> 2), kb = (int)(((uint32_t)nsub * (uint32_t)(wave + 1)) >> 2);
-            uint16_t* const stage = s_tokst[wave];
             for (int k0 = ka; k0 < kb;) {
                 const uint32_t P0 = k0 > 0 ? s_rec[k0 - 1].y >> 16 : 0u; // tokens of the group in front of this chunk
                 const uint32_t a0 = (gbase + P0) & 7u;                    // the stage mirrors the alignment of the run: piece p <-> tokens 8p .. 8p + 7
                 const int kk = k0 + lane;
-                const bool fits = kk < kb && a0 + ((s_rec[min(kk, nsub - 1)].y >> 16) - P0) <= (uint32_t)GJ_TOK_WSTAGE;
+                const bool fits = kk < kb && a0 + ((s_rec[min(kk, nsub - 1)].y >> 16) - P0) <= stage_cap;
                 const unsigned long long fm = __ballot(fits);
                 const int n = fm == ~0ull ? 64 : __builtin_ctzll(~fm); // leading lanes whose tokens fit (at least one: a sub-sequence has < 64 tokens)
                 gj_wave_sync(); // (the previous flush has read the stage)
                 if (lane < n) {
-                    const int j = s_subseg[kk];
+                    const int j = (int)(s_rec[kk].x >> 22);
                     const uint32_t kf = s_sub0[j];
                     const uint32_t i = (uint32_t)kk - kf;
                     const uint32_t before_k = kk > 0 ? s_rec[kk - 1].y : 0u, before_f = kf > 0 ? s_rec[kf - 1].y : 0u;
                     const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
                     uint32_t c;
-                    gj_tok_decode<1>(s_U, s_tab, s_zz, sb, eb, s_rec[kk].x & 0xFFFFu, c, stage + a0 + ((before_k >> 16) - P0), s_blkinfo + s_bb[j], before_k >> 16,
-                                     (before_k & 0xFFFFu) - (before_f & 0xFFFFu), s_bb[j + 1] - s_bb[j] - 1u, nullptr, &s_big);
+                    gj_tok_decode<1>(sm, sb, eb, s_rec[kk].x & 0x7FFu, c, stage + a0 + ((before_k >> 16) - P0), s_blkinfo + s_bb[j], before_k >> 16,
+                                     (before_k & 0xFFFFu) - (before_f & 0xFFFFu), s_bb[j + 1] - s_bb[j] - 1u, nullptr, &sm.big);
                 }
                 gj_wave_sync();
                 // flush
@@ -440,8 +485,9 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         }
         __syncthreads();
 
+        GJ_TRACE(7);
         // -- 5b. a coefficient did not fit a token: the group's blocks go through the coefficient planes instead (records say so)
-        const bool planes = s_big != 0 || gbase == 0xFFFFFFFFu;
+        const bool planes = sm.big != 0 || gbase == 0xFFFFFFFFu;
         if (planes) {
             for (int j = j0 + wave; j < j1; j += 4) {
                 const uint32_t chunks = (s_bb[j + 1] - s_bb[j] - 1u) * 8u;
@@ -450,13 +496,13 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
             }
             __syncthreads(); // (orders the zeros before the coefficient stores of the other lanes)
             for (int k = tid; k < nsub; k += 256) {
-                const int j = s_subseg[k];
+                const int j = (int)(s_rec[k].x >> 22);
                 const uint32_t kf = s_sub0[j];
                 const uint32_t i = (uint32_t)k - kf;
                 const uint32_t before_k = k > 0 ? s_rec[k - 1].y : 0u, before_f = kf > 0 ? s_rec[kf - 1].y : 0u;
                 const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
                 uint32_t c;
-                gj_tok_decode<2>(s_U, s_tab, s_zz, sb, eb, s_rec[k].x & 0xFFFFu, c, nullptr, s_blkinfo + s_bb[j], 0, (before_k & 0xFFFFu) - (before_f & 0xFFFFu),
+                gj_tok_decode<2>(sm, sb, eb, s_rec[k].x & 0x7FFu, c, nullptr, s_blkinfo + s_bb[j], 0, (before_k & 0xFFFFu) - (before_f & 0xFFFFu),
                                  s_bb[j + 1] - s_bb[j] - 1u, coefs + (uint64_t)s_first[j] * 64, nullptr);
             }
             __syncthreads();
@@ -491,6 +537,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
             }
         }
         __syncthreads();
+        GJ_TRACE(8);
         j0 = j1;
     }
 }

@@ -4,10 +4,10 @@
 // The default entropy decoder of large non-interleaved frames. A workgroup takes a batch of consecutive restart segments of one scan and
 //   1. copies their bytes into LDS without the stuffed zeros and the restart markers -- the whole batch is ONE contiguous piece of the
 //      stream, so all 256 lanes take an equal share of it (one prefix sum; segment boundaries fall out of the marker count),
-//   2. cuts every segment into sub-sequences of 16 bytes; a lane decodes its sub-sequence from an assumed state, takes its predecessor's
-//      exit state from the neighbouring lane (DPP) and decodes again if that differs -- Huffman codes self-synchronise, so after this
-//      pass most sub-sequences are right; the others go through rounds over dense work lists until nothing changes (Klein & Wiseman 2003,
-//      Weissenberger & Schmidt 2021). These passes only count: blocks completed and non-zero AC coefficients per sub-sequence,
+//   2. cuts every segment into sub-sequences of 16 bytes; a lane starts 64 bits in front of its sub-sequence in an assumed state -- Huffman
+//      codes self-synchronise, so it most likely enters its sub-sequence in the true state -- and decodes it; sub-sequences whose
+//      predecessor leaves in another state than they were entered with go through rounds over dense work lists until nothing changes
+//      (Klein & Wiseman 2003, Weissenberger & Schmidt 2021). These passes only count: blocks completed and non-zero AC coefficients,
 //   3. turns the counts into block and token positions with one prefix sum,
 //   4. decodes once more, now producing 16-bit TOKENS (value << 6 | natural position) for the non-zero AC coefficients. A wave stages the
 //      tokens of its 64 sub-sequences in LDS and flushes them with whole 16-byte pieces: the token array is written in full lines,
@@ -30,6 +30,9 @@
 // clamped to it all the same)
 #define GJ_TOK_MAX_SUBS (GJ_TOK_CAP_U / GJ_TOK_SUB + (GJ_TOK_SUB <= 17 ? GJ_TOK_GMAX / 2 : GJ_TOK_GMAX))
 #define GJ_TOK_WSTAGE 944                                       // tokens a wave can stage per flush at least (incl. up to 7 of alignment)
+#ifndef GJ_TOK_SYNC
+#define GJ_TOK_SYNC 64                                          // bits in front of a sub-sequence its lane decodes first to fall into step
+#endif
 #define GJ_TOK_CHUNK_MAX 48                                     // bytes of the batch's stream per lane in the cooperative copy
 
 // -DGJ_TRACE_PHASES (the `trace` target of the Makefile, tools/decoder_phases.py): the first work-item of every workgroup notes the wall
@@ -40,6 +43,15 @@ extern "C" GJ_HIP_API int gj_hip_trace_set(void* p) { return hipMemcpyToSymbol(H
 #define GJ_TRACE(slot) do { if (threadIdx.x == 0 && gj_trace_buf) gj_trace_buf[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GJ_TRACE(slot) ((void)0)
+#endif
+
+// -DGJ_TOK_STATS (CPU execution model only, tools/tok_sync_stats.py): how many sub-sequences every round has to decode again
+#ifdef GJ_TOK_STATS
+extern "C" GJ_HIP_API unsigned long long gj_tok_stats[16];
+unsigned long long gj_tok_stats[16];
+#define GJ_STAT(i, n) __atomic_fetch_add(&gj_tok_stats[i], (unsigned long long)(n), __ATOMIC_RELAXED)
+#else
+#define GJ_STAT(i, n) ((void)0)
 #endif
 
 // state between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag index
@@ -66,6 +78,30 @@ struct GjTokLds {
     uint32_t nwork[2], big;
     uint8_t zz[64 + 64];
 };
+
+// The run-in of the first pass: decode from bit `from` (most likely inside a block, hence the AC table) up to the sub-sequence that starts
+// at `start_bit`; returns the state there. Huffman codes self-synchronise: after a few symbols this decoding has fallen into step
+// with the true one, whatever it started with.
+__device__ __forceinline__ uint32_t gj_tok_run_in(const GjTokLds& sm, const uint32_t from, const uint32_t start_bit)
+{
+    uint32_t p1 = from - 1u;
+    const uint32_t e1 = start_bit - 1u;
+    uint32_t z = 1;
+    uint32_t toff = (uint32_t)GJ_DEC2_WORDS * 2u;
+    while (p1 < e1) {
+        const uint32_t wi = p1 >> 5;
+        const uint32_t win = __builtin_amdgcn_alignbit(sm.U[wi], sm.U[wi + 1], ~p1);
+        const uint16_t* t = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(sm.tab) + toff);
+        uint32_t e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
+        if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)];
+        p1 += e & 31u;
+        z += e >> 9;
+        const bool done = z >= 64u;
+        z = done ? 0u : z;
+        toff = done ? 0u : (uint32_t)GJ_DEC2_WORDS * 2u;
+    }
+    return (p1 - e1) | (z << 5);
+}
 
 // One pass over a sub-sequence. MODE 0: count. MODE 1: tokens into the wave's LDS stage, DC differences + token positions of the blocks
 // into the block slots. MODE 2: coefficients into the planes (batches with a coefficient beyond the token range).
@@ -95,12 +131,15 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
         if (MODE == 0) {
             ntok += (z != 0 && sz != 0) ? 1u : 0u;
         } else {
-            const uint32_t bits = sz ? (win << (tot - sz)) >> (32u - sz) : 0u;
-            const int v = (sz && bits < (1u << (sz - 1u))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+            // the sz magnitude bits behind the code, extended (ITU T.81 F.2.2.1); without magnitude bits the shifts wrap and v is
+            // meaningless: no coefficient is made of it, and the DC branch asks
+            const uint32_t x = win << (tot - sz);                       // magnitude bits, left aligned
+            const uint32_t neg = ~(uint32_t)((int32_t)x >> 31);         // all ones when the first of them is 0: a negative value
+            const int v = (int)(x >> ((32u - sz) & 31u)) - (int)(neg & ((1u << sz) - 1u));
             if (z == 0) {
                 // slot blk + nb of the segment: DC difference and where the block's tokens start; the slot behind the last block takes the
                 // start of a block the segment should not have (damaged stream): it ends the last block's tokens
-                if (blk + nb <= nblocks) s_blkinfo[blk + nb] = ((uint32_t)v & 0xFFFFu) | ((tok_rel + ntok) << 16);
+                if (blk + nb <= nblocks) s_blkinfo[blk + nb] = (sz ? (uint32_t)v & 0xFFFFu : 0u) | ((tok_rel + ntok) << 16);
             } else if (sz != 0) {
                 const uint32_t pos = z + adv - 1u; // (zz[64..127] = 63: damaged streams only)
                 if (MODE == 1) {
@@ -166,18 +205,30 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
     const int si0 = plan.first[pc] + ((int)blockIdx.x - plan.batch0[pc]) * G;
     if (si0 >= seg_count) return;
     const int nseg = min(min(G, plan.first[pc] + plan.count[pc] - si0), seg_count - si0);
+    // the Huffman tables of the batch's scan are on their way while the segment table is read (a batch cut per scan belongs to component
+    // `pc`; otherwise, or when a segment says something else, they are loaded where the groups are formed)
+    uint32_t loaded_tabs = 0xFFFFFFFFu;
+    auto load_tables = [&](const uint32_t tb) {
+        const uint4* src0 = reinterpret_cast<const uint4*>(tabs + (tb & 0xFFu) * GJ_DEC2_WORDS);
+        const uint4* src1 = reinterpret_cast<const uint4*>(tabs + (tb >> 8) * GJ_DEC2_WORDS);
+        uint4* dst = reinterpret_cast<uint4*>(sm.tab);
+        for (int t = tid; t < GJ_DEC2_WORDS / 8; t += 256) { dst[t] = src0[t]; dst[GJ_DEC2_WORDS / 8 + t] = src1[t]; }
+        loaded_tabs = tb;
+    };
+    if (plan.n > 1 && plan.n == g.comp_count) load_tables((uint32_t)(g.comp[pc].dc_table * 2 + 0) | ((uint32_t)(g.comp[pc].ac_table * 2 + 1) << 8));
     // (kept in registers of lanes 0 .. nseg - 1 for the groups: position, length, blocks)
     uint32_t my_pos = 0, my_len = 0, my_nblk = 0;
     {
         uint32_t first = 0, tb = 0;
         if (tid < nseg) {
             const uint32_t s = seg_index[si0 + tid];
+            const uint32_t p_ = seg_pos[si0 + tid], l_ = seg_len[si0 + tid]; // (independent loads: one trip to memory for the three)
             if (s < (uint32_t)g.segment_count) {
                 const GjSeg sg = gj_segment(g, (int)s);
                 const gj_comp_geom& kc = g.comp[sg.comp];
                 my_nblk = (uint32_t)sg.nblocks;
-                my_pos = seg_pos[si0 + tid];
-                my_len = seg_len[si0 + tid];
+                my_pos = p_;
+                my_len = l_;
                 first = (uint32_t)(kc.data_offset / 64) + (uint32_t)sg.mcu_first; // first block: record index = block index of the planes
                 tb = (uint32_t)(kc.dc_table * 2 + 0) | ((uint32_t)(kc.ac_table * 2 + 1) << 8);
                 if (((my_len + 3u) & ~3u) + 8u > (uint32_t)CAP_U || my_nblk > (uint32_t)MAX_BLOCKS) { // not for this kernel: the host decodes the frame again
@@ -203,7 +254,6 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
     const uint32_t stage0 = (2u * s_bb[nseg] + 7u) & ~7u, stage_cap = (((uint32_t)POOL - stage0) >> 2) & ~7u;
     uint16_t* const stage = s_pool + stage0 + (uint32_t)wave * stage_cap;
 
-    uint32_t loaded_tabs = 0xFFFFFFFFu;
     // ---- groups: consecutive segments with the same Huffman tables whose unstuffed bytes fit the LDS stage (normally one group = the batch)
     for (int j0 = 0; j0 < nseg;) {
         if (tid == 0) { sm.j1 = j0 + 1; sm.jstop = nseg; sm.big = 0; }
@@ -219,13 +269,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         GJ_TRACE(1);
 
         // -- 0. the group's Huffman tables
-        if (tb != loaded_tabs) {
-            const uint4* src0 = reinterpret_cast<const uint4*>(tabs + (tb & 0xFFu) * GJ_DEC2_WORDS);
-            const uint4* src1 = reinterpret_cast<const uint4*>(tabs + (tb >> 8) * GJ_DEC2_WORDS);
-            uint4* dst = reinterpret_cast<uint4*>(sm.tab);
-            for (int t = tid; t < GJ_DEC2_WORDS / 8; t += 256) { dst[t] = src0[t]; dst[GJ_DEC2_WORDS / 8 + t] = src1[t]; }
-            loaded_tabs = tb;
-        }
+        if (tb != loaded_tabs) load_tables(tb);
 
         // -- 1. the group's bytes without stuffing and markers. Layout of the stage: segment j at byte s_ubyte[j] (big-endian dwords), 8 zero
         //       bytes behind every segment (a symbol that straddles the end reads zeros, src/gpujpeg_huffman_cpu_decoder.c:80-118)
@@ -359,29 +403,19 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         __syncthreads();
 
         GJ_TRACE(3);
-        // -- 3. first pass: every sub-sequence from its assumed state (the first one of a segment: the true state; any other one most
-        //       likely starts in the middle of a block), then once more from what the neighbouring lane leaves, if that is different
+        // -- 3. first pass: the first sub-sequence of a segment starts in the true state; the lane of any other one runs in over the last
+        //       GJ_TOK_SYNC bits in front of it and takes the state it arrives in (right in most cases: the rounds below find the others)
         for (int k0 = 0; k0 < nsub; k0 += 256) {
             const int k = k0 + tid;
-            const bool act = k < nsub;
-            uint32_t e0 = 0, x0 = 0, c0 = 0, sb = 0, eb = 0;
-            bool first = true;
-            int j = 0;
-            if (act) {
-                j = (int)(s_rec[k].x >> 22);
+            if (k < nsub) {
+                const int j = (int)(s_rec[k].x >> 22);
                 const uint32_t i = (uint32_t)k - s_sub0[j];
-                first = i == 0;
-                sb = s_sbit[j] + i * SUB_BITS;
-                eb = min(sb + SUB_BITS, s_ebit[j]);
-                e0 = first ? 0u : (1u << 5);
-                x0 = gj_tok_decode<0>(sm, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+                const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
+                const uint32_t e0 = i == 0 ? 0u : gj_tok_run_in(sm, sb - (uint32_t)GJ_TOK_SYNC, sb);
+                uint32_t c0;
+                const uint32_t x0 = gj_tok_decode<0>(sm, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+                s_rec[k] = make_uint2(e0 | (x0 << 11) | ((uint32_t)j << 22), c0);
             }
-            const uint32_t xp = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x0, 0x138, 0xF, 0xF, false); // wave_shr:1 (lane 0: nobody in front)
-            if (act && !first && lane != 0 && xp != e0) {
-                e0 = xp;
-                x0 = gj_tok_decode<0>(sm, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
-            }
-            if (act) s_rec[k] = make_uint2(e0 | (x0 << 11) | ((uint32_t)j << 22), c0);
         }
         GJ_TRACE(4);
         // -- rounds: sub-sequences whose predecessor leaves in another state than they were entered with are decoded again, densely packed
@@ -404,6 +438,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
             }
             __syncthreads();
             const int nwork = (int)*cnt;
+            if (tid == 0) { GJ_STAT(0, round == 0 ? nsub : 0); GJ_STAT(1 + min(round, 13), nwork); GJ_STAT(15, nwork == 0 ? round : 0); }
             if (tid == 0) sm.nwork[(round + 1) & 1] = 0;
             if (nwork == 0) break;
             for (int w = tid; w < nwork; w += 256) {

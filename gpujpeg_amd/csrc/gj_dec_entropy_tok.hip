@@ -4,7 +4,7 @@
 // The default entropy decoder of large non-interleaved frames. A workgroup takes a batch of consecutive restart segments of one scan and
 //   1. copies their bytes into LDS without the stuffed zeros and the restart markers -- the whole batch is ONE contiguous piece of the
 //      stream, so all 256 lanes take an equal share of it (one prefix sum; segment boundaries fall out of the marker count),
-//   2. cuts every segment into sub-sequences of 16 bytes; a lane starts 64 bits in front of its sub-sequence in an assumed state -- Huffman
+//   2. cuts every segment into sub-sequences of 16 bytes; a lane starts 48 bits in front of its sub-sequence in an assumed state -- Huffman
 //      codes self-synchronise, so it most likely enters its sub-sequence in the true state -- and decodes it; sub-sequences whose
 //      predecessor leaves in another state than they were entered with go through rounds over dense work lists until nothing changes
 //      (Klein & Wiseman 2003, Weissenberger & Schmidt 2021). These passes only count: blocks completed and non-zero AC coefficients,
@@ -31,7 +31,7 @@
 #define GJ_TOK_MAX_SUBS (GJ_TOK_CAP_U / GJ_TOK_SUB + (GJ_TOK_SUB <= 17 ? GJ_TOK_GMAX / 2 : GJ_TOK_GMAX))
 #define GJ_TOK_WSTAGE 944                                       // tokens a wave can stage per flush at least (incl. up to 7 of alignment)
 #ifndef GJ_TOK_SYNC
-#define GJ_TOK_SYNC 64                                          // bits in front of a sub-sequence its lane decodes first to fall into step
+#define GJ_TOK_SYNC 48                                          // bits in front of a sub-sequence its lane decodes first to fall into step
 #endif
 #define GJ_TOK_CHUNK_MAX 48                                     // bytes of the batch's stream per lane in the cooperative copy
 

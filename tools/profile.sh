@@ -1,15 +1,22 @@
 #!/bin/bash
-# rocprofv3 passes on the GPU box: kernel trace + stats, then the HBM traffic counters in separate PMC passes
-# (FETCH_SIZE and WRITE_SIZE do not fit one pass; never combined with sys/hip traces) and the SQ instruction counters in a fourth. Results: gpurun_out/prof_*/
+# rocprofv3 passes on the GPU box for ONE workload of bench.py (WORKLOAD=hd|4k|8k|16k|16k422, default 8k; BATCH=256 for the 256 x 4K batch):
+# kernel trace + stats with one pipeline (the kernels alone: what bench.py's roofline.ms is compared with), then FETCH_SIZE, WRITE_SIZE
+# and the SQ instruction counters, each in its own PMC pass (never combined with sys / hip traces). Results: gpurun_out/<TAG>_*;
+# tools/rocprof_summary.py condenses them (and stamps the traffic JSON with the hash of the device sources).
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
+W=${WORKLOAD:-8k}
+TAG=${TAG:-r3_$W}
 rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq
-ARGS="--steps ${STEPS:-20} --warmup 3 --lean ${BENCH_ARGS}"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python bench.py $ARGS > $OUT/prof_stats.log 2>&1
-tail -1 $OUT/prof_stats.log | cut -c1-400
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python bench.py --steps 3 --warmup 1 --lean --min-seconds 0 --calibrate ${BENCH_ARGS} > $OUT/prof_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python bench.py --steps 3 --warmup 1 --lean --min-seconds 0 --calibrate ${BENCH_ARGS} > $OUT/prof_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/prof_sq -- python bench.py --steps 3 --warmup 1 --lean --min-seconds 0 --calibrate ${BENCH_ARGS} > $OUT/prof_sq.log 2>&1
-find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name "*.csv" | head -20
-python tools/rocprof_summary.py $OUT ${TAG:-r1_xx} || true
+ARGS="--workload $W --streams ${STREAMS:-1} --lean ${BENCH_ARGS}"
+if [ -n "$BATCH" ]; then ARGS="--workload 4k --batch $BATCH --streams ${STREAMS:-4} ${BENCH_ARGS}"; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python bench.py --steps ${STEPS:-20} --warmup 3 $ARGS > $OUT/prof_stats.log 2>&1
+tail -1 $OUT/prof_stats.log | cut -c1-300
+PM="--steps 3 --warmup 1 --min-seconds 0 --calibrate"
+if [ -n "$BATCH" ]; then PM="--steps 1 --warmup 1"; fi
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python bench.py $PM $ARGS > $OUT/prof_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python bench.py $PM $ARGS > $OUT/prof_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/prof_sq -- python bench.py $PM $ARGS > $OUT/prof_sq.log 2>&1
+python tools/rocprof_summary.py $OUT $TAG "cmd: rocprofv3 ... -- python bench.py $ARGS (kernel trace: --steps ${STEPS:-20}; PMC passes: $PM)" > $OUT/${TAG}_summary.log 2>&1 || true
+grep -E "^k_|^void k_" $OUT/${TAG}_kernel_stats.txt | head -14

@@ -4,109 +4,111 @@
 
 // ================================================================================================
 // Device-side segment discovery. Inside entropy-coded data 0xFF is followed by 0x00 (stuffing),
-// by 0xD0..0xD7 (restart marker = segment boundary) or by the marker that ends the scan. Three small launches turn
-// the bytes [begin, size) into the (offset, length, geometric index) table k_huffman_decode consumes, without the host
-// touching the stream (the reference walks it with memchr and copies every segment, src/gpujpeg_reader.c:1039-1155):
-//   k_marker_count   per 2 KiB chunk: number of RSTn; every other marker is appended (rare) to a small list
-//   k_marker_rank    exclusive scan of the chunk counts
-//   k_marker_emit    ordered list of RSTn positions
-//   k_build_segments segment table for every scan + the summary the host validates (gj_scan_summary)
+// by 0xD0..0xD7 (restart marker = segment boundary) or by the marker that ends the scan. Two launches turn the bytes
+// [begin, size) into the (offset, length, geometric index) table the entropy decoders consume, without the host touching the
+// stream (the reference walks it with memchr and copies every segment, src/gpujpeg_reader.c:1039-1155):
+//   k_marker_scan      per chunk of the stream: number of RSTn and the position of the last one; every other marker is appended (rare)
+//                      to a small list; compares the stream's header with the cached one (speculative launches)
+//   k_marker_segments  per chunk again: ranks its RSTn (sum of the counts in front, read by every workgroup: at most ~1000 chunks),
+//                      sorts the other markers into scans, and writes the table entries its markers end; the summary the host
+//                      validates (gj_scan_summary); clears the summary of the NEXT call (two summaries alternate, no memset launch)
+// A lane owns `tb` consecutive bytes (8 .. 64, chosen by the host from the stream's size), a workgroup 256 x tb.
 // ================================================================================================
-#define GJ_SCAN_CHUNK 2048
+#define GJ_SCAN_TB_MAX 64   // bytes per lane
+#define GJ_SCAN_LIST 2048   // restart markers a chunk may hold (a segment of 8 bytes on average at the largest chunk: beyond that the host walks)
 
-__device__ __forceinline__ int gj_marker_at(const uint8_t* __restrict__ jpeg, uint64_t p, uint64_t size)
+// bit i of the results: byte i of the lane's `tb` bytes at absolute offset b0 starts a restart marker / another marker
+__device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, const uint64_t size, const uint64_t b0, const uint32_t tb, uint64_t& rst, uint64_t& other)
 {
-    // 0: none, 1: RSTn, 2: other marker
-    if (p + 1 >= size || jpeg[p] != 0xFF) return 0;
-    const int m = jpeg[p + 1];
-    if (m == 0x00 || m == 0xFF) return 0;
-    return (m & 0xF8) == 0xD0 ? 1 : 2;
-}
-
-__global__ __launch_bounds__(256) void k_marker_count(const uint8_t* __restrict__ jpeg, uint64_t begin, uint64_t size,
-                                                      uint32_t* __restrict__ chunk_count, gj_scan_summary* __restrict__ sum)
-{
-    __shared__ uint32_t s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const uint64_t base = begin + (uint64_t)blockIdx.x * GJ_SCAN_CHUNK + threadIdx.x * 8u;
-    uint32_t n = 0;
+    rst = other = 0;
+    if (b0 + 1 >= size) return;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + b0;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t lead = (uint32_t)(a & 3);
+    const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + size + 3) & ~(uintptr_t)3);
+    uint32_t win[GJ_SCAN_TB_MAX / 4 + 2];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int k = gj_marker_at(jpeg, base + i, size);
-        if (k == 1) n++;
-        if (k == 2) { // scan boundary material: keep position, code and the 16 bytes that follow
-            const uint32_t slot = atomicAdd(&sum->other_count, 1u);
-            if (slot < GJ_SCAN_MAX_OTHER) {
-                sum->other_pos[slot] = (uint32_t)(base + i);
-                sum->other_code[slot] = jpeg[base + i + 1];
-                for (int b = 0; b < 16; b++) sum->other_bytes[slot][b] = base + i + 2 + b < size ? jpeg[base + i + 2 + b] : 0;
+    for (int i = 0; i < GJ_SCAN_TB_MAX / 4 + 2; i++) {
+        win[i] = 0;
+        if ((uint32_t)i < tb / 4 + 2u && src + i < end) win[i] = src[i];
+    }
+#pragma unroll
+    for (int i = 0; i < GJ_SCAN_TB_MAX / 4; i++) {
+        if ((uint32_t)(4 * i) < tb) {
+            const uint32_t w = __builtin_amdgcn_alignbyte(win[i + 1], win[i], lead);      // bytes 4i .. 4i + 3 of the lane's share
+            const uint32_t wn = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead); // (its first byte follows the last one of w)
+            // 0xFF bytes are rare: one test for the four of them
+            if ((~w - 0x01010101u) & w & 0x80808080u) { // (a zero byte in ~w; a borrow can only add a false alarm)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t b = (w >> (8 * k)) & 0xFFu;
+                    const uint32_t nx = k < 3 ? (w >> (8 * k + 8)) & 0xFFu : wn & 0xFFu;
+                    if (b == 0xFFu && nx != 0u && nx != 0xFFu && b0 + (uint64_t)(4 * i + k) + 1 < size) {
+                        if ((nx & 0xF8u) == 0xD0u) rst |= 1ull << (4 * i + k);
+                        else other |= 1ull << (4 * i + k);
+                    }
+                }
             }
         }
     }
-    if (n) atomicAdd(&s_n, n);
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_count[blockIdx.x] = s_n;
 }
 
-__global__ __launch_bounds__(1024) void k_marker_rank(uint32_t* __restrict__ chunk_count, uint32_t chunks, gj_scan_summary* __restrict__ sum)
+__global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size, const uint32_t tb,
+                                                     uint2* __restrict__ chunk_info, gj_scan_summary* __restrict__ sum,
+                                                     const uint8_t* __restrict__ hdr_ref, const uint32_t hdr_n)
 {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_carry = 0;
+    __shared__ uint32_t s_n, s_last;
+    if (threadIdx.x == 0) { s_n = 0; s_last = 0; }
     __syncthreads();
-    for (uint32_t base = 0; base < chunks; base += 1024) {
-        const uint32_t i = base + t;
-        const uint32_t v = i < chunks ? chunk_count[i] : 0;
-        const uint32_t inc = gj_wave_incl_scan(v);
-        if (lane == 63) s_w[wave] = inc;
-        __syncthreads();
-        uint32_t off = s_carry;
-        for (int w = 0; w < wave; w++) off += s_w[w];
-        if (i < chunks) chunk_count[i] = off + inc - v;
-        __syncthreads();
-        if (t == 1023) s_carry = off + inc;
+    const uint64_t b0 = begin + ((uint64_t)blockIdx.x * 256u + threadIdx.x) * tb;
+    uint64_t rst, other;
+    gj_scan_bytes(jpeg, size, b0, tb, rst, other);
+    if (rst) {
+        atomicAdd(&s_n, (uint32_t)__popcll(rst));
+        atomicMax(&s_last, (uint32_t)(b0 + 63u - (uint32_t)__builtin_clzll(rst)));
+    }
+    while (other) { // scan boundary material: keep position, code and the 16 bytes that follow
+        const uint64_t p = b0 + (uint32_t)__builtin_ctzll(other);
+        other &= other - 1;
+        const uint32_t slot = atomicAdd(&sum->other_count, 1u);
+        if (slot < GJ_SCAN_MAX_OTHER) {
+            sum->other_pos[slot] = (uint32_t)p;
+            sum->other_code[slot] = jpeg[p + 1];
+            for (int b = 0; b < 16; b++) sum->other_bytes[slot][b] = p + 2 + b < size ? jpeg[p + 2 + b] : 0;
+        }
+    }
+    if (blockIdx.x == 0 && hdr_ref != nullptr) { // does the stream start with the header the host assumed? (speculative launch)
+        int diff = 0;
+        for (uint32_t i = threadIdx.x; i < hdr_n; i += 256) diff |= jpeg[i] != hdr_ref[i];
+        diff = __syncthreads_or(diff);
+        if (threadIdx.x == 0) sum->header_differs = diff ? 1u : 0u;
+    } else {
         __syncthreads();
     }
-    if (t == 0) sum->rst_count = s_carry;
+    if (threadIdx.x == 0) chunk_info[blockIdx.x] = make_uint2(s_n, s_last);
 }
 
-__global__ __launch_bounds__(256) void k_marker_emit(const uint8_t* __restrict__ jpeg, uint64_t begin, uint64_t size,
-                                                     const uint32_t* __restrict__ chunk_rank, uint32_t* __restrict__ rst_pos, uint32_t max_rst)
-{
-    __shared__ uint32_t s_tmp[4];
-    const uint64_t base = begin + (uint64_t)blockIdx.x * GJ_SCAN_CHUNK + threadIdx.x * 8u;
-    uint32_t mask = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (gj_marker_at(jpeg, base + i, size) == 1) mask |= 1u << i;
-    const uint32_t n = (uint32_t)__popc(mask);
-    uint32_t total;
-    uint32_t r = chunk_rank[blockIdx.x] + gj_wg256_incl_scan(n, s_tmp, &total) - n;
-    while (mask) {
-        const int i = __builtin_ctz(mask);
-        mask &= mask - 1;
-        if (r < max_rst) rst_pos[r] = (uint32_t)(base + i);
-        r++;
-    }
-}
-
-// One thread per segment of the table. Scan s is bounded by the "other" markers: it starts after an SOS header and
-// ends at the next other marker. Scan 0 starts at `begin` (the host parsed its SOS).
-__global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint32_t* __restrict__ rst_pos, uint64_t begin, uint64_t size,
-                                                        gj_scan_summary* __restrict__ sum, uint32_t* __restrict__ seg_pos,
-                                                        uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, uint32_t max_segments)
+// Scan s is bounded by the "other" markers: it starts after an SOS header and ends at the next other marker. Scan 0 starts at
+// `begin` (the host parsed its SOS). Table order: the segments of scan 0, of scan 1, ...; restart marker k of a scan ends its segment k
+// and starts segment k + 1, so the lane that owns the marker writes the entry of segment k (and, for the last marker of a scan, the one
+// of the scan's last segment).
+__global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size, const uint32_t tb,
+                                                         const uint32_t chunks, const uint2* __restrict__ chunk_info, gj_scan_summary* __restrict__ sum,
+                                                         gj_scan_summary* __restrict__ sum_next, uint32_t* __restrict__ seg_pos,
+                                                         uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, const uint32_t max_segments)
 {
     __shared__ uint32_t s_start[GJ_MAX_COMP + 1], s_end[GJ_MAX_COMP + 1], s_first[GJ_MAX_COMP + 2];
-    __shared__ int s_scans;
+    __shared__ int s_scans, s_status;
     __shared__ uint32_t s_opos[GJ_SCAN_MAX_OTHER];
     __shared__ uint8_t s_order[GJ_SCAN_MAX_OTHER];
-    // rst_pos holds max_segments - GJ_MAX_COMP valid entries at most (k_marker_emit stops there): a stream with more restart markers
-    // than the geometry allows is damaged; the table is cut and the host, seeing the count, rejects it
-    const uint32_t n_rst = min(sum->rst_count, max_segments - GJ_MAX_COMP);
+    __shared__ uint32_t s_acc[GJ_MAX_COMP + 2]; // restart markers in the chunks in front of: this chunk, the chunk of every scan's start; all
+    __shared__ int s_prev_chunk;
+    __shared__ uint32_t s_tmp[4], s_maxlen;
+    __shared__ uint32_t s_mpos[GJ_SCAN_LIST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
-    if (threadIdx.x == 0) {
+    const uint32_t chunk_bytes = 256u * tb;
+    if (tid == 0) {
         // order the few other markers by position (insertion sort)
         for (uint32_t i = 0; i < n_other; i++) {
             uint32_t j = i;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
         int status = 0;
         for (uint32_t i = 0; i < n_other && scans < GJ_MAX_COMP; i++) {
             const uint32_t p = s_opos[i];
-                        if (p < start) continue; // lies inside a header we already skipped
+            if (p < start) continue; // lies inside a header we already skipped
             s_start[scans] = start;
             s_end[scans] = p;
             scans++;
@@ -134,95 +136,171 @@ __global__ __launch_bounds__(256) void k_build_segments(const gj_geom g, const u
         }
         if (status == 0) status = 3; // no EOI seen
         s_scans = scans;
+        s_status = status;
+        s_prev_chunk = -1;
+        s_maxlen = 0;
+    }
+    if (tid < GJ_MAX_COMP + 2) s_acc[tid] = 0;
+    __syncthreads();
+    const int scans = s_scans;
+    // ---- restart markers in front of this chunk, in front of the chunk every scan starts in, and all of them; the last chunk in front
+    //      of this one that has a marker
+    {
+        uint32_t acc[GJ_MAX_COMP + 2] = {0, 0, 0, 0, 0, 0};
+        uint32_t cs[GJ_MAX_COMP];
+#pragma unroll
+        for (int sc = 0; sc < GJ_MAX_COMP; sc++) cs[sc] = sc < scans ? (uint32_t)((s_start[sc] - begin) / chunk_bytes) : 0u;
+        int prev = -1;
+        for (uint32_t c = (uint32_t)tid; c < chunks; c += 256) {
+            const uint32_t n = chunk_info[c].x;
+            if (c < blockIdx.x) { acc[0] += n; if (n) prev = (int)c; }
+#pragma unroll
+            for (int sc = 0; sc < GJ_MAX_COMP; sc++)
+                if (c < cs[sc]) acc[1 + sc] += n;
+            acc[GJ_MAX_COMP + 1] += n;
+        }
+#pragma unroll
+        for (int i = 0; i < GJ_MAX_COMP + 2; i++) {
+            uint32_t v = gj_wave_incl_scan(acc[i]);
+            v = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            if (lane == 0 && v) atomicAdd(&s_acc[i], v);
+        }
+        if (prev >= 0) atomicMax(&s_prev_chunk, prev);
+    }
+    __syncthreads();
+    // ---- rank of the first restart marker of every scan: the markers of its start's chunk that lie in front of the start are counted
+    //      by wave sc (the chunk is read again: once per workgroup and scan)
+    if (wave < scans) {
+        const uint32_t c = (uint32_t)((s_start[wave] - begin) / chunk_bytes);
+        const uint64_t c0 = begin + (uint64_t)c * chunk_bytes;
+        uint32_t n = 0;
+        for (uint32_t t = (uint32_t)lane; t < 256u; t += 64) {
+            const uint64_t b0 = c0 + (uint64_t)t * tb;
+            if (b0 >= s_start[wave]) break;
+            uint64_t rst, other;
+            gj_scan_bytes(jpeg, size, b0, tb, rst, other);
+            const uint64_t below = s_start[wave] - b0; // bytes of this lane's share in front of the start
+            if (below < 64) rst &= (1ull << below) - 1ull;
+            n += (uint32_t)__popcll(rst);
+        }
+        n = gj_wave_incl_scan(n);
+        if (lane == 63) s_first[wave] = s_acc[1 + wave] + n;
+    }
+    if (tid == 0) s_first[scans] = s_acc[GJ_MAX_COMP + 1]; // sentinel: everything lies below the end
+    __syncthreads();
+    const uint32_t total = s_acc[GJ_MAX_COMP + 1];
+    // (a stream with more restart markers than the geometry allows is damaged: entries beyond the table are not written and the host,
+    //  seeing the count, rejects it)
+    // ---- the markers of this chunk, in order
+    const uint64_t b0 = begin + ((uint64_t)blockIdx.x * 256u + (uint32_t)tid) * tb;
+    uint64_t rst, other;
+    gj_scan_bytes(jpeg, size, b0, tb, rst, other);
+    uint32_t tot;
+    const uint32_t mine = (uint32_t)__popcll(rst);
+    uint32_t r = gj_wg256_incl_scan(mine, s_tmp, &tot) - mine;
+    const bool too_many = tot > (uint32_t)GJ_SCAN_LIST;
+    for (uint64_t m = rst; m && !too_many; m &= m - 1) s_mpos[r++] = (uint32_t)(b0 + (uint32_t)__builtin_ctzll(m));
+    __syncthreads();
+    uint32_t irregular = too_many ? 1u : 0u, maxlen = 0;
+    const uint32_t rank0 = s_acc[0];
+    const uint32_t prev_last = s_prev_chunk >= 0 ? chunk_info[s_prev_chunk].y : 0u; // the last marker in front of this chunk (if any)
+    for (uint32_t i = (uint32_t)tid; i < tot && !too_many && scans > 0; i += 256) {
+        const uint32_t p = s_mpos[i], rk = rank0 + i;
+        int sc = -1;
+#pragma unroll
+        for (int q = 0; q < GJ_MAX_COMP; q++)
+            if (q < scans && p >= s_start[q] && p < s_end[q]) sc = q;
+        if (sc < 0) { irregular = 1u; continue; } // (a restart marker outside every scan)
+        const uint32_t k = rk - s_first[sc];                       // the marker's number inside its scan = the segment it ends
+        const uint32_t c_s = s_first[sc + 1] - s_first[sc];        // RSTn inside this scan
+        if (rk < s_first[sc] || k >= c_s) { irregular = 1u; continue; }
+        const uint32_t before = i > 0 ? s_mpos[i - 1] : prev_last; // the marker in front of this one
+        const uint32_t from = (k == 0) ? s_start[sc] : before + 2;
+        // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
+        const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
+        const uint32_t limit = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].segment_count;
+        const uint32_t e = s_first[sc] + (uint32_t)sc + k;
+        // the marker that ends segment k must be RST(k mod 8), and the last segment of a scan must not be empty: anything else is a
+        // stream the reference reader treats specially, which the host walk reproduces
+        if (jpeg[p + 1] != (uint8_t)(0xD0 + (k & 7u))) irregular = 1u;
+        if (e < max_segments) {
+            seg_pos[e] = from;
+            seg_len[e] = p > from ? p - from : 0;
+            seg_index[e] = k < limit ? first + k : 0xFFFFFFFFu;
+            if (p > from) maxlen = max(maxlen, p - from);
+        }
+        if (k + 1 == c_s) { // the last marker of the scan: the segment behind it ends with the scan
+            const uint32_t from2 = p + 2, to2 = s_end[sc];
+            if (to2 <= from2) irregular = 1u;
+            if (e + 1 < max_segments) {
+                seg_pos[e + 1] = from2;
+                seg_len[e + 1] = to2 > from2 ? to2 - from2 : 0;
+                seg_index[e + 1] = k + 1 < limit ? first + k + 1 : 0xFFFFFFFFu;
+                if (to2 > from2) maxlen = max(maxlen, to2 - from2);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid < scans) { // scans without a restart marker: one segment
+        const int sc = tid;
+        if (s_first[sc + 1] == s_first[sc]) {
+            const uint32_t e = s_first[sc] + (uint32_t)sc;
+            const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
+            const uint32_t limit = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].segment_count;
+            if (e < max_segments) {
+                seg_pos[e] = s_start[sc];
+                seg_len[e] = s_end[sc] > s_start[sc] ? s_end[sc] - s_start[sc] : 0;
+                seg_index[e] = limit > 0 ? first : 0xFFFFFFFFu;
+                maxlen = max(maxlen, seg_len[e]);
+            }
+        }
+    }
+    if (maxlen) atomicMax(&s_maxlen, maxlen);
+    irregular = (uint32_t)__syncthreads_or((int)irregular);
+    if (tid == 0) {
+        if (s_maxlen) atomicMax(&sum->max_seg_len, s_maxlen);
+        if (irregular) sum->rst_irregular = 1u;
         if (blockIdx.x == 0) {
+            sum->rst_count = total;
             sum->scan_count = (uint32_t)scans;
-            sum->status = (uint32_t)status;
-            sum->segment_count = scans ? n_rst + (uint32_t)scans : 0u;
+            sum->status = (uint32_t)s_status;
+            sum->segment_count = scans ? total + (uint32_t)scans : 0u;
             for (int sc = 0; sc < scans; sc++) { sum->scan_start[sc] = s_start[sc]; sum->scan_end[sc] = s_end[sc]; }
         }
     }
-    __syncthreads();
-    {   // rank of the first RSTn of every scan (lower bound in the ordered list): wave sc searches for scan sc with 64 probes
-        // per round, i.e. three dependent loads instead of sixteen
-        const int sc = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (threadIdx.x == 0) s_first[s_scans] = n_rst; // sentinel: everything lies below the end
-        if (sc < s_scans) {
-            const uint32_t key = s_start[sc];
-            uint32_t lo = 0, hi = n_rst;
-            while (lo < hi) {
-                const uint32_t step = (hi - lo + 63u) / 64u;
-                const uint32_t idx = lo + (uint32_t)lane * step;
-                const bool below = idx < hi && rst_pos[idx] < key;
-                const uint32_t cnt = (uint32_t)__popcll(__ballot(below)); // the probes are ordered: the first cnt are below the key
-                if (step == 1) { lo += cnt; break; }
-                if (cnt < 64u) hi = min(hi, lo + cnt * step);
-                if (cnt) lo += (cnt - 1u) * step + 1u;
-            }
-            if (lane == 0) s_first[sc] = lo;
-        }
-    }
-    __syncthreads();
-    const int scans = s_scans;
-    const uint32_t gidx = blockIdx.x * 256u + threadIdx.x;
-    if (scans == 0) return; // no scan ends inside the data (truncated file, no marker at all): the host decides what to do
-    if (gidx >= n_rst + (uint32_t)scans || gidx >= max_segments) return;
-    int sc = 0;
-    while (sc + 1 < scans && gidx >= s_first[sc + 1] + (uint32_t)(sc + 1)) sc++;
-    const uint32_t k = gidx - s_first[sc] - (uint32_t)sc;       // index of the segment inside its scan
-    const uint32_t c_s = s_first[sc + 1] - s_first[sc];         // RSTn inside this scan
-    if (k > c_s) return;                                        // (inconsistent ranks: damaged stream)
-    const uint32_t from = k == 0 ? s_start[sc] : rst_pos[s_first[sc] + k - 1] + 2;
-    const uint32_t to = k == c_s ? s_end[sc] : rst_pos[s_first[sc] + k];
-    // the marker that ends segment k must be RST(k mod 8), and the last segment of a scan must not be empty: anything else is a
-    // stream the reference reader treats specially, which the host walk reproduces
-    if ((k < c_s && jpeg[to + 1] != (uint8_t)(0xD0 + (k & 7u))) || (k == c_s && c_s > 0 && to <= from)) sum->rst_irregular = 1u;
-    seg_pos[gidx] = from;
-    seg_len[gidx] = to > from ? to - from : 0;
-    if (to > from) atomicMax(&sum->max_seg_len, to - from);
-    // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
-    const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
-    const uint32_t limit = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].segment_count;
-    seg_index[gidx] = k < limit ? first + k : 0xFFFFFFFFu;
+    // the summary of the next call (the two alternate): its counters start at zero
+    if (blockIdx.x == 0 && sum_next != nullptr)
+        for (uint32_t i = (uint32_t)tid; i < sizeof(gj_scan_summary) / 4; i += 256) reinterpret_cast<uint32_t*>(sum_next)[i] = 0;
+}
+
+static uint32_t gj_scan_lane_bytes(uint64_t begin, uint64_t size)
+{
+    // at most ~1024 chunks (every workgroup of k_marker_segments reads all the chunk counts), 8 .. 64 bytes per lane
+    const uint64_t bytes = size - begin;
+    uint64_t tb = (bytes + 256ull * 1024 - 1) / (256ull * 1024);
+    tb = (tb + 7) & ~7ull;
+    return (uint32_t)(tb < 8 ? 8 : (tb > GJ_SCAN_TB_MAX ? GJ_SCAN_TB_MAX : tb));
 }
 
 extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
-                                    gj_scan_summary* d_summary, gj_stream_t stream, int debug_sync)
+                                    gj_scan_summary* d_summary, gj_scan_summary* d_summary_next, const uint8_t* d_hdr_ref, uint32_t hdr_n,
+                                    gj_stream_t stream, int debug_sync)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (size <= begin) return -1;
-    const uint32_t chunks = (uint32_t)((size - begin + GJ_SCAN_CHUNK - 1) / GJ_SCAN_CHUNK);
-    uint32_t* d_chunk = d_scratch;          // [chunks]
-    uint32_t* d_rst = d_scratch + chunks;   // [max_segments]
-    (void)hipMemsetAsync(d_summary, 0, sizeof(gj_scan_summary), st);
-    hipLaunchKernelGGL(k_marker_count, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary);
-    gj_debug_stage(debug_sync != 0, st, "k_marker_count");
-    hipLaunchKernelGGL(k_marker_rank, dim3(1), dim3(1024), 0, st, d_chunk, chunks, d_summary);
-    hipLaunchKernelGGL(k_marker_emit, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_rst, max_segments);
-    gj_debug_stage(debug_sync != 0, st, "k_marker_rank + k_marker_emit");
-    hipLaunchKernelGGL(k_build_segments, dim3((max_segments + GJ_MAX_COMP + 255) / 256), dim3(256), 0, st, *g, d_jpeg, d_rst, begin, size, d_summary,
+    if (size <= begin || size > 0xFFFFFFF0ull) return -1;
+    const uint32_t tb = gj_scan_lane_bytes(begin, size);
+    const uint32_t chunks = (uint32_t)((size - begin + 256ull * tb - 1) / (256ull * tb));
+    uint2* d_chunk = reinterpret_cast<uint2*>(d_scratch); // [chunks] restart markers, position of the last one
+    hipLaunchKernelGGL(k_marker_scan, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, tb, d_chunk, d_summary, d_hdr_ref, hdr_n);
+    gj_debug_stage(debug_sync != 0, st, "k_marker_scan");
+    hipLaunchKernelGGL(k_marker_segments, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, tb, chunks, d_chunk, d_summary, d_summary_next,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
-    gj_debug_stage(debug_sync != 0, st, "k_build_segments");
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-__global__ __launch_bounds__(256) void k_compare_header(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t n,
-                                                         gj_scan_summary* __restrict__ sum)
-{
-    int diff = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) diff |= a[i] != b[i];
-    diff = __syncthreads_or(diff);
-    if (threadIdx.x == 0) sum->header_differs = diff ? 1u : 0u;
-}
-
-extern "C" int gj_hip_compare_header(const uint8_t* d_jpeg, const uint8_t* d_ref, uint32_t n, gj_scan_summary* d_summary, gj_stream_t stream)
-{
-    hipLaunchKernelGGL(k_compare_header, dim3(1), dim3(256), 0, (hipStream_t)stream, d_jpeg, d_ref, n, d_summary);
+    gj_debug_stage(debug_sync != 0, st, "k_marker_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 extern "C" size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments)
 {
-    return (size_t)((size - begin + GJ_SCAN_CHUNK - 1) / GJ_SCAN_CHUNK) + max_segments + 16;
+    (void)max_segments;
+    return 2 * (size_t)((size - begin + 2047) / 2048) + 16;
 }
-

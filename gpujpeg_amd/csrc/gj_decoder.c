@@ -39,7 +39,8 @@ struct gpujpeg_decoder {
     /* device-side segment discovery */
     uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
     uint32_t* d_scan_scratch; size_t d_scan_scratch_cap;
-    gj_scan_summary* d_summary;
+    gj_scan_summary* d_summary;   /* [2]: the marker scan of a call uses one and clears the other for the next call */
+    int sum_idx;
     uint32_t last_max_seg_len;    /* longest segment of the last frame decoded with this header (speculative path) */
     uint32_t last_scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes per scan of the last frame decoded with this header (speculative path) */
     gj_scan_summary* h_summary;   /* pinned */
@@ -86,9 +87,10 @@ struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
     if (!d->d_huff_tab || !d->h_tabs) goto fail;
     d->d_qtab = d->d_huff_tab + 8 * GJ_DEC_TAB_WORDS;
     d->h_hdr = gj_hip_host_alloc(GJ_HDR_WINDOW);
-    d->d_summary = gj_hip_malloc(sizeof(gj_scan_summary));
+    d->d_summary = gj_hip_malloc(2 * sizeof(gj_scan_summary));
     d->h_summary = gj_hip_host_alloc(sizeof(gj_scan_summary));
     if (!d->h_hdr || !d->d_summary || !d->h_summary) goto fail;
+    if (gj_hip_memset(d->d_summary, 0, 2 * sizeof(gj_scan_summary), d->coder.stream) != 0 || gj_hip_stream_sync(d->coder.stream) != 0) goto fail;
     d->host_scan = d->tune.host_scan;
     return d;
 fail:
@@ -278,21 +280,27 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     /* ---- 3. segment table ---- */
     int seg_count = 0;
     const uint32_t* d_seg_count = NULL;
+    gj_scan_summary *sum_cur = d->d_summary + d->sum_idx, *sum_next = d->d_summary + (d->sum_idx ^ 1);
+    bool scanned = false;
     const size_t S = (size_t)g->segment_count + GJ_MAX_COMP;
     if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 4 + 8) * sizeof(uint32_t)) != 0) goto out;
     if (device_scan) {
         const size_t words = gj_hip_find_segments_scratch_words(r.scan_begin[0], image_size, (uint32_t)g->segment_count);
         if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
-        if (gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
-                                 d->d_scan_scratch, d->d_summary, c->stream, d->tune.debug_sync) != 0 ||
-            (spec && jpeg_on_device && gj_hip_compare_header(d_jpeg, d->d_hdr_cache, (uint32_t)d->hdr_cache_len, d->d_summary, c->stream) != 0) ||
-            gj_hip_memcpy_d2h(d->h_summary, d->d_summary, sizeof(gj_scan_summary), c->stream) != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
+        /* (a speculative launch on a device-resident stream has its header compared with the cached one by the scan's first kernel) */
+        const bool cmp = spec && jpeg_on_device;
+        const int frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
+                                             d->d_scan_scratch, sum_cur, sum_next, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, c->stream,
+                                             d->tune.debug_sync);
+        if (frc == 0) { scanned = true; d->sum_idx ^= 1; } /* (sum_next is clean once this call's kernels have run: it serves the next call) */
+        if (frc != 0 ||
+            gj_hip_memcpy_d2h(d->h_summary, sum_cur, sizeof(gj_scan_summary), c->stream) != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
             GJ_ERROR("Marker scan failed: %s\n", gj_hip_last_error());
             goto out;
         }
         if (spec) { /* the kernels take the segment count from the device; the summary is checked once everything has run */
             seg_count = g->segment_count;
-            d_seg_count = &d->d_summary->segment_count;
+            d_seg_count = &sum_cur->segment_count;
         } else if (accept_device_scan(d->h_summary, &r, g) == 0) {
             seg_count = (int)d->h_summary->segment_count;
             d_seg_count = NULL;
@@ -453,8 +461,10 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     job.tune = d->tune;
     job.tune.dec_careful = careful;
     /* bytes per scan: what the entropy decoder's batch sizes are cut to (luminance segments are 2-3 x the chrominance ones) */
-    job.d_overflow = &d->d_summary->seq_overflow;
-    if (!device_scan) gj_hip_memset(job.d_overflow, 0, sizeof(uint32_t), c->stream); /* (the marker scan clears the summary; the host walk has none) */
+    /* the word the entropy decoders raise: in this call's summary when the marker scan ran (clean, and cleared again before it is reused); a
+     * call without a scan borrows the other summary's, which the next scan clears before anybody looks at it */
+    job.d_overflow = scanned ? &sum_cur->seq_overflow : &sum_next->seq_overflow;
+    if (!device_scan) gj_hip_memset(job.d_overflow, 0, sizeof(uint32_t), c->stream);
     if (spec) {
         memcpy(job.scan_bytes, d->last_scan_bytes, sizeof job.scan_bytes);
         job.max_seg_len = d->last_max_seg_len;
@@ -477,7 +487,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         goto out;
     }
     /* (the lane-per-segment entropy decoder may have met a segment it cannot stage: known once everything has run) */
-    if (gj_hip_memcpy_d2h(&d->h_summary->seq_overflow, &d->d_summary->seq_overflow, sizeof(uint32_t), c->stream) != 0) goto out;
+    if (gj_hip_memcpy_d2h(&d->h_summary->seq_overflow, job.d_overflow, sizeof(uint32_t), c->stream) != 0) goto out;
 
     output->data_size = g->raw_size;
     output->param_image = c->param_image;

@@ -236,12 +236,14 @@ typedef struct gj_scan_summary {
                                                  resynchronises / drops it (src/gpujpeg_reader.c:1074-1135), so the host walks such a stream */
 } gj_scan_summary;
 
-/* sets d_summary->header_differs = (d_jpeg[0..n) != d_ref[0..n)); launch after gj_hip_find_segments (which clears the summary) */
-GJ_HIP_API int gj_hip_compare_header(const uint8_t* d_jpeg, const uint8_t* d_ref, uint32_t n, gj_scan_summary* d_summary, gj_stream_t stream);
 GJ_HIP_API size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments);
+/* d_summary: this call's summary, all zero on entry (a fresh allocation, or the d_summary_next of the previous call: the two alternate,
+ * so that no clearing launch is needed); d_summary_next (may be NULL) is cleared for the next call.
+ * d_hdr_ref (may be NULL): the cached header of a speculative launch; sets d_summary->header_differs = (d_jpeg[0..hdr_n) != d_hdr_ref[0..hdr_n)) */
 GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
-                                    gj_scan_summary* d_summary, gj_stream_t stream, int debug_sync);
+                                    gj_scan_summary* d_summary, gj_scan_summary* d_summary_next, const uint8_t* d_hdr_ref, uint32_t hdr_n,
+                                    gj_stream_t stream, int debug_sync);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import test_gpu_api as A
 import test_gpu_parity as T
 from conftest import CASES
 
@@ -86,3 +87,19 @@ def test_emu_random_configurations(O, G, emu_lib, seed):
 @pytest.mark.parametrize("seed", range(0, 40, 4))
 def test_emu_random_streams_all_decoder_paths(O, G, emu_lib, seed, monkeypatch):
     T.test_random_streams_all_decoder_paths(O, G, emu_lib, seed, monkeypatch)
+
+
+# ---- the API-level GPU tests that need no device tensors (tests/test_gpu_api.py): reader robustness, options, metadata
+def test_emu_error_paths_and_hostile_input(O, G, emu_lib):
+    A.test_error_paths(G, emu_lib)
+    A.test_hostile_tables_and_index(O, G, emu_lib)
+    A.test_damaged_streams_do_not_crash(O, G, emu_lib)
+
+
+def test_emu_output_buffers_and_stats(O, G, emu_lib):
+    A.test_output_buffer_ownership_and_pinned_option(O, G, emu_lib)
+
+
+def test_emu_metadata_and_exif(O, G, emu_lib):
+    A.test_encoder_metadata_orientation(O, G, emu_lib)
+    A.test_encoder_custom_exif_tags(O, G, emu_lib)

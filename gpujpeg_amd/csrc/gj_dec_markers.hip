@@ -14,11 +14,12 @@
 //                      validates (gj_scan_summary); clears the summary of the NEXT call (two summaries alternate, no memset launch)
 // A lane owns `tb` consecutive bytes (8 .. 64, chosen by the host from the stream's size), a workgroup 256 x tb.
 // ================================================================================================
-#define GJ_SCAN_TB_MAX 64   // bytes per lane
 #define GJ_SCAN_LIST 2048   // restart markers a chunk may hold (a segment of 8 bytes on average at the largest chunk: beyond that the host walks)
 
-// bit i of the results: byte i of the lane's `tb` bytes at absolute offset b0 starts a restart marker / another marker
-__device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, const uint64_t size, const uint64_t b0, const uint32_t tb, uint64_t& rst, uint64_t& other)
+// bit i of the results: byte i of the lane's TB bytes at absolute offset b0 starts a restart marker / another marker; `num`: the low three
+// bits of the restart markers' codes, 4 bits per marker in the order of their positions (at most 16 of them are recorded)
+template <int TB>
+__device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, const uint64_t size, const uint64_t b0, uint64_t& rst, uint64_t& other)
 {
     rst = other = 0;
     if (b0 + 1 >= size) return;
@@ -26,43 +27,39 @@ __device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, 
     const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
     const uint32_t lead = (uint32_t)(a & 3);
     const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + size + 3) & ~(uintptr_t)3);
-    uint32_t win[GJ_SCAN_TB_MAX / 4 + 2];
+    uint32_t win[TB / 4 + 2];
 #pragma unroll
-    for (int i = 0; i < GJ_SCAN_TB_MAX / 4 + 2; i++) {
-        win[i] = 0;
-        if ((uint32_t)i < tb / 4 + 2u && src + i < end) win[i] = src[i];
-    }
+    for (int i = 0; i < TB / 4 + 2; i++) win[i] = src + i < end ? src[i] : 0u;
 #pragma unroll
-    for (int i = 0; i < GJ_SCAN_TB_MAX / 4; i++) {
-        if ((uint32_t)(4 * i) < tb) {
-            const uint32_t w = __builtin_amdgcn_alignbyte(win[i + 1], win[i], lead);      // bytes 4i .. 4i + 3 of the lane's share
-            const uint32_t wn = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead); // (its first byte follows the last one of w)
-            // 0xFF bytes are rare: one test for the four of them
-            if ((~w - 0x01010101u) & w & 0x80808080u) { // (a zero byte in ~w; a borrow can only add a false alarm)
+    for (int i = 0; i < TB / 4; i++) {
+        const uint32_t w = __builtin_amdgcn_alignbyte(win[i + 1], win[i], lead);      // bytes 4i .. 4i + 3 of the lane's share
+        const uint32_t wn = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead); // (its first byte follows the last one of w)
+        if ((~w - 0x01010101u) & w & 0x80808080u) { // 0xFF bytes are rare: one test for the four (a zero byte in ~w; a borrow can only add a false alarm)
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t b = (w >> (8 * k)) & 0xFFu;
-                    const uint32_t nx = k < 3 ? (w >> (8 * k + 8)) & 0xFFu : wn & 0xFFu;
-                    if (b == 0xFFu && nx != 0u && nx != 0xFFu && b0 + (uint64_t)(4 * i + k) + 1 < size) {
-                        if ((nx & 0xF8u) == 0xD0u) rst |= 1ull << (4 * i + k);
-                        else other |= 1ull << (4 * i + k);
-                    }
+            for (int k = 0; k < 4; k++) {
+                const uint32_t b = (w >> (8 * k)) & 0xFFu;
+                const uint32_t nx = k < 3 ? (w >> (8 * k + 8)) & 0xFFu : wn & 0xFFu;
+                if (b == 0xFFu && nx != 0u && nx != 0xFFu && b0 + (uint64_t)(4 * i + k) + 1 < size) {
+                    if ((nx & 0xF8u) == 0xD0u) rst |= 1ull << (4 * i + k);
+                    else other |= 1ull << (4 * i + k);
                 }
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size, const uint32_t tb,
+template <int TB>
+__global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size,
                                                      uint2* __restrict__ chunk_info, gj_scan_summary* __restrict__ sum,
                                                      const uint8_t* __restrict__ hdr_ref, const uint32_t hdr_n)
 {
-    __shared__ uint32_t s_n, s_last;
-    if (threadIdx.x == 0) { s_n = 0; s_last = 0; }
+    __shared__ uint32_t s_n, s_last, s_nother, s_oq[4], s_oslot[4], s_oafter[4];
+    if (threadIdx.x == 0) { s_n = 0; s_last = 0; s_nother = 0; }
+    if (threadIdx.x < 4) s_oafter[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t b0 = begin + ((uint64_t)blockIdx.x * 256u + threadIdx.x) * tb;
+    const uint64_t b0 = begin + ((uint64_t)blockIdx.x * 256u + threadIdx.x) * TB;
     uint64_t rst, other;
-    gj_scan_bytes(jpeg, size, b0, tb, rst, other);
+    gj_scan_bytes<TB>(jpeg, size, b0, rst, other);
     if (rst) {
         atomicAdd(&s_n, (uint32_t)__popcll(rst));
         atomicMax(&s_last, (uint32_t)(b0 + 63u - (uint32_t)__builtin_clzll(rst)));
@@ -75,6 +72,9 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
             sum->other_pos[slot] = (uint32_t)p;
             sum->other_code[slot] = jpeg[p + 1];
             for (int b = 0; b < 16; b++) sum->other_bytes[slot][b] = p + 2 + b < size ? jpeg[p + 2 + b] : 0;
+            const uint32_t j = atomicAdd(&s_nother, 1u);
+            if (j < 4) { s_oq[j] = (uint32_t)p; s_oslot[j] = slot; }
+            else sum->other_after[slot] = 0xFFFFFFFFu; // (more than four in one chunk: not a stream the device table is used for)
         }
     }
     if (blockIdx.x == 0 && hdr_ref != nullptr) { // does the stream start with the header the host assumed? (speculative launch)
@@ -85,6 +85,18 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
     } else {
         __syncthreads();
     }
+    // restart markers of this chunk behind each of its other markers (an SOS: they are the first ones of the scan it starts)
+    const uint32_t no = min(s_nother, 4u);
+    if (no) { // (the same for the whole workgroup)
+        for (uint32_t j = 0; j < no; j++) {
+            const uint64_t q = s_oq[j];
+            uint64_t m = rst;
+            if (q >= b0) m = q - b0 >= 63 ? 0ull : m & ~((2ull << (q - b0)) - 1ull);
+            if (m) atomicAdd(&s_oafter[j], (uint32_t)__popcll(m));
+        }
+        __syncthreads();
+        if (threadIdx.x < no) sum->other_after[s_oslot[threadIdx.x]] = s_oafter[threadIdx.x];
+    }
     if (threadIdx.x == 0) chunk_info[blockIdx.x] = make_uint2(s_n, s_last);
 }
 
@@ -92,27 +104,32 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
 // `begin` (the host parsed its SOS). Table order: the segments of scan 0, of scan 1, ...; restart marker k of a scan ends its segment k
 // and starts segment k + 1, so the lane that owns the marker writes the entry of segment k (and, for the last marker of a scan, the one
 // of the scan's last segment).
-__global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size, const uint32_t tb,
+template <int TB>
+__global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size,
                                                          const uint32_t chunks, const uint2* __restrict__ chunk_info, gj_scan_summary* __restrict__ sum,
                                                          gj_scan_summary* __restrict__ sum_next, uint32_t* __restrict__ seg_pos,
                                                          uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, const uint32_t max_segments)
 {
     __shared__ uint32_t s_start[GJ_MAX_COMP + 1], s_end[GJ_MAX_COMP + 1], s_first[GJ_MAX_COMP + 2];
+    __shared__ uint32_t s_sos_chunk[GJ_MAX_COMP], s_sos_after[GJ_MAX_COMP]; // scan sc > 0: chunk of its SOS, restart markers of that chunk behind the SOS
     __shared__ int s_scans, s_status;
+    __shared__ gj_scan_summary s_sum; // (read once, together: the few other markers are sorted by one lane)
     __shared__ uint32_t s_opos[GJ_SCAN_MAX_OTHER];
     __shared__ uint8_t s_order[GJ_SCAN_MAX_OTHER];
-    __shared__ uint32_t s_acc[GJ_MAX_COMP + 2]; // restart markers in the chunks in front of: this chunk, the chunk of every scan's start; all
+    __shared__ uint32_t s_acc[GJ_MAX_COMP + 2]; // restart markers in the chunks up to: this chunk (excl.), the chunk of every later scan's SOS (incl.); all
     __shared__ int s_prev_chunk;
     __shared__ uint32_t s_tmp[4], s_maxlen;
-    __shared__ uint32_t s_mpos[GJ_SCAN_LIST];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
-    const uint32_t chunk_bytes = 256u * tb;
+    __shared__ uint32_t s_mpos[GJ_SCAN_LIST]; // position | code & 7 << 29 would not fit 32-bit positions: offset inside the chunk | code & 7 << 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr uint32_t chunk_bytes = 256u * TB;
+    for (uint32_t i = (uint32_t)tid; i < sizeof(gj_scan_summary) / 4; i += 256) reinterpret_cast<uint32_t*>(&s_sum)[i] = reinterpret_cast<const uint32_t*>(sum)[i];
+    __syncthreads();
+    const uint32_t n_other = min(s_sum.other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
     if (tid == 0) {
         // order the few other markers by position (insertion sort)
         for (uint32_t i = 0; i < n_other; i++) {
             uint32_t j = i;
-            const uint32_t p = sum->other_pos[i];
+            const uint32_t p = s_sum.other_pos[i];
             while (j > 0 && s_opos[j - 1] > p) { s_opos[j] = s_opos[j - 1]; s_order[j] = s_order[j - 1]; j--; }
             s_opos[j] = p;
             s_order[j] = (uint8_t)i;
@@ -120,16 +137,25 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         int scans = 0;
         uint32_t start = (uint32_t)begin;
         int status = 0;
+        uint32_t sos_chunk = 0, sos_after = 0;
         for (uint32_t i = 0; i < n_other && scans < GJ_MAX_COMP; i++) {
             const uint32_t p = s_opos[i];
             if (p < start) continue; // lies inside a header we already skipped
             s_start[scans] = start;
             s_end[scans] = p;
+            s_sos_chunk[scans] = sos_chunk;
+            s_sos_after[scans] = sos_after;
             scans++;
-            const uint8_t* hb = sum->other_bytes[s_order[i]];
+            const uint8_t* hb = s_sum.other_bytes[s_order[i]];
             const uint32_t mlen = ((uint32_t)hb[0] << 8) | hb[1];
-            const int m = sum->other_code[s_order[i]];
-            if (m == 0xDA) { start = p + 2 + mlen; continue; } // next scan
+            const int m = s_sum.other_code[s_order[i]];
+            if (m == 0xDA) { // next scan
+                start = p + 2 + mlen;
+                sos_chunk = (uint32_t)((p - begin) / chunk_bytes);
+                sos_after = s_sum.other_after[s_order[i]];
+                if (sos_after == 0xFFFFFFFFu) { status = 2; break; }
+                continue;
+            }
             if (m == 0xD9) { status = 1; break; }              // EOI: done
             status = 2;                                          // something else between scans: let the host walk it
             break;
@@ -143,24 +169,22 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     if (tid < GJ_MAX_COMP + 2) s_acc[tid] = 0;
     __syncthreads();
     const int scans = s_scans;
-    // ---- restart markers in front of this chunk, in front of the chunk every scan starts in, and all of them; the last chunk in front
+    // ---- restart markers in front of this chunk, up to the chunk of every later scan's SOS, and all of them; the last chunk in front
     //      of this one that has a marker
     {
         uint32_t acc[GJ_MAX_COMP + 2] = {0, 0, 0, 0, 0, 0};
-        uint32_t cs[GJ_MAX_COMP];
-#pragma unroll
-        for (int sc = 0; sc < GJ_MAX_COMP; sc++) cs[sc] = sc < scans ? (uint32_t)((s_start[sc] - begin) / chunk_bytes) : 0u;
         int prev = -1;
         for (uint32_t c = (uint32_t)tid; c < chunks; c += 256) {
             const uint32_t n = chunk_info[c].x;
             if (c < blockIdx.x) { acc[0] += n; if (n) prev = (int)c; }
 #pragma unroll
-            for (int sc = 0; sc < GJ_MAX_COMP; sc++)
-                if (c < cs[sc]) acc[1 + sc] += n;
+            for (int sc = 1; sc < GJ_MAX_COMP; sc++)
+                if (sc < scans && c <= s_sos_chunk[sc]) acc[sc] += n;
             acc[GJ_MAX_COMP + 1] += n;
         }
 #pragma unroll
         for (int i = 0; i < GJ_MAX_COMP + 2; i++) {
+            if (i == GJ_MAX_COMP) continue;
             uint32_t v = gj_wave_incl_scan(acc[i]);
             v = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
             if (lane == 0 && v) atomicAdd(&s_acc[i], v);
@@ -168,44 +192,31 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         if (prev >= 0) atomicMax(&s_prev_chunk, prev);
     }
     __syncthreads();
-    // ---- rank of the first restart marker of every scan: the markers of its start's chunk that lie in front of the start are counted
-    //      by wave sc (the chunk is read again: once per workgroup and scan)
-    if (wave < scans) {
-        const uint32_t c = (uint32_t)((s_start[wave] - begin) / chunk_bytes);
-        const uint64_t c0 = begin + (uint64_t)c * chunk_bytes;
-        uint32_t n = 0;
-        for (uint32_t t = (uint32_t)lane; t < 256u; t += 64) {
-            const uint64_t b0 = c0 + (uint64_t)t * tb;
-            if (b0 >= s_start[wave]) break;
-            uint64_t rst, other;
-            gj_scan_bytes(jpeg, size, b0, tb, rst, other);
-            const uint64_t below = s_start[wave] - b0; // bytes of this lane's share in front of the start
-            if (below < 64) rst &= (1ull << below) - 1ull;
-            n += (uint32_t)__popcll(rst);
-        }
-        n = gj_wave_incl_scan(n);
-        if (lane == 63) s_first[wave] = s_acc[1 + wave] + n;
-    }
-    if (tid == 0) s_first[scans] = s_acc[GJ_MAX_COMP + 1]; // sentinel: everything lies below the end
-    __syncthreads();
+    // rank of the first restart marker of every scan: the markers up to its SOS's chunk minus those of that chunk behind the SOS (the SOS
+    // header itself holds none); everything lies below the sentinel
+    if (tid <= scans) s_first[tid] = tid == 0 ? 0u : (tid == scans ? s_acc[GJ_MAX_COMP + 1] : s_acc[tid] - s_sos_after[tid]);
     const uint32_t total = s_acc[GJ_MAX_COMP + 1];
     // (a stream with more restart markers than the geometry allows is damaged: entries beyond the table are not written and the host,
     //  seeing the count, rejects it)
     // ---- the markers of this chunk, in order
-    const uint64_t b0 = begin + ((uint64_t)blockIdx.x * 256u + (uint32_t)tid) * tb;
+    const uint64_t c0 = begin + (uint64_t)blockIdx.x * chunk_bytes;
+    const uint64_t b0 = c0 + (uint64_t)tid * TB;
     uint64_t rst, other;
-    gj_scan_bytes(jpeg, size, b0, tb, rst, other);
+    gj_scan_bytes<TB>(jpeg, size, b0, rst, other);
     uint32_t tot;
     const uint32_t mine = (uint32_t)__popcll(rst);
     uint32_t r = gj_wg256_incl_scan(mine, s_tmp, &tot) - mine;
     const bool too_many = tot > (uint32_t)GJ_SCAN_LIST;
-    for (uint64_t m = rst; m && !too_many; m &= m - 1) s_mpos[r++] = (uint32_t)(b0 + (uint32_t)__builtin_ctzll(m));
+    for (uint64_t m = rst; m && !too_many; m &= m - 1) {
+        const uint32_t o = (uint32_t)tid * TB + (uint32_t)__builtin_ctzll(m);
+        s_mpos[r++] = o | ((uint32_t)(jpeg[c0 + o + 1] & 7u) << 16);
+    }
     __syncthreads();
     uint32_t irregular = too_many ? 1u : 0u, maxlen = 0;
     const uint32_t rank0 = s_acc[0];
     const uint32_t prev_last = s_prev_chunk >= 0 ? chunk_info[s_prev_chunk].y : 0u; // the last marker in front of this chunk (if any)
     for (uint32_t i = (uint32_t)tid; i < tot && !too_many && scans > 0; i += 256) {
-        const uint32_t p = s_mpos[i], rk = rank0 + i;
+        const uint32_t p = (uint32_t)c0 + (s_mpos[i] & 0xFFFFu), num = s_mpos[i] >> 16, rk = rank0 + i;
         int sc = -1;
 #pragma unroll
         for (int q = 0; q < GJ_MAX_COMP; q++)
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         const uint32_t k = rk - s_first[sc];                       // the marker's number inside its scan = the segment it ends
         const uint32_t c_s = s_first[sc + 1] - s_first[sc];        // RSTn inside this scan
         if (rk < s_first[sc] || k >= c_s) { irregular = 1u; continue; }
-        const uint32_t before = i > 0 ? s_mpos[i - 1] : prev_last; // the marker in front of this one
+        const uint32_t before = i > 0 ? (uint32_t)c0 + (s_mpos[i - 1] & 0xFFFFu) : prev_last; // the marker in front of this one
         const uint32_t from = (k == 0) ? s_start[sc] : before + 2;
         // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
         const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         const uint32_t e = s_first[sc] + (uint32_t)sc + k;
         // the marker that ends segment k must be RST(k mod 8), and the last segment of a scan must not be empty: anything else is a
         // stream the reference reader treats specially, which the host walk reproduces
-        if (jpeg[p + 1] != (uint8_t)(0xD0 + (k & 7u))) irregular = 1u;
+        if (num != (k & 7u)) irregular = 1u;
         if (e < max_segments) {
             seg_pos[e] = from;
             seg_len[e] = p > from ? p - from : 0;
@@ -247,10 +258,11 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
             const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
             const uint32_t limit = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].segment_count;
             if (e < max_segments) {
+                const uint32_t len = s_end[sc] > s_start[sc] ? s_end[sc] - s_start[sc] : 0;
                 seg_pos[e] = s_start[sc];
-                seg_len[e] = s_end[sc] > s_start[sc] ? s_end[sc] - s_start[sc] : 0;
+                seg_len[e] = len;
                 seg_index[e] = limit > 0 ? first : 0xFFFFFFFFu;
-                maxlen = max(maxlen, seg_len[e]);
+                maxlen = max(maxlen, len);
             }
         }
     }
@@ -276,9 +288,8 @@ static uint32_t gj_scan_lane_bytes(uint64_t begin, uint64_t size)
 {
     // at most ~1024 chunks (every workgroup of k_marker_segments reads all the chunk counts), 8 .. 64 bytes per lane
     const uint64_t bytes = size - begin;
-    uint64_t tb = (bytes + 256ull * 1024 - 1) / (256ull * 1024);
-    tb = (tb + 7) & ~7ull;
-    return (uint32_t)(tb < 8 ? 8 : (tb > GJ_SCAN_TB_MAX ? GJ_SCAN_TB_MAX : tb));
+    const uint64_t want = (bytes + 256ull * 1024 - 1) / (256ull * 1024);
+    return want <= 8 ? 8u : want <= 16 ? 16u : want <= 32 ? 32u : 64u;
 }
 
 extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
@@ -291,9 +302,11 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     const uint32_t tb = gj_scan_lane_bytes(begin, size);
     const uint32_t chunks = (uint32_t)((size - begin + 256ull * tb - 1) / (256ull * tb));
     uint2* d_chunk = reinterpret_cast<uint2*>(d_scratch); // [chunks] restart markers, position of the last one
-    hipLaunchKernelGGL(k_marker_scan, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, tb, d_chunk, d_summary, d_hdr_ref, hdr_n);
+    auto scan = tb == 8 ? k_marker_scan<8> : tb == 16 ? k_marker_scan<16> : tb == 32 ? k_marker_scan<32> : k_marker_scan<64>;
+    auto segs = tb == 8 ? k_marker_segments<8> : tb == 16 ? k_marker_segments<16> : tb == 32 ? k_marker_segments<32> : k_marker_segments<64>;
+    hipLaunchKernelGGL(scan, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary, d_hdr_ref, hdr_n);
     gj_debug_stage(debug_sync != 0, st, "k_marker_scan");
-    hipLaunchKernelGGL(k_marker_segments, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, tb, chunks, d_chunk, d_summary, d_summary_next,
+    hipLaunchKernelGGL(segs, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, chunks, d_chunk, d_summary, d_summary_next,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
     gj_debug_stage(debug_sync != 0, st, "k_marker_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;

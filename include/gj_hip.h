@@ -226,6 +226,7 @@ typedef struct gj_scan_summary {
     uint32_t other_pos[GJ_SCAN_MAX_OTHER];
     uint8_t other_code[GJ_SCAN_MAX_OTHER];
     uint8_t other_bytes[GJ_SCAN_MAX_OTHER][16]; /* the 16 bytes after each of them (length + start of the payload) */
+    uint32_t other_after[GJ_SCAN_MAX_OTHER];  /* RSTn markers behind it inside its chunk of the scan kernel (ranks the first RSTn of the scan an SOS starts) */
     uint32_t scan_count, segment_count;
     uint32_t status;                          /* 1 = clean (scans ... EOI), 2 = unexpected marker between scans, 3 = no EOI */
     uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];

@@ -19,9 +19,12 @@
 // bit i of the results: byte i of the lane's TB bytes at absolute offset b0 starts a restart marker / another marker; `num`: the low three
 // bits of the restart markers' codes, 4 bits per marker in the order of their positions (at most 16 of them are recorded)
 template <int TB>
-__device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, const uint64_t size, const uint64_t b0, uint64_t& rst, uint64_t& other)
+__device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, const uint64_t size, const uint64_t b0, uint64_t& rst, uint64_t& other, uint64_t* nums = nullptr)
 {
     rst = other = 0;
+    uint64_t nm = 0;
+    uint32_t nn = 0;
+    if (nums) *nums = 0;
     if (b0 + 1 >= size) return;
     const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + b0;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
@@ -40,12 +43,17 @@ __device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, 
                 const uint32_t b = (w >> (8 * k)) & 0xFFu;
                 const uint32_t nx = k < 3 ? (w >> (8 * k + 8)) & 0xFFu : wn & 0xFFu;
                 if (b == 0xFFu && nx != 0u && nx != 0xFFu && b0 + (uint64_t)(4 * i + k) + 1 < size) {
-                    if ((nx & 0xF8u) == 0xD0u) rst |= 1ull << (4 * i + k);
-                    else other |= 1ull << (4 * i + k);
+                    if ((nx & 0xF8u) == 0xD0u) {
+                        rst |= 1ull << (4 * i + k);
+                        if (nums) { nm |= (uint64_t)(nx & 7u) << ((4u * nn) & 63u); nn++; }
+                    } else {
+                        other |= 1ull << (4 * i + k);
+                    }
                 }
             }
         }
     }
+    if (nums) *nums = nm;
 }
 
 template <int TB>
@@ -106,7 +114,8 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
 // of the scan's last segment).
 template <int TB>
 __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size,
-                                                         const uint32_t chunks, const uint2* __restrict__ chunk_info, gj_scan_summary* __restrict__ sum,
+                                                         const uint32_t chunks, const uint2* __restrict__ chunk_info, uint32_t* __restrict__ chunk_maxlen,
+                                                         gj_scan_summary* __restrict__ sum,
                                                          gj_scan_summary* __restrict__ sum_next, uint32_t* __restrict__ seg_pos,
                                                          uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, const uint32_t max_segments)
 {
@@ -122,7 +131,21 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     __shared__ uint32_t s_mpos[GJ_SCAN_LIST]; // position | code & 7 << 29 would not fit 32-bit positions: offset inside the chunk | code & 7 << 16
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr uint32_t chunk_bytes = 256u * TB;
+    // everything this workgroup reads from memory is asked for at once: the summary, the counts of all chunks (registers: up to 8 per
+    // lane; more chunks are read again below), the last marker of the chunk in front, and the bytes of its own chunk
+    constexpr int KEEP = 8;
+    uint32_t cnt_reg[KEEP];
+#pragma unroll
+    for (int q = 0; q < KEEP; q++) {
+        const uint32_t c = (uint32_t)tid + 256u * q;
+        cnt_reg[q] = c < chunks ? chunk_info[c].x : 0u;
+    }
+    const uint32_t prev1_last = blockIdx.x > 0 ? chunk_info[blockIdx.x - 1].y : 0u;
     for (uint32_t i = (uint32_t)tid; i < sizeof(gj_scan_summary) / 4; i += 256) reinterpret_cast<uint32_t*>(&s_sum)[i] = reinterpret_cast<const uint32_t*>(sum)[i];
+    const uint64_t c0 = begin + (uint64_t)blockIdx.x * chunk_bytes;
+    const uint64_t b0 = c0 + (uint64_t)tid * TB;
+    uint64_t rst, other, nums;
+    gj_scan_bytes<TB>(jpeg, size, b0, rst, other, &nums);
     __syncthreads();
     const uint32_t n_other = min(s_sum.other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
     if (tid == 0) {
@@ -174,8 +197,14 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     {
         uint32_t acc[GJ_MAX_COMP + 2] = {0, 0, 0, 0, 0, 0};
         int prev = -1;
-        for (uint32_t c = (uint32_t)tid; c < chunks; c += 256) {
-            const uint32_t n = chunk_info[c].x;
+        for (uint32_t c = (uint32_t)tid, q = 0; c < chunks; c += 256, q++) {
+            uint32_t n = 0;
+            if (q < KEEP) {
+#pragma unroll
+                for (int u = 0; u < KEEP; u++) n = q == (uint32_t)u ? cnt_reg[u] : n;
+            } else {
+                n = chunk_info[c].x;
+            }
             if (c < blockIdx.x) { acc[0] += n; if (n) prev = (int)c; }
 #pragma unroll
             for (int sc = 1; sc < GJ_MAX_COMP; sc++)
@@ -199,22 +228,19 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     // (a stream with more restart markers than the geometry allows is damaged: entries beyond the table are not written and the host,
     //  seeing the count, rejects it)
     // ---- the markers of this chunk, in order
-    const uint64_t c0 = begin + (uint64_t)blockIdx.x * chunk_bytes;
-    const uint64_t b0 = c0 + (uint64_t)tid * TB;
-    uint64_t rst, other;
-    gj_scan_bytes<TB>(jpeg, size, b0, rst, other);
     uint32_t tot;
     const uint32_t mine = (uint32_t)__popcll(rst);
     uint32_t r = gj_wg256_incl_scan(mine, s_tmp, &tot) - mine;
-    const bool too_many = tot > (uint32_t)GJ_SCAN_LIST;
-    for (uint64_t m = rst; m && !too_many; m &= m - 1) {
+    const bool too_many = tot > (uint32_t)GJ_SCAN_LIST || __syncthreads_or(mine > 16u); // (a lane notes the numbers of 16 markers)
+    for (uint64_t m = rst; m && !too_many; m &= m - 1, nums >>= 4) {
         const uint32_t o = (uint32_t)tid * TB + (uint32_t)__builtin_ctzll(m);
-        s_mpos[r++] = o | ((uint32_t)(jpeg[c0 + o + 1] & 7u) << 16);
+        s_mpos[r++] = o | ((uint32_t)(nums & 7u) << 16);
     }
     __syncthreads();
     uint32_t irregular = too_many ? 1u : 0u, maxlen = 0;
     const uint32_t rank0 = s_acc[0];
-    const uint32_t prev_last = s_prev_chunk >= 0 ? chunk_info[s_prev_chunk].y : 0u; // the last marker in front of this chunk (if any)
+    // the last marker in front of this chunk (if any): normally in the chunk right in front
+    const uint32_t prev_last = s_prev_chunk < 0 ? 0u : (s_prev_chunk == (int)blockIdx.x - 1 ? prev1_last : chunk_info[s_prev_chunk].y);
     for (uint32_t i = (uint32_t)tid; i < tot && !too_many && scans > 0; i += 256) {
         const uint32_t p = (uint32_t)c0 + (s_mpos[i] & 0xFFFFu), num = s_mpos[i] >> 16, rk = rank0 + i;
         int sc = -1;
@@ -269,7 +295,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     if (maxlen) atomicMax(&s_maxlen, maxlen);
     irregular = (uint32_t)__syncthreads_or((int)irregular);
     if (tid == 0) {
-        if (s_maxlen) atomicMax(&sum->max_seg_len, s_maxlen);
+        chunk_maxlen[blockIdx.x] = s_maxlen; // (the host takes the maximum: a thousand workgroups raising one word one after the other took 10 us)
         if (irregular) sum->rst_irregular = 1u;
         if (blockIdx.x == 0) {
             sum->rst_count = total;
@@ -286,27 +312,32 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
 
 static uint32_t gj_scan_lane_bytes(uint64_t begin, uint64_t size)
 {
-    // at most ~1024 chunks (every workgroup of k_marker_segments reads all the chunk counts), 8 .. 64 bytes per lane
+    // at most ~2048 chunks (every workgroup of k_marker_segments reads all the chunk counts: 8 registers per lane), 8 .. 64 bytes per lane
+    // (measured at 8K, 7.4 MB: 8 B per lane 9.7 + 29.0 us, 16 B 10.0 + 17.5, 32 B 12.5 + 17.3, 64 B 17.1 + 17.9)
     const uint64_t bytes = size - begin;
-    const uint64_t want = (bytes + 256ull * 1024 - 1) / (256ull * 1024);
+    const uint64_t want = (bytes + 256ull * 2048 - 1) / (256ull * 2048);
     return want <= 8 ? 8u : want <= 16 ? 16u : want <= 32 ? 32u : 64u;
 }
 
 extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
                                     gj_scan_summary* d_summary, gj_scan_summary* d_summary_next, const uint8_t* d_hdr_ref, uint32_t hdr_n,
-                                    gj_stream_t stream, int debug_sync)
+                                    uint32_t** d_maxlen_parts, uint32_t* maxlen_part_count, gj_stream_t stream, const gj_tuning* tune)
 {
+    const int debug_sync = tune->debug_sync;
     hipStream_t st = (hipStream_t)stream;
     if (size <= begin || size > 0xFFFFFFF0ull) return -1;
-    const uint32_t tb = gj_scan_lane_bytes(begin, size);
+    const uint32_t tb = (tune->scan_tb == 8 || tune->scan_tb == 16 || tune->scan_tb == 32 || tune->scan_tb == 64) ? (uint32_t)tune->scan_tb : gj_scan_lane_bytes(begin, size);
     const uint32_t chunks = (uint32_t)((size - begin + 256ull * tb - 1) / (256ull * tb));
     uint2* d_chunk = reinterpret_cast<uint2*>(d_scratch); // [chunks] restart markers, position of the last one
+    uint32_t* d_maxlen = d_scratch + 2 * (size_t)chunks;  // [chunks] longest segment a chunk's markers end
+    *d_maxlen_parts = d_maxlen;
+    *maxlen_part_count = chunks;
     auto scan = tb == 8 ? k_marker_scan<8> : tb == 16 ? k_marker_scan<16> : tb == 32 ? k_marker_scan<32> : k_marker_scan<64>;
     auto segs = tb == 8 ? k_marker_segments<8> : tb == 16 ? k_marker_segments<16> : tb == 32 ? k_marker_segments<32> : k_marker_segments<64>;
     hipLaunchKernelGGL(scan, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary, d_hdr_ref, hdr_n);
     gj_debug_stage(debug_sync != 0, st, "k_marker_scan");
-    hipLaunchKernelGGL(segs, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, chunks, d_chunk, d_summary, d_summary_next,
+    hipLaunchKernelGGL(segs, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, chunks, d_chunk, d_maxlen, d_summary, d_summary_next,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
     gj_debug_stage(debug_sync != 0, st, "k_marker_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -315,5 +346,5 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
 extern "C" size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments)
 {
     (void)max_segments;
-    return 2 * (size_t)((size - begin + 2047) / 2048) + 16;
+    return 3 * (size_t)((size - begin + 2047) / 2048) + 16; /* (lanes take at least 8 bytes) */
 }

@@ -44,6 +44,8 @@ struct gpujpeg_decoder {
     uint32_t last_max_seg_len;    /* longest segment of the last frame decoded with this header (speculative path) */
     uint32_t last_scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes per scan of the last frame decoded with this header (speculative path) */
     gj_scan_summary* h_summary;   /* pinned */
+    uint32_t* h_maxlen; size_t h_maxlen_cap; /* pinned: per-chunk longest segments of the marker scan */
+    uint32_t maxlen_parts;
     int host_scan;                /* 1: always walk the stream on the host (reference behaviour) */
     gj_tuning tune;               /* developer switches, read from the environment when the decoder is created */
     /* header cache: a stream that starts with the same bytes (SOI .. first SOS header) as the previous one has the same
@@ -124,7 +126,7 @@ int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
     gj_hip_free(d->d_tok); gj_hip_free(d->d_blkrec);
     gj_hip_host_free(d->h_raw); gj_hip_host_free(d->h_seg); gj_hip_host_free(d->h_tabs);
     free(d->hdr_cache); gj_hip_free(d->d_hdr_cache);
-    gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
+    gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_host_free(d->h_maxlen); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
     free(d->segs.pos); free(d->segs.len); free(d->segs.index);
     free(d);
     return 0;
@@ -211,6 +213,16 @@ static int accept_device_scan(const gj_scan_summary* su, struct gj_reader_result
     return -1; /* no EOI */
 }
 
+/* the longest restart segment of the device's table: the maximum of the per-chunk values the marker scan left (valid once the stream has been
+ * waited for) */
+static void summary_take_maxlen(struct gpujpeg_decoder* d)
+{
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < d->maxlen_parts; i++)
+        if (d->h_maxlen[i] > m) m = d->h_maxlen[i];
+    d->h_summary->max_seg_len = m;
+}
+
 /* careful: this call must not use the entropy decoders that take whole restart segments into LDS (a previous attempt on this stream met a
  * segment that does not fit), and it does not launch on the header cache */
 static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t image_size, struct gpujpeg_decoder_output* output, bool careful)
@@ -289,15 +301,23 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
         /* (a speculative launch on a device-resident stream has its header compared with the cached one by the scan's first kernel) */
         const bool cmp = spec && jpeg_on_device;
-        const int frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
-                                             d->d_scan_scratch, sum_cur, sum_next, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, c->stream,
-                                             d->tune.debug_sync);
+        uint32_t* d_parts = NULL;
+        int frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
+                                       d->d_scan_scratch, sum_cur, sum_next, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, &d_parts,
+                                       &d->maxlen_parts, c->stream, &d->tune);
         if (frc == 0) { scanned = true; d->sum_idx ^= 1; } /* (sum_next is clean once this call's kernels have run: it serves the next call) */
-        if (frc != 0 ||
+        if (frc == 0 && (size_t)d->maxlen_parts * sizeof(uint32_t) > d->h_maxlen_cap) {
+            gj_hip_host_free(d->h_maxlen);
+            d->h_maxlen_cap = (size_t)d->maxlen_parts * sizeof(uint32_t) * 2;
+            d->h_maxlen = gj_hip_host_alloc(d->h_maxlen_cap);
+            if (!d->h_maxlen) { d->h_maxlen_cap = 0; frc = -1; }
+        }
+        if (frc != 0 || gj_hip_memcpy_d2h(d->h_maxlen, d_parts, (size_t)d->maxlen_parts * sizeof(uint32_t), c->stream) != 0 ||
             gj_hip_memcpy_d2h(d->h_summary, sum_cur, sizeof(gj_scan_summary), c->stream) != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
             GJ_ERROR("Marker scan failed: %s\n", gj_hip_last_error());
             goto out;
         }
+        if (!spec) summary_take_maxlen(d);
         if (spec) { /* the kernels take the segment count from the device; the summary is checked once everything has run */
             seg_count = g->segment_count;
             d_seg_count = &sum_cur->segment_count;
@@ -525,6 +545,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         return decoder_decode(d, image, image_size, output, true);
     }
     if (spec) { /* now the summary of this stream is on the host: was it what we assumed? */
+        summary_take_maxlen(d);
         struct gj_reader_result chk = r;
         bool ok = d->h_summary->header_differs == 0 && d->h_summary->seq_overflow == 0 && accept_device_scan(d->h_summary, &chk, g) == 0 &&
                   (int)d->h_summary->segment_count == g->segment_count; /* (a stream with missing segments needs the planes cleared first) */

@@ -115,6 +115,7 @@ typedef struct gj_tuning {
     int dec_no_spec;     /* GJ_DEC_NO_SPEC: no speculative launch on a cached header */
     int dec_seq;         /* GJ_DEC_SEQ: 1 = always the lane-per-segment entropy decoder in plane mode, 2 (GJ_DEC_SEQ=0) = never, 0 = by the frame */
     int debug_sync;      /* GJ_DEC_DEBUG_SYNC=1: wait after every decoder stage and name it on stderr */
+    int scan_tb;         /* GJ_SCAN_TB: bytes per lane of the marker scan (8, 16, 32, 64), 0 = by the stream's size (A/B) */
     int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
     int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that
                             does not fit (overflow flag) -- this call uses the kernels without that limit */
@@ -231,7 +232,7 @@ typedef struct gj_scan_summary {
     uint32_t status;                          /* 1 = clean (scans ... EOI), 2 = unexpected marker between scans, 3 = no EOI */
     uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];
     uint32_t header_differs;                  /* gj_hip_compare_header: 1 when the stream does not start with the cached header */
-    uint32_t max_seg_len;                     /* longest segment of the table */
+    uint32_t max_seg_len;                     /* longest segment of the table (filled in by the host from the per-chunk maxima) */
     uint32_t seq_overflow;                    /* set by k_huffman_decode_tok / _seq: a segment did not fit the LDS stage, decode the frame with the other kernel */
     uint32_t rst_irregular;                   /* an RSTn out of sequence, or an empty segment in front of the end of a scan: the reference reader
                                                  resynchronises / drops it (src/gpujpeg_reader.c:1074-1135), so the host walks such a stream */
@@ -240,11 +241,13 @@ typedef struct gj_scan_summary {
 GJ_HIP_API size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments);
 /* d_summary: this call's summary, all zero on entry (a fresh allocation, or the d_summary_next of the previous call: the two alternate,
  * so that no clearing launch is needed); d_summary_next (may be NULL) is cleared for the next call.
- * d_hdr_ref (may be NULL): the cached header of a speculative launch; sets d_summary->header_differs = (d_jpeg[0..hdr_n) != d_hdr_ref[0..hdr_n)) */
+ * d_hdr_ref (may be NULL): the cached header of a speculative launch; sets d_summary->header_differs = (d_jpeg[0..hdr_n) != d_hdr_ref[0..hdr_n))
+ * d_maxlen_parts / maxlen_part_count: the longest segment of the table is the maximum over that many device words (one per chunk of the
+ * scan; the host reads them back with the summary: d_summary->max_seg_len is not written by the device) */
 GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
                                     gj_scan_summary* d_summary, gj_scan_summary* d_summary_next, const uint8_t* d_hdr_ref, uint32_t hdr_n,
-                                    gj_stream_t stream, int debug_sync);
+                                    uint32_t** d_maxlen_parts, uint32_t* maxlen_part_count, gj_stream_t stream, const gj_tuning* tune);
 
 #ifdef __cplusplus
 }

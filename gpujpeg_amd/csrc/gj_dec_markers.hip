@@ -1,6 +1,7 @@
 // gj_dec_markers.hip -- MI355X (gfx950, wave64) JPEG decoder: device-side segment discovery (marker scan)
 // (part of the decoder's device code, see gj_dec_internal.h for the map of the files)
 #include "gj_dec_internal.h"
+#include <stddef.h>
 
 // ================================================================================================
 // Device-side segment discovery. Inside entropy-coded data 0xFF is followed by 0x00 (stuffing),
@@ -114,22 +115,19 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
 // of the scan's last segment).
 template <int TB>
 __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size,
-                                                         const uint32_t chunks, const uint2* __restrict__ chunk_info, uint32_t* __restrict__ chunk_maxlen,
-                                                         gj_scan_summary* __restrict__ sum,
+                                                         const uint32_t chunks, const uint2* __restrict__ chunk_info, uint32_t* __restrict__ chunk_maxlen /* host memory */,
+                                                         gj_scan_summary* __restrict__ sum, gj_scan_summary* __restrict__ hsum /* host memory: what the host reads */,
                                                          gj_scan_summary* __restrict__ sum_next, uint32_t* __restrict__ seg_pos,
                                                          uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, const uint32_t max_segments)
 {
     __shared__ uint32_t s_start[GJ_MAX_COMP + 1], s_end[GJ_MAX_COMP + 1], s_first[GJ_MAX_COMP + 2];
     __shared__ uint32_t s_sos_chunk[GJ_MAX_COMP], s_sos_after[GJ_MAX_COMP]; // scan sc > 0: chunk of its SOS, restart markers of that chunk behind the SOS
     __shared__ int s_scans, s_status;
-    __shared__ gj_scan_summary s_sum; // (read once, together: the few other markers are sorted by one lane)
-    __shared__ uint32_t s_opos[GJ_SCAN_MAX_OTHER];
-    __shared__ uint8_t s_order[GJ_SCAN_MAX_OTHER];
     __shared__ uint32_t s_acc[GJ_MAX_COMP + 2]; // restart markers in the chunks up to: this chunk (excl.), the chunk of every later scan's SOS (incl.); all
     __shared__ int s_prev_chunk;
     __shared__ uint32_t s_tmp[4], s_maxlen;
     __shared__ uint32_t s_mpos[GJ_SCAN_LIST]; // position | code & 7 << 29 would not fit 32-bit positions: offset inside the chunk | code & 7 << 16
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr uint32_t chunk_bytes = 256u * TB;
     // everything this workgroup reads from memory is asked for at once: the summary, the counts of all chunks (registers: up to 8 per
     // lane; more chunks are read again below), the last marker of the chunk in front, and the bytes of its own chunk
@@ -141,53 +139,55 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         cnt_reg[q] = c < chunks ? chunk_info[c].x : 0u;
     }
     const uint32_t prev1_last = blockIdx.x > 0 ? chunk_info[blockIdx.x - 1].y : 0u;
-    for (uint32_t i = (uint32_t)tid; i < sizeof(gj_scan_summary) / 4; i += 256) reinterpret_cast<uint32_t*>(&s_sum)[i] = reinterpret_cast<const uint32_t*>(sum)[i];
+    // the few other markers: lane i of the first wave takes marker i
+    const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
+    uint32_t o_pos = 0xFFFFFFFFu, o_code = 0, o_len = 0, o_after = 0;
+    if (wave == 0 && (uint32_t)lane < n_other) {
+        o_pos = sum->other_pos[lane];
+        o_code = sum->other_code[lane];
+        o_len = ((uint32_t)sum->other_bytes[lane][0] << 8) | sum->other_bytes[lane][1];
+        o_after = sum->other_after[lane];
+    }
     const uint64_t c0 = begin + (uint64_t)blockIdx.x * chunk_bytes;
     const uint64_t b0 = c0 + (uint64_t)tid * TB;
     uint64_t rst, other, nums;
     gj_scan_bytes<TB>(jpeg, size, b0, rst, other, &nums);
-    __syncthreads();
-    const uint32_t n_other = min(s_sum.other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
-    if (tid == 0) {
-        // order the few other markers by position (insertion sort)
-        for (uint32_t i = 0; i < n_other; i++) {
-            uint32_t j = i;
-            const uint32_t p = s_sum.other_pos[i];
-            while (j > 0 && s_opos[j - 1] > p) { s_opos[j] = s_opos[j - 1]; s_order[j] = s_order[j - 1]; j--; }
-            s_opos[j] = p;
-            s_order[j] = (uint8_t)i;
+    if (wave == 0) {
+        // their order by position (rank = markers in front), then a walk through them in that order with everything in scalar registers
+        // (this was one lane going through arrays in memory: 10 us of dependent loads per workgroup)
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n_other; j++) {
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)o_pos, (int)j);
+            rank += (pj < o_pos || (pj == o_pos && j < (uint32_t)lane)) ? 1u : 0u;
         }
-        int scans = 0;
-        uint32_t start = (uint32_t)begin;
-        int status = 0;
-        uint32_t sos_chunk = 0, sos_after = 0;
-        for (uint32_t i = 0; i < n_other && scans < GJ_MAX_COMP; i++) {
-            const uint32_t p = s_opos[i];
+        int scans = 0, status = 0;
+        uint32_t start = (uint32_t)begin, sos_chunk = 0, sos_after = 0;
+        for (uint32_t k = 0; k < n_other && scans < GJ_MAX_COMP; k++) {
+            const unsigned long long who = __ballot((uint32_t)lane < n_other && rank == k);
+            const int l = who ? __builtin_ctzll(who) : 0;
+            const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)o_pos, l), m = (uint32_t)__builtin_amdgcn_readlane((int)o_code, l);
+            const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)o_len, l), after = (uint32_t)__builtin_amdgcn_readlane((int)o_after, l);
             if (p < start) continue; // lies inside a header we already skipped
-            s_start[scans] = start;
-            s_end[scans] = p;
-            s_sos_chunk[scans] = sos_chunk;
-            s_sos_after[scans] = sos_after;
+            if (lane == 0) { s_start[scans] = start; s_end[scans] = p; s_sos_chunk[scans] = sos_chunk; s_sos_after[scans] = sos_after; }
             scans++;
-            const uint8_t* hb = s_sum.other_bytes[s_order[i]];
-            const uint32_t mlen = ((uint32_t)hb[0] << 8) | hb[1];
-            const int m = s_sum.other_code[s_order[i]];
             if (m == 0xDA) { // next scan
                 start = p + 2 + mlen;
                 sos_chunk = (uint32_t)((p - begin) / chunk_bytes);
-                sos_after = s_sum.other_after[s_order[i]];
-                if (sos_after == 0xFFFFFFFFu) { status = 2; break; }
+                sos_after = after;
+                if (after == 0xFFFFFFFFu) { status = 2; break; }
                 continue;
             }
-            if (m == 0xD9) { status = 1; break; }              // EOI: done
-            status = 2;                                          // something else between scans: let the host walk it
+            if (m == 0xD9) { status = 1; break; } // EOI: done
+            status = 2;                            // something else between scans: let the host walk it
             break;
         }
         if (status == 0) status = 3; // no EOI seen
-        s_scans = scans;
-        s_status = status;
-        s_prev_chunk = -1;
-        s_maxlen = 0;
+        if (lane == 0) {
+            s_scans = scans;
+            s_status = status;
+            s_prev_chunk = -1;
+            s_maxlen = 0;
+        }
     }
     if (tid < GJ_MAX_COMP + 2) s_acc[tid] = 0;
     __syncthreads();
@@ -296,13 +296,24 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     irregular = (uint32_t)__syncthreads_or((int)irregular);
     if (tid == 0) {
         chunk_maxlen[blockIdx.x] = s_maxlen; // (the host takes the maximum: a thousand workgroups raising one word one after the other took 10 us)
-        if (irregular) sum->rst_irregular = 1u;
-        if (blockIdx.x == 0) {
-            sum->rst_count = total;
-            sum->scan_count = (uint32_t)scans;
-            sum->status = (uint32_t)s_status;
-            sum->segment_count = scans ? total + (uint32_t)scans : 0u;
-            for (int sc = 0; sc < scans; sc++) { sum->scan_start[sc] = s_start[sc]; sum->scan_end[sc] = s_end[sc]; }
+        if (irregular) hsum->rst_irregular = 1u; // (the host cleared it before the launch)
+    }
+    if (blockIdx.x == 0) {
+        // what the host validates goes straight to its (pinned, device-visible) copy -- no copy launch behind the kernels: the other markers
+        // as the scan kernel left them, then the scan structure. The words other workgroups and later kernels raise (rst_irregular,
+        // seq_overflow) and the one the host fills in (max_seg_len) are left alone.
+        const uint32_t w_skip0 = (uint32_t)(offsetof(gj_scan_summary, max_seg_len) / 4), w_skip1 = (uint32_t)(offsetof(gj_scan_summary, seq_overflow) / 4),
+                       w_skip2 = (uint32_t)(offsetof(gj_scan_summary, rst_irregular) / 4);
+        for (uint32_t i = (uint32_t)tid; i < sizeof(gj_scan_summary) / 4; i += 256)
+            if (i != w_skip0 && i != w_skip1 && i != w_skip2) reinterpret_cast<uint32_t*>(hsum)[i] = reinterpret_cast<const uint32_t*>(sum)[i];
+        __syncthreads();
+        if (tid == 0) {
+            sum->segment_count = scans ? total + (uint32_t)scans : 0u; // (speculative launches: the entropy decoder reads the count from here)
+            hsum->rst_count = total;
+            hsum->scan_count = (uint32_t)scans;
+            hsum->status = (uint32_t)s_status;
+            hsum->segment_count = scans ? total + (uint32_t)scans : 0u;
+            for (int sc = 0; sc < scans; sc++) { hsum->scan_start[sc] = s_start[sc]; hsum->scan_end[sc] = s_end[sc]; }
         }
     }
     // the summary of the next call (the two alternate): its counters start at zero
@@ -322,7 +333,8 @@ static uint32_t gj_scan_lane_bytes(uint64_t begin, uint64_t size)
 extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
                                     gj_scan_summary* d_summary, gj_scan_summary* d_summary_next, const uint8_t* d_hdr_ref, uint32_t hdr_n,
-                                    uint32_t** d_maxlen_parts, uint32_t* maxlen_part_count, gj_stream_t stream, const gj_tuning* tune)
+                                    gj_scan_summary* h_summary, uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count,
+                                    gj_stream_t stream, const gj_tuning* tune)
 {
     const int debug_sync = tune->debug_sync;
     hipStream_t st = (hipStream_t)stream;
@@ -330,14 +342,13 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     const uint32_t tb = (tune->scan_tb == 8 || tune->scan_tb == 16 || tune->scan_tb == 32 || tune->scan_tb == 64) ? (uint32_t)tune->scan_tb : gj_scan_lane_bytes(begin, size);
     const uint32_t chunks = (uint32_t)((size - begin + 256ull * tb - 1) / (256ull * tb));
     uint2* d_chunk = reinterpret_cast<uint2*>(d_scratch); // [chunks] restart markers, position of the last one
-    uint32_t* d_maxlen = d_scratch + 2 * (size_t)chunks;  // [chunks] longest segment a chunk's markers end
-    *d_maxlen_parts = d_maxlen;
+    if (chunks > maxlen_capacity) return -1;
     *maxlen_part_count = chunks;
     auto scan = tb == 8 ? k_marker_scan<8> : tb == 16 ? k_marker_scan<16> : tb == 32 ? k_marker_scan<32> : k_marker_scan<64>;
     auto segs = tb == 8 ? k_marker_segments<8> : tb == 16 ? k_marker_segments<16> : tb == 32 ? k_marker_segments<32> : k_marker_segments<64>;
     hipLaunchKernelGGL(scan, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary, d_hdr_ref, hdr_n);
     gj_debug_stage(debug_sync != 0, st, "k_marker_scan");
-    hipLaunchKernelGGL(segs, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, chunks, d_chunk, d_maxlen, d_summary, d_summary_next,
+    hipLaunchKernelGGL(segs, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, chunks, d_chunk, h_maxlen_parts, d_summary, h_summary, d_summary_next,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
     gj_debug_stage(debug_sync != 0, st, "k_marker_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -346,5 +357,7 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
 extern "C" size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments)
 {
     (void)max_segments;
-    return 3 * (size_t)((size - begin + 2047) / 2048) + 16; /* (lanes take at least 8 bytes) */
+    return 2 * (size_t)((size - begin + 2047) / 2048) + 16; /* (lanes take at least 8 bytes) */
 }
+
+extern "C" size_t gj_hip_find_segments_max_chunks(uint64_t begin, uint64_t size) { return (size_t)((size - begin + 2047) / 2048) + 1; }

@@ -293,7 +293,6 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     int seg_count = 0;
     const uint32_t* d_seg_count = NULL;
     gj_scan_summary *sum_cur = d->d_summary + d->sum_idx, *sum_next = d->d_summary + (d->sum_idx ^ 1);
-    bool scanned = false;
     const size_t S = (size_t)g->segment_count + GJ_MAX_COMP;
     if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 4 + 8) * sizeof(uint32_t)) != 0) goto out;
     if (device_scan) {
@@ -301,19 +300,23 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
         /* (a speculative launch on a device-resident stream has its header compared with the cached one by the scan's first kernel) */
         const bool cmp = spec && jpeg_on_device;
-        uint32_t* d_parts = NULL;
-        int frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
-                                       d->d_scan_scratch, sum_cur, sum_next, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, &d_parts,
-                                       &d->maxlen_parts, c->stream, &d->tune);
-        if (frc == 0) { scanned = true; d->sum_idx ^= 1; } /* (sum_next is clean once this call's kernels have run: it serves the next call) */
-        if (frc == 0 && (size_t)d->maxlen_parts * sizeof(uint32_t) > d->h_maxlen_cap) {
+        /* the kernels write what the host validates straight into pinned host memory */
+        const size_t max_chunks = gj_hip_find_segments_max_chunks(r.scan_begin[0], image_size);
+        int frc = 0;
+        if (max_chunks * sizeof(uint32_t) > d->h_maxlen_cap) {
             gj_hip_host_free(d->h_maxlen);
-            d->h_maxlen_cap = (size_t)d->maxlen_parts * sizeof(uint32_t) * 2;
+            d->h_maxlen_cap = max_chunks * sizeof(uint32_t) * 2;
             d->h_maxlen = gj_hip_host_alloc(d->h_maxlen_cap);
             if (!d->h_maxlen) { d->h_maxlen_cap = 0; frc = -1; }
         }
-        if (frc != 0 || gj_hip_memcpy_d2h(d->h_maxlen, d_parts, (size_t)d->maxlen_parts * sizeof(uint32_t), c->stream) != 0 ||
-            gj_hip_memcpy_d2h(d->h_summary, sum_cur, sizeof(gj_scan_summary), c->stream) != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
+        d->h_summary->rst_irregular = 0;
+        d->h_summary->seq_overflow = 0;
+        if (frc == 0)
+            frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
+                                       d->d_scan_scratch, sum_cur, sum_next, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, d->h_summary,
+                                       d->h_maxlen, (uint32_t)(d->h_maxlen_cap / sizeof(uint32_t)), &d->maxlen_parts, c->stream, &d->tune);
+        if (frc == 0) d->sum_idx ^= 1; /* (sum_next is clean once this call's kernels have run: it serves the next call) */
+        if (frc != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
             GJ_ERROR("Marker scan failed: %s\n", gj_hip_last_error());
             goto out;
         }
@@ -481,10 +484,9 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     job.tune = d->tune;
     job.tune.dec_careful = careful;
     /* bytes per scan: what the entropy decoder's batch sizes are cut to (luminance segments are 2-3 x the chrominance ones) */
-    /* the word the entropy decoders raise: in this call's summary when the marker scan ran (clean, and cleared again before it is reused); a
-     * call without a scan borrows the other summary's, which the next scan clears before anybody looks at it */
-    job.d_overflow = scanned ? &sum_cur->seq_overflow : &sum_next->seq_overflow;
-    if (!device_scan) gj_hip_memset(job.d_overflow, 0, sizeof(uint32_t), c->stream);
+    /* the word the entropy decoders raise when they meet a segment they cannot stage: in the host's (pinned, device-visible) summary */
+    d->h_summary->seq_overflow = 0;
+    job.d_overflow = &d->h_summary->seq_overflow;
     if (spec) {
         memcpy(job.scan_bytes, d->last_scan_bytes, sizeof job.scan_bytes);
         job.max_seg_len = d->last_max_seg_len;
@@ -507,7 +509,6 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         goto out;
     }
     /* (the lane-per-segment entropy decoder may have met a segment it cannot stage: known once everything has run) */
-    if (gj_hip_memcpy_d2h(&d->h_summary->seq_overflow, job.d_overflow, sizeof(uint32_t), c->stream) != 0) goto out;
 
     output->data_size = g->raw_size;
     output->param_image = c->param_image;

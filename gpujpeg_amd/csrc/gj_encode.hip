@@ -1341,6 +1341,10 @@ __global__ __launch_bounds__(1024) void k_scan_segments(const gj_enc_job J, unsi
         J.d_seg_out[S] = end;
         J.d_result[0] = size;
         J.d_result[1] = (uint64_t)size > J.jpeg_capacity ? 1u : 0u;
+        if (J.h_result) { // the host's (pinned, device-visible) copy: no copy launch behind the kernels
+            J.h_result[0] = size;
+            J.h_result[1] = (uint64_t)size > J.jpeg_capacity ? 1u : 0u;
+        }
     }
 }
 

@@ -37,6 +37,7 @@ struct gpujpeg_encoder {
     /* host side */
     uint32_t* h_result; /* pinned */
     uint8_t* h_header;  /* pinned staging for the main header */
+    uint8_t* hdr_sent; size_t hdr_sent_len; const uint8_t* hdr_sent_to; /* the header bytes that are at the start of d_jpeg already */
     struct gj_exif_tags* exif_tags; /* enc_exif_tag */
     uint8_t* out_buf; size_t out_cap; bool out_buf_pinned;
     int use_fused;
@@ -93,7 +94,7 @@ int gpujpeg_encoder_destroy(struct gpujpeg_encoder* e)
     gj_hip_free(e->d_fwd_q[0]); gj_hip_free(e->d_fwd_q[1]); gj_hip_free(e->d_huff_lut); gj_hip_free(e->d_result);
     gj_hip_free(e->d_temp); gj_hip_free(e->d_scan_partial); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
     gj_hip_free(e->coder.d_raw_own); gj_hip_free(e->coder.d_planes); gj_hip_free(e->coder.d_coefs);
-    gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header);
+    gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header); free(e->hdr_sent);
     gj_exif_tags_destroy(e->exif_tags);
     if (e->out_buf_pinned) gj_hip_host_free(e->out_buf); else free(e->out_buf);
     free(e->scan_hdrs.bytes);
@@ -173,6 +174,7 @@ static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_par
     /* same sizing rule as the reference writer (writer.c:66-69) plus the scan headers */
     const size_t jpeg_cap = 1000 + e->scan_hdrs.size + (size_t)pi->width * pi->height * p->comp_count * 2 + 4096;
     if (gj_ensure_device_buffer((void**)&e->d_jpeg, &e->d_jpeg_cap, jpeg_cap) != 0) return -1;
+    e->hdr_sent_to = NULL; /* (the buffer may be a new one: the main header has to be uploaded again) */
     c->configured = true;
     return 0;
 }
@@ -238,7 +240,16 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
 
     /* main header: host bytes, placed at the start of the device stream */
     const size_t hdr = gj_write_main_header(e->h_header, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata, e->exif_tags);
-    if (gj_hip_memcpy_h2d(e->d_jpeg, e->h_header, hdr, c->stream) != 0) return -1;
+    /* (the kernels write behind it, so it is uploaded again only when it changes -- parameters, or the wall clock of an Exif header -- or
+     * the stream buffer was reallocated) */
+    if (!e->hdr_sent) e->hdr_sent = malloc(4096);
+    if (!e->hdr_sent || hdr > 4096) return -1;
+    if (e->hdr_sent_to != e->d_jpeg || e->hdr_sent_len != hdr || memcmp(e->hdr_sent, e->h_header, hdr) != 0) {
+        if (gj_hip_memcpy_h2d(e->d_jpeg, e->h_header, hdr, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) return -1; /* (h_header is rewritten by the next call) */
+        memcpy(e->hdr_sent, e->h_header, hdr);
+        e->hdr_sent_len = hdr;
+        e->hdr_sent_to = e->d_jpeg;
+    }
 
     gj_enc_job job;
     memset(&job, 0, sizeof job);
@@ -269,6 +280,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.d_jpeg = e->d_jpeg;
     job.jpeg_capacity = e->d_jpeg_cap;
     job.d_result = e->d_result;
+    job.h_result = e->h_result;
     job.d_scan_partial = e->d_scan_partial;
     if (++e->epoch == 0) e->epoch = 1;
     job.epoch = e->epoch;
@@ -285,7 +297,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
         return -1;
     }
     /* size first, then the bytes (:550-563) */
-    if (gj_hip_memcpy_d2h(e->h_result, e->d_result, 2 * sizeof(uint32_t), c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) {
+    if (gj_hip_stream_sync(c->stream) != 0) { /* (the two result words are in host memory once the kernels have run) */
         GJ_ERROR("Encoder failed: %s\n", gj_hip_last_error());
         return -1;
     }

@@ -136,6 +136,7 @@ typedef struct gj_enc_job {
     uint8_t* d_jpeg;               /* finished stream */
     uint64_t jpeg_capacity;
     uint32_t* d_result;            /* [0] total JPEG size, [1] overflow flag */
+    uint32_t* h_result;            /* optional: the same two words in pinned host memory, written by the kernel that computes them */
     uint64_t* d_scan_partial;      /* [ceil(segment_count / 1024)] epoch-tagged workgroup totals of the offset scan; zero at allocation */
     uint32_t epoch;                /* differs from the previous call's (and is never 0) */
     gj_tuning tune;
@@ -242,12 +243,16 @@ GJ_HIP_API size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t si
 /* d_summary: this call's summary, all zero on entry (a fresh allocation, or the d_summary_next of the previous call: the two alternate,
  * so that no clearing launch is needed); d_summary_next (may be NULL) is cleared for the next call.
  * d_hdr_ref (may be NULL): the cached header of a speculative launch; sets d_summary->header_differs = (d_jpeg[0..hdr_n) != d_hdr_ref[0..hdr_n))
- * d_maxlen_parts / maxlen_part_count: the longest segment of the table is the maximum over that many device words (one per chunk of the
- * scan; the host reads them back with the summary: d_summary->max_seg_len is not written by the device) */
+ * h_summary, h_maxlen_parts: PINNED HOST memory the kernels write directly (no copy launches behind them): the summary the host validates
+ * once the stream has been waited for (the host clears rst_irregular and seq_overflow in it before the launch; max_seg_len is not written
+ * by the device: the longest segment of the table is the maximum over *maxlen_part_count words of h_maxlen_parts, one per chunk) */
 GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
                                     gj_scan_summary* d_summary, gj_scan_summary* d_summary_next, const uint8_t* d_hdr_ref, uint32_t hdr_n,
-                                    uint32_t** d_maxlen_parts, uint32_t* maxlen_part_count, gj_stream_t stream, const gj_tuning* tune);
+                                    gj_scan_summary* h_summary, uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count,
+                                    gj_stream_t stream, const gj_tuning* tune);
+/* chunks the marker scan cuts [begin, size) into at most (capacity of h_maxlen_parts) */
+GJ_HIP_API size_t gj_hip_find_segments_max_chunks(uint64_t begin, uint64_t size);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE ONLY -- not part of the product, never linked into libgpujpeg.so.
  *
- * hipemu: a CPU execution model for the product's own gfx950 HIP kernels (gpujpeg_amd/csrc/*.hip), so that the CPU test
+ * hipemu: a CPU execution model for the product's own gfx950 HIP kernels (the .hip files of gpujpeg_amd/csrc), so that the CPU test
  * tier can run the real kernel code -- wave64 cross-lane operations, LDS, workgroup barriers, atomics -- against the oracle
  * without a GPU (tests/test_emu_parity.py), and so that a kernel can be debugged with host tools (gdb, ASan on LDS arrays).
  * The .hip files are compiled unmodified by clang++ for x86-64 with this directory in front of the include path and

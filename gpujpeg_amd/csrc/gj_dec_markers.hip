@@ -15,6 +15,13 @@
 //                      validates (gj_scan_summary); clears the summary of the NEXT call (two summaries alternate, no memset launch)
 // A lane owns `tb` consecutive bytes (8 .. 64, chosen by the host from the stream's size), a workgroup 256 x tb.
 // ================================================================================================
+#ifdef GJ_TRACE_PHASES
+static __device__ unsigned long long* gj_trace_buf_m;
+extern "C" GJ_HIP_API int gj_hip_trace_set_markers(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(gj_trace_buf_m), &p, sizeof p) == hipSuccess ? 0 : -1; }
+#define GJ_TRACE_M(slot) do { if (threadIdx.x == 0 && gj_trace_buf_m) gj_trace_buf_m[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GJ_TRACE_M(slot) ((void)0)
+#endif
 #define GJ_SCAN_LIST 2048   // restart markers a chunk may hold (a segment of 8 bytes on average at the largest chunk: beyond that the host walks)
 
 // bit i of the results: byte i of the lane's TB bytes at absolute offset b0 starts a restart marker / another marker; `num`: the low three
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     __shared__ uint32_t s_start[GJ_MAX_COMP + 1], s_end[GJ_MAX_COMP + 1], s_first[GJ_MAX_COMP + 2];
     __shared__ uint32_t s_sos_chunk[GJ_MAX_COMP], s_sos_after[GJ_MAX_COMP]; // scan sc > 0: chunk of its SOS, restart markers of that chunk behind the SOS
     __shared__ int s_scans, s_status;
+    __shared__ uint32_t s_geo_first[GJ_MAX_COMP], s_geo_limit[GJ_MAX_COMP]; // per scan: geometric index of its first segment, segments it may have
     __shared__ uint32_t s_acc[GJ_MAX_COMP + 2]; // restart markers in the chunks up to: this chunk (excl.), the chunk of every later scan's SOS (incl.); all
     __shared__ int s_prev_chunk;
     __shared__ uint32_t s_tmp[4], s_maxlen;
@@ -139,6 +147,12 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         cnt_reg[q] = c < chunks ? chunk_info[c].x : 0u;
     }
     const uint32_t prev1_last = blockIdx.x > 0 ? chunk_info[blockIdx.x - 1].y : 0u;
+    GJ_TRACE_M(0);
+    if (tid < GJ_MAX_COMP) { // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
+        const int c = tid < g.comp_count ? tid : 0;
+        s_geo_first[tid] = g.interleaved ? 0u : (uint32_t)g.comp[c].first_segment;
+        s_geo_limit[tid] = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[c].segment_count;
+    }
     // the few other markers: lane i of the first wave takes marker i
     const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
     uint32_t o_pos = 0xFFFFFFFFu, o_code = 0, o_len = 0, o_after = 0;
@@ -190,7 +204,9 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         }
     }
     if (tid < GJ_MAX_COMP + 2) s_acc[tid] = 0;
+    GJ_TRACE_M(1);
     __syncthreads();
+    GJ_TRACE_M(2);
     const int scans = s_scans;
     // ---- restart markers in front of this chunk, up to the chunk of every later scan's SOS, and all of them; the last chunk in front
     //      of this one that has a marker
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         if (prev >= 0) atomicMax(&s_prev_chunk, prev);
     }
     __syncthreads();
+    GJ_TRACE_M(3);
     // rank of the first restart marker of every scan: the markers up to its SOS's chunk minus those of that chunk behind the SOS (the SOS
     // header itself holds none); everything lies below the sentinel
     if (tid <= scans) s_first[tid] = tid == 0 ? 0u : (tid == scans ? s_acc[GJ_MAX_COMP + 1] : s_acc[tid] - s_sos_after[tid]);
@@ -237,6 +254,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         s_mpos[r++] = o | ((uint32_t)(nums & 7u) << 16);
     }
     __syncthreads();
+    GJ_TRACE_M(4);
     uint32_t irregular = too_many ? 1u : 0u, maxlen = 0;
     const uint32_t rank0 = s_acc[0];
     // the last marker in front of this chunk (if any): normally in the chunk right in front
@@ -253,9 +271,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         if (rk < s_first[sc] || k >= c_s) { irregular = 1u; continue; }
         const uint32_t before = i > 0 ? (uint32_t)c0 + (s_mpos[i - 1] & 0xFFFFu) : prev_last; // the marker in front of this one
         const uint32_t from = (k == 0) ? s_start[sc] : before + 2;
-        // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
-        const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
-        const uint32_t limit = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].segment_count;
+        const uint32_t first = s_geo_first[sc], limit = s_geo_limit[sc];
         const uint32_t e = s_first[sc] + (uint32_t)sc + k;
         // the marker that ends segment k must be RST(k mod 8), and the last segment of a scan must not be empty: anything else is a
         // stream the reference reader treats specially, which the host walk reproduces
@@ -281,8 +297,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         const int sc = tid;
         if (s_first[sc + 1] == s_first[sc]) {
             const uint32_t e = s_first[sc] + (uint32_t)sc;
-            const uint32_t first = g.interleaved ? 0u : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].first_segment;
-            const uint32_t limit = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[sc < g.comp_count ? sc : 0].segment_count;
+            const uint32_t first = s_geo_first[sc], limit = s_geo_limit[sc];
             if (e < max_segments) {
                 const uint32_t len = s_end[sc] > s_start[sc] ? s_end[sc] - s_start[sc] : 0;
                 seg_pos[e] = s_start[sc];
@@ -294,6 +309,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     }
     if (maxlen) atomicMax(&s_maxlen, maxlen);
     irregular = (uint32_t)__syncthreads_or((int)irregular);
+    GJ_TRACE_M(5);
     if (tid == 0) {
         chunk_maxlen[blockIdx.x] = s_maxlen; // (the host takes the maximum: a thousand workgroups raising one word one after the other took 10 us)
         if (irregular) hsum->rst_irregular = 1u; // (the host cleared it before the launch)
@@ -316,6 +332,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
             for (int sc = 0; sc < scans; sc++) { hsum->scan_start[sc] = s_start[sc]; hsum->scan_end[sc] = s_end[sc]; }
         }
     }
+    GJ_TRACE_M(6);
     // the summary of the next call (the two alternate): its counters start at zero
     if (blockIdx.x == 0 && sum_next != nullptr)
         for (uint32_t i = (uint32_t)tid; i < sizeof(gj_scan_summary) / 4; i += 256) reinterpret_cast<uint32_t*>(sum_next)[i] = 0;

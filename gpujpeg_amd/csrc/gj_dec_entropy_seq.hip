@@ -20,13 +20,19 @@
 #define GJ_SEQ_STAGE 26112 // bytes of unstuffed stream per group (incl. 8 B of zero padding per segment)
 #define GJ_SEQ_NS 128      // segments per workgroup
 
-template <bool INTERLEAVED>
+// TOK (token mode): instead of scattering the coefficients into the (zero-filled) planes, a lane appends the non-zero AC
+// coefficients of its segment as 16-bit tokens (value << 6 | natural position) to the segment's own run of the token array -- it starts at
+// token 4 x the segment's byte offset: a token takes at least 3 bits of the stream, so runs cannot overlap -- four tokens per 8-byte store,
+// and writes one record per block in coding order (first token, count, DC term). A coefficient beyond a token's 10 value bits raises
+// `overflow` (the host decodes the frame again through the planes).
+template <bool INTERLEAVED, bool TOK>
 __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                                const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                                const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                                const uint32_t* __restrict__ seg_count_ptr, const int NS,
                                                                const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs, const int zero_fill,
-                                                               uint32_t* __restrict__ overflow)
+                                                               uint32_t* __restrict__ overflow, uint16_t* __restrict__ d_tok, const uint32_t tok_cap,
+                                                               uint2* __restrict__ d_rec)
 {
     __shared__ uint32_t s_U[GJ_SEQ_STAGE / 4 + 4];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
             for (int q = 0; q < 8; q++) {
                 const int j = jb + 4 * q;
                 if (j >= j1) break;
-                if (zero_fill && s_idx[j] != 0xFFFFFFFFu) {
+                if (!TOK && zero_fill && s_idx[j] != 0xFFFFFFFFu) {
                     const GjSeg sg = gj_segment(g, (int)s_idx[j]);
                     for (int c = lane; c < sg.nblocks * 8; c += 64) {
                         uint64_t off;
@@ -166,12 +172,19 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
             }
             int dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
             int z = 0;
+            // token mode: the segment's run of tokens, the 4-token buffer, the block in progress (record index in coding order, its first token, its DC term)
+            const uint32_t tbase = 4u * s_pos[j];
+            const bool tok_ok = !TOK || (tbase <= tok_cap && 4u * s_len[j] + 8u <= tok_cap - tbase); // (always, with the capacity the host allocates)
+            uint32_t ntok = 0, blk_first = 0, blk_dc = 0, big = 0;
+            uint64_t tbuf = 0;
+            uint32_t rec = INTERLEAVED ? (uint32_t)sg.mcu_first * (uint32_t)P : (uint32_t)sg.first_block;
             uint32_t bitpos = 0, rd = 1, nxt = U[1];
             uint64_t acc = (uint64_t)U[0] << 32;
             int n = 32;
             while (left > 0) {
                 int v = 0, adv = 64; // (data exhausted: the block ends here, its remaining coefficients stay zero)
                 bool coef = false;
+                uint32_t e_sz = 0;
                 if (bitpos < end_bit) {
                     if (n <= 32) {
                         acc |= (uint64_t)nxt << (32 - n);
@@ -189,6 +202,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
                     const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
                     v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
                     coef = sz != 0;
+                    e_sz = (uint32_t)sz;
                     acc <<= tot;
                     n -= tot;
                     bitpos = tot ? bitpos + (uint32_t)tot : end_bit;
@@ -198,15 +212,29 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
                     if (INTERLEAVED) pred = comp == 0 ? dc0 : comp == 1 ? dc1 : comp == 2 ? dc2 : dc3;
                     v += pred;
                     if (!INTERLEAVED || comp == 0) dc0 = v; else if (comp == 1) dc1 = v; else if (comp == 2) dc2 = v; else dc3 = v;
-                    coefs[off] = (int16_t)v;
+                    if (TOK) blk_dc = (uint32_t)v;
+                    else coefs[off] = (int16_t)v;
                 } else if (coef) {
                     const int pos = z + adv - 1;
-                    if (pos < 64) coefs[off + s_zz[pos]] = (int16_t)v;
+                    if (TOK) {
+                        big |= (e_sz >= 10u) ? 1u : 0u;
+                        tbuf = (tbuf >> 16) | ((uint64_t)(uint16_t)(((uint32_t)v << 6) | s_zz[pos]) << 48);
+                        ntok++;
+                        if ((ntok & 3u) == 0 && tok_ok) *reinterpret_cast<uint2*>(d_tok + tbase + ntok - 4u) = make_uint2((uint32_t)tbuf, (uint32_t)(tbuf >> 32));
+                    } else if (pos < 64) {
+                        coefs[off + s_zz[pos]] = (int16_t)v;
+                    }
                 }
                 z += adv;
                 if (z >= 64) { // next block of this segment
                     z = 0;
                     left--;
+                    if (TOK) { // the block's record: where its tokens are, how many, the DC term
+                        d_rec[rec] = make_uint2(tok_ok ? tbase + blk_first : 0u, ((tok_ok ? min(ntok - blk_first, 63u) : 0u) << 16) | (blk_dc & 0xFFFFu));
+                        rec++;
+                        blk_first = ntok;
+                        blk_dc = 0;
+                    }
                     if (!INTERLEAVED) {
                         off += 64;
                     } else {
@@ -218,6 +246,11 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
                     }
                 }
             }
+            if (TOK) {
+                if (tok_ok) // the last one to three tokens
+                    for (uint32_t r = ntok & 3u, i = 0; i < r; i++) d_tok[tbase + (ntok & ~3u) + i] = (uint16_t)(tbuf >> (16u * (4u - r + i)));
+                if (big) *overflow = 1u; // a value beyond a token's 10 bits: the host decodes the frame again through the planes
+            }
         }
         __syncthreads();
         j0 = j1;
@@ -225,12 +258,14 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
 }
 
 
-void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st)
+void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st, const bool tokens)
 {
     const gj_geom& g = job->g;
     const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
     const int NS = max(1, min(GJ_SEQ_NS, (int)((GJ_SEQ_STAGE * 7u / 8u) / avg)));
-    auto kernel = g.interleaved ? k_huffman_decode_seq<true> : k_huffman_decode_seq<false>;
+    auto kernel = tokens ? (g.interleaved ? k_huffman_decode_seq<true, true> : k_huffman_decode_seq<false, true>)
+                         : (g.interleaved ? k_huffman_decode_seq<true, false> : k_huffman_decode_seq<false, false>);
     hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + NS - 1) / NS), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                       job->d_seg_index, job->seg_count, job->d_seg_count, NS, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, job->d_overflow);
+                       job->d_seg_index, job->seg_count, job->d_seg_count, NS, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, job->d_overflow,
+                       (uint16_t*)job->d_tok, job->tok_cap, (uint2*)job->d_blkrec);
 }

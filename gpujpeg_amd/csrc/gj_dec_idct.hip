@@ -342,6 +342,96 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
 }
 
 // ================================================================================================
+// Token-fed IDCT for interleaved 4:2:2 scans with packed UYVY output and no colour transform (BASELINE config 4): one lane
+// per BLOCK in coding order (Y0 Y1 Cb Cr of MCU 0, of MCU 1, ...), so a workgroup's 256 records and its tokens are dense
+// ranges. After the transform the four lanes of an MCU exchange their rows with quad-permute DPP moves and every lane
+// stores 8 of the MCU's 32 bytes per pixel row (a wave writes 512 contiguous bytes per row).
+// ================================================================================================
+__global__ __launch_bounds__(256, 4) void k_idct_tok_uyvy422(const gj_geom g, const int16_t* __restrict__ coefs, const uint2* __restrict__ d_rec,
+                                                             const uint16_t* __restrict__ d_tok, const uint32_t tok_cap,
+                                                             const float* __restrict__ qtab, uint8_t* __restrict__ raw)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
+    __shared__ __attribute__((aligned(16))) uint16_t s_stage[4][GJ_TOK_STAGE];
+    // dequantisation tables: [0] for blocks rebuilt from tokens (AC entries / 64, see gj_slot_put), [1] for blocks from the coefficient planes
+    __shared__ __attribute__((aligned(8))) float s_q[2][3][64];
+    if (threadIdx.x < 192) {
+        const float q = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
+        s_q[0][threadIdx.x >> 6][threadIdx.x & 63] = (threadIdx.x & 63) ? q * 0.015625f : q;
+        s_q[1][threadIdx.x >> 6][threadIdx.x & 63] = q;
+    }
+    const gj_comp_geom& kc = g.comp[1];
+    const unsigned nm = (unsigned)(kc.blocks_x * kc.blocks_y);
+    const int p = threadIdx.x & 3; // Y0 Y1 Cb Cr
+    const unsigned m = blockIdx.x * 64u + (threadIdx.x >> 2);
+    const unsigned my = m / (unsigned)kc.blocks_x, mx = m - my * (unsigned)kc.blocks_x;
+    const int c = p < 2 ? 0 : p - 1;
+    const int lane = threadIdx.x & 63;
+    uint8_t* slot = s_blk + threadIdx.x * 128;
+    uint16_t* stage = s_stage[threadIdx.x >> 6];
+    uint32_t start = 0, cnt = 0, dc = 0;
+    bool in_plane = false;
+    if (m < nm) {
+        const uint2 r = d_rec[(size_t)m * 4 + p];
+        start = r.x;
+        cnt = r.y >> 16;
+        dc = r.y & 0xFFFFu;
+        if (cnt == 0xFFFFu) { in_plane = true; cnt = 0; }
+        else if (cnt > 63u || start > tok_cap || cnt > tok_cap - start) cnt = 0; // (a record nobody wrote: damaged stream)
+    }
+    const GjTokRange tr = gj_tok_fetch(d_tok, start, cnt, lane);
+    if (tr.fast) {
+        *reinterpret_cast<uint4*>(stage + lane * 8) = tr.t0;
+        if (lane * 8 + 512 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 8 + 512) = tr.t1;
+    }
+    __syncthreads(); // (s_q)
+    const size_t blk = p < 2 ? (size_t)my * g.comp[0].blocks_x + 2 * mx + p : (size_t)m; // (plane address: blocks of long segments only)
+    gj_tok_to_slot(slot, stage, lane, tr.fast, tr.S, start, cnt, dc, in_plane,
+                   reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (m < nm ? blk : 0) * 64), d_tok);
+    uint32_t wb[32];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint4 v = *gj_slot_row(slot, lane, r);
+        wb[r * 4] = v.x; wb[r * 4 + 1] = v.y; wb[r * 4 + 2] = v.z; wb[r * 4 + 3] = v.w;
+    }
+    uint32_t px[16];
+    gj_idct_pk(wb, s_q[in_plane ? 1 : 0][c], px);
+
+    // ---- UYVY: dword k of an MCU row = U_k | Y_2k << 8 | V_k << 16 | Y_2k+1 << 24; lane p writes dwords 2p and 2p + 1
+    const size_t pitch = (size_t)g.width * 2 + g.width_padding;
+    const bool interior = m < nm && (mx * 16 + 16 <= (unsigned)g.width) && (my * 8 + 8 <= (unsigned)g.height);
+    const bool aligned = ((pitch | (size_t)raw) & 7) == 0;
+    const uint32_t sel_uv = (p & 1) ? 0x07030602u : 0x05010400u; // [U_2p, V_2p, U_2p+1, V_2p+1] out of the chroma lanes' dwords
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int a0 = (int)px[2 * r], a1 = (int)px[2 * r + 1];
+        // quad_perm broadcasts: lane 0 = Y0, 1 = Y1, 2 = Cb, 3 = Cr of this MCU
+        const uint32_t y00 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0x00, 0xF, 0xF, false), y01 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0x00, 0xF, 0xF, false);
+        const uint32_t y10 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0x55, 0xF, 0xF, false), y11 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0x55, 0xF, 0xF, false);
+        const uint32_t u0 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0xAA, 0xF, 0xF, false), u1 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0xAA, 0xF, 0xF, false);
+        const uint32_t v0 = (uint32_t)__builtin_amdgcn_update_dpp(0, a0, 0xFF, 0xF, 0xF, false), v1 = (uint32_t)__builtin_amdgcn_update_dpp(0, a1, 0xFF, 0xF, 0xF, false);
+        const uint32_t ys = p == 0 ? y00 : p == 1 ? y01 : p == 2 ? y10 : y11; // Y_4p .. Y_4p+3
+        const uint32_t us = (p >> 1) ? u1 : u0, vs = (p >> 1) ? v1 : v0;
+        const uint32_t uv = __builtin_amdgcn_perm(vs, us, sel_uv);
+        const uint32_t d0 = __builtin_amdgcn_perm(ys, uv, 0x05010400u), d1 = __builtin_amdgcn_perm(ys, uv, 0x07030602u);
+        const unsigned y = my * 8 + r;
+        if (interior && aligned) {
+            *reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)mx * 32 + p * 8) = make_uint2(d0, d1);
+        } else if (m < nm && y < (unsigned)g.height) {
+            // the generic store writes chroma only with the even pixel and whole pixels only (k_postprocess)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t d = k ? d1 : d0;
+                const unsigned x0 = mx * 16 + 2 * (2 * p + k);
+                uint8_t* q = raw + (size_t)y * pitch + (size_t)x0 * 2;
+                if (x0 < (unsigned)g.raw_width) { q[0] = (uint8_t)d; q[1] = (uint8_t)(d >> 8); }
+                if (x0 + 1 < (unsigned)g.raw_width) { q[2] = (uint8_t)(d >> 16); q[3] = (uint8_t)(d >> 24); }
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // Fused fast path for packed 4:2:2 (UYVY) output without colour transform (BASELINE config 4): one thread per MCU takes
 // its two luminance blocks (256 contiguous bytes), Cb and Cr, transforms them in registers, interleaves the samples with
 // byte permutes and stores 8 rows x 32 B. Replaces k_idct + k_postprocess (one thread per pixel) and the planar round trip.
@@ -525,10 +615,15 @@ bool gj_is_uyvy422(const gj_geom& g)
            g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
 }
 
-// the token-fed IDCT kernel for this configuration, or nullptr (non-interleaved 4:4:4 scans: plane order == coding order)
+// the token-fed IDCT kernel for this configuration, or nullptr: non-interleaved 4:4:4 scans (plane order == coding order), and the
+// interleaved scan of packed 4:2:2 (one lane per block in coding order)
 gj_idct_tok_t gj_idct_tok_for(const gj_geom& g)
 {
-    return g.interleaved ? nullptr : gj_idct_tok_kernel(g);
+    if (!g.interleaved) return gj_idct_tok_kernel(g);
+    if (gj_is_uyvy422(g) && g.blocks_per_mcu == 4 && g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.mcu_comp[0] == 0 && g.mcu_comp[1] == 0 &&
+        g.mcu_comp[2] == 1 && g.mcu_comp[3] == 2 && g.mcu_bx[0] == 0 && g.mcu_bx[1] == 1)
+        return k_idct_tok_uyvy422;
+    return nullptr;
 }
 
 void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_tok, gj_event_t* ev)
@@ -537,7 +632,7 @@ void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_to
     const bool uyvy = job->use_fused && gj_is_uyvy422(g);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
     if (idct_tok) {
-        const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block position
+        const unsigned nb = g.interleaved ? (unsigned)g.block_count : (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block (position)
         hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, (const uint16_t*)job->d_tok, job->tok_cap,
                            job->d_qtabf, job->d_raw);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);

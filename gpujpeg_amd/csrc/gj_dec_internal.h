@@ -31,7 +31,7 @@ static inline void gj_debug_stage(const bool on, hipStream_t st, const char* wha
 // ---- entropy decoders: each launches its kernel for the whole segment table of the job
 void gj_launch_huffman_serial(const gj_dec_job* job, hipStream_t st);
 void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st);
-void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st);
+void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st, bool tokens);
 void gj_launch_huffman_tok(const gj_dec_job* job, hipStream_t st);
 
 // Batches of the sub-sequence decoders: consecutive table entries, cut per scan -- the luminance segments of a photograph carry two to

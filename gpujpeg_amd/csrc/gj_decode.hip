@@ -14,7 +14,9 @@ extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, 
     if (g->seg_blocks > GJ_TOK_MAX_BLOCKS || g->restart_interval == 0) return 0; // (k_huffman_decode_tok takes whole segments into its LDS stage)
     if (tune->dec_sub) return 0; // (the tuning aid sweeps the plane-mode kernels)
     if (tune->dec_tokens == 1) return 1;
-    return g->block_count >= 900000 && jpeg_size <= (uint64_t)g->block_count * 8u;
+    // (interleaved scans -- packed 4:2:2, BASELINE config 4 at q90: 10.4 B per block -- go through the lane-per-segment kernel, whose plane mode
+    // pays for the zero fill and the scattered stores of 128-byte blocks: tokens win up to denser streams there)
+    return g->block_count >= 900000 && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
 }
 
 extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4])
@@ -25,13 +27,18 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
     bool par = job->d_huff_tab2 != nullptr && job->seg_count > 0;
     if (job->tune.dec_serial) par = false; // the lane-per-segment kernel (A/B measurements, tests)
+    const bool fast_ok = par && !job->tune.dec_careful && job->d_overflow != nullptr; // kernels that take whole segments into LDS are allowed
+    // interleaved scans with many short segments: one lane per segment (k_huffman_decode_seq); the host vouches for the longest segment
+    // (this stream's, or the previous frame's on the speculative path, where `d_overflow` is checked afterwards)
+    const bool seq = fast_ok && job->tune.dec_seq != 2 &&
+                     (job->tune.dec_seq == 1 || (g.interleaved && job->max_seg_len != 0 && job->max_seg_len <= 1024u && job->seg_count >= 16384));
     // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
-    // record per block instead of through the coefficient planes
-    // (k_huffman_decode_tok needs every segment in its LDS stage: the host vouches for the longest one -- this stream's, or the previous
-    // frame's on the speculative path, where `d_overflow` is checked afterwards)
-    gj_idct_tok_t idct_tok = (par && !job->tune.dec_careful && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && job->d_overflow && job->max_seg_len != 0 &&
-                              job->max_seg_len + 12u <= (uint32_t)GJ_TOK_CAP_U && gj_hip_decode_wants_tokens(&g, job->jpeg_size, &job->tune))
-                                 ? gj_idct_tok_for(g) : nullptr;
+    // record per block instead of through the coefficient planes: k_huffman_decode_tok for non-interleaved scans (every segment has to
+    // fit its LDS stage), the lane-per-segment kernel for interleaved ones
+    const bool tok_wanted = fast_ok && job->tokens && job->use_fused && job->d_tok && job->d_blkrec && gj_hip_decode_wants_tokens(&g, job->jpeg_size, &job->tune);
+    const bool tok_sub = tok_wanted && !g.interleaved && !seq && job->max_seg_len != 0 && job->max_seg_len + 12u <= (uint32_t)GJ_TOK_CAP_U;
+    const bool tok_seq = tok_wanted && seq;
+    gj_idct_tok_t idct_tok = (tok_sub || tok_seq) ? gj_idct_tok_for(g) : nullptr;
     const bool tokens = idct_tok != nullptr;
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
     // decodes itself; clear_coefs asks for a full clear first (segments missing from the table, lane-per-segment kernel).
@@ -40,12 +47,8 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     } else if (job->clear_coefs || !par) {
         (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
     }
-    // interleaved scans with many short segments in plane mode: one lane per segment (k_huffman_decode_seq); the host vouches for the
-    // longest segment (this stream's, or the previous frame's on the speculative path, where `d_overflow` is checked afterwards)
-    const bool seq = par && !tokens && !job->tune.dec_careful && job->d_overflow != nullptr && job->tune.dec_seq != 2 &&
-                     (job->tune.dec_seq == 1 || (g.interleaved && job->max_seg_len != 0 && job->max_seg_len <= 1024u && job->seg_count >= 16384));
-    if (tokens) gj_launch_huffman_tok(job, st);
-    else if (seq) gj_launch_huffman_seq(job, st);
+    if (tokens && tok_sub) gj_launch_huffman_tok(job, st);
+    else if (seq) gj_launch_huffman_seq(job, st, tokens);
     else if (par) gj_launch_huffman_par(job, st);
     else gj_launch_huffman_serial(job, st);
     gj_debug_stage(job->tune.debug_sync != 0, st, "entropy decoder");

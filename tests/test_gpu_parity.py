@@ -393,6 +393,11 @@ def test_token_mode_decoder(O, G, gpu_lib, tc, monkeypatch):
         assert np.array_equal(px, want)
         assert np.array_equal(dec.decode(other)[0], O.decode(other)[0])
     dec.close()
+    monkeypatch.setenv("GJ_DEC_SEQ", "1")  # token mode through the lane-per-segment kernel
+    dec = G.Decoder(gpu_lib)
+    assert np.array_equal(dec.decode(jpeg)[0], want)
+    dec.close()
+    monkeypatch.delenv("GJ_DEC_SEQ")
     monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")  # (the switches are read when a decoder is created)
     dec = G.Decoder(gpu_lib)
     assert np.array_equal(dec.decode(jpeg)[0], want)
@@ -456,6 +461,13 @@ def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
     for _ in range(2):
         assert np.array_equal(dec.decode(jpeg)[0], want)
     dec.close()
+    monkeypatch.setenv("GJ_DEC_SEQ", "1")  # token mode through the lane-per-segment kernel + k_idct_tok_uyvy422 (what BASELINE config 4 takes by itself)
+    dec = G.Decoder(gpu_lib)
+    dec.set_output_format(3, 3)
+    for _ in range(2):
+        assert np.array_equal(dec.decode(jpeg)[0], want)
+    dec.close()
+    monkeypatch.delenv("GJ_DEC_SEQ")
     monkeypatch.setenv("GJ_DEC_NO_TOKENS", "1")
     dec = G.Decoder(gpu_lib)
     dec.set_output_format(3, 3)
@@ -513,7 +525,8 @@ def test_random_streams_all_decoder_paths(O, G, gpu_lib, seed, monkeypatch):
            ((np.arange(n, dtype=np.int64) // 5 + (O.noise(n, seed=seed) & 7)) % 256).astype(np.uint8))
     jpeg = O.encode(oracle_image(O, case), raw)
     want = O.decode(jpeg, case[3], case[4])[0] if uyvy else O.decode(jpeg)[0]
-    for env in ({"GJ_DEC_TOKENS": "1"}, {"GJ_DEC_NO_TOKENS": "1"}, {"GJ_DEC_ENTROPY": "serial"}, {"GPUJPEG_NO_FUSED": "1"}, {"GJ_DEC_NO_TOKENS": "1", "GJ_DEC_SEQ": "1"}):
+    for env in ({"GJ_DEC_TOKENS": "1"}, {"GJ_DEC_NO_TOKENS": "1"}, {"GJ_DEC_ENTROPY": "serial"}, {"GPUJPEG_NO_FUSED": "1"}, {"GJ_DEC_NO_TOKENS": "1", "GJ_DEC_SEQ": "1"},
+                {"GJ_DEC_TOKENS": "1", "GJ_DEC_SEQ": "1"}):
         for k in ("GJ_DEC_TOKENS", "GJ_DEC_NO_TOKENS", "GJ_DEC_ENTROPY", "GPUJPEG_NO_FUSED", "GJ_DEC_SEQ"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                             if (lane == 63) wn0 = w1_first;
                             uint32_t d0 = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn0, w0, (uint32_t)lead));
                             uint32_t d1 = __builtin_bswap32(__builtin_amdgcn_alignbyte(wn1, w1, (uint32_t)lead));
-                            const uint32_t full = len >> 2, rest = len & 3u, cut = 0xFFFFFFFFu << (32u - 8u * rest); // (the bytes behind the end are zero padding)
+                            const uint32_t full = len >> 2, rest = len & 3u, cut = 0xFFFFFFFFu << ((32u - 8u * rest) & 31u); // (the bytes behind the end are zero padding; used when rest != 0)
                             const uint32_t nout = full + (rest ? 1u : 0u), m0 = (uint32_t)lane, m1 = m0 + 64u;
                             if (m0 == full && rest) d0 &= cut;
                             if (m1 == full && rest) d1 &= cut;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
             const uint32_t tb = s_tabs[j];
             int nb;
             gj_decode_sub<true, INTERLEAVED>(s_U + ((s_ub[j] - ub0) >> 2), i * SUB_BITS, endb, s_rec[k].x & 0xFFFFu, s_tab, s_ptab, P, GJ_TABP(s_tab, tb & 0xFFFFu),
-                                             GJ_TABP(s_tab, tb >> 16), nb, coefs, s_first[j], s_blk + s_bb[j], s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz);
+                                             GJ_TABP(s_tab, tb >> 16), nb, coefs, s_first[j], INTERLEAVED ? s_blk + s_bb[j] : nullptr, s_dc + s_bb[j], (int)before, (int)s_nblk[j], s_zz);
         }
         __syncthreads();
 

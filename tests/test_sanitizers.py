@@ -1,0 +1,46 @@
+"""-m "not gpu": AddressSanitizer + UndefinedBehaviorSanitizer over the WHOLE library -- the host C (reader, writer, tables, image file
+I/O) and, through the CPU execution model (tests/hipemu), every kernel -- driven by hostile input: the fuzzer of tools/fuzz_decoder.py
+(damaged entropy data, stray / renumbered restart markers, truncation, damaged headers, over-subscribed DHT, lying APP13 index) in all
+entropy decoder modes, the hostile-table corpus of the API tests, and truncated / damaged image files. A finding aborts the subprocess.
+(the heap overflow of round 1 in gj_tables.c is the kind of bug this tier is for.)"""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU_DIR = os.path.join(HERE, "hipemu")
+ASAN_DIR = os.path.join(EMU_DIR, "_build_asan")
+ASAN_LIB = os.path.join(ASAN_DIR, "libgpujpeg_emu.so")
+CLANG_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+@pytest.fixture(scope="session")
+def asan_env():
+    if not os.path.exists(CLANG_RT) or shutil.which("make") is None:
+        pytest.skip("needs ROCm's clang with its AddressSanitizer runtime")
+    r = subprocess.run(["make", "-s", "-j8", "-C", EMU_DIR, "SAN=1", "OPT=-O1", f"OUT={ASAN_DIR}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return dict(os.environ, LD_PRELOAD=CLANG_RT, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0:abort_on_error=1",
+                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", GJ_FUZZ_LIB=ASAN_LIB, FUZZ_TRIALS="18")
+
+
+def _run(env, args, timeout=900):
+    r = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    tail = (r.stdout[-1500:] + "\n" + "\n".join(ln for ln in r.stderr.splitlines() if not ln.startswith("[GPUJPEG]"))[-3000:])
+    assert r.returncode == 0, tail
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, tail
+    return r.stdout
+
+
+@pytest.mark.parametrize("config", ["rgb_auto", "rgb_r0", "rgb_il", "rgb_420_il", "uyvy_il", "gray", "rgba"])
+def test_fuzzed_streams_under_sanitizers(asan_env, config):
+    out = _run(asan_env, [os.path.join(ROOT, "tools", "fuzz_decoder.py"), config])
+    assert "fuzz failures: 0" in out, out[-1500:]
+
+
+def test_hostile_corpus_under_sanitizers(asan_env):
+    _run(asan_env, [os.path.join(HERE, "sanitizer_driver.py"), ASAN_LIB])

@@ -1,6 +1,7 @@
-"""Decoder robustness sweep for a GPU box: damaged streams must end in an error return or a decoded image, never in a GPU
-fault or a hang, and the decoder object must work afterwards. One subprocess per (configuration, mode) so that a fault is
-attributed; the trial number is printed before each decode."""
+"""Decoder robustness sweep: damaged streams must end in an error return or a decoded image, never in a fault or a hang, and the decoder
+object must work afterwards. One subprocess per (configuration, mode) so that a fault is attributed; the trial number is printed before
+each decode. On a GPU box it drives the product; with GJ_FUZZ_LIB=<path> any other build of the library -- tests/test_sanitizers.py runs it
+on the AddressSanitizer + UndefinedBehaviorSanitizer build of the CPU execution model (tests/hipemu), tests/test_gpu_fuzz.py on the GPU."""
 import os
 import subprocess
 import sys
@@ -34,7 +35,10 @@ def child(name, mode):
     if mode == "seq":  # the lane-per-segment entropy decoder over an LDS stage (plane mode)
         os.environ["GJ_DEC_NO_TOKENS"] = "1"
         os.environ["GJ_DEC_SEQ"] = "1"
-    lib = G.Library()
+    if mode == "seqtok":  # the same kernel in token mode
+        os.environ["GJ_DEC_TOKENS"] = "1"
+        os.environ["GJ_DEC_SEQ"] = "1"
+    lib = G.Library(os.environ.get("GJ_FUZZ_LIB") or None)
     assert lib.L.gpujpeg_init_device(0, 0) == 0
     w, h, pf, cs, q, ri, il, ss, outfmt = CONFIGS[name]
     case = (name, w, h, pf, cs, q, ri, il, ss, 3)
@@ -104,8 +108,9 @@ if __name__ == "__main__":
         child(sys.argv[1], sys.argv[2])
         sys.exit(0)
     bad = 0
-    for name in CONFIGS:
-        for mode in ("default", "tokens", "seq"):
+    only = [a for a in sys.argv[1:] if a in CONFIGS]
+    for name in (only or CONFIGS):
+        for mode in ("default", "tokens", "seq", "seqtok"):
             try:
                 r = subprocess.run([sys.executable, __file__, name, mode], capture_output=True, text=True, timeout=300)
                 lines = r.stdout.strip().splitlines()

@@ -72,11 +72,21 @@ def load_traffic(key="kernels", workload="8k"):
         return {}
 
 
-# The kernels of this path are bound by vector-instruction issue, not by HBM: a wave64 instruction occupies its SIMD for 4
-# cycles (tools/ubench/valu_rate.hip on this GPU: 4.1-4.6 cycles for shifts, bit-field, compare, convert, packed-fp32 and three-operand
-# integer instructions; 2.3-2.6 for add / and / or / mov / mul / fma; the 4-cycle figure is used for all), there are 256 CUs x 4
-# SIMDs, and the clock is taken at its 2.4 GHz peak, so `valu_issue_frac` = time the counted instructions need at that rate / duration.
-VALU_CYCLES, SIMDS, CLOCK_HZ = 4.0, 1024, 2.4e9
+# The kernels of this path are bound by vector-instruction issue, not by HBM. A wave64 instruction occupies its SIMD for ~2.4
+# cycles when it is a plain add / sub / and / or / xor / mov / not / ashr / fp32 mul-add-fma and for ~4.3 cycles otherwise (shifts, bit-field,
+# compare, select, convert, packed-fp32, three-operand integer: tools/ubench/valu_rate.hip on this GPU, profiles/r2_09_ubench.txt). The
+# issue floor of a kernel = SQ_INSTS_VALU per launch (PMC pass) x the cycles of its class mix (static mix of the kernel's code,
+# tools/isa_loops.py --mix -> profiles/r3_isa_mix.json) / 1024 SIMDs / 2.4 GHz; the floors with every instruction in the fast and in
+# the slow class bracket it.
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+
+
+def load_isa_mix():
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r3_isa_mix.json")))
+        return d["cycles"], {k: v["whole"]["share4"] for k, v in d["kernels"].items()}
+    except Exception:
+        return {"valu2": 2.4, "valu4": 4.3}, {}
 
 
 def synth_frame(lib, width, height, pattern, seed, device):
@@ -595,12 +605,18 @@ def main():
         dom = max(live, key=lambda i: solo[i])
         valu = load_traffic("valu_insts", args.workload) if traffic else {}
 
+        cyc, share4 = load_isa_mix()
+
         def issue(name, ms):
             n = valu.get(name)
             if not n or ms <= 0:
                 return {}
-            floor_ms = n * VALU_CYCLES / SIMDS / CLOCK_HZ * 1e3
-            return {"valu_insts": n, "valu_issue_floor_ms": round(floor_ms, 4), "valu_issue_frac": round(floor_ms / ms, 3)}
+            s4 = share4.get(name, 1.0)  # (a kernel without a counted mix: the slow class for all, the conservative floor)
+            per = lambda c: n * c / SIMDS / CLOCK_HZ * 1e3  # noqa: E731
+            weighted = per((1.0 - s4) * cyc["valu2"] + s4 * cyc["valu4"])
+            return {"valu_insts": n, "valu_share_4cycle_class": s4, "valu_issue_floor_ms": round(weighted, 4),
+                    "valu_issue_floor_ms_if_all_2cycle": round(per(cyc["valu2"]), 4), "valu_issue_floor_ms_if_all_4cycle": round(per(cyc["valu4"]), 4),
+                    "valu_issue_frac": round(weighted / ms, 3)}
 
         by_kernel = [dict(roof(names[i], solo[i]), traffic=traffic.get(names[i]), **issue(names[i], solo[i])) for i in live]
         r = roof(names[dom], solo[dom])
@@ -620,8 +636,9 @@ def main():
             "decode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["dec_wall"] / 1e6, 2) if args.mode != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"],
                          "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg), **issue(names[dom], solo[dom]),
-                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r3_traffic.json) x 4 cycles / 1024 SIMDs / 2.4 GHz / duration -- "
-                                      "the roofline that actually bounds these kernels (HBM traffic already equals the algorithmic bytes for the encoder)",
+                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r3_traffic.json) x the cycles of the kernel's instruction class mix "
+                                      "(2.4 / 4.3 cycles per wave64 instruction, profiles/r3_isa_mix.json) / 1024 SIMDs / 2.4 GHz / duration -- the roofline that "
+                                      "actually bounds these kernels; the all-2-cycle and all-4-cycle floors bracket it",
                          "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
                                    "coder's stream); profiles/r3_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
                          "by_kernel": by_kernel,

@@ -103,3 +103,32 @@ def test_emu_output_buffers_and_stats(O, G, emu_lib):
 def test_emu_metadata_and_exif(O, G, emu_lib):
     A.test_encoder_metadata_orientation(O, G, emu_lib)
     A.test_encoder_custom_exif_tags(O, G, emu_lib)
+
+
+def test_emu_marker_between_scans_like_the_reference(O, G, emu_lib, _ref_lib):
+    """A baseline multi-scan file may legally carry DHT / DQT / COM segments between its scans. The reference reader does not accept them
+    (src/gpujpeg_reader.c:1131-1145: any marker other than RSTn, EOI, SOS or APPn inside the scan data is an error), and the product mirrors
+    that decision instead of guessing ("what the reader accepts"): the same return code from both."""
+    import ctypes as C
+    import numpy as np
+    from conftest import natural_image, oracle_image
+    case = ("ms", 96, 64, 1, 1, 75, 4, 0, None, 3)
+    jpeg = O.encode(oracle_image(O, case), natural_image(96, 64, 3, seed=4))
+    sos = [int(i) for i in np.nonzero((jpeg[:-1] == 0xFF) & (jpeg[1:] == 0xDA))[0]]
+    assert len(sos) == 3
+    com = np.array([0xFF, 0xFE, 0x00, 0x05, 0x61, 0x62, 0x63], np.uint8)  # COM "abc" in front of the second scan's SOS
+    bad = np.concatenate([jpeg[:sos[1]], com, jpeg[sos[1]:]])
+
+    def rc_of(lib):
+        dec = G.Decoder(lib)
+        out = G.DecoderOutput()
+        out.type = G.DECODER_OUTPUT_INTERNAL_BUFFER
+        b = np.ascontiguousarray(bad)
+        rc = lib.L.gpujpeg_decoder_decode(dec.h, b.ctypes.data, b.size, C.byref(out))
+        ok = np.array_equal(dec.decode(jpeg)[0], O.decode(jpeg)[0])  # the decoder still works
+        dec.close()
+        return rc, ok
+
+    rc, ok = rc_of(emu_lib)
+    rc_ref, _ = rc_of(_ref_lib)
+    assert ok and rc == rc_ref and rc != 0, (rc, rc_ref)

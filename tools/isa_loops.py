@@ -53,7 +53,57 @@ def klass(m):
     return "salu"
 
 
+def mix_json():
+    """--mix: the share of 4-cycle-class vector instructions of the product's hot kernels, over their loop bodies (the code that runs per
+    symbol / per token) and over the whole kernel, as JSON for bench.py's class-weighted issue floor"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kernels = {"enc:k_encode_rgb444": ("gj_encode.o", "k_encode_rgb444<1, 3>"), "enc:k_assemble": ("gj_encode.o", "k_assemble"),
+               "enc:k_encode_uyvy422": ("gj_encode.o", "k_encode_uyvy422"),
+               "dec:k_huffman_decode_tok": ("gj_dec_entropy_tok.o", "k_huffman_decode_tok<true>"), "dec:k_idct_tok_rgb444": ("gj_dec_idct.o", "k_idct_tok_rgb444<3, 1>"),
+               "dec:k_huffman_decode_seq": ("gj_dec_entropy_seq.o", "k_huffman_decode_seq<true, true>"), "dec:k_idct_tok_uyvy422": ("gj_dec_idct.o", "k_idct_tok_uyvy422"),
+               "dec:k_huffman_decode_par": ("gj_dec_entropy_par.o", "k_huffman_decode_par<false, 16>"), "dec:k_idct_fused_rgb444": ("gj_dec_idct.o", "k_idct_fused_rgb444<3, 1>")}
+    out = {}
+    for key, (obj, name) in kernels.items():
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", code_object(os.path.join(root, "build", "obj", obj))], capture_output=True, text=True).stdout
+        cur, body = None, []
+        for ln in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+            if m:
+                cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+                continue
+            m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
+            if m and cur == name:
+                body.append((int(m.group(3), 16), m.group(1), m.group(2)))
+        if not body:
+            continue
+        idx = {a: i for i, (a, _, _) in enumerate(body)}
+        inloop = [False] * len(body)
+        for i, (a, mn, ops) in enumerate(body):
+            if mn.startswith(("s_cbranch", "s_branch")):
+                try:
+                    off = int(ops.split()[0])
+                except (ValueError, IndexError):
+                    continue
+                off = off - 65536 if off >= 32768 else off
+                tgt = a + 4 + 4 * off
+                if tgt <= a and tgt in idx:
+                    for q in range(idx[tgt], i + 1):
+                        inloop[q] = True
+        def share(sel):
+            v2 = sum(1 for (x, f) in zip(body, sel) if f and klass(x[1]) == "valu2")
+            v4 = sum(1 for (x, f) in zip(body, sel) if f and klass(x[1]) == "valu4")
+            return {"valu2": v2, "valu4": v4, "share4": round(v4 / max(1, v2 + v4), 3)}
+        out[key] = {"kernel": name, "loops": share(inloop), "whole": share([True] * len(body))}
+    print(json.dumps({"note": "static instruction mix (tools/isa_loops.py --mix): vector instructions of the 2.4-cycle class (add / sub / and / or / xor / mov / not / "
+                              "ashr / fp32 mul-add-fma) and of the 4.3-cycle class (everything else) as issue rates were measured on this GPU "
+                              "(profiles/r2_09_ubench.txt); `loops` = instructions inside loops (what runs per symbol / token), `whole` = the kernel's whole text",
+                      "cycles": {"valu2": FAST_CYC, "valu4": SLOW_CYC}, "kernels": out}, indent=1))
+
+
 def main():
+    if "--mix" in sys.argv:
+        return mix_json()
     path, name = sys.argv[1], sys.argv[2]
     show_all = "--all" in sys.argv
     dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", code_object(path)], capture_output=True, text=True).stdout

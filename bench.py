@@ -271,7 +271,7 @@ def kernel_names(spec, enc_ms, token_mode):
     whole = enc_ms[1] < 0.02 * max(1.0, spec.pixels / 33e6)  # fully fused encoder: pixels -> segment streams in one kernel (slots 0/1 empty)
     fmt = "uyvy422" if spec.is422 else "rgb444"
     return ["enc:k_preprocess", f"enc:k_fused_{fmt}", f"enc:k_encode_{fmt}" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
-            "dec:k_huffman_decode_tok" if token_mode else ("dec:k_huffman_decode_seq" if spec.is422 and spec.pixels > 3e7 else "dec:k_huffman_decode_par"),
+            "dec:k_huffman_decode_seq" if spec.is422 and spec.pixels > 3e7 else ("dec:k_huffman_decode_tok" if token_mode else "dec:k_huffman_decode_par"),
             f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}", "dec:k_postprocess"]
 
 
@@ -590,7 +590,7 @@ def main():
     if rank == 0:
         S, reps, jsize = head["streams"], head["reps"], head["jpeg_bytes"]
         nblocks = ((width + 7) // 8) * ((height + 7) // 8) * (2 if spec.is422 else 3)
-        token_mode = (not spec.is422) and nblocks >= 900000 and jsize <= 8 * nblocks and not args.keep_coefs and not os.environ.get("GJ_DEC_NO_TOKENS")
+        token_mode = nblocks >= 900000 and jsize <= (12 if spec.is422 else 8) * nblocks and not args.keep_coefs and not os.environ.get("GJ_DEC_NO_TOKENS")
         names = kernel_names(spec, head["solo_ms"], token_mode)
         alg = spec.raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (the same sum)
         solo, cont = head["solo_ms"], head["kernel_ms"]
@@ -701,8 +701,23 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
         for name in ("hd", "4k", "16k", "16k422"):
             sp = Spec(lib, name, args.pattern, args.quality, device, 12345)
             m = measure(lib, sp, device, dev_index, barrier, mode="both", streams=args.streams, steps=5, warmup=2, min_seconds=0.3, want_solo=True)
+            # the same roofline statement as for the headline workload: algorithmic bytes (raw + JPEG) per launch against 8 TB/s, for the
+            # dominant kernel and for each direction (durations: hipEvents with one pipeline, the GPU otherwise idle)
+            alg = sp.raw_bytes + m["jpeg_bytes"]
+            nblk = ((sp.width + 7) // 8) * ((sp.height + 7) // 8) * (2 if sp.is422 else 3)
+            tokm = nblk >= 900000 and m["jpeg_bytes"] <= (12 if sp.is422 else 8) * nblk and not os.environ.get("GJ_DEC_NO_TOKENS")
+            nm = kernel_names(sp, m["solo_ms"], tokm)
+            solo_ = m["solo_ms"]
+            live_ = [i for i in range(8) if solo_[i] > 0.006]
+            dom_ = max(live_, key=lambda i: solo_[i])
+            tr_ = load_traffic("kernels", name)
+            fr = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None  # noqa: E731
             table[name] = dict(brief(sp, m), workload=sp.describe(),
-                               solo_gpu_ms={"encode": round(float(m["solo_ms"][:5].sum()), 4), "decode": round(float(m["solo_ms"][5:].sum()), 4)})
+                               solo_gpu_ms={"encode": round(float(solo_[:5].sum()), 4), "decode": round(float(solo_[5:].sum()), 4)},
+                               roofline={"bound": "hbm", "kernel": nm[dom_], "ms": round(float(solo_[dom_]), 4), "frac": fr(float(solo_[dom_])),
+                                         "algorithmic_bytes_per_launch": int(alg), "traffic": tr_.get(nm[dom_]),
+                                         "frac_encode_direction": fr(float(solo_[:5].sum())), "frac_decode_direction": fr(float(solo_[5:].sum())),
+                                         "by_kernel": {nm[i]: round(float(solo_[i]), 4) for i in live_}})
             del sp
             torch.cuda.empty_cache()
         ba = argparse.Namespace(**vars(args))

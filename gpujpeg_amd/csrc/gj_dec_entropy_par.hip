@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
         uint32_t e = t[fast];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
         const int tot = (int)(e & 31u);
-        const int adv = (int)(e >> 9);
+        const int adv = (int)((e >> 9) & 63u);
         if (WRITE) {
             const int sz = (int)((e >> 5) & 15u);
             const int used = tot - sz;

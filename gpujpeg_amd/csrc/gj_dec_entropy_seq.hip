@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
                     uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
                     if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
                     const int tot = (int)(e & 31u), sz = (int)((e >> 5) & 15u);
-                    adv = tot ? (int)(e >> 9) : 64; // (an entry of a table the stream never defined: give up on the block)
+                    adv = tot ? (int)((e >> 9) & 63u) : 64; // (an entry of a table the stream never defined: give up on the block)
                     const int used = tot - sz;
                     const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
                     v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;

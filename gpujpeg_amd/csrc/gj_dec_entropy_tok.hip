@@ -23,7 +23,8 @@
 // LDS budget: 4 workgroups per CU need <= 40960 B (granted in steps of 1280 B, tools/ubench/lds_occupancy.hip), and an 8K frame has to be
 // ONE generation of workgroups (a second, partial generation doubles the kernel's duration): hence the stage of 10.5 KB.
 #ifndef GJ_TOK_SUB
-#define GJ_TOK_SUB 16                                           // bytes per sub-sequence
+#define GJ_TOK_SUB 16                                           // bytes per sub-sequence ...
+#define GJ_TOK_SUB_MAX 20                                       // ... or up to so many when that saves the group a pass
 #endif
 // n segments of a group hold at most CAP_U - 8 n unstuffed bytes (8 B of padding each) and every one ends with a partial sub-sequence:
 // (CAP_U - 8 n) / 16 + 15 n / 16 < CAP_U / 16 + n / 2 sub-sequences (this bound needs sub-sequences of at most 17 bytes; the table is
@@ -47,11 +48,17 @@ extern "C" GJ_HIP_API int gj_hip_trace_set(void* p) { return hipMemcpyToSymbol(H
 
 // -DGJ_TOK_STATS (CPU execution model only, tools/tok_sync_stats.py): how many sub-sequences every round has to decode again
 #ifdef GJ_TOK_STATS
-extern "C" GJ_HIP_API unsigned long long gj_tok_stats[16];
-unsigned long long gj_tok_stats[16];
+extern "C" GJ_HIP_API unsigned long long gj_tok_stats[64];
+unsigned long long gj_tok_stats[64];
+// lane utilisation of a pass: every lane notes its symbols (tokens + DC and end-of-block per block), lane 0 adds the wave's sum and 64 x max
+#define GJ_STAT_WAVE(sm, i, lane, sym) do { gj_wave_sync(); (sm).statsym[threadIdx.x] = (sym); gj_wave_sync(); if ((lane) == 0) { \
+    unsigned long long s_ = 0, m_ = 0; for (int q_ = 0; q_ < 64; q_++) { const unsigned v_ = (sm).statsym[(threadIdx.x & ~63) + q_]; s_ += v_; if (v_ > m_) m_ = v_; } \
+    GJ_STAT(i, s_); GJ_STAT((i) + 1, 64 * m_); GJ_STAT((i) + 2, 1); } } while (0)
+#define GJ_SYMS(c) (((c) >> 16) + 2u * ((c) & 0xFFFFu))
 #define GJ_STAT(i, n) __atomic_fetch_add(&gj_tok_stats[i], (unsigned long long)(n), __ATOMIC_RELAXED)
 #else
 #define GJ_STAT(i, n) ((void)0)
+#define GJ_STAT_WAVE(sm, i, lane, sym) ((void)0)
 #endif
 
 // state between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag index
@@ -74,9 +81,11 @@ struct GjTokLds {
     // per segment of the group: first and end bit in the stage, first sub-sequence
     uint32_t sbit[GJ_TOK_GMAX], ebit[GJ_TOK_GMAX], sub0[GJ_TOK_GMAX + 1];
     uint32_t tmp[4];
-    int j1, jstop;
     uint32_t nwork[2], big;
     uint8_t zz[64 + 64];
+#ifdef GJ_TOK_STATS
+    uint32_t statsym[256];
+#endif
 };
 
 // The run-in of the first pass: decode from bit `from` (most likely inside a block, hence the AC table) up to the sub-sequence that starts
@@ -95,10 +104,10 @@ __device__ __forceinline__ uint32_t gj_tok_run_in(const GjTokLds& sm, const uint
         uint32_t e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)];
         p1 += e & 31u;
-        z += e >> 9;
-        const bool done = z >= 64u;
-        z = done ? 0u : z;
-        toff = done ? 0u : (uint32_t)GJ_DEC2_WORDS * 2u;
+        z += (e >> 9) & 63u;
+        const uint32_t inside = (uint32_t)((int32_t)(z - 64u) >> 31); // all ones until the block is complete
+        z &= inside;
+        toff = ((uint32_t)GJ_DEC2_WORDS * 2u) & inside;
     }
     return (p1 - e1) | (z << 5);
 }
@@ -121,43 +130,48 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
     uint32_t z = (entry >> 5) & 63u;
     uint32_t toff = z == 0 ? 0u : (uint32_t)GJ_DEC2_WORDS * 2u; // byte offset of the table: DC in front of a block, AC inside
     uint32_t nb = 0, ntok = 0, mx = 0;
+    uint16_t* tp = tok_out; // MODE 1: where the next token goes (ntok follows from it at the end)
     while (p1 < e1) {
         const uint32_t wi = p1 >> 5;
         const uint32_t win = __builtin_amdgcn_alignbit(sm.U[wi], sm.U[wi + 1], ~p1); // the next 32 bits of the stream
         const uint16_t* t = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(sm.tab) + toff);
         uint32_t e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)]; // codes longer than 10 bits
-        const uint32_t tot = e & 31u, adv = e >> 9, sz = (e >> 5) & 15u;
+        const uint32_t tot = e & 31u, adv = (e >> 9) & 63u, sz = (e >> 5) & 15u;
         if (MODE == 0) {
-            ntok += (z != 0 && sz != 0) ? 1u : 0u;
+            ntok += e >> 15; // a non-zero AC coefficient
         } else {
             // the sz magnitude bits behind the code, extended (ITU T.81 F.2.2.1); without magnitude bits the shifts wrap and v is
             // meaningless: no coefficient is made of it, and the DC branch asks
             const uint32_t x = win << (tot - sz);                       // magnitude bits, left aligned
-            const uint32_t neg = ~(uint32_t)((int32_t)x >> 31);         // all ones when the first of them is 0: a negative value
-            const int v = (int)(x >> ((32u - sz) & 31u)) - (int)(neg & ((1u << sz) - 1u));
-            if (z == 0) {
-                // slot blk + nb of the segment: DC difference and where the block's tokens start; the slot behind the last block takes the
-                // start of a block the segment should not have (damaged stream): it ends the last block's tokens
-                if (blk + nb <= nblocks) s_blkinfo[blk + nb] = (sz ? (uint32_t)v & 0xFFFFu : 0u) | ((tok_rel + ntok) << 16);
-            } else if (sz != 0) {
+            uint32_t neg = (uint32_t)((int32_t)~x >> 31);               // all ones when the first of them is 0: a negative value, whose
+            GJ_KEEP(neg);                                               // magnitude is the complement of the bits (kept as arithmetic:
+            const uint32_t mag = (x ^ neg) >> ((32u - sz) & 31u);       // the compiler would turn it into compare + 2 selects, which
+            const int v = (int)((mag ^ neg) - neg);                     // issue at half the rate of these)
+            if ((int16_t)e < 0) { // a non-zero AC coefficient
                 const uint32_t pos = z + adv - 1u; // (zz[64..127] = 63: damaged streams only)
                 if (MODE == 1) {
                     mx = max(mx, sz);
-                    tok_out[ntok] = (uint16_t)(((uint32_t)v << 6) | sm.zz[pos]);
-                } else if (blk + nb < nblocks && pos < 64u) {
-                    coefs[(uint64_t)(blk + nb) * 64 + sm.zz[pos]] = (int16_t)v;
+                    *tp++ = (uint16_t)(((uint32_t)v << 6) | sm.zz[pos]);
+                } else {
+                    if (blk + nb < nblocks && pos < 64u) coefs[(uint64_t)(blk + nb) * 64 + sm.zz[pos]] = (int16_t)v;
+                    ntok++;
                 }
-                ntok++;
+            } else if (z == 0) {
+                // slot blk + nb of the segment: DC difference and where the block's tokens start; the slot behind the last block takes the
+                // start of a block the segment should not have (damaged stream): it ends the last block's tokens
+                const uint32_t t = MODE == 1 ? tok_rel + (uint32_t)(tp - tok_out) : tok_rel + ntok;
+                if (blk + nb <= nblocks) s_blkinfo[blk + nb] = (sz ? (uint32_t)v & 0xFFFFu : 0u) | (t << 16);
             }
         }
         p1 += tot;
         z += adv;
-        const bool done = z >= 64u; // the block is complete
-        z = done ? 0u : z;
-        toff = done ? 0u : (uint32_t)GJ_DEC2_WORDS * 2u;
-        nb += done ? 1u : 0u;
+        const uint32_t inside = (uint32_t)((int32_t)(z - 64u) >> 31); // all ones until the block is complete
+        z &= inside;
+        toff = ((uint32_t)GJ_DEC2_WORDS * 2u) & inside;
+        nb += 1u + inside;
     }
+    if (MODE == 1) ntok = (uint32_t)(tp - tok_out);
     if (MODE == 1 && mx >= 10u) *s_big = 1u; // a value that does not fit a token's 10 bits: the batch goes through the planes
     counts = nb | (ntok << 16);
     return (p1 - e1) | (z << 5);
@@ -173,7 +187,6 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                                                                uint32_t* __restrict__ overflow)
 {
     constexpr int CAP_U = GJ_TOK_CAP_U, MAX_BLOCKS = GJ_TOK_MAX_BLOCKS, GMAX = GJ_TOK_GMAX, MAX_SUBS = GJ_TOK_MAX_SUBS;
-    constexpr uint32_t SUB_BITS = GJ_TOK_SUB * 8;
     __shared__ GjTokLds sm;
     constexpr int POOL = sizeof(sm.pool) / 2; // 16-bit units
     uint32_t* const s_stage = sm.U + 1;      // where the unstuffed bytes go: bit position 32 of the reader
@@ -198,11 +211,14 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
     const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
 
     // ---- batch setup: lane j describes segment j of the batch
-    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
     int pc = 0;
     while (pc + 1 < plan.n && (int)blockIdx.x >= plan.batch0[pc + 1]) pc++;
     const int G = plan.g[pc];
     const int si0 = plan.first[pc] + ((int)blockIdx.x - plan.batch0[pc]) * G;
+    // (the segment table is asked for before the segment count is known: one trip to memory for the four loads)
+    uint32_t ld_s = 0xFFFFFFFFu, ld_p = 0, ld_l = 0;
+    if (tid < G && si0 + tid < seg_count_max) { ld_s = seg_index[si0 + tid]; ld_p = seg_pos[si0 + tid]; ld_l = seg_len[si0 + tid]; }
+    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
     if (si0 >= seg_count) return;
     const int nseg = min(min(G, plan.first[pc] + plan.count[pc] - si0), seg_count - si0);
     // the Huffman tables of the batch's scan are on their way while the segment table is read (a batch cut per scan belongs to component
@@ -221,8 +237,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
     {
         uint32_t first = 0, tb = 0;
         if (tid < nseg) {
-            const uint32_t s = seg_index[si0 + tid];
-            const uint32_t p_ = seg_pos[si0 + tid], l_ = seg_len[si0 + tid]; // (independent loads: one trip to memory for the three)
+            const uint32_t s = ld_s, p_ = ld_p, l_ = ld_l;
             if (s < (uint32_t)g.segment_count) {
                 const GjSeg sg = gj_segment(g, (int)s);
                 const gj_comp_geom& kc = g.comp[sg.comp];
@@ -242,13 +257,13 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
             s_first[tid] = first;
             sm.tabsel[tid] = (uint16_t)tb;
         }
-        uint32_t tot;
-        const uint32_t a = gj_wg256_incl_scan(tid < nseg ? my_nblk + 1u : 0u, s_tmp, &tot); // (one slot more per segment, see gj_tok_decode)
-        if (tid < GMAX) s_bb[tid + 1] = a;
-        const uint32_t b = gj_wg256_incl_scan(my_len ? ((my_len + 3u) & ~3u) + 8u : 0u, s_tmp, &tot);
-        if (tid < GMAX) s_cap[tid + 1] = b;
+        if (wave == 0) { // (a batch has at most GMAX = 64 segments: its table is the business of one wave)
+            s_bb[tid + 1] = gj_wave_incl_scan(tid < nseg ? my_nblk + 1u : 0u); // (one slot more per segment, see gj_tok_decode)
+            s_cap[tid + 1] = gj_wave_incl_scan(my_len ? ((my_len + 3u) & ~3u) + 8u : 0u);
+        }
         if (tid == 0) { s_bb[0] = 0; s_cap[0] = 0; sm.nwork[0] = 0; sm.nwork[1] = 0; }
     }
+    static_assert(GMAX == 64, "one wave holds the batch's segment table");
     __syncthreads();
     // the waves' token stages: what the batch's block slots leave of the pool, in four equal 16-byte aligned parts
     const uint32_t stage0 = (2u * s_bb[nseg] + 7u) & ~7u, stage_cap = (((uint32_t)POOL - stage0) >> 2) & ~7u;
@@ -256,16 +271,17 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
 
     // ---- groups: consecutive segments with the same Huffman tables whose unstuffed bytes fit the LDS stage (normally one group = the batch)
     for (int j0 = 0; j0 < nseg;) {
-        if (tid == 0) { sm.j1 = j0 + 1; sm.jstop = nseg; sm.big = 0; }
+        if (tid == 0) sm.big = 0;
         if (tid < nseg) { s_pos[tid] = my_pos; s_len[tid] = my_len; }
-        __syncthreads();
+        // (every wave works the group out for itself from the batch's table: lane l looks at segment l, then at the end l + 1)
         const uint32_t tb = sm.tabsel[j0];
-        if (tid > j0 && tid < nseg && my_nblk != 0 && sm.tabsel[tid] != tb) atomicMin(&sm.jstop, tid); // other tables (the next scan) end the group
-        __syncthreads();
-        if (tid > j0 && tid <= sm.jstop && s_cap[tid] - s_cap[j0] <= (uint32_t)CAP_U) atomicMax(&sm.j1, tid);
-        __syncthreads();
-        const int j1 = sm.j1;
+        const bool other = lane > j0 && lane < nseg && s_bb[lane + 1] - s_bb[lane] != 1u && sm.tabsel[lane] != tb; // other tables (the next scan) end the group
+        const unsigned long long mo = __ballot(other);
+        const int jstop = mo ? (int)__builtin_ctzll(mo) : nseg;
+        const unsigned long long mf = __ballot(lane + 1 > j0 && lane + 1 <= jstop && s_cap[lane + 1] - s_cap[j0] <= (uint32_t)CAP_U);
+        const int j1 = max(j0 + 1, mf ? 64 - (int)__builtin_clzll(mf) : 0);
         const int ng = j1 - j0;
+        __syncthreads();
         GJ_TRACE(1);
 
         // -- 0. the group's Huffman tables
@@ -375,16 +391,27 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
 
         GJ_TRACE(2);
         // -- 2. sub-sequence table
+        //       Sub-sequences of GJ_TOK_SUB bytes, unless the group then needs a little more than a whole number of passes of the 256 lanes
+        //       (an 8K frame's luminance batches: ~530 sub-sequences of 16 bytes = two full passes and a third one of 18 lanes, which takes as
+        //       long as a full one): somewhat longer sub-sequences that fit one pass less are cheaper (2 x 17 instead of 3 x 16).
+        uint32_t sub_bytes = GJ_TOK_SUB;
         {
-            uint32_t my_nsub = 0;
+            uint32_t ulen = 0;
             if (tid >= j0 && tid < j1) {
-                const uint32_t ulen = my_nblk ? s_ulen[tid] : 0u;
-                my_nsub = (ulen + GJ_TOK_SUB - 1) / GJ_TOK_SUB;
+                ulen = my_nblk ? s_ulen[tid] : 0u;
                 s_sbit[tid] = s_ubyte[tid] * 8u + 32u; // (the stage starts at dword 1 of the reader's address space)
                 s_ebit[tid] = (s_ubyte[tid] + ulen) * 8u + 32u;
             }
             uint32_t tot;
-            const uint32_t a = gj_wg256_incl_scan(my_nsub, s_tmp, &tot);
+            uint32_t a = gj_wg256_incl_scan(((ulen + GJ_TOK_SUB - 1) / GJ_TOK_SUB) | (ulen << 16), s_tmp, &tot) & 0xFFFFu; // (sums < 2^16 both)
+            const uint32_t passes = ((tot & 0xFFFFu) + 255u) >> 8, bytes = tot >> 16;
+            if (passes >= 2) {
+#pragma unroll
+                for (uint32_t s = GJ_TOK_SUB + 1; s <= GJ_TOK_SUB_MAX; s++) // (a segment of n bytes has at most n / s + 1 sub-sequences)
+                    if (sub_bytes == GJ_TOK_SUB && bytes / s + (uint32_t)ng <= 256u * (passes - 1u)) sub_bytes = s;
+            }
+            sub_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub_bytes);
+            if (sub_bytes != GJ_TOK_SUB) a = gj_wg256_incl_scan((ulen + sub_bytes - 1u) / sub_bytes, s_tmp, &tot);
             // (a segment of n bytes has n / 16 + 1 sub-sequences at most: MAX_SUBS cannot be exceeded; the clamp keeps a fault in the
             // arithmetic above from becoming a write behind s_rec)
             if (tid >= j0 && tid < j1) s_sub0[tid + 1] = min(a, (uint32_t)MAX_SUBS);
@@ -392,6 +419,8 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         }
         __syncthreads();
         const int nsub = (int)s_sub0[j1];
+        const uint32_t sub_bits = sub_bytes * 8u;
+        if (tid == 0) GJ_STAT(32 + min(nsub / 32, 31), 1);
         for (int k = tid; k < nsub; k += 256) {
             int lo = j0, hi = j1; // segment j with s_sub0[j] <= k < s_sub0[j + 1]
             while (hi - lo > 1) {
@@ -407,15 +436,16 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         //       GJ_TOK_SYNC bits in front of it and takes the state it arrives in (right in most cases: the rounds below find the others)
         for (int k0 = 0; k0 < nsub; k0 += 256) {
             const int k = k0 + tid;
+            uint32_t c0 = 0;
             if (k < nsub) {
                 const int j = (int)(s_rec[k].x >> 22);
                 const uint32_t i = (uint32_t)k - s_sub0[j];
-                const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
+                const uint32_t sb = s_sbit[j] + i * sub_bits, eb = min(sb + sub_bits, s_ebit[j]);
                 const uint32_t e0 = i == 0 ? 0u : gj_tok_run_in(sm, sb - (uint32_t)GJ_TOK_SYNC, sb);
-                uint32_t c0;
                 const uint32_t x0 = gj_tok_decode<0>(sm, sb, eb, e0, c0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
                 s_rec[k] = make_uint2(e0 | (x0 << 11) | ((uint32_t)j << 22), c0);
             }
+            GJ_STAT_WAVE(sm, 16, lane, GJ_SYMS(c0));
         }
         GJ_TRACE(4);
         // -- rounds: sub-sequences whose predecessor leaves in another state than they were entered with are decoded again, densely packed
@@ -445,7 +475,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                 const int k = s_work[w];
                 const int j = (int)(s_rec[k].x >> 22);
                 const uint32_t i = (uint32_t)k - s_sub0[j];
-                const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
+                const uint32_t sb = s_sbit[j] + i * sub_bits, eb = min(sb + sub_bits, s_ebit[j]);
                 const uint32_t e = (s_rec[k - 1].x >> 11) & 0x7FFu;
                 uint32_t c;
                 const uint32_t x = gj_tok_decode<0>(sm, sb, eb, e, c, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
@@ -493,17 +523,18 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                 const unsigned long long fm = __ballot(fits);
                 const int n = fm == ~0ull ? 64 : __builtin_ctzll(~fm); // leading lanes whose tokens fit (at least one: a sub-sequence has < 64 tokens)
                 gj_wave_sync(); // (the previous flush has read the stage)
+                uint32_t c = 0;
                 if (lane < n) {
                     const int j = (int)(s_rec[kk].x >> 22);
                     const uint32_t kf = s_sub0[j];
                     const uint32_t i = (uint32_t)kk - kf;
                     const uint32_t before_k = kk > 0 ? s_rec[kk - 1].y : 0u, before_f = kf > 0 ? s_rec[kf - 1].y : 0u;
-                    const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
-                    uint32_t c;
+                    const uint32_t sb = s_sbit[j] + i * sub_bits, eb = min(sb + sub_bits, s_ebit[j]);
                     gj_tok_decode<1>(sm, sb, eb, s_rec[kk].x & 0x7FFu, c, stage + a0 + ((before_k >> 16) - P0), s_blkinfo + s_bb[j], before_k >> 16,
                                      (before_k & 0xFFFFu) - (before_f & 0xFFFFu), s_bb[j + 1] - s_bb[j] - 1u, nullptr, &sm.big);
                 }
                 gj_wave_sync();
+                GJ_STAT_WAVE(sm, 20, lane, GJ_SYMS(c));
                 // flush
                 const uint32_t cnt = (s_rec[k0 + n - 1].y >> 16) - P0;
                 uint16_t* const dst = d_tok + (size_t)(gbase + P0 - a0); // 16-byte aligned; stage[s] <-> dst[s]
@@ -516,6 +547,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                     }
                 }
                 k0 += n;
+                if (lane == 0) { GJ_STAT(24, 1); GJ_STAT(25, n); GJ_STAT(26, k0 >= kb ? (kb - ka + 63) / 64 : 0); GJ_STAT(27, k0 >= kb ? 1 : 0); }
             }
         }
         __syncthreads();
@@ -535,7 +567,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                 const uint32_t kf = s_sub0[j];
                 const uint32_t i = (uint32_t)k - kf;
                 const uint32_t before_k = k > 0 ? s_rec[k - 1].y : 0u, before_f = kf > 0 ? s_rec[kf - 1].y : 0u;
-                const uint32_t sb = s_sbit[j] + i * SUB_BITS, eb = min(sb + SUB_BITS, s_ebit[j]);
+                const uint32_t sb = s_sbit[j] + i * sub_bits, eb = min(sb + sub_bits, s_ebit[j]);
                 uint32_t c;
                 gj_tok_decode<2>(sm, sb, eb, s_rec[k].x & 0x7FFu, c, nullptr, s_blkinfo + s_bb[j], 0, (before_k & 0xFFFFu) - (before_f & 0xFFFFu),
                                  s_bb[j + 1] - s_bb[j] - 1u, coefs + (uint64_t)s_first[j] * 64, nullptr);

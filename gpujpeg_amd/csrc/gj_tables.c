@@ -143,7 +143,7 @@ int gj_huffman_decoder_table2(const uint8_t bits[17], const uint8_t* vals, int i
 {
     /* what a code that is not in the table decodes to: 16 bits consumed, symbol 0 (as the canonical search of the
      * lane-per-segment kernel does) */
-    const uint16_t invalid = (uint16_t)(16 | (0 << 5) | ((is_ac ? 64 : 1) << 9));
+    const uint16_t invalid = (uint16_t)(16 | (0 << 5) | ((is_ac ? 63 : 1) << 9));
     for (int i = 0; i < GJ_DEC2_WORDS; i++) out[i] = invalid;
     int subtables = 0;
     int sub_of_prefix[1024];
@@ -157,8 +157,9 @@ int gj_huffman_decoder_table2(const uint8_t bits[17], const uint8_t* vals, int i
             int adv;
             if (!is_ac) adv = run + 1;
             else if (sz != 0) adv = run + 1;
-            else adv = run == 15 ? 16 : 64;
-            const uint16_t e = (uint16_t)((len + sz) | (sz << 5) | (adv << 9));
+            else adv = run == 15 ? 16 : 63; /* end of block: from any position inside the block (>= 1) to 64 or beyond */
+            const int coefficient = is_ac && sz != 0;
+            const uint16_t e = (uint16_t)((len + sz) | (sz << 5) | (adv << 9) | (coefficient << 15));
             if (len <= GJ_DEC_FAST_BITS) {
                 const int shift = GJ_DEC_FAST_BITS - len;
                 for (int f = 0; f < (1 << shift); f++) out[(code << shift) | f] = e;

@@ -209,7 +209,8 @@ GJ_HIP_API int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, 
 /* two-level table of the sub-sequence decoder: 1024 first-level entries indexed by the next 10 bits, then up to
  * GJ_DEC2_SUBTABLES second-level tables of 64 entries indexed by the 6 bits after those. Entry: bits [0,5) code length +
  * magnitude bits (0 in the first level = go to the second level, whose word offset is entry >> 5), [5,9) magnitude bits,
- * [9,16) zig-zag advance (DC: 1 + high nibble; AC: run + 1, 16 for ZRL, 64 for EOB). */
+ * [9,15) zig-zag advance (DC: 1 + high nibble; AC: run + 1, 16 for ZRL, 63 for EOB: the position inside a block is >= 1, so
+ * the block is complete at >= 64), bit 15 set for a non-zero AC coefficient (what the token decoder counts and stores). */
 #define GJ_DEC2_SUBTABLES 6
 #define GJ_DEC2_WORDS (1024 + 64 * GJ_DEC2_SUBTABLES)
 

@@ -19,7 +19,7 @@ ap.add_argument("--workload", default="8k")
 ap.add_argument("--pattern", default="natural")
 ap.add_argument("--quality", type=int, default=75)
 args = ap.parse_args()
-lib = G.Library(os.path.join(ROOT, "gpujpeg_amd", "lib", "libgpujpeg_trace.so"))
+lib = G.Library(os.environ.get("GJ_TRACE_LIB") or os.path.join(ROOT, "gpujpeg_amd", "lib", "libgpujpeg_trace.so"))
 assert lib.L.gpujpeg_init_device(0, 0) == 0
 dev = torch.device("cuda", 0)
 spec = bench.Spec(lib, args.workload, args.pattern, args.quality, dev, 12345)

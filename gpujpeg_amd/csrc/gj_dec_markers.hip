@@ -66,7 +66,7 @@ __device__ __forceinline__ void gj_scan_bytes(const uint8_t* __restrict__ jpeg, 
 
 template <int TB>
 __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size,
-                                                     uint2* __restrict__ chunk_info, gj_scan_summary* __restrict__ sum,
+                                                     uint16_t* __restrict__ chunk_cnt, uint32_t* __restrict__ chunk_last, gj_scan_summary* __restrict__ sum,
                                                      const uint8_t* __restrict__ hdr_ref, const uint32_t hdr_n)
 {
     __shared__ uint32_t s_n, s_last, s_nother, s_oq[4], s_oslot[4], s_oafter[4];
@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
         __syncthreads();
         if (threadIdx.x < no) sum->other_after[s_oslot[threadIdx.x]] = s_oafter[threadIdx.x];
     }
-    if (threadIdx.x == 0) chunk_info[blockIdx.x] = make_uint2(s_n, s_last);
+    if (threadIdx.x == 0) { // (a chunk is 16 KiB at most: its count fits 16 bits)
+        chunk_cnt[blockIdx.x] = (uint16_t)s_n;
+        chunk_last[blockIdx.x] = s_last;
+    }
 }
 
 // Scan s is bounded by the "other" markers: it starts after an SOS header and ends at the next other marker. Scan 0 starts at
@@ -122,7 +125,8 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
 // of the scan's last segment).
 template <int TB>
 __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size,
-                                                         const uint32_t chunks, const uint2* __restrict__ chunk_info, uint32_t* __restrict__ chunk_maxlen /* host memory */,
+                                                         const uint32_t chunks, const uint16_t* __restrict__ chunk_cnt /* 16-byte aligned, readable up to a multiple of 8 */,
+                                                         const uint32_t* __restrict__ chunk_last, uint32_t* __restrict__ chunk_maxlen /* host memory */,
                                                          gj_scan_summary* __restrict__ sum, gj_scan_summary* __restrict__ hsum /* host memory: what the host reads */,
                                                          gj_scan_summary* __restrict__ sum_next, uint32_t* __restrict__ seg_pos,
                                                          uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index, const uint32_t max_segments)
@@ -137,16 +141,15 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     __shared__ uint32_t s_mpos[GJ_SCAN_LIST]; // position | code & 7 << 29 would not fit 32-bit positions: offset inside the chunk | code & 7 << 16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr uint32_t chunk_bytes = 256u * TB;
-    // everything this workgroup reads from memory is asked for at once: the summary, the counts of all chunks (registers: up to 8 per
-    // lane; more chunks are read again below), the last marker of the chunk in front, and the bytes of its own chunk
-    constexpr int KEEP = 8;
-    uint32_t cnt_reg[KEEP];
-#pragma unroll
-    for (int q = 0; q < KEEP; q++) {
-        const uint32_t c = (uint32_t)tid + 256u * q;
-        cnt_reg[q] = c < chunks ? chunk_info[c].x : 0u;
-    }
-    const uint32_t prev1_last = blockIdx.x > 0 ? chunk_info[blockIdx.x - 1].y : 0u;
+    // everything this workgroup reads from memory is asked for at once: the summary, the counts of all chunks (16-bit: a lane takes eight of
+    // them with one 16-byte load, the workgroup 2048; two such loads are kept in registers, more chunks are read again below), the last
+    // marker of the chunk in front, and the bytes of its own chunk. Every workgroup reads all the counts: as 32-bit halves of 8-byte records
+    // that was 29 MB through the L2 for an 8K frame and a third of this kernel's time.
+    const uint32_t cvecs = (chunks + 7u) >> 3; // 16-byte pieces of the count array
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const uint4 cnt_reg0 = (uint32_t)tid < cvecs ? reinterpret_cast<const uint4*>(chunk_cnt)[tid] : zero4;
+    const uint4 cnt_reg1 = (uint32_t)tid + 256u < cvecs ? reinterpret_cast<const uint4*>(chunk_cnt)[tid + 256] : zero4;
+    const uint32_t prev1_last = blockIdx.x > 0 ? chunk_last[blockIdx.x - 1] : 0u;
     GJ_TRACE_M(0);
     if (tid < GJ_MAX_COMP) { // scan i carries component i when the stream is not interleaved (src/gpujpeg_reader.c:1345)
         const int c = tid < g.comp_count ? tid : 0;
@@ -154,14 +157,16 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
         s_geo_limit[tid] = g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[c].segment_count;
     }
     // the few other markers: lane i of the first wave takes marker i
-    const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
+    // (all 16 slots are read whether they are in use or not: asking for the count first would be a second trip to memory)
     uint32_t o_pos = 0xFFFFFFFFu, o_code = 0, o_len = 0, o_after = 0;
-    if (wave == 0 && (uint32_t)lane < n_other) {
+    if (wave == 0 && lane < GJ_SCAN_MAX_OTHER) {
         o_pos = sum->other_pos[lane];
         o_code = sum->other_code[lane];
         o_len = ((uint32_t)sum->other_bytes[lane][0] << 8) | sum->other_bytes[lane][1];
         o_after = sum->other_after[lane];
     }
+    const uint32_t n_other = min(sum->other_count, (uint32_t)GJ_SCAN_MAX_OTHER);
+    if ((uint32_t)lane >= n_other) o_pos = 0xFFFFFFFFu;
     const uint64_t c0 = begin + (uint64_t)blockIdx.x * chunk_bytes;
     const uint64_t b0 = c0 + (uint64_t)tid * TB;
     uint64_t rst, other, nums;
@@ -211,22 +216,31 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     // ---- restart markers in front of this chunk, up to the chunk of every later scan's SOS, and all of them; the last chunk in front
     //      of this one that has a marker
     {
-        uint32_t acc[GJ_MAX_COMP + 2] = {0, 0, 0, 0, 0, 0};
+        static_assert(GJ_MAX_COMP == 4, "accumulators below");
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, aall = 0; // (scalars, not an array: the loop below is not unrolled)
         int prev = -1;
-        for (uint32_t c = (uint32_t)tid, q = 0; c < chunks; c += 256, q++) {
-            uint32_t n = 0;
-            if (q < KEEP) {
-#pragma unroll
-                for (int u = 0; u < KEEP; u++) n = q == (uint32_t)u ? cnt_reg[u] : n;
-            } else {
-                n = chunk_info[c].x;
+        const uint32_t t1 = scans > 1 ? s_sos_chunk[1] + 1u : 0u, t2 = scans > 2 ? s_sos_chunk[2] + 1u : 0u, t3 = scans > 3 ? s_sos_chunk[3] + 1u : 0u;
+        for (uint32_t v = (uint32_t)tid, q = 0; v < cvecs; v += 256, q++) {
+            uint4 w;
+            if (q == 0) w = cnt_reg0;
+            else if (q == 1) w = cnt_reg1;
+            else w = reinterpret_cast<const uint4*>(chunk_cnt)[v];
+#pragma unroll 1 // (unrolled, the forty comparisons' masks cost an eighth of the occupancy in scalar registers)
+            for (uint32_t c = v * 8u; c < v * 8u + 8u; c++) {
+                const uint32_t n = c < chunks ? w.x & 0xFFFFu : 0u; // (the array's last piece ends with stale counts)
+                w.x = __builtin_amdgcn_alignbit(w.y, w.x, 16); // the next count moves down
+                w.y = __builtin_amdgcn_alignbit(w.z, w.y, 16);
+                w.z = __builtin_amdgcn_alignbit(w.w, w.z, 16);
+                w.w >>= 16;
+                a0 += c < blockIdx.x ? n : 0u;
+                prev = (c < blockIdx.x && n) ? (int)c : prev;
+                a1 += c < t1 ? n : 0u;
+                a2 += c < t2 ? n : 0u;
+                a3 += c < t3 ? n : 0u;
+                aall += n;
             }
-            if (c < blockIdx.x) { acc[0] += n; if (n) prev = (int)c; }
-#pragma unroll
-            for (int sc = 1; sc < GJ_MAX_COMP; sc++)
-                if (sc < scans && c <= s_sos_chunk[sc]) acc[sc] += n;
-            acc[GJ_MAX_COMP + 1] += n;
         }
+        const uint32_t acc[GJ_MAX_COMP + 2] = {a0, a1, a2, a3, 0u, aall};
 #pragma unroll
         for (int i = 0; i < GJ_MAX_COMP + 2; i++) {
             if (i == GJ_MAX_COMP) continue;
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256) void k_marker_segments(const gj_geom g, const 
     uint32_t irregular = too_many ? 1u : 0u, maxlen = 0;
     const uint32_t rank0 = s_acc[0];
     // the last marker in front of this chunk (if any): normally in the chunk right in front
-    const uint32_t prev_last = s_prev_chunk < 0 ? 0u : (s_prev_chunk == (int)blockIdx.x - 1 ? prev1_last : chunk_info[s_prev_chunk].y);
+    const uint32_t prev_last = s_prev_chunk < 0 ? 0u : (s_prev_chunk == (int)blockIdx.x - 1 ? prev1_last : chunk_last[s_prev_chunk]);
     for (uint32_t i = (uint32_t)tid; i < tot && !too_many && scans > 0; i += 256) {
         const uint32_t p = (uint32_t)c0 + (s_mpos[i] & 0xFFFFu), num = s_mpos[i] >> 16, rk = rank0 + i;
         int sc = -1;
@@ -358,14 +372,15 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     if (size <= begin || size > 0xFFFFFFF0ull) return -1;
     const uint32_t tb = (tune->scan_tb == 8 || tune->scan_tb == 16 || tune->scan_tb == 32 || tune->scan_tb == 64) ? (uint32_t)tune->scan_tb : gj_scan_lane_bytes(begin, size);
     const uint32_t chunks = (uint32_t)((size - begin + 256ull * tb - 1) / (256ull * tb));
-    uint2* d_chunk = reinterpret_cast<uint2*>(d_scratch); // [chunks] restart markers, position of the last one
+    uint32_t* d_last = d_scratch;                                                            // [chunks] position of the chunk's last restart marker
+    uint16_t* d_cnt = reinterpret_cast<uint16_t*>(d_scratch + (((size_t)chunks + 3) & ~(size_t)3)); // [chunks rounded up to 8] restart markers in the chunk
     if (chunks > maxlen_capacity) return -1;
     *maxlen_part_count = chunks;
     auto scan = tb == 8 ? k_marker_scan<8> : tb == 16 ? k_marker_scan<16> : tb == 32 ? k_marker_scan<32> : k_marker_scan<64>;
     auto segs = tb == 8 ? k_marker_segments<8> : tb == 16 ? k_marker_segments<16> : tb == 32 ? k_marker_segments<32> : k_marker_segments<64>;
-    hipLaunchKernelGGL(scan, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_chunk, d_summary, d_hdr_ref, hdr_n);
+    hipLaunchKernelGGL(scan, dim3(chunks), dim3(256), 0, st, d_jpeg, begin, size, d_cnt, d_last, d_summary, d_hdr_ref, hdr_n);
     gj_debug_stage(debug_sync != 0, st, "k_marker_scan");
-    hipLaunchKernelGGL(segs, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, chunks, d_chunk, h_maxlen_parts, d_summary, h_summary, d_summary_next,
+    hipLaunchKernelGGL(segs, dim3(chunks), dim3(256), 0, st, *g, d_jpeg, begin, size, chunks, d_cnt, d_last, h_maxlen_parts, d_summary, h_summary, d_summary_next,
                        d_seg_pos, d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
     gj_debug_stage(debug_sync != 0, st, "k_marker_segments");
     return hipGetLastError() == hipSuccess ? 0 : -1;

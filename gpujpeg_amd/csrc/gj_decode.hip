@@ -16,7 +16,8 @@ extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, 
     if (tune->dec_tokens == 1) return 1;
     // (interleaved scans -- packed 4:2:2, BASELINE config 4 at q90: 10.4 B per block -- go through the lane-per-segment kernel, whose plane mode
     // pays for the zero fill and the scattered stores of 128-byte blocks: tokens win up to denser streams there)
-    return g->block_count >= 900000 && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
+    // (round 3, k_huffman_decode_tok: a 4K RGB frame -- 389 K blocks -- gains 9 % enc+dec and 7 % decode-only, an HD frame loses 4 %)
+    return g->block_count >= (g->interleaved ? 900000 : 300000) && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
 }
 
 extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4])

@@ -14,7 +14,10 @@ if [ -n "$BATCH" ]; then ARGS="--workload 4k --batch $BATCH --streams ${STREAMS:
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python bench.py --steps ${STEPS:-20} --warmup 3 $ARGS > $OUT/prof_stats.log 2>&1
 tail -1 $OUT/prof_stats.log | cut -c1-300
 PM="--steps 3 --warmup 1 --min-seconds 0 --calibrate"
-if [ -n "$BATCH" ]; then PM="--steps 1 --warmup 1"; fi
+if [ -n "$BATCH" ]; then # (the counter passes crash rocprofv3 with four host threads launching: one pipeline, a batch of 32 -- the traffic per frame is the same)
+  PM="--steps 1 --warmup 1"
+  ARGS="--workload 4k --batch 32 --streams 1 ${BENCH_ARGS}"
+fi
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python bench.py $PM $ARGS > $OUT/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python bench.py $PM $ARGS > $OUT/prof_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/prof_sq -- python bench.py $PM $ARGS > $OUT/prof_sq.log 2>&1

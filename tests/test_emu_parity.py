@@ -25,7 +25,10 @@ EMU_LIB = os.path.join(EMU_DIR, "_build", "libgpujpeg_emu.so")
 def emu_lib(G):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("make") is None:
         pytest.skip("hipemu needs ROCm's clang++ (host compilation of the .hip files)")
-    r = subprocess.run(["make", "-s", "-j8", "-C", EMU_DIR], capture_output=True, text=True)
+    import fcntl
+    with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:  # (pytest-xdist: one worker builds, the others wait for it)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-s", "-j8", "-C", EMU_DIR], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
     lib = G.Library(EMU_LIB)
     assert lib.L.gpujpeg_init_device(0, 0) == 0

@@ -412,7 +412,9 @@ def cpu_baseline_all_cores(spec, frame_host, max_procs=64):
         os.unlink(path)
     return {"value": round(spec.pixels * procs / max(inner) / 1e6, 3), "unit": "Mpix/s", "cores": procs, "host_cores": os.cpu_count(), "kind": "reference",
             "sample": f"{procs} processes x 1 encode+decode of the same {spec.width}x{spec.height} frame at once (frame-level parallelism, the only kind the "
-                      f"reference's CPU code admits), gcc -O3 -march=native; slowest process {max(inner):.2f} s, {wall:.1f} s including start-up"}
+                      f"reference's CPU code admits), gcc -O3 -march=native; slowest process {max(inner):.2f} s, {wall:.1f} s including start-up",
+            "cap": "64 processes is this host's best, not a shortcut: the work is bound by memory bandwidth (64 processes = 13 x one), and with 128 / "
+                   "256 processes (one per core) the same box measured 164.6 / 158.4 Mpix/s in 27 / 58 s (round 3, DESIGN 4.2)"}
 
 
 def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=True):

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         __syncthreads();
         const int nsub = (int)s_sub0[j1];
         const uint32_t sub_bits = sub_bytes * 8u;
-        if (tid == 0) GJ_STAT(32 + min(nsub / 32, 31), 1);
+        if (tid == 0) { GJ_STAT(32 + min(nsub / 32, 31), 1); GJ_STAT(28, sub_bytes != GJ_TOK_SUB ? 1 : 0); }
         for (int k = tid; k < nsub; k += 256) {
             int lo = j0, hi = j1; // segment j with s_sub0[j] <= k < s_sub0[j + 1]
             while (hi - lo > 1) {

@@ -62,6 +62,10 @@ def test_emu_token_mode_decoder(O, G, emu_lib, tc, monkeypatch):
     T.test_token_mode_decoder(O, G, emu_lib, tc, monkeypatch)
 
 
+def test_emu_token_mode_longer_sub_sequences(O, G, emu_lib, monkeypatch):
+    T.test_token_mode_longer_sub_sequences(O, G, emu_lib, monkeypatch)
+
+
 def test_emu_token_mode_damaged_streams(O, G, emu_lib, monkeypatch):
     T.test_token_mode_damaged_streams(O, G, emu_lib, monkeypatch)
 

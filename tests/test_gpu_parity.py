@@ -404,6 +404,24 @@ def test_token_mode_decoder(O, G, gpu_lib, tc, monkeypatch):
     dec.close()
 
 
+def test_token_mode_longer_sub_sequences(O, G, gpu_lib, monkeypatch):
+    """k_huffman_decode_tok cuts a group into sub-sequences of 17..20 bytes instead of 16 when that saves it a whole pass of its 256 lanes
+    (an 8K frame's luminance batches). Forced here on a small frame: batches of GJ_DEC_G segments whose groups hold a little more than
+    256 (and a little more than 512) sub-sequences of 16 bytes."""
+    w, h, q, ri = 1024, 512, 92, 8
+    case = ("longsub", w, h, 1, 1, q, ri, 0, None, 3)
+    raw = natural_image(w, h, 3, seed=17)
+    jpeg = O.encode(oracle_image(O, case), raw)
+    want = O.decode(jpeg)[0]
+    nseg = 3 * ((w // 8) * (h // 8) // ri)
+    monkeypatch.setenv("GJ_DEC_TOKENS", "1")
+    for group_bytes in (4500, 4900, 8600):  # (6 - 13 of the ~50 groups of each run take longer sub-sequences: GJ_TOK_STATS build, tools/tok_lane_stats.py)
+        monkeypatch.setenv("GJ_DEC_G", str(max(1, min(64, round(group_bytes * nseg / jpeg.size)))))
+        dec = G.Decoder(gpu_lib)
+        assert np.array_equal(dec.decode(jpeg)[0], want)
+        dec.close()
+
+
 def test_token_mode_damaged_streams(O, G, gpu_lib, monkeypatch):
     """Token mode on damaged input: flipped bytes and truncation must neither fault nor hang (records nobody wrote, token
     counts that no longer match)."""

@@ -258,9 +258,235 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
 }
 
 
+// ================================================================================================
+// The same idea without the stage (round 3, token mode only): ONE LANE PER RESTART SEGMENT OVER A 96-BYTE RING.
+//
+// What bounds the kernel above is not instruction issue but the latency of a wave's dependent chain (~100 vector instructions and three LDS
+// round trips per symbol, 1 700 cycles per symbol and wave measured on config 4) at the 1.4 decoding waves per SIMD its stage admits: a
+// lane needs its whole segment (~250 B) in LDS, a workgroup's 26 KB hold 87 segments, and the 172 800 segments of config 4 take two
+// generations of workgroups. Here a lane owns a ring of 24 dwords and tops it up itself: all 172 800 segments are resident at once
+// (675 workgroups of 256 lanes, 2.6 decoding waves per SIMD), there is no stage, no cooperative unstuffing, no barrier after the tables
+// have been loaded, and a segment may be of any length.
+//   * refill, wave-synchronous: as soon as ANY lane of a wave has fewer than 16 bytes in front of its bit position, EVERY lane of the
+//     wave tops its ring up (a refill on demand per lane would run the refill code in almost every iteration for somebody): 16-byte
+//     pieces of the lane's own part of the stream (four guarded dword loads), byte by byte without the stuffed zeros into a dword
+//     that is written to the ring when it is complete (big-endian, as the bit reader wants it). Behind the last byte of the segment go
+//     8 zero bytes (a symbol that straddles the end reads zeros, src/gpujpeg_huffman_cpu_decoder.c:80-118);
+//   * the reader keeps 33..64 bits in a 64-bit accumulator and the next dword in a register; it never loads a dword the writer has not
+//     completed (that is what the 16 bytes in front are for);
+//   * symbols, tokens and block records exactly as in k_huffman_decode_seq<il, true>.
+// ================================================================================================
+#define GJ_WIN_DW 24     // dwords of a lane's ring
+#define GJ_WIN_STRIDE 25 // dwords between the rings of neighbouring lanes (odd: the lanes of a half wave hit different banks)
+#define GJ_WIN_AHEAD 128 // complete-dword bits the ring must hold in front of the bit position before a symbol is decoded
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+                                                               const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
+                                                               const uint32_t* __restrict__ seg_index, const int seg_count_max,
+                                                               const uint32_t* __restrict__ seg_count_ptr, const uint16_t* __restrict__ tabs,
+                                                               uint32_t* __restrict__ overflow, uint16_t* __restrict__ d_tok, const uint32_t tok_cap,
+                                                               uint2* __restrict__ d_rec)
+{
+    __shared__ uint32_t s_ring[256 * GJ_WIN_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
+    __shared__ uint8_t s_zz[64 + 64];
+    __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS]; // per MCU block: byte offsets of its DC | AC << 16 tables in s_tab
+    __shared__ uint32_t s_pcomp[GJ_MAX_MCU_BLOCKS];
+    const int tid = threadIdx.x;
+    if (tid < GJ_MAX_MCU_BLOCKS) {
+        const int pp = tid < g.blocks_per_mcu ? tid : 0;
+        const int c = INTERLEAVED ? g.mcu_comp[pp] : 0;
+        s_ptab[tid] = (uint32_t)((g.comp[c].dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((g.comp[c].ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
+        s_pcomp[tid] = (uint32_t)c;
+    }
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(tabs);
+        uint4* dst = reinterpret_cast<uint4*>(s_tab);
+        for (int t = tid; t < 4 * GJ_DEC2_WORDS / 8; t += 256) dst[t] = src[t];
+    }
+    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    const uint32_t* const end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
+    const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
+    const int s = (int)blockIdx.x * 256 + tid;
+    uint32_t pos = 0, len = 0, idx = 0xFFFFFFFFu;
+    if (s < seg_count) {
+        idx = seg_index[s];
+        pos = seg_pos[s];
+        len = seg_len[s];
+        if (idx >= (uint32_t)g.segment_count || (uint64_t)pos + len > jpeg_size) { idx = 0xFFFFFFFFu; len = 0; }
+    }
+    __syncthreads(); // (tables; nothing below crosses waves)
+    bool active = idx != 0xFFFFFFFFu;
+    GjSeg sg;
+    sg.nblocks = 0; sg.comp = 0; sg.mcu_first = 0; sg.first_block = 0;
+    if (active) sg = gj_segment(g, (int)idx);
+    int left = active ? sg.nblocks : 0;
+    active = left > 0;
+    if (__ballot(active) == 0ull) return;
+    const int P = g.blocks_per_mcu;
+    uint32_t* const R = s_ring + tid * GJ_WIN_STRIDE;
+
+    // ---- the writer: stuffed bytes taken, unstuffed bytes written, the dword being filled, its slot in the ring
+    uint32_t src = 0, wr = 0, wacc = 0, wslot = 0;
+    bool prev_ff = false, final = !active;
+    uint32_t end_bit = 0xFFFFFFFFu; // known once the last byte has been written
+    // ---- the reader: `ld` dwords have left the ring (into the accumulator and `nxt`), `rslot` = slot of the next one
+    uint32_t ld = 0, rslot = 0, bitpos = 0, nxt = 0;
+    uint64_t acc = 0;
+    int n = 0;
+
+    auto refill = [&]() {
+        // every lane takes as many bytes as its ring has room for (K), the wave walks through max K in 16-byte pieces
+        uint32_t K = final ? 0u : min(len - src, (ld + (uint32_t)GJ_WIN_DW) * 4u - wr);
+        const bool ends = !final && K == len - src; // the segment's last byte is among them: the 8 zero bytes follow (12 bytes of room are kept for them)
+        if (ends && (ld + (uint32_t)GJ_WIN_DW) * 4u - wr < K + 12u) K = K > 12u ? K - 12u : 0u; // (no room for the tail yet: next time)
+        const bool ends_now = !final && K == len - src;
+        uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + pos + src;
+        const uint32_t* base = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)15);
+        uint32_t skip = (uint32_t)(a & 15);
+        src += K;
+        while (__ballot(K != 0u)) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[q] = (K != 0u && base + q < end) ? base[q] : 0u;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t byte = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                const bool take = (uint32_t)b >= skip && (uint32_t)b - skip < K;
+                const bool keep = take && !(prev_ff && byte == 0u); // (a zero behind 0xFF is stuffing)
+                if (take) prev_ff = byte == 0xFFu;
+                if (keep) {
+                    wacc |= byte << (24u - 8u * (wr & 3u));
+                    wr++;
+                    if ((wr & 3u) == 0) {
+                        R[wslot] = wacc;
+                        wslot = wslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : wslot + 1u;
+                        wacc = 0;
+                    }
+                }
+            }
+            K -= min(K, 16u - skip);
+            skip = 0;
+            base += 4;
+        }
+        if (ends_now) { // the partial dword and 8 zero bytes (two whole dwords of zeros behind it are enough: a symbol has at most 27 bits)
+            end_bit = wr * 8u;
+            R[wslot] = wacc;
+            wslot = wslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : wslot + 1u;
+            R[wslot] = 0;
+            wslot = wslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : wslot + 1u;
+            R[wslot] = 0;
+            wr = ((wr + 3u) & ~3u) + 8u;
+            final = true;
+        }
+    };
+
+    // ---- the first fill and the reader's start
+    refill();
+    acc = (uint64_t)R[0] << 32;
+    n = 32;
+    nxt = R[1];
+    ld = 2;
+    rslot = 2;
+
+    // ---- decode: src/gpujpeg_huffman_gpu_decoder.cu:397-495 / src/gpujpeg_huffman_cpu_decoder.c:245-372
+    int p = 0, comp = INTERLEAVED ? (int)s_pcomp[0] : sg.comp;
+    uint32_t tdc, tac; // byte offsets of the block's tables in s_tab
+    {
+        const uint32_t pt = INTERLEAVED ? s_ptab[0] : ((uint32_t)((g.comp[comp].dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((g.comp[comp].ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16));
+        tdc = (pt & 0xFFFFu) * 2u;
+        tac = (pt >> 16) * 2u;
+    }
+    int dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
+    int z = 0;
+    const uint32_t tbase = 4u * pos;
+    const bool tok_ok = tbase <= tok_cap && 4u * len + 8u <= tok_cap - tbase; // (always, with the capacity the host allocates)
+    uint32_t ntok = 0, blk_first = 0, blk_dc = 0, big = 0;
+    uint64_t tbuf = 0;
+    uint32_t rec = INTERLEAVED ? (uint32_t)sg.mcu_first * (uint32_t)P : (uint32_t)sg.first_block;
+    const uint8_t* const tab8 = reinterpret_cast<const uint8_t*>(s_tab);
+    while (__ballot(active)) {
+        if (__ballot(active && !final && (wr & ~3u) * 8u < bitpos + (uint32_t)GJ_WIN_AHEAD)) refill();
+        if (active) {
+            int v = 0, adv = 64; // (data exhausted: the block ends here, its remaining coefficients stay zero)
+            bool coef = false;
+            uint32_t e_sz = 0;
+            if (bitpos < end_bit) {
+                if (n <= 32) {
+                    acc |= (uint64_t)nxt << (32 - n);
+                    n += 32;
+                    nxt = R[rslot];
+                    rslot = rslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : rslot + 1u;
+                    ld++;
+                }
+                const uint32_t hi = (uint32_t)(acc >> 32);
+                const uint16_t* t = reinterpret_cast<const uint16_t*>(tab8 + (z == 0 ? tdc : tac));
+                uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
+                if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
+                const int tot = (int)(e & 31u), sz = (int)((e >> 5) & 15u);
+                adv = tot ? (int)((e >> 9) & 63u) : 64; // (an entry of a table the stream never defined: give up on the block)
+                const int used = tot - sz;
+                const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
+                v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
+                coef = sz != 0;
+                e_sz = (uint32_t)sz;
+                acc <<= tot;
+                n -= tot;
+                bitpos = tot ? bitpos + (uint32_t)tot : end_bit;
+                if (tot == 0) final = true; // (nothing more is read from this segment)
+            }
+            if (z == 0) { // DC: predicted from the previous block of the component inside this segment
+                int pred = dc0;
+                if (INTERLEAVED) pred = comp == 0 ? dc0 : comp == 1 ? dc1 : comp == 2 ? dc2 : dc3;
+                v += pred;
+                if (!INTERLEAVED || comp == 0) dc0 = v; else if (comp == 1) dc1 = v; else if (comp == 2) dc2 = v; else dc3 = v;
+                blk_dc = (uint32_t)v;
+            } else if (coef) {
+                const int zp = z + adv - 1;
+                big |= (e_sz >= 10u) ? 1u : 0u;
+                tbuf = (tbuf >> 16) | ((uint64_t)(uint16_t)(((uint32_t)v << 6) | s_zz[zp]) << 48);
+                ntok++;
+                if ((ntok & 3u) == 0 && tok_ok) *reinterpret_cast<uint2*>(d_tok + tbase + ntok - 4u) = make_uint2((uint32_t)tbuf, (uint32_t)(tbuf >> 32));
+            }
+            z += adv;
+            if (z >= 64) { // next block of this segment: its record (where its tokens are, how many, the DC term)
+                z = 0;
+                left--;
+                d_rec[rec] = make_uint2(tok_ok ? tbase + blk_first : 0u, ((tok_ok ? min(ntok - blk_first, 63u) : 0u) << 16) | (blk_dc & 0xFFFFu));
+                rec++;
+                blk_first = ntok;
+                blk_dc = 0;
+                if (INTERLEAVED) {
+                    if (++p == P) p = 0;
+                    comp = (int)s_pcomp[p];
+                    const uint32_t pt = s_ptab[p];
+                    tdc = (pt & 0xFFFFu) * 2u;
+                    tac = (pt >> 16) * 2u;
+                }
+                if (left == 0) {
+                    active = false;
+                    if (tok_ok) // the last one to three tokens
+                        for (uint32_t r = ntok & 3u, i = 0; i < r; i++) d_tok[tbase + (ntok & ~3u) + i] = (uint16_t)(tbuf >> (16u * (4u - r + i)));
+                    if (big) *overflow = 1u; // a value beyond a token's 10 bits: the host decodes the frame again through the planes
+                }
+            }
+        }
+    }
+}
+
 void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st, const bool tokens)
 {
     const gj_geom& g = job->g;
+#ifndef GJ_SEQ_NO_RING
+    if (tokens) { // (token mode: the ring kernel; -DGJ_SEQ_NO_RING builds the A/B variant with the staged one)
+        auto kernel = g.interleaved ? k_huffman_decode_win<true> : k_huffman_decode_win<false>;
+        hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + 255u) / 256u), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
+                           job->d_seg_index, job->seg_count, job->d_seg_count, job->d_huff_tab2, job->d_overflow, (uint16_t*)job->d_tok, job->tok_cap,
+                           (uint2*)job->d_blkrec);
+        return;
+    }
+#endif
     const unsigned avg = (unsigned)(job->jpeg_size / (uint64_t)job->seg_count) + 12u;
     const int NS = max(1, min(GJ_SEQ_NS, (int)((GJ_SEQ_STAGE * 7u / 8u) / avg)));
     auto kernel = tokens ? (g.interleaved ? k_huffman_decode_seq<true, true> : k_huffman_decode_seq<false, true>)

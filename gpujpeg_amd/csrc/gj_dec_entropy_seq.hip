@@ -293,12 +293,18 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
     __shared__ uint8_t s_zz[64 + 64];
     __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS]; // per MCU block: byte offsets of its DC | AC << 16 tables in s_tab
     __shared__ uint32_t s_pcomp[GJ_MAX_MCU_BLOCKS];
+    __shared__ uint32_t s_sel[16];
     const int tid = threadIdx.x;
     if (tid < GJ_MAX_MCU_BLOCKS) {
         const int pp = tid < g.blocks_per_mcu ? tid : 0;
         const int c = INTERLEAVED ? g.mcu_comp[pp] : 0;
         s_ptab[tid] = (uint32_t)((g.comp[c].dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((g.comp[c].ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
         s_pcomp[tid] = (uint32_t)c;
+        uint32_t sel = 0x0C0C0C0Cu; // (0x0C selects a zero byte)
+        int at = 3;
+        for (int k = 0; k < 4; k++)
+            if (tid & (1 << k)) { sel = (sel & ~(0xFFu << (8 * at))) | ((uint32_t)k << (8 * at)); at--; }
+        s_sel[tid] = sel;
     }
     {
         const uint4* src = reinterpret_cast<const uint4*>(tabs);
@@ -329,66 +335,89 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
 
     // ---- the writer: stuffed bytes taken, unstuffed bytes written, the dword being filled, its slot in the ring
     uint32_t src = 0, wr = 0, wacc = 0, wslot = 0;
-    bool prev_ff = false, final = !active;
-    uint32_t end_bit = 0xFFFFFFFFu; // known once the last byte has been written
-    // ---- the reader: `ld` dwords have left the ring (into the accumulator and `nxt`), `rslot` = slot of the next one
-    uint32_t ld = 0, rslot = 0, bitpos = 0, nxt = 0;
-    uint64_t acc = 0;
-    int n = 0;
-
-    auto refill = [&]() {
-        // every lane takes as many bytes as its ring has room for (K), the wave walks through max K in 16-byte pieces
-        uint32_t K = final ? 0u : min(len - src, (ld + (uint32_t)GJ_WIN_DW) * 4u - wr);
-        const bool ends = !final && K == len - src; // the segment's last byte is among them: the 8 zero bytes follow (12 bytes of room are kept for them)
-        if (ends && (ld + (uint32_t)GJ_WIN_DW) * 4u - wr < K + 12u) K = K > 12u ? K - 12u : 0u; // (no room for the tail yet: next time)
-        const bool ends_now = !final && K == len - src;
-        uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + pos + src;
-        const uint32_t* base = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)15);
-        uint32_t skip = (uint32_t)(a & 15);
-        src += K;
-        while (__ballot(K != 0u)) {
-            uint32_t w[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) w[q] = (K != 0u && base + q < end) ? base[q] : 0u;
-#pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const uint32_t byte = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                const bool take = (uint32_t)b >= skip && (uint32_t)b - skip < K;
-                const bool keep = take && !(prev_ff && byte == 0u); // (a zero behind 0xFF is stuffing)
-                if (take) prev_ff = byte == 0xFFu;
-                if (keep) {
-                    wacc |= byte << (24u - 8u * (wr & 3u));
-                    wr++;
-                    if ((wr & 3u) == 0) {
-                        R[wslot] = wacc;
-                        wslot = wslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : wslot + 1u;
-                        wacc = 0;
-                    }
-                }
-            }
-            K -= min(K, 16u - skip);
-            skip = 0;
-            base += 4;
-        }
-        if (ends_now) { // the partial dword and 8 zero bytes (two whole dwords of zeros behind it are enough: a symbol has at most 27 bits)
-            end_bit = wr * 8u;
-            R[wslot] = wacc;
-            wslot = wslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : wslot + 1u;
-            R[wslot] = 0;
-            wslot = wslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : wslot + 1u;
-            R[wslot] = 0;
-            wr = ((wr + 3u) & ~3u) + 8u;
-            final = true;
-        }
+    bool final = !active;
+    // ---- the reader (as in gj_dec_entropy_tok.hip): rp = bit position - 1 inside the ring (0 .. 767, wraps), the next 32 bits are
+    //      v_alignbit_b32(R[rp >> 5], R[(rp >> 5) + 1], ~rp) -- slot 24 mirrors slot 0 --; `ahead` = bits between the bit position and the
+    //      end of the complete dwords in the ring; a symbol is decoded while ahead > stop (stop = the zero tail once the segment's last
+    //      byte has been written: then that is "bit position < end of the segment")
+    uint32_t rp = 32u * GJ_WIN_DW - 1u;
+    int ahead = 0, stop = 0;
+    auto put = [&](const uint32_t v) { // a complete dword into the ring
+        R[wslot] = v;
+        if (wslot == 0) R[GJ_WIN_DW] = v;
+        wslot = wslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : wslot + 1u;
     };
 
-    // ---- the first fill and the reader's start
-    refill();
-    acc = (uint64_t)R[0] << 32;
-    n = 32;
-    nxt = R[1];
-    ld = 2;
-    rslot = 2;
+    // s_sel[m]: byte selector (v_perm_b32) that moves the bytes of a dword whose bit k of m is set to the top of the result, first byte
+    // of the stream in the most significant position; the others are zero
+    auto refill = [&]() {
+        // every lane takes as many bytes as its ring has room for (K), the wave walks through max K in 16-byte pieces; the loads of the
+        // next piece are in flight while this one is worked on. In use: from the dword of the bit position to the last byte written
+        const uint32_t room = 4u * GJ_WIN_DW - (((uint32_t)ahead + ((rp + 1u) & 31u)) >> 3) - (wr & 3u);
+        uint32_t K = final ? 0u : min(len - src, room);
+        // the segment's last byte among them: a partial dword and 8 zero bytes follow (12 bytes of room are kept for them, else next time)
+        if (!final && K == len - src && room < K + 12u) K = K > 12u ? K - 12u : 0u;
+        const bool ends_now = !final && K == len - src;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(jpeg) + pos + src;
+        const uint32_t* base = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)15);
+        uint32_t lo = (uint32_t)(a & 15), hi = lo + K; // the bytes [lo, hi) of the pieces from `base` on are this lane's
+        src += K;
+        const uint32_t wr0 = wr;
+        uint32_t w[4], wn[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = (hi > 0u && base + q < end) ? base[q] : 0u;
+        // 0xFF marks (bit 7 per byte) of the dword in front of the first piece: its last byte decides about a zero at the start of the piece
+        // (all bytes in front of `lo` are the segment's own, taken earlier, or what precedes the segment: the end of a marker, never 0xFF)
+        uint32_t ffcarry = 0;
+        if (hi > 0u && reinterpret_cast<uintptr_t>(base) > reinterpret_cast<uintptr_t>(jpeg) + 4u) {
+            const uint32_t x = base[-1];
+            ffcarry = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
+        }
+        while (__ballot(hi > lo)) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) wn[q] = (hi > 16u && base + 4 + q < end) ? base[4 + q] : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t x = w[q];
+                const uint32_t eq = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;         // bit 7 of the bytes that are 0xFF
+                const uint32_t zr = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;      // ... of the bytes that are 0x00
+                const uint32_t before = __builtin_amdgcn_alignbit(eq, ffcarry, 24);               // ... of the bytes behind a 0xFF
+                ffcarry = eq;
+                // this lane's bytes of the dword: [lo, hi) cut to [4q, 4q + 4)
+                const uint32_t b0 = min(max(lo, 4u * q), 4u * q + 4u) - 4u * q, b1 = min(max(hi, 4u * q), 4u * q + 4u) - 4u * q;
+                const uint32_t below0 = b0 >= 4u ? 0xFFFFFFFFu : (1u << (8u * b0)) - 1u, below1 = b1 >= 4u ? 0xFFFFFFFFu : (1u << (8u * b1)) - 1u;
+                const uint32_t mine = below1 & ~below0;
+                const uint32_t keep = mine & ~(before & zr) & 0x80808080u; // (a zero behind 0xFF is stuffing)
+                const uint32_t m = (((keep >> 7) * 0x01020408u) >> 24) & 15u;
+                const uint32_t c = (uint32_t)__popc(keep);
+                const uint32_t comp = __builtin_amdgcn_perm(0u, x, s_sel[m]);
+                // append the c bytes of `comp` (left aligned) to the dword being filled
+                const uint32_t sh = 8u * (wr & 3u);
+                const uint32_t top = wacc | (comp >> sh), rest = __builtin_amdgcn_alignbit(comp, 0u, sh); // (sh = 0: rest = 0)
+                const bool full = (wr & 3u) + c >= 4u;
+                if (full) put(top);
+                wacc = full ? rest : top;
+                wr += c;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[q] = wn[q];
+            lo = lo > 16u ? lo - 16u : 0u;
+            hi = hi > 16u ? hi - 16u : 0u;
+            base += 4;
+        }
+        if (ends_now) { // the partial dword and 8 zero bytes (a symbol has at most 27 bits)
+            const uint32_t real = wr;
+            put(wacc);
+            put(0u);
+            put(0u);
+            wr = ((wr + 3u) & ~3u) + 8u;
+            stop = (int)((wr - real) * 8u);
+            final = true;
+        }
+        ahead += (int)(((wr & ~3u) - (wr0 & ~3u)) * 8u);
+    };
+
+    refill(); // the first fill
 
     // ---- decode: src/gpujpeg_huffman_gpu_decoder.cu:397-495 / src/gpujpeg_huffman_cpu_decoder.c:245-372
     int p = 0, comp = INTERLEAVED ? (int)s_pcomp[0] : sg.comp;
@@ -399,58 +428,60 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
         tac = (pt >> 16) * 2u;
     }
     int dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
-    int z = 0;
+    uint32_t z = 0, toff = tdc;
     const uint32_t tbase = 4u * pos;
     const bool tok_ok = tbase <= tok_cap && 4u * len + 8u <= tok_cap - tbase; // (always, with the capacity the host allocates)
-    uint32_t ntok = 0, blk_first = 0, blk_dc = 0, big = 0;
-    uint64_t tbuf = 0;
+    uint32_t ntok = 0, blk_first = 0, blk_dc = 0, mx = 0, tb_lo = 0, tb_hi = 0;
     uint32_t rec = INTERLEAVED ? (uint32_t)sg.mcu_first * (uint32_t)P : (uint32_t)sg.first_block;
     const uint8_t* const tab8 = reinterpret_cast<const uint8_t*>(s_tab);
     while (__ballot(active)) {
-        if (__ballot(active && !final && (wr & ~3u) * 8u < bitpos + (uint32_t)GJ_WIN_AHEAD)) refill();
+        if (__ballot(active && !final && ahead < GJ_WIN_AHEAD)) refill();
         if (active) {
-            int v = 0, adv = 64; // (data exhausted: the block ends here, its remaining coefficients stay zero)
-            bool coef = false;
-            uint32_t e_sz = 0;
-            if (bitpos < end_bit) {
-                if (n <= 32) {
-                    acc |= (uint64_t)nxt << (32 - n);
-                    n += 32;
-                    nxt = R[rslot];
-                    rslot = rslot + 1u == (uint32_t)GJ_WIN_DW ? 0u : rslot + 1u;
-                    ld++;
-                }
-                const uint32_t hi = (uint32_t)(acc >> 32);
-                const uint16_t* t = reinterpret_cast<const uint16_t*>(tab8 + (z == 0 ? tdc : tac));
-                uint32_t e = t[hi >> (32 - GJ_DEC_FAST_BITS)];
-                if ((e & 31u) == 0) e = t[(e >> 5) + ((hi >> 16) & 63u)]; // codes longer than 10 bits
-                const int tot = (int)(e & 31u), sz = (int)((e >> 5) & 15u);
-                adv = tot ? (int)((e >> 9) & 63u) : 64; // (an entry of a table the stream never defined: give up on the block)
-                const int used = tot - sz;
-                const uint32_t bits = sz ? (hi << used) >> (32 - sz) : 0u;
-                v = (sz && bits < (1u << (sz - 1))) ? (int)bits - (int)((1u << sz) - 1u) : (int)bits;
-                coef = sz != 0;
-                e_sz = (uint32_t)sz;
-                acc <<= tot;
-                n -= tot;
-                bitpos = tot ? bitpos + (uint32_t)tot : end_bit;
-                if (tot == 0) final = true; // (nothing more is read from this segment)
+            uint32_t adv = 64, e = 0, sz = 0; // (data exhausted: the block ends here, its remaining coefficients stay zero)
+            int v = 0;
+            if (ahead > stop) {
+                const uint32_t wi = rp >> 5;
+                const uint32_t win = __builtin_amdgcn_alignbit(R[wi], R[wi + 1], ~rp); // the next 32 bits of the segment
+                const uint16_t* t = reinterpret_cast<const uint16_t*>(tab8 + toff);
+                e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
+                if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)]; // codes longer than 10 bits (the host rejects streams whose scans
+                                                                            // refer to tables they never defined: no entry is 0 after this)
+                const uint32_t tot = e & 31u;
+                sz = (e >> 5) & 15u;
+                adv = (e >> 9) & 63u;
+                // the sz magnitude bits behind the code, extended (ITU T.81 F.2.2.1), as in gj_tok_decode; meaningless without magnitude bits
+                const uint32_t x = win << (tot - sz);
+                uint32_t neg = (uint32_t)((int32_t)~x >> 31);
+                GJ_KEEP(neg);
+                const uint32_t mag = (x ^ neg) >> ((32u - sz) & 31u);
+                v = (int)((mag ^ neg) - neg);
+                rp += tot;
+                rp = min(rp, rp - 32u * GJ_WIN_DW); // (wraps: the smaller of the two is the one inside the ring)
+                ahead -= (int)tot;
             }
-            if (z == 0) { // DC: predicted from the previous block of the component inside this segment
-                int pred = dc0;
-                if (INTERLEAVED) pred = comp == 0 ? dc0 : comp == 1 ? dc1 : comp == 2 ? dc2 : dc3;
-                v += pred;
-                if (!INTERLEAVED || comp == 0) dc0 = v; else if (comp == 1) dc1 = v; else if (comp == 2) dc2 = v; else dc3 = v;
-                blk_dc = (uint32_t)v;
-            } else if (coef) {
-                const int zp = z + adv - 1;
-                big |= (e_sz >= 10u) ? 1u : 0u;
-                tbuf = (tbuf >> 16) | ((uint64_t)(uint16_t)(((uint32_t)v << 6) | s_zz[zp]) << 48);
+            if ((int16_t)e < 0) { // a non-zero AC coefficient
+                mx = max(mx, sz);
+                const uint32_t tok = (((uint32_t)v << 6) | s_zz[z + adv - 1u]) & 0xFFFFu;
+                tb_lo = __builtin_amdgcn_alignbit(tb_hi, tb_lo, 16); // the four-token buffer moves down by one
+                tb_hi = (tb_hi >> 16) | (tok << 16);
                 ntok++;
-                if ((ntok & 3u) == 0 && tok_ok) *reinterpret_cast<uint2*>(d_tok + tbase + ntok - 4u) = make_uint2((uint32_t)tbuf, (uint32_t)(tbuf >> 32));
+                if ((ntok & 3u) == 0 && tok_ok) *reinterpret_cast<uint2*>(d_tok + tbase + ntok - 4u) = make_uint2(tb_lo, tb_hi);
+            } else if (z == 0) { // DC: predicted from the previous block of the component inside this segment
+                const int d = sz ? v : 0;
+                const bool c0 = !INTERLEAVED || comp == 0, c1 = comp == 1, c2 = comp == 2;
+                const int pred = c0 ? dc0 : c1 ? dc1 : c2 ? dc2 : dc3;
+                const int dc = d + pred;
+                dc0 = c0 ? dc : dc0;
+                if (INTERLEAVED) {
+                    dc1 = c1 ? dc : dc1;
+                    dc2 = c2 ? dc : dc2;
+                    dc3 = (c0 || c1 || c2) ? dc3 : dc;
+                }
+                blk_dc = (uint32_t)dc;
             }
             z += adv;
-            if (z >= 64) { // next block of this segment: its record (where its tokens are, how many, the DC term)
+            toff = tac;
+            if (z >= 64u) { // next block of this segment: its record (where its tokens are, how many, the DC term)
                 z = 0;
                 left--;
                 d_rec[rec] = make_uint2(tok_ok ? tbase + blk_first : 0u, ((tok_ok ? min(ntok - blk_first, 63u) : 0u) << 16) | (blk_dc & 0xFFFFu));
@@ -464,11 +495,14 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
                     tdc = (pt & 0xFFFFu) * 2u;
                     tac = (pt >> 16) * 2u;
                 }
+                toff = tdc;
                 if (left == 0) {
                     active = false;
-                    if (tok_ok) // the last one to three tokens
+                    if (tok_ok) { // the last one to three tokens
+                        const uint64_t tbuf = ((uint64_t)tb_hi << 32) | tb_lo;
                         for (uint32_t r = ntok & 3u, i = 0; i < r; i++) d_tok[tbase + (ntok & ~3u) + i] = (uint16_t)(tbuf >> (16u * (4u - r + i)));
-                    if (big) *overflow = 1u; // a value beyond a token's 10 bits: the host decodes the frame again through the planes
+                    }
+                    if (mx >= 10u) *overflow = 1u; // a value beyond a token's 10 bits: the host decodes the frame again through the planes
                 }
             }
         }

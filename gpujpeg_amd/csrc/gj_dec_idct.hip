@@ -221,6 +221,8 @@ __device__ __forceinline__ GjTokRange gj_tok_fetch(const uint16_t* __restrict__ 
 
 // One block per lane: zeros, the DC term and the lane's tokens go into its tile slot. `fast`: the wave's tokens are in the stage
 // already (dense range starting at token S).
+// MULTI: several ranges are staged together when they fit (the kernels fed by the lane-per-segment decoders, where that is the normal case)
+template <bool MULTI>
 __device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint16_t* stage, const int lane, const bool fast, const uint32_t S, const uint32_t start,
                                                const uint32_t cnt, const uint32_t dc, const bool in_plane, const uint4* __restrict__ plane_block,
                                                const uint16_t* __restrict__ d_tok)
@@ -246,24 +248,53 @@ __device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint16_t* stage, c
         }
         if (a < b) gj_slot_put(slot, swz, stage[a]);
     } else {
-        // several ranges (a decoder batch ended inside the wave's blocks) or more tokens than the stage holds: range by range,
-        // chunk by chunk
+        // several ranges (a decoder batch ended inside the wave's blocks; the lane-per-segment decoders start a range per restart segment:
+        // two or three in every wave of config 4) or more tokens than the stage holds
         const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)end, 0x138, 0xF, 0xF, false);
-        unsigned long long runs = __ballot(lane == 0 || start != prev_end);
-        while (runs) {
+        const unsigned long long runs0 = __ballot(lane == 0 || start != prev_end);
+        // all ranges behind each other in the stage, each from its 16-byte piece on: their loads are in flight together
+        uint32_t total = 0, my_at = 0;
+        for (unsigned long long runs = MULTI ? runs0 : 0ull; runs;) {
             const int d = __builtin_ctzll(runs);
             runs &= runs - 1;
             const int dn = runs ? __builtin_ctzll(runs) : 64;
             const uint32_t RS = (uint32_t)__builtin_amdgcn_readlane((int)start, d), RE = (uint32_t)__builtin_amdgcn_readlane((int)end, dn - 1);
-            const bool mine = lane >= d && lane < dn;
-            for (uint32_t base = RS & ~7u; base < RE; base += GJ_TOK_STAGE) {
-                gj_wave_sync();
-                for (uint32_t i = (uint32_t)lane * 8u; i < GJ_TOK_STAGE && base + i < RE; i += 512u)
-                    *reinterpret_cast<uint4*>(stage + i) = *reinterpret_cast<const uint4*>(d_tok + base + i);
-                gj_wave_sync();
-                if (mine) {
-                    const uint32_t b = min(end, base + GJ_TOK_STAGE);
-                    for (uint32_t a = max(start, base); a < b; a++) gj_slot_put(slot, swz, stage[a - base]);
+            if (lane >= d && lane < dn) my_at = total + (start - (RS & ~7u));
+            total += RE > (RS & ~7u) ? (RE - (RS & ~7u) + 7u) & ~7u : 0u;
+            if (RE < RS) total = GJ_TOK_STAGE + 1u; // (records of a damaged stream: the careful way below)
+        }
+        if (MULTI && total <= GJ_TOK_STAGE) {
+            gj_wave_sync();
+            uint32_t at = 0;
+            for (unsigned long long runs = runs0; runs;) {
+                const int d = __builtin_ctzll(runs);
+                runs &= runs - 1;
+                const int dn = runs ? __builtin_ctzll(runs) : 64;
+                const uint32_t RS = (uint32_t)__builtin_amdgcn_readlane((int)start, d) & ~7u, RE = (uint32_t)__builtin_amdgcn_readlane((int)end, dn - 1);
+                for (uint32_t i = (uint32_t)lane * 8u; RS + i < RE; i += 512u)
+                    *reinterpret_cast<uint4*>(stage + at + i) = *reinterpret_cast<const uint4*>(d_tok + RS + i);
+                at += RE > RS ? (RE - RS + 7u) & ~7u : 0u;
+            }
+            gj_wave_sync();
+            for (uint32_t a = 0; a < cnt; a++) gj_slot_put(slot, swz, stage[my_at + a]);
+        } else {
+            // range by range, chunk by chunk
+            unsigned long long runs = runs0;
+            while (runs) {
+                const int d = __builtin_ctzll(runs);
+                runs &= runs - 1;
+                const int dn = runs ? __builtin_ctzll(runs) : 64;
+                const uint32_t RS = (uint32_t)__builtin_amdgcn_readlane((int)start, d), RE = (uint32_t)__builtin_amdgcn_readlane((int)end, dn - 1);
+                const bool mine = lane >= d && lane < dn;
+                for (uint32_t base = RS & ~7u; base < RE; base += GJ_TOK_STAGE) {
+                    gj_wave_sync();
+                    for (uint32_t i = (uint32_t)lane * 8u; i < GJ_TOK_STAGE && base + i < RE; i += 512u)
+                        *reinterpret_cast<uint4*>(stage + i) = *reinterpret_cast<const uint4*>(d_tok + base + i);
+                    gj_wave_sync();
+                    if (mine) {
+                        const uint32_t b = min(end, base + GJ_TOK_STAGE);
+                        for (uint32_t a = max(start, base); a < b; a++) gj_slot_put(slot, swz, stage[a - base]);
+                    }
                 }
             }
         }
@@ -325,7 +356,7 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
             if (lane * 8 + 512 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 8 + 512) = cur.t1;
         }
         if (c < 2) cur = gj_tok_fetch(d_tok, start[c + 1], cnt[c + 1], lane);
-        gj_tok_to_slot(slot, stage, lane, fast, S, start[c], cnt[c], dc[c], in_plane[c],
+        gj_tok_to_slot<false>(slot, stage, lane, fast, S, start[c], cnt[c], dc[c], in_plane[c],
                        reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (size_t)lb * 64), d_tok);
         // the block as rows; dequantisation + IDCT
         uint32_t wb[32];
@@ -386,7 +417,7 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_uyvy422(const gj_geom g, co
     }
     __syncthreads(); // (s_q)
     const size_t blk = p < 2 ? (size_t)my * g.comp[0].blocks_x + 2 * mx + p : (size_t)m; // (plane address: blocks of long segments only)
-    gj_tok_to_slot(slot, stage, lane, tr.fast, tr.S, start, cnt, dc, in_plane,
+    gj_tok_to_slot<true>(slot, stage, lane, tr.fast, tr.S, start, cnt, dc, in_plane,
                    reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (m < nm ? blk : 0) * 64), d_tok);
     uint32_t wb[32];
 #pragma unroll

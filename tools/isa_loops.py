@@ -61,7 +61,7 @@ def mix_json():
     kernels = {"enc:k_encode_rgb444": ("gj_encode.o", "k_encode_rgb444<1, 3>"), "enc:k_assemble": ("gj_encode.o", "k_assemble"),
                "enc:k_encode_uyvy422": ("gj_encode.o", "k_encode_uyvy422"),
                "dec:k_huffman_decode_tok": ("gj_dec_entropy_tok.o", "k_huffman_decode_tok<true>"), "dec:k_idct_tok_rgb444": ("gj_dec_idct.o", "k_idct_tok_rgb444<3, 1>"),
-               "dec:k_huffman_decode_seq": ("gj_dec_entropy_seq.o", "k_huffman_decode_seq<true, true>"), "dec:k_idct_tok_uyvy422": ("gj_dec_idct.o", "k_idct_tok_uyvy422"),
+               "dec:k_huffman_decode_win": ("gj_dec_entropy_seq.o", "k_huffman_decode_win<true>"), "dec:k_huffman_decode_seq": ("gj_dec_entropy_seq.o", "k_huffman_decode_seq<true, false>"), "dec:k_idct_tok_uyvy422": ("gj_dec_idct.o", "k_idct_tok_uyvy422"),
                "dec:k_huffman_decode_par": ("gj_dec_entropy_par.o", "k_huffman_decode_par<false, 16>"), "dec:k_idct_fused_rgb444": ("gj_dec_idct.o", "k_idct_fused_rgb444<3, 1>")}
     out = {}
     for key, (obj, name) in kernels.items():

@@ -276,12 +276,13 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
 //     completed (that is what the 16 bytes in front are for);
 //   * symbols, tokens and block records exactly as in k_huffman_decode_seq<il, true>.
 // ================================================================================================
-#define GJ_WIN_DW 24     // dwords of a lane's ring
-#define GJ_WIN_STRIDE 25 // dwords between the rings of neighbouring lanes (odd: the lanes of a half wave hit different banks)
+#define GJ_WIN_DW 20     // dwords of a lane's ring
+#define GJ_WIN_STRIDE 21 // dwords between the rings of neighbouring lanes: the ring + the mirror of its slot 0 (odd: the lanes of a half wave hit different banks)
+#define GJ_WIN_OUT 17    // dwords of a lane's output stage: 16 tokens, 4 block records (+ 1: odd again)
 #define GJ_WIN_AHEAD 128 // complete-dword bits the ring must hold in front of the bit position before a symbol is decoded
 
 template <bool INTERLEAVED>
-__global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+__global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                                const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                                const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                                const uint32_t* __restrict__ seg_count_ptr, const uint16_t* __restrict__ tabs,
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
                                                                uint2* __restrict__ d_rec)
 {
     __shared__ uint32_t s_ring[256 * GJ_WIN_STRIDE];
+    __shared__ uint32_t s_out[256 * GJ_WIN_OUT];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
     __shared__ uint8_t s_zz[64 + 64];
     __shared__ uint32_t s_ptab[GJ_MAX_MCU_BLOCKS]; // per MCU block: byte offsets of its DC | AC << 16 tables in s_tab
@@ -429,10 +431,16 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
     }
     int dc0 = 0, dc1 = 0, dc2 = 0, dc3 = 0;
     uint32_t z = 0, toff = tdc;
-    const uint32_t tbase = 4u * pos;
-    const bool tok_ok = tbase <= tok_cap && 4u * len + 8u <= tok_cap - tbase; // (always, with the capacity the host allocates)
-    uint32_t ntok = 0, blk_first = 0, blk_dc = 0, mx = 0, tb_lo = 0, tb_hi = 0;
-    uint32_t rec = INTERLEAVED ? (uint32_t)sg.mcu_first * (uint32_t)P : (uint32_t)sg.first_block;
+    // Output: the segment's tokens form a run inside its own part of the token array (4 tokens per stream byte: a token takes at least
+    // 3 bits) that starts on a 32-byte boundary; sixteen tokens, and the records of four blocks, are collected in LDS and leave as whole
+    // aligned 32-byte pieces -- 8-byte stores from 172 800 lanes at once kept two partial lines per lane open in the L2 and wrote 670 MB
+    // for 86 MB of tokens and records. (A segment too short to leave room for the alignment keeps the 8-byte boundary it starts on.)
+    const uint32_t tbase = len >= 6u ? (4u * pos + 15u) & ~15u : 4u * pos;
+    const bool tok_ok = 4u * pos <= tok_cap && 4u * len + 8u <= tok_cap - 4u * pos; // (always, with the capacity the host allocates)
+    uint32_t* const OT = s_out + tid * GJ_WIN_OUT;
+    uint16_t* const OT16 = reinterpret_cast<uint16_t*>(OT);
+    uint32_t ntok = 0, blk_first = 0, blk_dc = 0, mx = 0;
+    uint32_t rec = INTERLEAVED ? (uint32_t)sg.mcu_first * (uint32_t)P : (uint32_t)sg.first_block, nrec = 0;
     const uint8_t* const tab8 = reinterpret_cast<const uint8_t*>(s_tab);
     while (__ballot(active)) {
         if (__ballot(active && !final && ahead < GJ_WIN_AHEAD)) refill();
@@ -462,10 +470,17 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
             if ((int16_t)e < 0) { // a non-zero AC coefficient
                 mx = max(mx, sz);
                 const uint32_t tok = (((uint32_t)v << 6) | s_zz[z + adv - 1u]) & 0xFFFFu;
-                tb_lo = __builtin_amdgcn_alignbit(tb_hi, tb_lo, 16); // the four-token buffer moves down by one
-                tb_hi = (tb_hi >> 16) | (tok << 16);
+                OT16[ntok & 15u] = (uint16_t)tok;
                 ntok++;
-                if ((ntok & 3u) == 0 && tok_ok) *reinterpret_cast<uint2*>(d_tok + tbase + ntok - 4u) = make_uint2(tb_lo, tb_hi);
+                if ((ntok & 15u) == 0 && tok_ok) { // sixteen tokens: one 32-byte piece (16-byte aligned when the run starts on the segment's own boundary)
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(d_tok + tbase + ntok - 16u);
+                    if ((tbase & 7u) == 0) {
+                        reinterpret_cast<uint4*>(dst)[0] = make_uint4(OT[0], OT[1], OT[2], OT[3]);
+                        reinterpret_cast<uint4*>(dst)[1] = make_uint4(OT[4], OT[5], OT[6], OT[7]);
+                    } else {
+                        for (int q = 0; q < 4; q++) reinterpret_cast<uint2*>(dst)[q] = make_uint2(OT[2 * q], OT[2 * q + 1]);
+                    }
+                }
             } else if (z == 0) { // DC: predicted from the previous block of the component inside this segment
                 const int d = sz ? v : 0;
                 const bool c0 = !INTERLEAVED || comp == 0, c1 = comp == 1, c2 = comp == 2;
@@ -484,7 +499,23 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
             if (z >= 64u) { // next block of this segment: its record (where its tokens are, how many, the DC term)
                 z = 0;
                 left--;
-                d_rec[rec] = make_uint2(tok_ok ? tbase + blk_first : 0u, ((tok_ok ? min(ntok - blk_first, 63u) : 0u) << 16) | (blk_dc & 0xFFFFu));
+                {
+                    const uint32_t r0 = tok_ok ? tbase + blk_first : 0u, r1 = ((tok_ok ? min(ntok - blk_first, 63u) : 0u) << 16) | (blk_dc & 0xFFFFu);
+                    const uint32_t slot = rec & 3u;
+                    OT[8u + 2u * slot] = r0;
+                    OT[9u + 2u * slot] = r1;
+                    nrec++;
+                    if (slot == 3u || left == 0) { // the group of four records ends (or the segment does): whole if all four are this lane's
+                        if (nrec == 4u) {
+                            uint4* dst = reinterpret_cast<uint4*>(d_rec + (rec & ~3u));
+                            dst[0] = make_uint4(OT[8], OT[9], OT[10], OT[11]);
+                            dst[1] = make_uint4(OT[12], OT[13], OT[14], OT[15]);
+                        } else {
+                            for (uint32_t q = slot + 1u - nrec; q <= slot; q++) d_rec[(rec & ~3u) + q] = make_uint2(OT[8u + 2u * q], OT[9u + 2u * q]);
+                        }
+                        nrec = 0;
+                    }
+                }
                 rec++;
                 blk_first = ntok;
                 blk_dc = 0;
@@ -498,9 +529,14 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_win(const gj_geom g, 
                 toff = tdc;
                 if (left == 0) {
                     active = false;
-                    if (tok_ok) { // the last one to three tokens
-                        const uint64_t tbuf = ((uint64_t)tb_hi << 32) | tb_lo;
-                        for (uint32_t r = ntok & 3u, i = 0; i < r; i++) d_tok[tbase + (ntok & ~3u) + i] = (uint16_t)(tbuf >> (16u * (4u - r + i)));
+                    if (tok_ok && (ntok & 15u) != 0) { // the last one to fifteen tokens: as a whole piece when the segment's part of the array has room for it
+                        if ((tbase & 7u) == 0 && tbase + ((ntok + 15u) & ~15u) <= 4u * pos + 4u * len + 8u) {
+                            uint4* dst = reinterpret_cast<uint4*>(d_tok + tbase + (ntok & ~15u));
+                            dst[0] = make_uint4(OT[0], OT[1], OT[2], OT[3]);
+                            if ((ntok & 15u) > 8u) dst[1] = make_uint4(OT[4], OT[5], OT[6], OT[7]);
+                        } else {
+                            for (uint32_t r = ntok & 15u, i = 0; i < r; i++) d_tok[tbase + (ntok & ~15u) + i] = OT16[i];
+                        }
                     }
                     if (mx >= 10u) *overflow = 1u; // a value beyond a token's 10 bits: the host decodes the frame again through the planes
                 }

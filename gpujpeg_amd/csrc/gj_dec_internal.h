@@ -1,11 +1,12 @@
 // gj_dec_internal.h -- what the files of the decoder's device code share.
 //
 //   gj_decode.hip               gj_hip_decode: picks the kernels of a frame and launches them
-//   gj_dec_markers.hip          k_marker_count / rank / emit, k_build_segments, k_compare_header: segment table built on the device
+//   gj_dec_markers.hip          k_marker_scan, k_marker_segments: segment table built on the device, summary for the host in pinned memory
 //   gj_dec_entropy_tok.hip      k_huffman_decode_tok: sub-sequence parallel entropy decoding into 16-bit TOKENS + one record per block
 //                               (the default for large non-interleaved frames)
 //   gj_dec_entropy_par.hip      k_huffman_decode_par: sub-sequence parallel entropy decoding into the coefficient planes (segments of any length)
-//   gj_dec_entropy_seq.hip      k_huffman_decode_seq: one lane per restart segment over an LDS stage (interleaved scans with many short segments)
+//   gj_dec_entropy_seq.hip      one lane per restart segment (interleaved scans with many short segments): k_huffman_decode_win over a ring the
+//                               lane refills itself (token mode), k_huffman_decode_seq over an LDS stage (plane mode)
 //   gj_dec_entropy_serial.hip   k_huffman_decode: one lane per restart segment, stream windows (Huffman tables that do not fit the two-level layout)
 //   gj_dec_idct.hip             k_idct_fused_* (from the planes), k_idct_tok_* (from tokens), k_idct / k_postprocess / k_copy_planes_out (generic)
 //   gj_bitreader.h              unstuffing of a restart segment into an LDS stage, two-level table look-up

@@ -233,7 +233,7 @@ typedef struct gj_scan_summary {
     uint32_t scan_count, segment_count;
     uint32_t status;                          /* 1 = clean (scans ... EOI), 2 = unexpected marker between scans, 3 = no EOI */
     uint32_t scan_start[GJ_MAX_COMP], scan_end[GJ_MAX_COMP];
-    uint32_t header_differs;                  /* gj_hip_compare_header: 1 when the stream does not start with the cached header */
+    uint32_t header_differs;                  /* k_marker_scan: 1 when the stream does not start with the cached header (speculative launches) */
     uint32_t max_seg_len;                     /* longest segment of the table (filled in by the host from the per-chunk maxima) */
     uint32_t seq_overflow;                    /* set by k_huffman_decode_tok / _seq: a segment did not fit the LDS stage, decode the frame with the other kernel */
     uint32_t rst_irregular;                   /* an RSTn out of sequence, or an empty segment in front of the end of a scan: the reference reader

@@ -49,6 +49,10 @@ for i in range(1, 9):
     print(f"  phase -> {names[i]:20s}: mean {d.mean():6.1f} p50 {np.median(d):6.1f} p90 {np.percentile(d, 90):6.1f} max {d.max():6.1f}")
 tot = (t[:, 8] - t[:, 0]) / 100.0
 print("  workgroup total: mean %.1f p50 %.1f p90 %.1f max %.1f; kernel span %.1f" % (tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max(), (t[:, 8].max() - t0) / 100.0))
+slow = np.argsort(tot)[-max(1, len(t) // 20):]  # the slowest 5 % of the workgroups: what sets them apart?
+ph = np.diff(t[:, :9], axis=1) / 100.0
+print("  slowest 5 %: workgroups " + ", ".join(f"{int(i)}" for i in sorted(slow)[:12]) + " ...; their phases minus everybody's mean: " +
+      " ".join(f"{x:+5.1f}" for x in (ph[slow].mean(0) - ph.mean(0))))
 n = len(t)
 for q in range(0, n, max(1, n // 8)):
     sel = np.arange(q, min(n, q + max(1, n // 8)))

@@ -19,6 +19,16 @@
 #include "gj_device.h"
 #include "gj_hip.h"
 
+// -DGJ_TRACE_PHASES (the `trace` target of the Makefile, tools/encoder_phases.py): the first work-item of every workgroup of the fused encoders
+// notes the wall clock (100 MHz) at the phase boundaries in a buffer the tool hands over (16 slots per workgroup); the release build has none of it
+#ifdef GJ_TRACE_PHASES
+static __device__ unsigned long long* gj_trace_buf_e;
+extern "C" GJ_HIP_API int gj_hip_trace_set_encoder(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(gj_trace_buf_e), &p, sizeof p) == hipSuccess ? 0 : -1; }
+#define GJ_TRACE_E(slot) do { if (threadIdx.x == 0 && gj_trace_buf_e) gj_trace_buf_e[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GJ_TRACE_E(slot) ((void)0)
+#endif
+
 // ================================================================================================
 // Generic preprocessor: one thread per pixel of the full-resolution grid.
 // Restates src/gpujpeg_preprocessor.cu:88-202 (loads, colour transform, point-sampled store).
@@ -755,8 +765,9 @@ __device__ __forceinline__ void gj_walk_ac(uint8_t* col, const uint32_t mlo, con
 __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, const int j, const int k, const bool active, const int spt,
                                              const int B, const int nblocks, const int table, const int dc_dist, const int seg_count_left,
                                              uint8_t* __restrict__ temp, const uint64_t first_block, uint32_t* __restrict__ seg_bytes,
-                                             uint32_t* __restrict__ seg_ff, const uint32_t first_segment)
+                                             uint32_t* __restrict__ seg_ff, const uint32_t first_segment, const int trace0 = -1)
 {
+    (void)trace0;
     const int lane = i & 63, wave = i >> 6;
     uint8_t* const col = reinterpret_cast<uint8_t*>(L.coef) + i * 4;
     uint32_t* const s_bits = L.coef + GJ_ENC_PRIV_ROWS * 256;
@@ -808,6 +819,7 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
     }
     const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill;
 
+    if (trace0 >= 0) GJ_TRACE_E(trace0 + 1); // walk done (this wave)
     // ---- 4. bit positions
     const uint32_t winc = gj_wave_incl_scan(len);
     if (lane == 63) L.wsum[wave] = winc;
@@ -826,6 +838,7 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
         z[1] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads(); // B3: segment ends visible, window cleared
+    if (trace0 >= 0) GJ_TRACE_E(trace0 + 2); // positions known
     // segment books, redundantly in every wave (lane l keeps local segment l): bits with ones-padding to a byte, dword base
     uint32_t sbits = 0, sdw = 0;
     if (lane < spt && lane < seg_count_left) {
@@ -897,6 +910,7 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
         }
     }
     __syncthreads(); // B5: 0xFF counts complete; the coefficient area may be overwritten by the next component
+    if (trace0 >= 0) GJ_TRACE_E(trace0 + 3); // merged and drained
     if (i < nseg) {
         seg_bytes[first_segment + i] = (L.segbits[i] + 7u) >> 3;
         seg_ff[first_segment + i] = L.segff[i];
@@ -941,6 +955,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
+    GJ_TRACE_E(0);
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
 
@@ -961,6 +976,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     uint32_t pk[3][16];
     gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, active, pk);
     __syncthreads(); // tables are in LDS
+    GJ_TRACE_E(1); // pixels loaded and converted
 
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -969,8 +985,9 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
 #pragma unroll
         for (int t = 0; t < 16; t++) GJ_KEEP(pk[c][t]);
         gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
+        GJ_TRACE_E(2 + 4 * c); // transformed (this wave)
         gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0, temp,
-                     kc.data_offset / 64 + (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0));
+                     kc.data_offset / 64 + (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
     }
 }
 

@@ -259,22 +259,25 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
 
 
 // ================================================================================================
-// The same idea without the stage (round 3, token mode only): ONE LANE PER RESTART SEGMENT OVER A 96-BYTE RING.
+// The same idea without the stage (round 3, token mode only): ONE LANE PER RESTART SEGMENT OVER AN 80-BYTE RING.
 //
 // What bounds the kernel above is not instruction issue but the latency of a wave's dependent chain (~100 vector instructions and three LDS
 // round trips per symbol, 1 700 cycles per symbol and wave measured on config 4) at the 1.4 decoding waves per SIMD its stage admits: a
 // lane needs its whole segment (~250 B) in LDS, a workgroup's 26 KB hold 87 segments, and the 172 800 segments of config 4 take two
-// generations of workgroups. Here a lane owns a ring of 24 dwords and tops it up itself: all 172 800 segments are resident at once
+// generations of workgroups. Here a lane owns a ring of 20 dwords and tops it up itself: all 172 800 segments are resident at once
 // (675 workgroups of 256 lanes, 2.6 decoding waves per SIMD), there is no stage, no cooperative unstuffing, no barrier after the tables
 // have been loaded, and a segment may be of any length.
 //   * refill, wave-synchronous: as soon as ANY lane of a wave has fewer than 16 bytes in front of its bit position, EVERY lane of the
 //     wave tops its ring up (a refill on demand per lane would run the refill code in almost every iteration for somebody): 16-byte
-//     pieces of the lane's own part of the stream (four guarded dword loads), byte by byte without the stuffed zeros into a dword
-//     that is written to the ring when it is complete (big-endian, as the bit reader wants it). Behind the last byte of the segment go
-//     8 zero bytes (a symbol that straddles the end reads zeros, src/gpujpeg_huffman_cpu_decoder.c:80-118);
-//   * the reader keeps 33..64 bits in a 64-bit accumulator and the next dword in a register; it never loads a dword the writer has not
-//     completed (that is what the 16 bytes in front are for);
-//   * symbols, tokens and block records exactly as in k_huffman_decode_seq<il, true>.
+//     pieces of the lane's own part of the stream (four guarded dword loads, the next piece's in flight), the stuffed zeros removed
+//     dword by dword -- byte classes with SWAR arithmetic, the kept bytes compacted by v_perm_b32 with a selector from a 16-entry LDS
+//     table -- and appended to a dword that goes to the ring when it is complete (big-endian, as the bit reader wants it). Behind the
+//     last byte of the segment go 8 zero bytes (a symbol that straddles the end reads zeros, src/gpujpeg_huffman_cpu_decoder.c:80-118);
+//   * the reader is the one of gj_dec_entropy_tok.hip: bit position - 1 inside the ring, the next 32 bits with one v_alignbit_b32 over two
+//     neighbouring slots (slot 20 mirrors slot 0); it never reads a dword the writer has not completed (that is what the 16 bytes in
+//     front are for);
+//   * symbols as in k_huffman_decode_seq<il, true>; sixteen tokens and four block records are collected in LDS and leave as aligned
+//     32-byte pieces (see "Output" below).
 // ================================================================================================
 #define GJ_WIN_DW 20     // dwords of a lane's ring
 #define GJ_WIN_STRIDE 21 // dwords between the rings of neighbouring lanes: the ring + the mirror of its slot 0 (odd: the lanes of a half wave hit different banks)
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
     uint32_t src = 0, wr = 0, wacc = 0, wslot = 0;
     bool final = !active;
     // ---- the reader (as in gj_dec_entropy_tok.hip): rp = bit position - 1 inside the ring (0 .. 767, wraps), the next 32 bits are
-    //      v_alignbit_b32(R[rp >> 5], R[(rp >> 5) + 1], ~rp) -- slot 24 mirrors slot 0 --; `ahead` = bits between the bit position and the
+    //      v_alignbit_b32(R[rp >> 5], R[(rp >> 5) + 1], ~rp) -- slot GJ_WIN_DW mirrors slot 0 --; `ahead` = bits between the bit position and the
     //      end of the complete dwords in the ring; a symbol is decoded while ahead > stop (stop = the zero tail once the segment's last
     //      byte has been written: then that is "bit position < end of the segment")
     uint32_t rp = 32u * GJ_WIN_DW - 1u;

@@ -298,9 +298,6 @@ def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, step
     L.warm(2)  # buffers allocated, tables uploaded, a stream for the decoders to start from
     solo = L.solo_kernel_ms() if want_solo else None
     # fix the batch: frames per pipeline and step so that `steps` steps last >= min_seconds
-    t_probe, *_ = L.run(mode, 1, 2, sync, local_rank)
-    per_frame = max(t_probe / 2, 1e-6)
-    reps = max(1, int(np.ceil(1.15 * min_seconds / (steps * per_frame)))) if min_seconds > 0 else 1
     fresh = [k for k in ((str(device), i) for i in range(len(L.lanes))) if k not in _PREROLLED]
     if fresh:
         # once per HIP stream and process: about 4000 commands (200-250 frames) into a new stream the HIP runtime halts every queue of the
@@ -308,6 +305,9 @@ def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, step
         # size). That is process start-up, like the first import; run past it before anything is timed.
         L.run(mode, 1, PREROLL_FRAMES, sync, local_rank)
         _PREROLLED.update(fresh)
+    t_probe, *_ = L.run(mode, 1, 8, sync, local_rank)  # (after the pre-roll: the first frames of a new stream are slower than the steady state)
+    per_frame = max(t_probe / 8, 1e-6)
+    reps = max(1, int(np.ceil(1.15 * min_seconds / (steps * per_frame)))) if min_seconds > 0 else 1
     if warmup > 0:  # W untimed steps of exactly the shape of the timed ones (same threads, same frames per step)
         L.run(mode, warmup, reps, sync, local_rank)
     elapsed, enc_wall, dec_wall, kms = L.run(mode, steps, reps, barrier, local_rank)

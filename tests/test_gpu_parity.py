@@ -455,6 +455,7 @@ TOKEN_422_CASES = [
     ("restart0", 512, 128, 85, 0, False),           # every block arrives through the planes
     ("r1", 320, 40, 50, 1, False),
     ("one_mcu", 16, 8, 90, 3, True),
+    ("long_segments_noise", 640, 64, 95, 40, True),  # segments of 160 blocks, several KB each: the ring decoder refills dozens of times per segment
 ]
 
 

@@ -7,15 +7,9 @@
 
 #define GJ_WAVE 64
 
-// GJ_HIPEMU: defined only by the CPU execution model of the test tier (tests/hipemu), which compiles these files for the host. The one
-// thing it switches is the meaning of the inline-assembly helpers below (the instruction on the GPU, its C++ meaning on the CPU).
-#ifdef GJ_HIPEMU
-#define GJ_KEEP(x) ((void)0)
-#define GJ_KEEP6(a, b, c, d, e, f) ((void)0)
-#else
-#define GJ_KEEP6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
-#define GJ_KEEP(x) asm volatile("" : "+v"(x)) // pins a value in its register here: a scheduling fence for the compiler
-#endif
+// the handful of helpers that ARE single gfx950 instructions (inline assembly): GJ_KEEP, gj_bfe_u32, gj_pk_min_u16, gj_ubyte_f_opaque,
+// gj_scale256_f, and the gj_f2 / gj_ubyte_f they build on
+#include <gj_device_asm.h>
 
 // ------------------------------------------------------------------------------------------------
 // zig-zag order (ITU T.81 figure A.6): position in scan -> natural (row-major) index.
@@ -125,30 +119,6 @@ __device__ __forceinline__ uint32_t gj_wave_incl_scan(uint32_t v)
     return (uint32_t)x;
 }
 
-// bits [OFF, OFF + WIDTH) of v as the instruction itself: written as a shift the compiler folds it into the address arithmetic that
-// follows and ends up with shift + mask + add where bit-field extract + shift-add do
-template <int OFF, int WIDTH> __device__ __forceinline__ uint32_t gj_bfe_u32(uint32_t v)
-{
-#ifdef GJ_HIPEMU
-    return (v >> OFF) & ((1u << WIDTH) - 1u);
-#else
-    uint32_t r;
-    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(OFF), "n"(WIDTH));
-    return r;
-#endif
-}
-
-// per-half minimum of two packed u16 pairs (the compiler scalarises the vector form, hence the instruction itself)
-__device__ __forceinline__ uint32_t gj_pk_min_u16(uint32_t a, uint32_t b)
-{
-#ifdef GJ_HIPEMU
-    return min(a & 0xFFFFu, b & 0xFFFFu) | (min(a >> 16, b >> 16) << 16);
-#else
-    uint32_t r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#endif
-}
 
 // inclusive scan over a 256-thread workgroup; s_tmp needs 4 words; all threads must call
 __device__ __forceinline__ uint32_t gj_wg256_incl_scan(uint32_t v, uint32_t* s_tmp, uint32_t* total)
@@ -242,44 +212,7 @@ __device__ __forceinline__ void gj_color_transform(int from, int to, int& a, int
 // The functions return that sum; the caller converts. Checked against the integer path for all 2^24 inputs per matrix
 // on the device (tests/test_gpu_parity.py::test_exhaustive_colour_transform_fused).
 // ------------------------------------------------------------------------------------------------
-typedef float gj_f2 __attribute__((ext_vector_type(2)));
-
-// byte k of a dword as float: the AMDGPU back end selects v_cvt_f32_ubyte<k> for this pattern
-template <int K> __device__ __forceinline__ float gj_ubyte_f(uint32_t w) { return (float)((w >> (8 * K)) & 0xFFu); }
-
-// the same as the instruction itself, for the inputs of the transforms: from the C expression the optimiser learns that the value
-// is a small integer and rewrites the first butterfly (float(a) + float(b)) into per-sample integer SDWA adds followed by 72
-// conversions per block -- 216 scalar operations where 64 conversions + 32 packed adds do. (Not for the colour transform: there
-// the compiler needs to know that the value is no signalling NaN, or every v_max_f32 gets a canonicalising twin.)
-template <int K> __device__ __forceinline__ float gj_ubyte_f_opaque(uint32_t w)
-{
-#ifdef GJ_HIPEMU
-    return gj_ubyte_f<K>(w);
-#else
-    float r;
-    if (K == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(w));
-    else if (K == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(w));
-    else if (K == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(w));
-    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
-    return r;
-#endif
-}
-
-// c * 256 / 255 for an integer c in [0, 255]: c + (c == 255). The indicator is the clamp-to-[0, 1] output modifier on c - 254 (two
-// packed instructions per pixel pair; max(c, 256 c - 65024) costs a packed FMA and two v_max_f32, which have no packed form and
-// issue at half the rate of an add, profiles/r2_09_ubench.txt).
-__device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
-{
-    gj_f2 d;
-#ifdef GJ_HIPEMU
-    d = v + (gj_f2)-254.0f;
-    d.x = d.x < 0.0f ? 0.0f : (d.x > 1.0f ? 1.0f : d.x);
-    d.y = d.y < 0.0f ? 0.0f : (d.y > 1.0f ? 1.0f : d.y);
-#else
-    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(v), "v"((gj_f2)-254.0f));
-#endif
-    return v + d;
-}
+// (gj_f2, gj_ubyte_f<K>, gj_ubyte_f_opaque<K> and gj_scale256_f -- c * 256 / 255 for an integer c in [0, 255] -- live in gj_device_asm.h)
 
 __device__ __forceinline__ void gj_matrix_to_f(gj_f2& c0, gj_f2& c1, gj_f2& c2, const int m0, const int m1, const int m2, const int m3, const int m4,
                                                const int m5, const int m6, const int m7, const int m8, const int b0, const int b1, const int b2)

@@ -759,13 +759,18 @@ __device__ __forceinline__ void gj_walk_ac(uint8_t* col, const uint32_t mlo, con
     }
 }
 
-// Steps 2-5 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
+// Steps 2-6 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
 // nblocks = blocks of that segment, table = 0 luminance / 1 chrominance tables, dc_dist = lanes back to the previous block of the
-// same component; first_block = coding-order index of the tile's first block (addresses d_temp), first_segment = its first segment.
-__device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, const int j, const int k, const bool active, const int spt,
-                                             const int B, const int nblocks, const int table, const int dc_dist, const int seg_count_left,
-                                             uint8_t* __restrict__ temp, const uint64_t first_block, uint32_t* __restrict__ seg_bytes,
-                                             uint32_t* __restrict__ seg_ff, const uint32_t first_segment, const int trace0 = -1)
+// same component; region = the tile's area of d_temp (GJ_STAGE_BYTES_PER_BLOCK per block: the finished stream from its start, block
+// i's spill slot in the upper half of its own bytes), seg_count_left = segments of the scan from the tile's first one on (the last one
+// of a scan gets no restart marker), index0 = index of the tile's first segment in its scan (restart marker numbers);
+// seg_bytes / seg_ff (only with `seg_sizes`: the APP13 index wants them) = unstuffed size and 0xFF count per segment.
+// Returns the size of the tile's finished stream (the same in every thread).
+__device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int i, const int j, const int k, const bool active, const int spt,
+                                                 const int nblocks, const int table, const int dc_dist, const int seg_count_left,
+                                                 uint8_t* __restrict__ region, const int index0, const bool seg_sizes,
+                                                 uint32_t* __restrict__ seg_bytes, uint32_t* __restrict__ seg_ff, const uint32_t first_segment,
+                                                 const int trace0 = -1)
 {
     (void)trace0;
     const int lane = i & 63, wave = i >> 6;
@@ -799,7 +804,7 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
 
     // ---- 3. the walk
     GjWalk w = {0, 0, 0, 0, 1};
-    uint32_t* const spill = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)i) * GJ_TEMP_BYTES_PER_BLOCK); // (lane i = block i of the tile)
+    uint32_t* const spill = reinterpret_cast<uint32_t*>(region + (size_t)i * GJ_STAGE_BYTES_PER_BLOCK + GJ_STAGE_BYTES_PER_BLOCK / 2); // (lane i = block i of the tile)
     int dc_diff = 0;
     {
         // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342)
@@ -862,19 +867,26 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
         if (active && k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
     }
 
-    // ---- 5. merge into the window, drain the window to HBM
+    // ---- 5. merge into the window
     // The lane's stream is its `produced` completed dwords, then the accumulator and the ones-padding of a segment's last block as
     // one 64-bit tail; it lands `start_bit & 31` bits into dword `start_bit >> 5` of the tile stream, so every output dword is
     // one funnel shift (v_alignbit_b32) of two neighbouring stream dwords and one ds_or_b32.
+    // ---- 6. the window's streams -> the tile's FINISHED stream: 0x00 behind every 0xFF, RSTn behind every segment but a scan's last
+    // (src/gpujpeg_huffman_gpu_encoder.cu:417-503 serialisation + :563-613 compaction + the host's stitching, src/gpujpeg_encoder.c:567-629).
+    // A tile whose streams fit one window (all but noise-like content) builds the finished bytes in the dead private rows of the
+    // coefficient area and leaves as whole 16-byte pieces; larger tiles store their bytes one by one, window after window.
     const uint32_t sh = start_bit & 31u, d0 = start_bit >> 5;
     uint64_t tail = (uint64_t)w.hi << 32;
     if (pad_bits) tail |= (uint64_t)((1u << pad_bits) - 1u) << (64 - w.fill - pad_bits);
     const int ndw = w.produced + (w.fill + pad_bits > 32 ? 2 : (w.fill + pad_bits > 0 ? 1 : 0)); // stream dwords incl. the tail
     const int nseg = min(spt, seg_count_left);
+    const bool staged = total_dw <= (uint32_t)GJ_ENC_WIN_DW;
+    uint8_t* const stage = reinterpret_cast<uint8_t*>(L.coef); // rows 0 .. GJ_ENC_PRIV_ROWS - 1: 24 KB >= 2 x the window + the markers
+    uint32_t piece_pos = 0, ff_total = 0;
     for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {
         const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_ENC_WIN_DW);
         if (wbase) {
-            __syncthreads(); // previous window drained
+            __syncthreads(); // previous window consumed
             for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
             __syncthreads();
         }
@@ -893,28 +905,252 @@ __device__ __forceinline__ void gj_code_tile(const GjCoderLds& L, const int i, c
             }
         }
         __syncthreads(); // B4: window complete
-        // every wave drains whole segments: no search for the owner of a dword, the 0xFF count of a segment is one wave reduction
+        // 6a. every wave takes whole segments: the 0xFF bytes of a segment's part of this window are one wave reduction
         for (int sl = wave; sl < nseg; sl += 4) {
             const uint32_t sb = L.segbase[sl], nfl = (L.segbits[sl] + 31u) >> 5;
             const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
-            uint32_t* const dst = reinterpret_cast<uint32_t*>(temp + (first_block + (uint64_t)sl * B) * GJ_TEMP_BYTES_PER_BLOCK);
             uint32_t ffc = 0;
             for (uint32_t d = lo + (uint32_t)lane; d < hi; d += 64) {
                 const uint32_t v = s_bits[d - wbase];
                 // 0xFF bytes (the unused low bytes of a segment's last dword are zero)
                 ffc += (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
-                dst[d - sb] = __builtin_bswap32(v);
             }
             ffc = gj_wave_incl_scan(ffc);
-            if (lane == 63 && ffc) L.segff[sl] += ffc;
+            if (lane == 63) L.segff[sl] = ffc;
+        }
+        __syncthreads(); // B5: 0xFF counts
+        // 6b. sizes and places of the parts, redundantly in every wave (lane l keeps local segment l)
+        uint32_t psz = 0;
+        if (lane < nseg) {
+            const uint32_t sb = L.segbase[lane], nb = L.segbits[lane] >> 3, nfl = (nb + 3u) >> 2;
+            const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
+            if (hi > lo) {
+                const bool ends = hi == sb + nfl;
+                const uint32_t ff = L.segff[lane];
+                ff_total += ff;
+                psz = (ends ? nb - 4u * (lo - sb) : 4u * (hi - lo)) + ff + (ends && lane != seg_count_left - 1 ? 2u : 0u);
+            }
+        }
+        const uint32_t pincl = gj_wave_incl_scan(psz);
+        const uint32_t poff = pincl - psz;
+        const uint32_t wsize = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+        // 6c. stuffing: a lane takes a dword, the wave's prefix sum of the byte counts places it
+        for (int sl = wave; sl < nseg; sl += 4) {
+            const uint32_t sb = L.segbase[sl], nb = L.segbits[sl] >> 3, nfl = (nb + 3u) >> 2;
+            const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
+            uint32_t run = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)poff) + (staged ? 0u : piece_pos);
+            for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
+                const uint32_t d = c0 + (uint32_t)lane;
+                uint32_t v = 0;
+                int vb = 0;
+                if (d < hi) {
+                    v = s_bits[d - wbase];
+                    vb = (int)min(4u, nb - 4u * (d - sb));
+                }
+                const uint32_t cnt = (uint32_t)vb + (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
+                const uint32_t inc = gj_wave_incl_scan(cnt);
+                uint32_t p = run + inc - cnt;
+                if (staged) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (b < vb) {
+                            const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
+                            stage[p++] = (uint8_t)byte;
+                            if (byte == 0xFFu) stage[p++] = 0;
+                        }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (b < vb) {
+                            const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
+                            region[p++] = (uint8_t)byte;
+                            if (byte == 0xFFu) region[p++] = 0;
+                        }
+                }
+                run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+            if (hi > lo && hi == sb + nfl && sl != seg_count_left - 1 && lane == 0) { // the segment ends here: RSTn (src/gpujpeg_huffman_gpu_encoder.cu:497-502)
+                const uint8_t m = (uint8_t)(0xD0 + ((index0 + sl) & 7));
+                if (staged) { stage[run] = 0xFF; stage[run + 1] = m; }
+                else { region[run] = 0xFF; region[run + 1] = m; }
+            }
+        }
+        if (staged) {
+            __syncthreads(); // B6: the finished stream is in the stage
+            const uint4* src = reinterpret_cast<const uint4*>(stage);
+            uint4* dst = reinterpret_cast<uint4*>(region);
+            for (uint32_t q = i; q * 16u < wsize; q += 256) dst[q] = src[q];
+        }
+        piece_pos += wsize;
+    }
+    if (seg_sizes && wave == 0 && lane < nseg) {
+        seg_bytes[first_segment + lane] = L.segbits[lane] >> 3;
+        seg_ff[first_segment + lane] = ff_total;
+    }
+    __syncthreads(); // B7: the coefficient area may be overwritten by the next component
+    if (trace0 >= 0) GJ_TRACE_E(trace0 + 3); // merged, stuffed and stored
+    return piece_pos;
+}
+
+// ================================================================================================
+// The gathering tail of the one-launch encoders (replaces k_scan_segments + k_assemble and their two launches for k_encode_*).
+//
+// A workgroup leaves the FINISHED stream of its tile (stuffed, restart markers in place) at the start of the tile's area of d_temp
+// and notes its size. Where a tile's bytes go in the file depends on the sizes of all tiles in front of it -- for the chrominance
+// scans of k_encode_rgb444 on tiles that have not even started --, so nobody waits for a position: the workgroups that finish
+// LAST gather. A workgroup that is among the last `shares` to finish, and finds that every workgroup of the launch has started
+// (then everything unfinished is running and will finish: waiting cannot deadlock, whatever else occupies the device), waits for
+// the last tile and takes shares of the tile list from a counter: it reads all tile sizes (one trip: the place of its share in the
+// file and the size of the stream), then every lane copies whole 16-byte pieces of the file -- found by a search over the share's
+// tiles in LDS, all loads of a round in flight together --, the ends of a tile byte by byte; scan headers and EOI come from the
+// share that meets them. The workgroup that finishes last always gathers, so the list is always emptied.
+// Counters: two sets that alternate with the call's epoch; the last finisher clears the other set for the next call.
+// ================================================================================================
+typedef uint32_t gj_u4 __attribute__((ext_vector_type(4)));
+typedef gj_u4 __attribute__((aligned(1))) gj_u4_unaligned; // a 16-byte global load from any address (one instruction on gfx950)
+struct GjTail {
+    uint32_t* ctr;        // [0] workgroups started, [1] finished, [2] next share, [3] every tile stream is complete
+    uint32_t* ctr_other;  // the next call's set
+    uint2* piece;         // [npieces] tile streams in FILE order: x = size | scan << 28, y = offset in d_temp / 16
+    const uint8_t* temp;
+    uint8_t* jpeg;
+    uint64_t capacity;
+    const uint8_t* scan_hdr;
+    uint32_t hdr_end[GJ_MAX_COMP]; // bytes of the scan headers up to and including scan s
+    uint32_t main_hdr;
+    uint32_t npieces, shares;
+    uint32_t* d_result;
+    uint32_t* h_result;
+    int seg_sizes;        // the APP13 index is wanted: per-segment sizes to d_seg_bytes / d_seg_ff
+};
+
+__device__ __forceinline__ uint32_t gj_tail_hdr_end(const GjTail& T, const uint32_t scan)
+{
+    return scan == 0 ? T.hdr_end[0] : scan == 1 ? T.hdr_end[1] : scan == 2 ? T.hdr_end[2] : T.hdr_end[3];
+}
+
+// s_mem: >= 1300 words of LDS nothing else uses any more
+__device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem, const int i)
+{
+    uint32_t* const s_tmp = s_mem;      // [4] scans, [4] role, [5] share
+    uint32_t* const tF = s_mem + 16;    // [256] file offset of the tile stream
+    uint32_t* const tsrc = tF + 256;    // [256] offset in d_temp / 16
+    uint32_t* const tsize = tsrc + 256; // [256]
+    uint32_t* const tcs = tsize + 256;  // [256] first 16-byte piece (in the share's numbering)
+    const uint32_t ntiles = gridDim.x;
+    __threadfence(); // this thread's part of the tile streams is out
+    __syncthreads();
+    if (i == 0) {
+        const uint32_t d = __hip_atomic_fetch_add(&T.ctr[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t role = 0;
+        if (d + 1 == ntiles) {
+            for (int q = 0; q < 8; q++) T.ctr_other[q] = 0;
+            __hip_atomic_store(&T.ctr[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            role = 1;
+        } else if (d + T.shares >= ntiles && __hip_atomic_load(&T.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntiles) {
+            role = 1;
+        }
+        s_tmp[4] = role;
+    }
+    __syncthreads();
+    if (!s_tmp[4]) return;
+    GJ_TRACE_E(14);
+    if (i == 0)
+        while (__hip_atomic_load(&T.ctr[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+    __threadfence(); // (acquire for every thread: the other workgroups' streams and sizes)
+    const uint32_t P = T.npieces, K = T.shares;
+    for (;;) {
+        __syncthreads();
+        if (i == 0) s_tmp[5] = atomicAdd(&T.ctr[2], 1u);
+        __syncthreads();
+        const uint32_t share = s_tmp[5];
+        if (share >= K) break;
+        const uint32_t pa = (uint32_t)((uint64_t)share * P / K), pb = (uint32_t)((uint64_t)(share + 1) * P / K);
+        // all tile sizes: the bytes in front of this share, and the whole stream
+        uint32_t before = 0, all = 0;
+        for (uint32_t p = i; p < P; p += 256) {
+            const uint32_t sz = T.piece[p].x & 0x0FFFFFFFu;
+            all += sz;
+            before += p < pa ? sz : 0u;
+        }
+        uint32_t done_bytes, all_bytes;
+        gj_wg256_incl_scan(before, s_tmp, &done_bytes);
+        gj_wg256_incl_scan(all, s_tmp, &all_bytes);
+        const uint32_t last_scan = T.piece[P - 1].x >> 28;
+        const uint64_t total = (uint64_t)T.main_hdr + gj_tail_hdr_end(T, last_scan) + all_bytes + 2u;
+        const bool overflow = total > T.capacity;
+        for (uint32_t p0 = pa; p0 < pb; p0 += 256) {
+            const uint32_t p = p0 + (uint32_t)i;
+            const bool have = p < pb;
+            uint2 st = make_uint2(0, 0);
+            if (have) st = T.piece[p];
+            const uint32_t size = st.x & 0x0FFFFFFFu, scan = st.x >> 28;
+            uint32_t batch_bytes, C;
+            const uint32_t incl = gj_wg256_incl_scan(size, s_tmp, &batch_bytes);
+            const uint32_t F = T.main_hdr + gj_tail_hdr_end(T, scan) + done_bytes + incl - size;
+            const uint32_t nch = have ? ((F & 15u) + size + 15u) >> 4 : 0u;
+            const uint32_t cincl = gj_wg256_incl_scan(nch, s_tmp, &C);
+            tF[i] = F;
+            tsrc[i] = st.y;
+            tsize[i] = size;
+            tcs[i] = cincl - nch; // (= C for the lanes behind the share's last tile)
+            if (have && !overflow) {
+                const uint32_t prev_scan = p == 0 ? 0xFFFFFFFFu : (T.piece[p - 1].x >> 28);
+                if (scan != prev_scan) { // first tile of a scan: its header (APP13 placeholders + SOS) sits right in front
+                    const uint32_t h1 = gj_tail_hdr_end(T, scan), h0 = scan == 0 ? 0u : gj_tail_hdr_end(T, scan - 1);
+                    for (uint32_t b = 0; b < h1 - h0; b++) T.jpeg[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
+                }
+                if (p == P - 1) {
+                    T.jpeg[F + size] = 0xFF;
+                    T.jpeg[F + size + 1] = 0xD9;
+                }
+            }
+            if (have && p == P - 1) {
+                T.d_result[0] = (uint32_t)total;
+                T.d_result[1] = overflow ? 1u : 0u;
+                if (T.h_result) { // the host's (pinned, device-visible) copy: no copy launch behind the kernel
+                    T.h_result[0] = (uint32_t)total;
+                    T.h_result[1] = overflow ? 1u : 0u;
+                }
+            }
+            __syncthreads();
+            if (!overflow) {
+                for (uint32_t q0 = 0; q0 < C; q0 += 1024) {
+                    gj_u4 val[4];
+                    uint32_t dlo[4], dhi[4];
+                    const uint8_t* src[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t q = q0 + (uint32_t)u * 256u + (uint32_t)i;
+                        dlo[u] = dhi[u] = 0;
+                        src[u] = T.temp;
+                        val[u] = (gj_u4)0u;
+                        if (q < C) {
+                            uint32_t lo = 0;
+#pragma unroll
+                            for (uint32_t step = 128; step; step >>= 1)
+                                if (tcs[lo + step] <= q) lo += step;
+                            const uint32_t f = tF[lo], c_lo = (f & ~15u) + 16u * (q - tcs[lo]);
+                            dlo[u] = max(f, c_lo);
+                            dhi[u] = min(f + tsize[lo], c_lo + 16u);
+                            src[u] = T.temp + (uint64_t)tsrc[lo] * 16u + (dlo[u] - f);
+                        }
+                        if (dhi[u] - dlo[u] == 16u) val[u] = *reinterpret_cast<const gj_u4_unaligned*>(src[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (dhi[u] - dlo[u] == 16u) *reinterpret_cast<gj_u4*>(T.jpeg + dlo[u]) = val[u];
+                        else
+                            for (uint32_t b = 0; b < dhi[u] - dlo[u]; b++) T.jpeg[dlo[u] + b] = src[u][b];
+                    }
+                }
+            }
+            done_bytes += batch_bytes;
+            __syncthreads();
         }
     }
-    __syncthreads(); // B5: 0xFF counts complete; the coefficient area may be overwritten by the next component
-    if (trace0 >= 0) GJ_TRACE_E(trace0 + 3); // merged and drained
-    if (i < nseg) {
-        seg_bytes[first_segment + i] = (L.segbits[i] + 7u) >> 3;
-        seg_ff[first_segment + i] = L.segff[i];
-    }
+    GJ_TRACE_E(15);
 }
 
 // the workgroup's Huffman tables in the layout of GjCoderLds::lut, from the host's (code << 8 | size) tables [type * 2 + is_ac][symbol]
@@ -944,7 +1180,7 @@ template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                          uint32_t* __restrict__ seg_ff)
+                                                          uint32_t* __restrict__ seg_ff, const GjTail T)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
@@ -956,6 +1192,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
 
     const int i = threadIdx.x;
     GJ_TRACE_E(0);
+    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // started
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
 
@@ -986,9 +1223,14 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
         for (int t = 0; t < 16; t++) GJ_KEEP(pk[c][t]);
         gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         GJ_TRACE_E(2 + 4 * c); // transformed (this wave)
-        gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0, temp,
-                     kc.data_offset / 64 + (uint64_t)seg0 * B, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
+        const uint64_t first_block = kc.data_offset / 64 + (uint64_t)seg0 * B; // coding-order index of the tile's first block of this component
+        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
+                                           temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
+                                           (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
+        // file order: the luminance scan's tiles, then the two chrominance scans'
+        if (i == 0) T.piece[(uint32_t)c * gridDim.x + blockIdx.x] = make_uint2(size | ((uint32_t)c << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
     }
+    gj_encode_tail(T, s_coef, i);
 }
 
 // ================================================================================================
@@ -1002,7 +1244,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
 __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                            const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                            uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                           uint32_t* __restrict__ seg_ff)
+                                                           uint32_t* __restrict__ seg_ff, const GjTail T)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
@@ -1013,6 +1255,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
+    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // started
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
 
@@ -1092,10 +1335,13 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
 #pragma unroll
         for (int t = 0; t < 16; t++) GJ_KEEP(px[t]);
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
-        gj_code_tile(L, i, j, k, active, spt, B, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
-                     p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0, temp, (uint64_t)seg0 * B, seg_bytes,
-                     seg_ff, (uint32_t)seg0);
+        const uint64_t first_block = (uint64_t)seg0 * B;
+        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
+                                           p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0,
+                                           temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff, (uint32_t)seg0);
+        if (i == 0) T.piece[blockIdx.x] = make_uint2(size, (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
     }
+    gj_encode_tail(T, s_coef, i);
 }
 
 // ================================================================================================
@@ -1127,7 +1373,7 @@ template <bool PLANAR>
 __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                          uint32_t* __restrict__ seg_ff)
+                                                          uint32_t* __restrict__ seg_ff, const GjTail T)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
@@ -1138,6 +1384,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
+    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // started
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
 
@@ -1286,9 +1533,14 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
 #pragma unroll
         for (int t = 0; t < 16; t++) GJ_KEEP(px[t]);
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
-        gj_code_tile(L, i, j, k, active, spt, B, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0, temp, s_first_block,
-                     seg_bytes, seg_ff, (uint32_t)(scan_first + seg0));
+        const uint64_t first_block = s_first_block;
+        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0,
+                                           temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
+                                           (uint32_t)(scan_first + seg0));
+        // (workgroups are numbered in file order: the tiles of scan 0, of scan 1, ...)
+        if (i == 0) T.piece[blockIdx.x] = make_uint2(size | ((uint32_t)scan << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
     }
+    gj_encode_tail(T, s_coef, i);
 }
 
 // ================================================================================================
@@ -1471,7 +1723,30 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // Launcher
 // ================================================================================================
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
-typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*);
+typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail);
+
+#define GJ_TAIL_SHARES 256 // default number of parts the gathering tail cuts the tile list into (GJ_ENC_TAIL overrides)
+// the tail's arguments for a launch of `tiles` workgroups that leave `pieces` tile streams
+static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces)
+{
+    GjTail T;
+    T.ctr = job->d_tail + (job->tail_set & 1) * 8;
+    T.ctr_other = job->d_tail + ((job->tail_set + 1) & 1) * 8;
+    T.piece = reinterpret_cast<uint2*>(job->d_tail + 16);
+    T.temp = job->d_temp;
+    T.jpeg = job->d_jpeg;
+    T.capacity = job->jpeg_capacity;
+    T.scan_hdr = job->d_scan_hdr;
+    for (int s = 0; s < GJ_MAX_COMP; s++) T.hdr_end[s] = job->scan_hdr_offset[s + 1];
+    T.main_hdr = job->main_hdr_size;
+    T.npieces = pieces;
+    const unsigned want = job->tune.enc_tail_shares > 0 ? (unsigned)job->tune.enc_tail_shares : (unsigned)GJ_TAIL_SHARES;
+    T.shares = want < pieces ? want : pieces;
+    T.d_result = job->d_result;
+    T.h_result = job->h_result;
+    T.seg_sizes = job->segment_info && job->g.restart_interval > 0;
+    return T;
+}
 
 // fused kernel for this configuration, or nullptr when the generic path has to be used
 static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
@@ -1525,6 +1800,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const unsigned n = (unsigned)g.width * (unsigned)g.height;
         hipLaunchKernelGGL(k_channel_remap, dim3((n + 255) / 256), dim3(256), 0, st, g, const_cast<uint8_t*>(job->d_raw), job->channel_remap & 0xFFFFu);
     }
+    bool one_launch = true; // k_encode_*: the stream is complete when the kernel ends
     gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
     const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 && g.no_transform == 0 &&
@@ -1539,7 +1815,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff);
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs));
     } else if (!whole && job->use_fused && !job->keep_coefs && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT &&
                gj_blocks_kernel_mode(g) >= 0) {
         // every other layout with short restart segments: one lane per block in coding order (k_encode_blocks)
@@ -1551,15 +1827,16 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         else
             for (int c = 0; c < g.comp_count; c++) wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
-                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff);
+                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs));
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
-                           job->d_seg_bytes, job->d_seg_ff);
+                           job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, 3 * wgs));
     } else {
+    one_launch = false;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);
@@ -1589,11 +1866,15 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                        job->d_seg_ff);
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
+    const bool seg_info = job->segment_info && g.restart_interval > 0;
+    // (the one-launch encoders need the segment offsets only for the APP13 index)
     const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_segments, dim3(scan_wgs), dim3(1024), 0, st, *job, (unsigned long long*)job->d_scan_partial, job->epoch);
+    if (!one_launch || seg_info)
+        hipLaunchKernelGGL(k_scan_segments, dim3(scan_wgs), dim3(1024), 0, st, *job, (unsigned long long*)job->d_scan_partial, job->epoch);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[4], st);
-    hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 4 * GJ_ASM_SEGS - 1) / (4 * GJ_ASM_SEGS)), dim3(256), 0, st, *job);
-    if (job->segment_info && g.restart_interval > 0)
+    if (!one_launch)
+        hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 4 * GJ_ASM_SEGS - 1) / (4 * GJ_ASM_SEGS)), dim3(256), 0, st, *job);
+    if (seg_info)
         hipLaunchKernelGGL(k_segment_info, dim3(((unsigned)g.segment_count + 255) / 256), dim3(256), 0, st, *job);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[5], st);
     return hipGetLastError() == hipSuccess ? 0 : -1;

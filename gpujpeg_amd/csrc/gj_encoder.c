@@ -12,6 +12,7 @@
 #include "gj_internal.h"
 
 enum { GJ_OUT_PAGEABLE = 0, GJ_OUT_PINNED = 1, GJ_OUT_DEVICE = 2 };
+#define GJ_MAIN_HEADER_CAP 4096 /* staging of the main header (the writer never stores behind it and reports the size it would need) */
 
 struct gpujpeg_encoder {
     struct gj_coder coder;
@@ -31,6 +32,8 @@ struct gpujpeg_encoder {
     uint8_t* d_jpeg; size_t d_jpeg_cap;
     uint32_t* d_result;
     uint64_t* d_scan_partial; size_t d_scan_partial_cap;
+    uint32_t* d_tail; size_t d_tail_cap; /* the gathering tail of the one-launch kernels: two counter sets + one entry per tile stream */
+    int tail_set;                        /* the counter set the next call uses */
     uint32_t epoch;
     uint8_t* d_scan_hdr; size_t d_scan_hdr_cap;
     struct gj_scan_headers scan_hdrs;
@@ -74,7 +77,7 @@ struct gpujpeg_encoder* gpujpeg_encoder_create(cudaStream_t stream)
     e->d_huff_lut = gj_hip_malloc(4 * 256 * sizeof(uint32_t));
     e->d_result = gj_hip_malloc(4 * sizeof(uint32_t));
     e->h_result = gj_hip_host_alloc(4 * sizeof(uint32_t));
-    e->h_header = gj_hip_host_alloc(4096);
+    e->h_header = gj_hip_host_alloc(GJ_MAIN_HEADER_CAP);
     if (!e->d_fwd_q[0] || !e->d_fwd_q[1] || !e->d_huff_lut || !e->d_result || !e->h_result || !e->h_header) goto fail;
     uint32_t lut[4 * 256];
     gj_huffman_encoder_lut(lut);
@@ -92,7 +95,7 @@ int gpujpeg_encoder_destroy(struct gpujpeg_encoder* e)
     gj_coder_process_stats_overall(&e->coder);
     gj_timers_destroy(&e->coder.timers);
     gj_hip_free(e->d_fwd_q[0]); gj_hip_free(e->d_fwd_q[1]); gj_hip_free(e->d_huff_lut); gj_hip_free(e->d_result);
-    gj_hip_free(e->d_temp); gj_hip_free(e->d_scan_partial); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
+    gj_hip_free(e->d_temp); gj_hip_free(e->d_tail); gj_hip_free(e->d_scan_partial); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
     gj_hip_free(e->coder.d_raw_own); gj_hip_free(e->coder.d_planes); gj_hip_free(e->coder.d_coefs);
     gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header); free(e->hdr_sent);
     gj_exif_tags_destroy(e->exif_tags);
@@ -159,7 +162,11 @@ static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_par
     /* planes are needed by the generic path only; zero filled once, padding is never written (common.c:941-944) */
     if (gj_ensure_device_buffer((void**)&c->d_planes, &c->d_planes_cap, g->data_size) != 0) return -1;
     if (gj_hip_memset(c->d_planes, 0, g->data_size, c->stream) != 0) return -1;
-    if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_TEMP_BYTES_PER_BLOCK + 256) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_STAGE_BYTES_PER_BLOCK + 256) != 0) return -1;
+    /* the tail's counters are zero between calls (the kernel leaves them so); cleared here in case a failed launch did not */
+    if (gj_ensure_device_buffer((void**)&e->d_tail, &e->d_tail_cap, (16 + 2 * ((size_t)g->segment_count + 1)) * sizeof(uint32_t)) != 0) return -1;
+    if (gj_hip_memset(e->d_tail, 0, 16 * sizeof(uint32_t), c->stream) != 0) return -1;
+    e->tail_set = 0;
     {
         const size_t need = (((size_t)g->segment_count + 1023) / 1024 + 1) * sizeof(uint64_t);
         const size_t had = e->d_scan_partial_cap;
@@ -239,11 +246,15 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     }
 
     /* main header: host bytes, placed at the start of the device stream */
-    const size_t hdr = gj_write_main_header(e->h_header, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata, e->exif_tags);
+    const size_t hdr = gj_write_main_header(e->h_header, GJ_MAIN_HEADER_CAP, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata, e->exif_tags);
+    if (hdr > GJ_MAIN_HEADER_CAP) {
+        GJ_ERROR("The main header (%zu B: Exif tags, metadata) does not fit its %d B staging buffer.\n", hdr, GJ_MAIN_HEADER_CAP);
+        return -1;
+    }
     /* (the kernels write behind it, so it is uploaded again only when it changes -- parameters, or the wall clock of an Exif header -- or
      * the stream buffer was reallocated) */
-    if (!e->hdr_sent) e->hdr_sent = malloc(4096);
-    if (!e->hdr_sent || hdr > 4096) return -1;
+    if (!e->hdr_sent) e->hdr_sent = malloc(GJ_MAIN_HEADER_CAP);
+    if (!e->hdr_sent) return -1;
     if (e->hdr_sent_to != e->d_jpeg || e->hdr_sent_len != hdr || memcmp(e->hdr_sent, e->h_header, hdr) != 0) {
         if (gj_hip_memcpy_h2d(e->d_jpeg, e->h_header, hdr, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) return -1; /* (h_header is rewritten by the next call) */
         memcpy(e->hdr_sent, e->h_header, hdr);
@@ -282,6 +293,9 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.d_result = e->d_result;
     job.h_result = e->h_result;
     job.d_scan_partial = e->d_scan_partial;
+    job.d_tail = e->d_tail;
+    job.tail_set = e->tail_set;
+    e->tail_set ^= 1;
     if (++e->epoch == 0) e->epoch = 1;
     job.epoch = e->epoch;
     job.tune = e->tune;
@@ -294,11 +308,13 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.keep_coefs = e->keep_coefs;
     if (gj_hip_encode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Encoder kernels failed: %s\n", gj_hip_last_error());
+        c->configured = false; /* (the next call sets the device-side state up again) */
         return -1;
     }
     /* size first, then the bytes (:550-563) */
     if (gj_hip_stream_sync(c->stream) != 0) { /* (the two result words are in host memory once the kernels have run) */
         GJ_ERROR("Encoder failed: %s\n", gj_hip_last_error());
+        c->configured = false;
         return -1;
     }
     const size_t size = e->h_result[0];
@@ -361,7 +377,7 @@ size_t gpujpeg_encoder_max_memory(struct gpujpeg_parameters* param, struct gpujp
     if (p.restart_interval == RESTART_AUTO) p.restart_interval = gpujpeg_encoder_suggest_restart_interval(&t, gj_make_sampling_factor(p.comp_count, p.sampling_factor), p.interleaved, -1);
     gj_geom g;
     if (gj_geom_init(&g, &p, &t, true) != 0) return 0;
-    size_t total = g.data_size * 3 + (size_t)g.block_count * GJ_TEMP_BYTES_PER_BLOCK + (size_t)g.segment_count * 12 +
+    size_t total = g.data_size * 3 + (size_t)g.block_count * GJ_STAGE_BYTES_PER_BLOCK + (size_t)g.segment_count * 20 +
                    1000 + (size_t)t.width * t.height * p.comp_count * 2;
     if (type == GPUJPEG_ENCODER_INPUT_IMAGE) total += g.raw_size;
     return total;
@@ -554,14 +570,14 @@ size_t gpujpeg_amd_host_headers_exif(const struct gpujpeg_parameters* param, con
     uint8_t qraw[2][64];
     gj_quant_table_raw(0, p.quality, qraw[0]);
     gj_quant_table_raw(1, p.quality, qraw[1]);
-    uint8_t hdr[4096];
-    const size_t n = gj_write_main_header(hdr, &g, &p, (enum gpujpeg_header_type)header_type, (const uint8_t(*)[64])qraw, &md, tags);
+    uint8_t hdr[GJ_MAIN_HEADER_CAP];
+    const size_t n = gj_write_main_header(hdr, sizeof hdr, &g, &p, (enum gpujpeg_header_type)header_type, (const uint8_t(*)[64])qraw, &md, tags);
     gj_exif_tags_destroy(tags);
     struct gj_scan_headers sh;
     memset(&sh, 0, sizeof sh);
     if (gj_write_scan_headers(&sh, &g, &p) != 0) return 0;
     size_t total = 0;
-    if (n + sh.size <= capacity) {
+    if (n <= sizeof hdr && n + sh.size <= capacity) {
         memcpy(dst, hdr, n);
         memcpy(dst + n, sh.bytes, sh.size);
         total = n + sh.size;

@@ -96,7 +96,7 @@ struct gj_scan_headers {
 struct gj_exif_tags; /* user Exif tags (enc_exif_tag), gj_writer.c */
 int gj_exif_add_tag(struct gj_exif_tags** tags, const char* cfg); /* 0 = added, -1 = error or "help" */
 void gj_exif_tags_destroy(struct gj_exif_tags* tags);
-size_t gj_write_main_header(uint8_t* out, const gj_geom* g, const struct gpujpeg_parameters* param, enum gpujpeg_header_type header_type,
+size_t gj_write_main_header(uint8_t* out, size_t out_cap, const gj_geom* g, const struct gpujpeg_parameters* param, enum gpujpeg_header_type header_type,
                             const uint8_t qraw[2][64], const struct gpujpeg_image_metadata* metadata, const struct gj_exif_tags* exif_tags);
 int gj_write_scan_headers(struct gj_scan_headers* sh, const gj_geom* g, const struct gpujpeg_parameters* param);
 

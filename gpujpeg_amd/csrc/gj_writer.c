@@ -16,13 +16,14 @@
 
 struct bw {
     uint8_t* p;
-    size_t n;
+    size_t n;   /* bytes the content needs so far */
+    size_t cap; /* bytes of p: nothing is ever written behind them, n keeps counting (the caller compares) */
 };
-static void b1(struct bw* w, unsigned v) { w->p[w->n++] = (uint8_t)v; }
+static void b1(struct bw* w, unsigned v) { if (w->n < w->cap) w->p[w->n] = (uint8_t)v; w->n++; }
 static void b2(struct bw* w, unsigned v) { b1(w, v >> 8); b1(w, v); }
 static void b4(struct bw* w, unsigned v) { b2(w, v >> 16); b2(w, v); }
 static void marker(struct bw* w, unsigned m) { b1(w, 0xFF); b1(w, m); }
-static void text(struct bw* w, const char* s, size_t n) { memcpy(w->p + w->n, s, n); w->n += n; }
+static void text(struct bw* w, const char* s, size_t n) { for (size_t i = 0; i < n; i++) b1(w, (unsigned char)s[i]); }
 
 static unsigned component_id(const gj_geom* g, int i) /* writer.c:303-311 */
 {
@@ -261,7 +262,7 @@ static void exif_record(struct bw* w, size_t start, size_t* end, unsigned id, un
         size /= 2;
     }
     const size_t total = (size_t)size * count;
-    struct bw v = {w->p, w->n};
+    struct bw v = {w->p, w->n, w->cap};
     if (total > 4) {
         b4(w, (unsigned)(*end - start));
         v.n = *end;
@@ -307,7 +308,7 @@ static void exif_ifd(struct bw* w, size_t start, struct exif_builtin* builtin, s
     const size_t first = w->n;
     for (size_t i = 0; i < written; i++) exif_record(w, start, &end, builtin[i].id, builtin[i].type, builtin[i].count, builtin[i].u, builtin[i].s);
     for (size_t i = 0; i < n_custom; i++) exif_record(w, start, &end, custom[i].id, custom[i].type, custom[i].count, custom[i].u, custom[i].s);
-    if (n_custom) qsort(w->p + first, all, 12, exif_record_cmp);
+    if (n_custom && w->n <= w->cap) qsort(w->p + first, all, 12, exif_record_cmp);
     b4(w, 0); /* no next IFD */
     w->n = end;
 }
@@ -343,7 +344,7 @@ static void exif_app1(struct bw* w, const gj_geom* g, const struct gpujpeg_image
     };
     const size_t ifd0 = w->n;
     exif_ifd(w, start, tiff, sizeof tiff / sizeof tiff[0], 0, custom ? custom->v[0] : NULL, custom ? custom->n[0] : 0);
-    {   /* the Exif IFD starts here: store its offset in the pointer record (the reference reads a compound literal that is out of
+    if (w->n <= w->cap) { /* the Exif IFD starts here: store its offset in the pointer record (the reference reads a compound literal that is out of
          * scope at that point, src/gpujpeg_exif.c:297-300, i.e. writes an unspecified value) */
         const unsigned n = ((unsigned)w->p[ifd0] << 8) | w->p[ifd0 + 1];
         for (unsigned i = 0; i < n; i++) {
@@ -364,14 +365,16 @@ static void exif_app1(struct bw* w, const gj_geom* g, const struct gpujpeg_image
      * last record in its files; we reproduce its bytes (tests/test_oracle_vs_ref.py compares the APP1 segments of both libraries) */
     exif_ifd(w, start, priv, sizeof priv / sizeof priv[0], sizeof priv / sizeof priv[0], custom ? custom->v[1] : NULL, custom ? custom->n[1] : 0);
     const size_t length = w->n - len_at;
-    w->p[len_at] = (uint8_t)(length >> 8);
-    w->p[len_at + 1] = (uint8_t)length;
+    if (len_at + 1 < w->cap) {
+        w->p[len_at] = (uint8_t)(length >> 8);
+        w->p[len_at + 1] = (uint8_t)length;
+    }
 }
 
-size_t gj_write_main_header(uint8_t* out, const gj_geom* g, const struct gpujpeg_parameters* param, enum gpujpeg_header_type header_type,
+size_t gj_write_main_header(uint8_t* out, size_t out_cap, const gj_geom* g, const struct gpujpeg_parameters* param, enum gpujpeg_header_type header_type,
                             const uint8_t qraw[2][64], const struct gpujpeg_image_metadata* md, const struct gj_exif_tags* exif_tags)
 {
-    struct bw w = {out, 0};
+    struct bw w = {out, 0, out_cap}; /* (returns the size the header needs: larger than out_cap = it does not fit, and was cut) */
     marker(&w, 0xD8);
     enum gpujpeg_header_type h = header_type;
     if (h == GPUJPEG_HEADER_DEFAULT) { /* writer.c:456-474 */
@@ -457,7 +460,7 @@ int gj_write_scan_headers(struct gj_scan_headers* sh, const gj_geom* g, const st
     free(sh->bytes);
     sh->bytes = calloc(1, need);
     if (!sh->bytes) return -1;
-    struct bw w = {sh->bytes, 0};
+    struct bw w = {sh->bytes, 0, need};
     for (int s = 0; s < g->scan_count; s++) {
         sh->offset[s] = (uint32_t)w.n;
         sh->info_payload[s] = 0;

@@ -361,6 +361,46 @@ def test_packed_422_whole_frame_encoder(O, G, gpu_lib, w, h, restart):
         enc.close()
 
 
+# name, w, h, pixel format, colour space, quality, restart, interleaved, subsampling, noise?
+TAIL_CASES = [
+    ("rgb_many_tiles", 1024, 520, 1, 1, 75, -1, 0, None, False),          # k_encode_rgb444: 3 x 33 tile streams, chroma behind all luminance
+    ("rgb_noise_q100_windows", 512, 264, 1, 1, 100, 32, 0, None, True),   # tile streams of ~25 KB: several LDS windows, bytes stored one by one
+    ("rgb_noise_q90", 640, 368, 1, 1, 90, -1, 0, None, True),             # 0xFF bytes in most segments
+    ("rgb_short_last_tile", 1000, 200, 1, 1, 60, 7, 0, None, False),      # the scan's last tile is a partial one
+    ("uyvy_il", 1288, 240, 3, 3, 90, -1, 1, None, True),                  # k_encode_uyvy422: one scan
+    ("rgb_420_il", 644, 482, 1, 1, 75, -1, 1, [(2, 2), (1, 1), (1, 1)], False),   # k_encode_blocks, interleaved
+    ("rgb_422_nonil", 800, 300, 1, 1, 80, 5, 0, [(2, 1), (1, 1), (1, 1)], True),  # k_encode_blocks: scans with different tile counts
+    ("planar420", 642, 482, 5, 3, 75, -1, 0, None, True),
+    ("gray", 999, 333, 0, 3, 75, 6, 0, None, False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shares", [0, 1, 3, 100000], ids=lambda s: f"shares{s}")
+@pytest.mark.parametrize("tc", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_one_launch_encoder_tail(O, G, gpu_lib, tc, shares, monkeypatch):
+    """The one-launch encoders (k_encode_*): every workgroup leaves its tile's finished stream (stuffed, RSTn in place) in d_temp, the
+    last workgroups gather them into the file (scan headers, EOI, size). Replaces src/gpujpeg_huffman_gpu_encoder.cu:417-613 and the
+    host stitching of src/gpujpeg_encoder.c:567-629; the bytes must be the oracle's whatever the number of shares the tail cuts the
+    tile list into (GJ_ENC_TAIL: 1 = one workgroup gathers everything, more shares than tiles = one tile stream per share), with
+    and without the APP13 index, twice in a row on the same coder (the tail's counters alternate between two sets)."""
+    name, w, h, pf, cs, q, restart, il, sub, noisy = tc
+    if shares:
+        monkeypatch.setenv("GJ_ENC_TAIL", str(shares))
+    else:
+        monkeypatch.delenv("GJ_ENC_TAIL", raising=False)
+    case = (name, w, h, pf, cs, q, restart, il, sub, 3)
+    comps = {0: 1, 1: 3}.get(pf)
+    raw = natural_image(w, h, comps, seed=w) if comps and not noisy else O.noise(O.raw_size(w, h, pf), seed=w * 7 + h)
+    enc = G.Encoder(gpu_lib)  # (reads the switch)
+    for seg_info in (0, 1, 0):
+        want = O.encode(oracle_image(O, case, segment_info=seg_info), raw)
+        p, pi = api_params(gpu_lib, G, case, segment_info=seg_info)
+        got = enc.encode(p, pi, raw)
+        assert got.size == want.size and np.array_equal(got, want), (name, shares, seg_info, got.size, want.size)
+    enc.close()
+
+
 TOKEN_CASES = [
     # name, w, h, quality, restart, noise? (non-interleaved RGB 4:4:4: the configurations the token-fed IDCT serves)
     ("natural_auto", 1920, 136, 75, -1, False),

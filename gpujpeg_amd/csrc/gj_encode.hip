@@ -759,6 +759,25 @@ __device__ __forceinline__ void gj_walk_ac(uint8_t* col, const uint32_t mlo, con
     }
 }
 
+// step 5 of gj_code_tile for one lane and one window [wbase, wend) of the tile stream
+__device__ __forceinline__ void gj_merge_stream(const GjWalk& w, const uint8_t* col, const uint32_t* __restrict__ spill, const uint64_t tail,
+                                                const int ndw, const uint32_t sh, const uint32_t d0, uint32_t* s_bits, const uint32_t wbase,
+                                                const uint32_t wend)
+{
+    uint32_t prevv = 0;
+    for (int f = 0; f <= ndw; f++) { // (iteration ndw only flushes the carry)
+        uint32_t cur = 0;
+        if (f < w.stored) cur = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
+        else if (f < w.produced) cur = spill[f];
+        else if (f == w.produced) cur = (uint32_t)(tail >> 32);
+        else if (f == w.produced + 1) cur = (uint32_t)tail;
+        const uint32_t out = __builtin_amdgcn_alignbit(prevv, cur, sh);
+        const uint32_t d = d0 + (uint32_t)f;
+        if (out && d >= wbase && d < wend) atomicOr(&s_bits[d - wbase], out);
+        prevv = cur;
+    }
+}
+
 // Steps 2-6 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
 // nblocks = blocks of that segment, table = 0 luminance / 1 chrominance tables, dc_dist = lanes back to the previous block of the
 // same component; region = the tile's area of d_temp (GJ_STAGE_BYTES_PER_BLOCK per block: the finished stream from its start, block
@@ -873,123 +892,150 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
     // one funnel shift (v_alignbit_b32) of two neighbouring stream dwords and one ds_or_b32.
     // ---- 6. the window's streams -> the tile's FINISHED stream: 0x00 behind every 0xFF, RSTn behind every segment but a scan's last
     // (src/gpujpeg_huffman_gpu_encoder.cu:417-503 serialisation + :563-613 compaction + the host's stitching, src/gpujpeg_encoder.c:567-629).
-    // A tile whose streams fit one window (all but noise-like content) builds the finished bytes in the dead private rows of the
-    // coefficient area and leaves as whole 16-byte pieces; larger tiles store their bytes one by one, window after window.
     const uint32_t sh = start_bit & 31u, d0 = start_bit >> 5;
     uint64_t tail = (uint64_t)w.hi << 32;
     if (pad_bits) tail |= (uint64_t)((1u << pad_bits) - 1u) << (64 - w.fill - pad_bits);
     const int ndw = w.produced + (w.fill + pad_bits > 32 ? 2 : (w.fill + pad_bits > 0 ? 1 : 0)); // stream dwords incl. the tail
     const int nseg = min(spt, seg_count_left);
-    const bool staged = total_dw <= (uint32_t)GJ_ENC_WIN_DW;
     uint8_t* const stage = reinterpret_cast<uint8_t*>(L.coef); // rows 0 .. GJ_ENC_PRIV_ROWS - 1: 24 KB >= 2 x the window + the markers
-    uint32_t piece_pos = 0, ff_total = 0;
-    for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {
-        const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_ENC_WIN_DW);
-        if (wbase) {
-            __syncthreads(); // previous window consumed
-            for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
-            __syncthreads();
-        }
-        if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) {
-            uint32_t prevv = 0;
-            for (int f = 0; f <= ndw; f++) { // (iteration ndw only flushes the carry)
-                uint32_t cur = 0;
-                if (f < w.stored) cur = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
-                else if (f < w.produced) cur = spill[f];
-                else if (f == w.produced) cur = (uint32_t)(tail >> 32);
-                else if (f == w.produced + 1) cur = (uint32_t)tail;
-                const uint32_t out = __builtin_amdgcn_alignbit(prevv, cur, sh);
-                const uint32_t d = d0 + (uint32_t)f;
-                if (out && d >= wbase && d < wend) atomicOr(&s_bits[d - wbase], out);
-                prevv = cur;
-            }
-        }
-        __syncthreads(); // B4: window complete
-        // 6a. every wave takes whole segments: the 0xFF bytes of a segment's part of this window are one wave reduction
-        for (int sl = wave; sl < nseg; sl += 4) {
-            const uint32_t sb = L.segbase[sl], nfl = (L.segbits[sl] + 31u) >> 5;
-            const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
-            uint32_t ffc = 0;
-            for (uint32_t d = lo + (uint32_t)lane; d < hi; d += 64) {
-                const uint32_t v = s_bits[d - wbase];
-                // 0xFF bytes (the unused low bytes of a segment's last dword are zero)
-                ffc += (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
-            }
-            ffc = gj_wave_incl_scan(ffc);
-            if (lane == 63) L.segff[sl] = ffc;
-        }
-        __syncthreads(); // B5: 0xFF counts
-        // 6b. sizes and places of the parts, redundantly in every wave (lane l keeps local segment l)
-        uint32_t psz = 0;
-        if (lane < nseg) {
-            const uint32_t sb = L.segbase[lane], nb = L.segbits[lane] >> 3, nfl = (nb + 3u) >> 2;
-            const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
-            if (hi > lo) {
-                const bool ends = hi == sb + nfl;
-                const uint32_t ff = L.segff[lane];
-                ff_total += ff;
-                psz = (ends ? nb - 4u * (lo - sb) : 4u * (hi - lo)) + ff + (ends && lane != seg_count_left - 1 ? 2u : 0u);
-            }
-        }
-        const uint32_t pincl = gj_wave_incl_scan(psz);
-        const uint32_t poff = pincl - psz;
-        const uint32_t wsize = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
-        // 6c. stuffing: a lane takes a dword, the wave's prefix sum of the byte counts places it
-        for (int sl = wave; sl < nseg; sl += 4) {
+    uint32_t piece_size = 0;
+    if (total_dw <= (uint32_t)GJ_ENC_WIN_DW) {
+        // A tile whose streams fit one window (all but noise-like content): ONE pass. A wave takes a quarter of the segments, one after
+        // the other; a lane takes a dword, the wave's prefix sum of the byte counts places its bytes. The wave's bytes go to a place of
+        // their own in the dead private rows of the coefficient area (twice the unstuffed bytes in front of them is an upper bound of
+        // what the waves before it write), then leave as whole 16-byte pieces behind those of the waves before it.
+        if (active) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, 0u, total_dw);
+        __syncthreads(); // B4: window complete; the private streams are dead
+        const int sa = (wave * nseg) >> 2, sz = ((wave + 1) * nseg) >> 2; // this wave's segments
+        const uint32_t R = sa < nseg ? ((8u * L.segbase[sa] + 2u * (uint32_t)sa + 15u) & ~15u) + 16u * (uint32_t)wave : 0u;
+        uint32_t run = R;
+        for (int sl = sa; sl < sz; sl++) {
             const uint32_t sb = L.segbase[sl], nb = L.segbits[sl] >> 3, nfl = (nb + 3u) >> 2;
-            const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
-            uint32_t run = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)poff) + (staged ? 0u : piece_pos);
-            for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
+            const uint32_t run0 = run;
+            for (uint32_t c0 = 0; c0 < nfl; c0 += 64) {
                 const uint32_t d = c0 + (uint32_t)lane;
                 uint32_t v = 0;
                 int vb = 0;
-                if (d < hi) {
-                    v = s_bits[d - wbase];
-                    vb = (int)min(4u, nb - 4u * (d - sb));
+                if (d < nfl) {
+                    v = s_bits[sb + d];
+                    vb = (int)min(4u, nb - 4u * d);
                 }
+                // 0xFF bytes (the unused low bytes of a segment's last dword are zero)
                 const uint32_t cnt = (uint32_t)vb + (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
                 const uint32_t inc = gj_wave_incl_scan(cnt);
                 uint32_t p = run + inc - cnt;
-                if (staged) {
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (b < vb) {
-                            const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
-                            stage[p++] = (uint8_t)byte;
-                            if (byte == 0xFFu) stage[p++] = 0;
-                        }
-                } else {
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (b < vb) {
-                            const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
-                            region[p++] = (uint8_t)byte;
-                            if (byte == 0xFFu) region[p++] = 0;
-                        }
-                }
+                for (int b = 0; b < 4; b++)
+                    if (b < vb) {
+                        const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
+                        stage[p++] = (uint8_t)byte;
+                        if (byte == 0xFFu) stage[p++] = 0;
+                    }
                 run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             }
-            if (hi > lo && hi == sb + nfl && sl != seg_count_left - 1 && lane == 0) { // the segment ends here: RSTn (src/gpujpeg_huffman_gpu_encoder.cu:497-502)
-                const uint8_t m = (uint8_t)(0xD0 + ((index0 + sl) & 7));
-                if (staged) { stage[run] = 0xFF; stage[run + 1] = m; }
-                else { region[run] = 0xFF; region[run + 1] = m; }
+            if (seg_sizes && lane == 0) {
+                seg_bytes[first_segment + sl] = nb;
+                seg_ff[first_segment + sl] = run - run0 - nb;
+            }
+            if (sl != seg_count_left - 1) { // RSTn (src/gpujpeg_huffman_gpu_encoder.cu:497-502)
+                if (lane == 0) {
+                    stage[run] = 0xFF;
+                    stage[run + 1] = (uint8_t)(0xD0 + ((index0 + sl) & 7));
+                }
+                run += 2;
             }
         }
-        if (staged) {
-            __syncthreads(); // B6: the finished stream is in the stage
-            const uint4* src = reinterpret_cast<const uint4*>(stage);
-            uint4* dst = reinterpret_cast<uint4*>(region);
-            for (uint32_t q = i; q * 16u < wsize; q += 256) dst[q] = src[q];
+        if (lane == 0) L.wsum[wave] = run - R;
+        __syncthreads(); // B5: every wave's bytes and their count
+        const uint32_t n0 = L.wsum[0], n1 = L.wsum[1], n2 = L.wsum[2], n3 = L.wsum[3];
+        const uint32_t O = wave == 0 ? 0u : wave == 1 ? n0 : wave == 2 ? n0 + n1 : n0 + n1 + n2, n = run - R;
+        piece_size = n0 + n1 + n2 + n3;
+        for (uint32_t q = (uint32_t)lane * 16u; q < n; q += 1024) {
+            if (q + 16u <= n) {
+                gj_store16_agent(region + O + q, *reinterpret_cast<const gj_u4*>(stage + R + q));
+            } else {
+                for (uint32_t b = q; b < n; b++) gj_store1_agent(region + O + b, stage[R + b]);
+            }
         }
-        piece_pos += wsize;
-    }
-    if (seg_sizes && wave == 0 && lane < nseg) {
-        seg_bytes[first_segment + lane] = L.segbits[lane] >> 3;
-        seg_ff[first_segment + lane] = ff_total;
+    } else {
+        // noise-like content: window after window; the bytes are counted first (6a, 6b), then stored one by one (6c)
+        uint32_t ff_total = 0;
+        for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {
+            const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_ENC_WIN_DW);
+            if (wbase) {
+                __syncthreads(); // previous window consumed
+                for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
+                __syncthreads();
+            }
+            if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, wbase, wend);
+            __syncthreads(); // B4: window complete
+            // 6a. every wave takes whole segments: the 0xFF bytes of a segment's part of this window are one wave reduction
+            for (int sl = wave; sl < nseg; sl += 4) {
+                const uint32_t sb = L.segbase[sl], nfl = (L.segbits[sl] + 31u) >> 5;
+                const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
+                uint32_t ffc = 0;
+                for (uint32_t d = lo + (uint32_t)lane; d < hi; d += 64) {
+                    const uint32_t v = s_bits[d - wbase];
+                    ffc += (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
+                }
+                ffc = gj_wave_incl_scan(ffc);
+                if (lane == 63) L.segff[sl] = ffc;
+            }
+            __syncthreads(); // B5: 0xFF counts
+            // 6b. sizes and places of the parts, redundantly in every wave (lane l keeps local segment l)
+            uint32_t psz = 0;
+            if (lane < nseg) {
+                const uint32_t sb = L.segbase[lane], nb = L.segbits[lane] >> 3, nfl = (nb + 3u) >> 2;
+                const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
+                if (hi > lo) {
+                    const bool ends = hi == sb + nfl;
+                    const uint32_t ff = L.segff[lane];
+                    ff_total += ff;
+                    psz = (ends ? nb - 4u * (lo - sb) : 4u * (hi - lo)) + ff + (ends && lane != seg_count_left - 1 ? 2u : 0u);
+                }
+            }
+            const uint32_t pincl = gj_wave_incl_scan(psz);
+            const uint32_t poff = pincl - psz;
+            // 6c. stuffing: a lane takes a dword, the wave's prefix sum of the byte counts places it
+            for (int sl = wave; sl < nseg; sl += 4) {
+                const uint32_t sb = L.segbase[sl], nb = L.segbits[sl] >> 3, nfl = (nb + 3u) >> 2;
+                const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
+                uint32_t run = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)poff) + piece_size;
+                for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
+                    const uint32_t d = c0 + (uint32_t)lane;
+                    uint32_t v = 0;
+                    int vb = 0;
+                    if (d < hi) {
+                        v = s_bits[d - wbase];
+                        vb = (int)min(4u, nb - 4u * (d - sb));
+                    }
+                    const uint32_t cnt = (uint32_t)vb + (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
+                    const uint32_t inc = gj_wave_incl_scan(cnt);
+                    uint32_t p = run + inc - cnt;
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (b < vb) {
+                            const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
+                            gj_store1_agent(region + p++, byte);
+                            if (byte == 0xFFu) gj_store1_agent(region + p++, 0u);
+                        }
+                    run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                }
+                if (hi > lo && hi == sb + nfl && sl != seg_count_left - 1 && lane == 0) { // the segment ends here: RSTn
+                    gj_store1_agent(region + run, 0xFFu);
+                    gj_store1_agent(region + run + 1, 0xD0u + (uint32_t)((index0 + sl) & 7));
+                }
+            }
+            piece_size += (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+        }
+        if (seg_sizes && wave == 0 && lane < nseg) {
+            seg_bytes[first_segment + lane] = L.segbits[lane] >> 3;
+            seg_ff[first_segment + lane] = ff_total;
+        }
     }
     __syncthreads(); // B7: the coefficient area may be overwritten by the next component
     if (trace0 >= 0) GJ_TRACE_E(trace0 + 3); // merged, stuffed and stored
-    return piece_pos;
+    return piece_size;
 }
 
 // ================================================================================================
@@ -1006,8 +1052,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
 // share that meets them. The workgroup that finishes last always gathers, so the list is always emptied.
 // Counters: two sets that alternate with the call's epoch; the last finisher clears the other set for the next call.
 // ================================================================================================
-typedef uint32_t gj_u4 __attribute__((ext_vector_type(4)));
-typedef gj_u4 __attribute__((aligned(1))) gj_u4_unaligned; // a 16-byte global load from any address (one instruction on gfx950)
+typedef gj_u4 __attribute__((aligned(1))) gj_u4_unaligned; // a 16-byte global store to any address (one instruction on gfx950)
 struct GjTail {
     uint32_t* ctr;        // [0] workgroups started, [1] finished, [2] next share, [3] every tile stream is complete
     uint32_t* ctr_other;  // the next call's set
@@ -1029,74 +1074,89 @@ __device__ __forceinline__ uint32_t gj_tail_hdr_end(const GjTail& T, const uint3
     return scan == 0 ? T.hdr_end[0] : scan == 1 ? T.hdr_end[1] : scan == 2 ? T.hdr_end[2] : T.hdr_end[3];
 }
 
-// s_mem: >= 1300 words of LDS nothing else uses any more
+// one entry of the tile list (written and read with device scope, see gj_store16_agent)
+__device__ __forceinline__ void gj_piece_put(const GjTail& T, const uint32_t p, const uint32_t size_scan, const uint32_t off16)
+{
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(T.piece) + p, (uint64_t)size_scan | ((uint64_t)off16 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint2 gj_piece_get(const GjTail& T, const uint32_t p)
+{
+    const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(T.piece) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+// s_mem: >= 1100 words of LDS nothing else uses any more
 __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem, const int i)
 {
     uint32_t* const s_tmp = s_mem;      // [4] scans, [4] role, [5] share
     uint32_t* const tF = s_mem + 16;    // [256] file offset of the tile stream
     uint32_t* const tsrc = tF + 256;    // [256] offset in d_temp / 16
     uint32_t* const tsize = tsrc + 256; // [256]
-    uint32_t* const tcs = tsize + 256;  // [256] first 16-byte piece (in the share's numbering)
-    const uint32_t ntiles = gridDim.x;
-    __threadfence(); // this thread's part of the tile streams is out
+    uint32_t* const tcs = tsize + 256;  // [256] first 16-byte piece (in the batch's numbering)
+    const uint32_t ntiles = gridDim.x, P = T.npieces, K = T.shares;
+    gj_wait_stores(); // this wave's part of the tile streams (and the tile's list entries) is out: device-scope stores, no fence
     __syncthreads();
     if (i == 0) {
-        const uint32_t d = __hip_atomic_fetch_add(&T.ctr[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t role = 0;
+        const uint32_t started = __hip_atomic_load(&T.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t d = __hip_atomic_fetch_add(&T.ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t role = 0, share = K;
         if (d + 1 == ntiles) {
-            for (int q = 0; q < 8; q++) T.ctr_other[q] = 0;
-            __hip_atomic_store(&T.ctr[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < 8; q++) T.ctr_other[q] = 0; // (read by the next launch only)
+            __hip_atomic_store(&T.ctr[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             role = 1;
-        } else if (d + T.shares >= ntiles && __hip_atomic_load(&T.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ntiles) {
+        } else if (d + K >= ntiles && started == ntiles) {
             role = 1;
         }
+        if (role) share = __hip_atomic_fetch_add(&T.ctr[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (asked for before the wait)
         s_tmp[4] = role;
+        s_tmp[5] = share;
     }
     __syncthreads();
     if (!s_tmp[4]) return;
     GJ_TRACE_E(14);
     if (i == 0)
-        while (__hip_atomic_load(&T.ctr[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(&T.ctr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
     __syncthreads();
-    __threadfence(); // (acquire for every thread: the other workgroups' streams and sizes)
-    const uint32_t P = T.npieces, K = T.shares;
-    for (;;) {
-        __syncthreads();
-        if (i == 0) s_tmp[5] = atomicAdd(&T.ctr[2], 1u);
-        __syncthreads();
-        const uint32_t share = s_tmp[5];
-        if (share >= K) break;
+    uint32_t share = s_tmp[5];
+    while (share < K) {
         const uint32_t pa = (uint32_t)((uint64_t)share * P / K), pb = (uint32_t)((uint64_t)(share + 1) * P / K);
-        // all tile sizes: the bytes in front of this share, and the whole stream
+        // all tile sizes in one trip, starting with the share's own tiles (lane i: tile pa + i): the bytes in front of the share and the
+        // size of the whole stream
         uint32_t before = 0, all = 0;
-        for (uint32_t p = i; p < P; p += 256) {
-            const uint32_t sz = T.piece[p].x & 0x0FFFFFFFu;
+        uint2 mine = make_uint2(0, 0);
+        for (uint32_t idx = i; idx < P; idx += 256) {
+            uint32_t p = pa + idx;
+            const bool wrapped = p >= P;
+            if (wrapped) p -= P;
+            const uint2 st = gj_piece_get(T, p);
+            if (idx == (uint32_t)i) mine = st;
+            const uint32_t sz = st.x & 0x0FFFFFFFu;
             all += sz;
-            before += p < pa ? sz : 0u;
+            before += wrapped ? sz : 0u;
         }
         uint32_t done_bytes, all_bytes;
         gj_wg256_incl_scan(before, s_tmp, &done_bytes);
         gj_wg256_incl_scan(all, s_tmp, &all_bytes);
-        const uint32_t last_scan = T.piece[P - 1].x >> 28;
+        const uint32_t last_scan = gj_piece_get(T, P - 1).x >> 28;
         const uint64_t total = (uint64_t)T.main_hdr + gj_tail_hdr_end(T, last_scan) + all_bytes + 2u;
         const bool overflow = total > T.capacity;
         for (uint32_t p0 = pa; p0 < pb; p0 += 256) {
             const uint32_t p = p0 + (uint32_t)i;
             const bool have = p < pb;
             uint2 st = make_uint2(0, 0);
-            if (have) st = T.piece[p];
+            if (have) st = p0 == pa ? mine : gj_piece_get(T, p);
             const uint32_t size = st.x & 0x0FFFFFFFu, scan = st.x >> 28;
             uint32_t batch_bytes, C;
             const uint32_t incl = gj_wg256_incl_scan(size, s_tmp, &batch_bytes);
             const uint32_t F = T.main_hdr + gj_tail_hdr_end(T, scan) + done_bytes + incl - size;
-            const uint32_t nch = have ? ((F & 15u) + size + 15u) >> 4 : 0u;
+            const uint32_t nch = (size + 15u) >> 4; // 16-byte pieces of the tile stream (aligned in d_temp)
             const uint32_t cincl = gj_wg256_incl_scan(nch, s_tmp, &C);
             tF[i] = F;
             tsrc[i] = st.y;
             tsize[i] = size;
             tcs[i] = cincl - nch; // (= C for the lanes behind the share's last tile)
             if (have && !overflow) {
-                const uint32_t prev_scan = p == 0 ? 0xFFFFFFFFu : (T.piece[p - 1].x >> 28);
+                const uint32_t prev_scan = p == 0 ? 0xFFFFFFFFu : (gj_piece_get(T, p - 1).x >> 28);
                 if (scan != prev_scan) { // first tile of a scan: its header (APP13 placeholders + SOS) sits right in front
                     const uint32_t h1 = gj_tail_hdr_end(T, scan), h0 = scan == 0 ? 0u : gj_tail_hdr_end(T, scan - 1);
                     for (uint32_t b = 0; b < h1 - h0; b++) T.jpeg[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
@@ -1116,39 +1176,47 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
             }
             __syncthreads();
             if (!overflow) {
+                const uint64_t* const src64 = reinterpret_cast<const uint64_t*>(T.temp);
                 for (uint32_t q0 = 0; q0 < C; q0 += 1024) {
-                    gj_u4 val[4];
-                    uint32_t dlo[4], dhi[4];
-                    const uint8_t* src[4];
+                    uint64_t lo64[4], hi64[4];
+                    uint32_t dst[4], nbytes[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const uint32_t q = q0 + (uint32_t)u * 256u + (uint32_t)i;
-                        dlo[u] = dhi[u] = 0;
-                        src[u] = T.temp;
-                        val[u] = (gj_u4)0u;
+                        dst[u] = nbytes[u] = 0;
+                        lo64[u] = hi64[u] = 0;
                         if (q < C) {
                             uint32_t lo = 0;
 #pragma unroll
                             for (uint32_t step = 128; step; step >>= 1)
                                 if (tcs[lo + step] <= q) lo += step;
-                            const uint32_t f = tF[lo], c_lo = (f & ~15u) + 16u * (q - tcs[lo]);
-                            dlo[u] = max(f, c_lo);
-                            dhi[u] = min(f + tsize[lo], c_lo + 16u);
-                            src[u] = T.temp + (uint64_t)tsrc[lo] * 16u + (dlo[u] - f);
+                            const uint32_t k = q - tcs[lo];
+                            dst[u] = tF[lo] + 16u * k;
+                            nbytes[u] = min(16u, tsize[lo] - 16u * k);
+                            const uint64_t* s8 = src64 + ((uint64_t)tsrc[lo] + k) * 2u;
+                            lo64[u] = __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hi64[u] = __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        if (dhi[u] - dlo[u] == 16u) val[u] = *reinterpret_cast<const gj_u4_unaligned*>(src[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (dhi[u] - dlo[u] == 16u) *reinterpret_cast<gj_u4*>(T.jpeg + dlo[u]) = val[u];
-                        else
-                            for (uint32_t b = 0; b < dhi[u] - dlo[u]; b++) T.jpeg[dlo[u] + b] = src[u][b];
+                        if (nbytes[u] == 16u) {
+                            gj_u4 v;
+                            v.x = (uint32_t)lo64[u]; v.y = (uint32_t)(lo64[u] >> 32); v.z = (uint32_t)hi64[u]; v.w = (uint32_t)(hi64[u] >> 32);
+                            *reinterpret_cast<gj_u4_unaligned*>(T.jpeg + dst[u]) = v;
+                        } else {
+                            for (uint32_t b = 0; b < nbytes[u]; b++) T.jpeg[dst[u] + b] = (uint8_t)((b < 8 ? lo64[u] : hi64[u]) >> (8 * (b & 7)));
+                        }
                     }
                 }
             }
             done_bytes += batch_bytes;
             __syncthreads();
         }
+        if (i == 0) s_tmp[5] = __hip_atomic_fetch_add(&T.ctr[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        share = s_tmp[5];
+        __syncthreads();
     }
     GJ_TRACE_E(15);
 }
@@ -1228,7 +1296,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
                                            temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
                                            (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
         // file order: the luminance scan's tiles, then the two chrominance scans'
-        if (i == 0) T.piece[(uint32_t)c * gridDim.x + blockIdx.x] = make_uint2(size | ((uint32_t)c << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+        if (i == 0) gj_piece_put(T, (uint32_t)c * gridDim.x + blockIdx.x, size | ((uint32_t)c << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
     }
     gj_encode_tail(T, s_coef, i);
 }
@@ -1339,7 +1407,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
                                            p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0,
                                            temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff, (uint32_t)seg0);
-        if (i == 0) T.piece[blockIdx.x] = make_uint2(size, (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+        if (i == 0) gj_piece_put(T, blockIdx.x, size, (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
     }
     gj_encode_tail(T, s_coef, i);
 }
@@ -1538,7 +1606,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
                                            temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
                                            (uint32_t)(scan_first + seg0));
         // (workgroups are numbered in file order: the tiles of scan 0, of scan 1, ...)
-        if (i == 0) T.piece[blockIdx.x] = make_uint2(size | ((uint32_t)scan << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+        if (i == 0) gj_piece_put(T, blockIdx.x, size | ((uint32_t)scan << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
     }
     gj_encode_tail(T, s_coef, i);
 }

@@ -27,3 +27,9 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
     d.y = d.y < 0.0f ? 0.0f : (d.y > 1.0f ? 1.0f : d.y);
     return v + d;
 }
+
+// device-scope (write-through) stores and the wait for them: plain stores and a fence between OS threads
+typedef uint32_t gj_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gj_store16_agent(void* p, gj_u4 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ void gj_store1_agent(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
+__device__ __forceinline__ void gj_wait_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }

@@ -1053,8 +1053,12 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
 // Counters: two sets that alternate with the call's epoch; the last finisher clears the other set for the next call.
 // ================================================================================================
 typedef gj_u4 __attribute__((aligned(1))) gj_u4_unaligned; // a 16-byte global store to any address (one instruction on gfx950)
+#define GJ_TAIL_STARTED 0   // workgroups that have started
+#define GJ_TAIL_DONE 32     // workgroups whose tile streams are complete
+#define GJ_TAIL_SHARE 64    // next share of the tile list
+#define GJ_TAIL_CTR_WORDS 96 // (every counter on a 128-byte line of its own: the waiting workgroups poll one of them)
 struct GjTail {
-    uint32_t* ctr;        // [0] workgroups started, [1] finished, [2] next share, [3] every tile stream is complete
+    uint32_t* ctr;        // this call's counters (GJ_TAIL_*), zero when the kernel starts
     uint32_t* ctr_other;  // the next call's set
     uint2* piece;         // [npieces] tile streams in FILE order: x = size | scan << 28, y = offset in d_temp / 16
     const uint8_t* temp;
@@ -1094,28 +1098,30 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
     uint32_t* const tsize = tsrc + 256; // [256]
     uint32_t* const tcs = tsize + 256;  // [256] first 16-byte piece (in the batch's numbering)
     const uint32_t ntiles = gridDim.x, P = T.npieces, K = T.shares;
+    // (asked for before the wait below, which hides the trip: has every workgroup of the launch started?)
+    uint32_t started = 0;
+    if (i == 0) started = __hip_atomic_load(&T.ctr[GJ_TAIL_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     gj_wait_stores(); // this wave's part of the tile streams (and the tile's list entries) is out: device-scope stores, no fence
     __syncthreads();
     if (i == 0) {
-        const uint32_t started = __hip_atomic_load(&T.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t d = __hip_atomic_fetch_add(&T.ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t role = 0, share = K;
+        const uint32_t d = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t share = 0xFFFFFFFFu; // not gathering
         if (d + 1 == ntiles) {
-            for (int q = 0; q < 8; q++) T.ctr_other[q] = 0; // (read by the next launch only)
-            __hip_atomic_store(&T.ctr[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            role = 1;
+            share = K - 1; // the last one to finish gathers whatever happens; its share is reserved (no trip to the counter on the critical path)
+            T.ctr_other[GJ_TAIL_STARTED] = 0; // (read by the next launch only)
+            T.ctr_other[GJ_TAIL_DONE] = 0;
+            T.ctr_other[GJ_TAIL_SHARE] = 0;
         } else if (d + K >= ntiles && started == ntiles) {
-            role = 1;
+            share = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_SHARE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a trip the wait below hides)
+            if (share >= K - 1) share = 0xFFFFFFFFu;
         }
-        if (role) share = __hip_atomic_fetch_add(&T.ctr[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (asked for before the wait)
-        s_tmp[4] = role;
         s_tmp[5] = share;
     }
     __syncthreads();
-    if (!s_tmp[4]) return;
+    if (s_tmp[5] == 0xFFFFFFFFu) return;
     GJ_TRACE_E(14);
     if (i == 0)
-        while (__hip_atomic_load(&T.ctr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+        while (__hip_atomic_load(&T.ctr[GJ_TAIL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ntiles) __builtin_amdgcn_s_sleep(8);
     __syncthreads();
     uint32_t share = s_tmp[5];
     while (share < K) {
@@ -1213,7 +1219,11 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
             done_bytes += batch_bytes;
             __syncthreads();
         }
-        if (i == 0) s_tmp[5] = __hip_atomic_fetch_add(&T.ctr[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // more shares than gathering workgroups? (the counter hands out 0 .. K - 2)
+        if (i == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_SHARE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_tmp[5] = t < K - 1 ? t : K;
+        }
         __syncthreads();
         share = s_tmp[5];
         __syncthreads();
@@ -1260,7 +1270,6 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
 
     const int i = threadIdx.x;
     GJ_TRACE_E(0);
-    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // started
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
 
@@ -1282,6 +1291,8 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, active, pk);
     __syncthreads(); // tables are in LDS
     GJ_TRACE_E(1); // pixels loaded and converted
+    // "started", for the tail. Behind the pixel loads: memory operations complete in order, and this one queues up with everybody else's
+    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -1323,7 +1334,6 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
-    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // started
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
 
@@ -1398,6 +1408,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
         }
     }
     __syncthreads(); // tables are in LDS
+    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // "started" (behind the pixel loads, see k_encode_rgb444)
     {
         const int table = p < 2 ? g.comp[0].type : g.comp[1].type;
 #pragma unroll
@@ -1452,7 +1463,6 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
-    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // started
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
 
@@ -1596,6 +1606,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
         }
     }
     __syncthreads(); // tables are in LDS
+    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // "started" (behind the pixel loads, see k_encode_rgb444)
     {
         const int table = kc.type;
 #pragma unroll
@@ -1793,14 +1804,15 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
 typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail);
 
+#define GJ_TAIL_WORDS (2 * GJ_TAIL_CTR_WORDS) // counters in front of the tile list in d_tail
 #define GJ_TAIL_SHARES 256 // default number of parts the gathering tail cuts the tile list into (GJ_ENC_TAIL overrides)
 // the tail's arguments for a launch of `tiles` workgroups that leave `pieces` tile streams
 static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces)
 {
     GjTail T;
-    T.ctr = job->d_tail + (job->tail_set & 1) * 8;
-    T.ctr_other = job->d_tail + ((job->tail_set + 1) & 1) * 8;
-    T.piece = reinterpret_cast<uint2*>(job->d_tail + 16);
+    T.ctr = job->d_tail + (job->tail_set & 1) * GJ_TAIL_CTR_WORDS;
+    T.ctr_other = job->d_tail + ((job->tail_set + 1) & 1) * GJ_TAIL_CTR_WORDS;
+    T.piece = reinterpret_cast<uint2*>(job->d_tail + GJ_TAIL_WORDS);
     T.temp = job->d_temp;
     T.jpeg = job->d_jpeg;
     T.capacity = job->jpeg_capacity;
@@ -1870,6 +1882,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     }
     bool one_launch = true; // k_encode_*: the stream is complete when the kernel ends
     gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
+    if (whole && job->tune.enc_by_blocks > 0 && gj_blocks_kernel_mode(g) == 0) whole = nullptr; // (k_encode_blocks below)
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
     const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 && g.no_transform == 0 &&
                       (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&

@@ -64,6 +64,7 @@ GJ_HIP_API float gj_hip_event_elapsed_ms(gj_event_t start, gj_event_t stop); /* 
  * of >= 4 blocks < 416 B per block --, and block i's private spill slot is the upper half of its own 416 bytes, which the stream cannot
  * reach before block i has been merged into it */
 #define GJ_STAGE_BYTES_PER_BLOCK 416
+#define GJ_TAIL_HEAD_WORDS 192 /* words of gj_enc_job.d_tail in front of the tile list (the gathering tail's counters) */
 
 enum { GJ_PF_U8 = 0, GJ_PF_444_P012 = 1, GJ_PF_444_P0P1P2 = 2, GJ_PF_422_P1020 = 3, GJ_PF_422_P0P1P2 = 4,
        GJ_PF_420_P0P1P2 = 5, GJ_PF_4444_P0123 = 6 };
@@ -122,6 +123,8 @@ typedef struct gj_tuning {
     int debug_sync;      /* GJ_DEC_DEBUG_SYNC=1: wait after every decoder stage and name it on stderr */
     int scan_tb;         /* GJ_SCAN_TB: bytes per lane of the marker scan (8, 16, 32, 64), 0 = by the stream's size (A/B) */
     int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
+    int enc_by_blocks;   /* GJ_ENC_BLOCKS: packed RGB 4:4:4 through k_encode_blocks (a workgroup codes one component of its tile: three times the
+                            workgroups, a third of the work each) 1 = always, -1 = never, 0 = small frames only */
     int enc_tail_shares; /* GJ_ENC_TAIL: parts the gathering tail of the one-launch encoders cuts the stream into (0 = default) */
     int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that
                             does not fit (overflow flag) -- this call uses the kernels without that limit */
@@ -143,7 +146,7 @@ typedef struct gj_enc_job {
     uint64_t jpeg_capacity;
     uint32_t* d_result;            /* [0] total JPEG size, [1] overflow flag */
     uint32_t* h_result;            /* optional: the same two words in pinned host memory, written by the kernel that computes them */
-    uint32_t* d_tail;              /* one-launch encoders: 2 x 8 counter words (two sets, alternating by epoch parity; zero at allocation and
+    uint32_t* d_tail;              /* one-launch encoders: GJ_TAIL_HEAD_WORDS counter words (two sets, used alternately; zero at allocation and
                                       after every call) followed by one uint2 per tile stream: size | scan << 28, offset in d_temp / 16 */
     int tail_set;                  /* which of d_tail's two counter sets this call uses: alternates from call to call */
     uint64_t* d_scan_partial;      /* [ceil(segment_count / 1024)] epoch-tagged workgroup totals of the offset scan; zero at allocation */

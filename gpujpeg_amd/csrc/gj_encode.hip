@@ -1066,6 +1066,7 @@ struct GjTail {
     uint64_t capacity;
     const uint8_t* scan_hdr;
     uint32_t hdr_end[GJ_MAX_COMP]; // bytes of the scan headers up to and including scan s
+    uint32_t scan_first[GJ_MAX_COMP]; // index in the list of the first tile stream of scan s (0xFFFFFFFF behind the last scan)
     uint32_t main_hdr;
     uint32_t npieces, shares;
     uint32_t* d_result;
@@ -1076,6 +1077,11 @@ struct GjTail {
 __device__ __forceinline__ uint32_t gj_tail_hdr_end(const GjTail& T, const uint32_t scan)
 {
     return scan == 0 ? T.hdr_end[0] : scan == 1 ? T.hdr_end[1] : scan == 2 ? T.hdr_end[2] : T.hdr_end[3];
+}
+// the scan tile stream p belongs to
+__device__ __forceinline__ uint32_t gj_tail_scan_of(const GjTail& T, const uint32_t p)
+{
+    return (p >= T.scan_first[1] ? 1u : 0u) + (p >= T.scan_first[2] ? 1u : 0u) + (p >= T.scan_first[3] ? 1u : 0u);
 }
 
 // one entry of the tile list (written and read with device scope, see gj_store16_agent)
@@ -1126,24 +1132,32 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
     uint32_t share = s_tmp[5];
     while (share < K) {
         const uint32_t pa = (uint32_t)((uint64_t)share * P / K), pb = (uint32_t)((uint64_t)(share + 1) * P / K);
-        // all tile sizes in one trip, starting with the share's own tiles (lane i: tile pa + i): the bytes in front of the share and the
-        // size of the whole stream
+        // all tile sizes in one trip (eight loads in flight per lane and round), starting with the share's own tiles (lane i: tile
+        // pa + i): the bytes in front of the share and the size of the whole stream
         uint32_t before = 0, all = 0;
         uint2 mine = make_uint2(0, 0);
-        for (uint32_t idx = i; idx < P; idx += 256) {
-            uint32_t p = pa + idx;
-            const bool wrapped = p >= P;
-            if (wrapped) p -= P;
-            const uint2 st = gj_piece_get(T, p);
-            if (idx == (uint32_t)i) mine = st;
-            const uint32_t sz = st.x & 0x0FFFFFFFu;
-            all += sz;
-            before += wrapped ? sz : 0u;
+        for (uint32_t idx0 = 0; idx0 < P; idx0 += 2048) {
+            uint2 st[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t idx = idx0 + (uint32_t)u * 256u + (uint32_t)i;
+                uint32_t p = pa + idx;
+                if (p >= P) p -= P;
+                st[u] = idx < P ? gj_piece_get(T, p) : make_uint2(0, 0);
+            }
+            if (idx0 == 0) mine = st[0];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t idx = idx0 + (uint32_t)u * 256u + (uint32_t)i;
+                const uint32_t sz = st[u].x & 0x0FFFFFFFu;
+                all += sz;
+                before += pa + idx >= P ? sz : 0u; // (wrapped around: a tile in front of the share)
+            }
         }
         uint32_t done_bytes, all_bytes;
         gj_wg256_incl_scan(before, s_tmp, &done_bytes);
         gj_wg256_incl_scan(all, s_tmp, &all_bytes);
-        const uint32_t last_scan = gj_piece_get(T, P - 1).x >> 28;
+        const uint32_t last_scan = gj_tail_scan_of(T, P - 1);
         const uint64_t total = (uint64_t)T.main_hdr + gj_tail_hdr_end(T, last_scan) + all_bytes + 2u;
         const bool overflow = total > T.capacity;
         for (uint32_t p0 = pa; p0 < pb; p0 += 256) {
@@ -1151,7 +1165,7 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
             const bool have = p < pb;
             uint2 st = make_uint2(0, 0);
             if (have) st = p0 == pa ? mine : gj_piece_get(T, p);
-            const uint32_t size = st.x & 0x0FFFFFFFu, scan = st.x >> 28;
+            const uint32_t size = st.x & 0x0FFFFFFFu, scan = gj_tail_scan_of(T, p);
             uint32_t batch_bytes, C;
             const uint32_t incl = gj_wg256_incl_scan(size, s_tmp, &batch_bytes);
             const uint32_t F = T.main_hdr + gj_tail_hdr_end(T, scan) + done_bytes + incl - size;
@@ -1162,8 +1176,7 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
             tsize[i] = size;
             tcs[i] = cincl - nch; // (= C for the lanes behind the share's last tile)
             if (have && !overflow) {
-                const uint32_t prev_scan = p == 0 ? 0xFFFFFFFFu : (gj_piece_get(T, p - 1).x >> 28);
-                if (scan != prev_scan) { // first tile of a scan: its header (APP13 placeholders + SOS) sits right in front
+                if (p == T.scan_first[0] || p == T.scan_first[1] || p == T.scan_first[2] || p == T.scan_first[3]) { // first tile of a scan: its header (APP13 placeholders + SOS) sits right in front
                     const uint32_t h1 = gj_tail_hdr_end(T, scan), h0 = scan == 0 ? 0u : gj_tail_hdr_end(T, scan - 1);
                     for (uint32_t b = 0; b < h1 - h0; b++) T.jpeg[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
                 }
@@ -1183,11 +1196,11 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
             __syncthreads();
             if (!overflow) {
                 const uint64_t* const src64 = reinterpret_cast<const uint64_t*>(T.temp);
-                for (uint32_t q0 = 0; q0 < C; q0 += 1024) {
-                    uint64_t lo64[4], hi64[4];
-                    uint32_t dst[4], nbytes[4];
+                for (uint32_t q0 = 0; q0 < C; q0 += 2048) { // (eight 16-byte pieces in flight per lane and round)
+                    uint64_t lo64[8], hi64[8];
+                    uint32_t dst[8], nbytes[8];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < 8; u++) {
                         const uint32_t q = q0 + (uint32_t)u * 256u + (uint32_t)i;
                         dst[u] = nbytes[u] = 0;
                         lo64[u] = hi64[u] = 0;
@@ -1205,7 +1218,7 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < 8; u++) {
                         if (nbytes[u] == 16u) {
                             gj_u4 v;
                             v.x = (uint32_t)lo64[u]; v.y = (uint32_t)(lo64[u] >> 32); v.z = (uint32_t)hi64[u]; v.w = (uint32_t)(hi64[u] >> 32);
@@ -1806,10 +1819,11 @@ typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, 
 
 #define GJ_TAIL_WORDS (2 * GJ_TAIL_CTR_WORDS) // counters in front of the tile list in d_tail
 #define GJ_TAIL_SHARES 256 // default number of parts the gathering tail cuts the tile list into (GJ_ENC_TAIL overrides)
-// the tail's arguments for a launch of `tiles` workgroups that leave `pieces` tile streams
-static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces)
+// the tail's arguments for a launch that leaves `pieces` tile streams, scan s beginning with stream scan_first[s]
+static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const unsigned (&scan_first)[GJ_MAX_COMP])
 {
     GjTail T;
+    for (int s = 0; s < GJ_MAX_COMP; s++) T.scan_first[s] = scan_first[s];
     T.ctr = job->d_tail + (job->tail_set & 1) * GJ_TAIL_CTR_WORDS;
     T.ctr_other = job->d_tail + ((job->tail_set + 1) & 1) * GJ_TAIL_CTR_WORDS;
     T.piece = reinterpret_cast<uint2*>(job->d_tail + GJ_TAIL_WORDS);
@@ -1896,26 +1910,29 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs));
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u}));
     } else if (!whole && job->use_fused && !job->keep_coefs && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT &&
                gj_blocks_kernel_mode(g) >= 0) {
         // every other layout with short restart segments: one lane per block in coding order (k_encode_blocks)
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
-        unsigned wgs = 0;
+        unsigned wgs = 0, scan_first[GJ_MAX_COMP] = {0u, ~0u, ~0u, ~0u};
         if (g.interleaved) wgs = ((unsigned)g.segment_count + spt - 1) / spt;
         else
-            for (int c = 0; c < g.comp_count; c++) wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
+            for (int c = 0; c < g.comp_count; c++) {
+                scan_first[c] = wgs;
+                wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
+            }
         hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
-                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs));
+                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs, scan_first));
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
-                           job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, 3 * wgs));
+                           job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}));
     } else {
     one_launch = false;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU

@@ -1061,6 +1061,9 @@ struct GjTail {
     uint32_t* ctr;        // this call's counters (GJ_TAIL_*), zero when the kernel starts
     uint32_t* ctr_other;  // the next call's set
     uint2* piece;         // [npieces] tile streams in FILE order: x = size | scan << 28, y = offset in d_temp / 16
+    uint32_t* group;      // [ngroups] bytes of the tile streams 32 g .. 32 g + 31, added up by the tiles themselves; zero when the kernel starts
+    uint32_t* group_other; // the next call's
+    uint32_t ngroups;
     const uint8_t* temp;
     uint8_t* jpeg;
     uint64_t capacity;
@@ -1088,6 +1091,18 @@ __device__ __forceinline__ uint32_t gj_tail_scan_of(const GjTail& T, const uint3
 __device__ __forceinline__ void gj_piece_put(const GjTail& T, const uint32_t p, const uint32_t size_scan, const uint32_t off16)
 {
     __hip_atomic_store(reinterpret_cast<uint64_t*>(T.piece) + p, (uint64_t)size_scan | ((uint64_t)off16 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a gathering workgroup reads these totals and the few list entries around its share, not the whole list: 256 workgroups reading
+    // the same 50 KB past their L2s kept a dozen memory channels busy for 10 us, profiles/r4_02_*)
+    (void)__hip_atomic_fetch_add(&T.group[p >> 5], size_scan & 0x0FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// loads of what other workgroups of the same launch have written (device scope), or plain ones (a launch of its own)
+template <bool COHERENT> __device__ __forceinline__ uint32_t gj_tail_ld32(const uint32_t* p)
+{
+    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COHERENT> __device__ __forceinline__ uint64_t gj_tail_ld64(const uint64_t* p)
+{
+    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 __device__ __forceinline__ uint2 gj_piece_get(const GjTail& T, const uint32_t p)
 {
@@ -1095,15 +1110,134 @@ __device__ __forceinline__ uint2 gj_piece_get(const GjTail& T, const uint32_t p)
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
-// s_mem: >= 1100 words of LDS nothing else uses any more
-__device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem, const int i)
+// One share of the tile list -> its place in the file. s_mem: >= 1100 words of LDS nothing else uses any more; all 256 threads.
+template <bool COHERENT>
+__device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem, const int i, const uint32_t share)
 {
-    uint32_t* const s_tmp = s_mem;      // [4] scans, [4] role, [5] share
+    uint32_t* const s_tmp = s_mem;      // [4] scans
     uint32_t* const tF = s_mem + 16;    // [256] file offset of the tile stream
     uint32_t* const tsrc = tF + 256;    // [256] offset in d_temp / 16
     uint32_t* const tsize = tsrc + 256; // [256]
     uint32_t* const tcs = tsize + 256;  // [256] first 16-byte piece (in the batch's numbering)
-    const uint32_t ntiles = gridDim.x, P = T.npieces, K = T.shares;
+    const uint32_t P = T.npieces, K = T.shares, NG = T.ngroups;
+    const uint64_t* const piece64 = reinterpret_cast<const uint64_t*>(T.piece);
+    const uint32_t pa = (uint32_t)((uint64_t)share * P / K), pb = (uint32_t)((uint64_t)(share + 1) * P / K);
+    // one trip: the group totals (the bytes of the groups in front of the share's first one, and of the whole stream), the tiles of that
+    // first group in front of the share, the share's own tiles (lane i: tile pa + i)
+    const uint32_t ga = pa >> 5;
+    uint32_t before = 0, all = 0;
+    for (uint32_t g0 = 0; g0 < NG; g0 += 1024) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t g = g0 + (uint32_t)u * 256u + (uint32_t)i;
+            v[u] = g < NG ? gj_tail_ld32<COHERENT>(&T.group[g]) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t g = g0 + (uint32_t)u * 256u + (uint32_t)i;
+            all += v[u];
+            before += g < ga ? v[u] : 0u;
+        }
+    }
+    if ((uint32_t)i < (pa & 31u)) before += (uint32_t)gj_tail_ld64<COHERENT>(piece64 + (ga << 5) + i) & 0x0FFFFFFFu;
+    uint64_t mine = 0;
+    if (pa + (uint32_t)i < pb) mine = gj_tail_ld64<COHERENT>(piece64 + pa + i);
+    uint32_t done_bytes, all_bytes;
+    gj_wg256_incl_scan(before, s_tmp, &done_bytes);
+    gj_wg256_incl_scan(all, s_tmp, &all_bytes);
+    const uint64_t total = (uint64_t)T.main_hdr + gj_tail_hdr_end(T, gj_tail_scan_of(T, P - 1)) + all_bytes + 2u;
+    const bool overflow = total > T.capacity;
+    for (uint32_t p0 = pa; p0 < pb; p0 += 256) {
+        const uint32_t p = p0 + (uint32_t)i;
+        const bool have = p < pb;
+        uint64_t st = 0;
+        if (have) st = p0 == pa ? mine : gj_tail_ld64<COHERENT>(piece64 + p);
+        const uint32_t size = (uint32_t)st & 0x0FFFFFFFu, scan = gj_tail_scan_of(T, p);
+        uint32_t batch_bytes, C;
+        const uint32_t incl = gj_wg256_incl_scan(size, s_tmp, &batch_bytes);
+        const uint32_t F = T.main_hdr + gj_tail_hdr_end(T, scan) + done_bytes + incl - size;
+        const uint32_t nch = (size + 15u) >> 4; // 16-byte pieces of the tile stream (aligned in d_temp)
+        const uint32_t cincl = gj_wg256_incl_scan(nch, s_tmp, &C);
+        tF[i] = F;
+        tsrc[i] = (uint32_t)(st >> 32);
+        tsize[i] = size;
+        tcs[i] = cincl - nch; // (= C for the lanes behind the share's last tile)
+        if (have && !overflow) {
+            if (p == T.scan_first[0] || p == T.scan_first[1] || p == T.scan_first[2] || p == T.scan_first[3]) { // first tile of a scan:
+                // its header (APP13 placeholders + SOS) sits right in front
+                const uint32_t h1 = gj_tail_hdr_end(T, scan), h0 = scan == 0 ? 0u : gj_tail_hdr_end(T, scan - 1);
+                for (uint32_t b = 0; b < h1 - h0; b++) T.jpeg[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
+            }
+            if (p == P - 1) {
+                T.jpeg[F + size] = 0xFF;
+                T.jpeg[F + size + 1] = 0xD9;
+            }
+        }
+        if (have && p == P - 1) {
+            T.d_result[0] = (uint32_t)total;
+            T.d_result[1] = overflow ? 1u : 0u;
+            if (T.h_result) { // the host's (pinned, device-visible) copy: no copy launch behind the kernel
+                T.h_result[0] = (uint32_t)total;
+                T.h_result[1] = overflow ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        if (!overflow) {
+            const uint64_t* const src64 = reinterpret_cast<const uint64_t*>(T.temp);
+            for (uint32_t q0 = 0; q0 < C; q0 += 2048) { // (eight 16-byte pieces in flight per lane and round)
+                uint64_t lo64[8], hi64[8];
+                uint32_t dst[8], nbytes[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t q = q0 + (uint32_t)u * 256u + (uint32_t)i;
+                    dst[u] = nbytes[u] = 0;
+                    lo64[u] = hi64[u] = 0;
+                    if (q < C) {
+                        uint32_t lo = 0;
+#pragma unroll
+                        for (uint32_t step = 128; step; step >>= 1)
+                            if (tcs[lo + step] <= q) lo += step;
+                        const uint32_t k = q - tcs[lo];
+                        dst[u] = tF[lo] + 16u * k;
+                        nbytes[u] = min(16u, tsize[lo] - 16u * k);
+                        const uint64_t* s8 = src64 + ((uint64_t)tsrc[lo] + k) * 2u;
+                        lo64[u] = gj_tail_ld64<COHERENT>(s8);
+                        hi64[u] = gj_tail_ld64<COHERENT>(s8 + 1);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (nbytes[u] == 16u) {
+                        gj_u4 v;
+                        v.x = (uint32_t)lo64[u]; v.y = (uint32_t)(lo64[u] >> 32); v.z = (uint32_t)hi64[u]; v.w = (uint32_t)(hi64[u] >> 32);
+                        *reinterpret_cast<gj_u4_unaligned*>(T.jpeg + dst[u]) = v;
+                    } else {
+                        for (uint32_t b = 0; b < nbytes[u]; b++) T.jpeg[dst[u] + b] = (uint8_t)((b < 8 ? lo64[u] : hi64[u]) >> (8 * (b & 7)));
+                    }
+                }
+            }
+        }
+        done_bytes += batch_bytes;
+        __syncthreads();
+    }
+}
+
+// the counters and group totals of the NEXT call (read by the next launch only): all 256 threads of one workgroup
+__device__ __forceinline__ void gj_tail_reset_next(const GjTail& T, const int i)
+{
+    if (i == 0) T.ctr_other[GJ_TAIL_STARTED] = 0;
+    if (i == 1) T.ctr_other[GJ_TAIL_DONE] = 0;
+    if (i == 2) T.ctr_other[GJ_TAIL_SHARE] = 0;
+    for (uint32_t g = i; g < T.ngroups; g += 256) T.group_other[g] = 0;
+}
+
+// the end of a one-launch encoder kernel: s_mem as for gj_gather_share
+__device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem, const int i)
+{
+    const uint32_t ntiles = gridDim.x, K = T.shares;
+    if (K == 0) return; // (the gathering is a launch of its own: k_gather)
+    uint32_t* const s_tmp = s_mem;
     // (asked for before the wait below, which hides the trip: has every workgroup of the launch started?)
     uint32_t started = 0;
     if (i == 0) started = __hip_atomic_load(&T.ctr[GJ_TAIL_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1114,124 +1248,23 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
         uint32_t share = 0xFFFFFFFFu; // not gathering
         if (d + 1 == ntiles) {
             share = K - 1; // the last one to finish gathers whatever happens; its share is reserved (no trip to the counter on the critical path)
-            T.ctr_other[GJ_TAIL_STARTED] = 0; // (read by the next launch only)
-            T.ctr_other[GJ_TAIL_DONE] = 0;
-            T.ctr_other[GJ_TAIL_SHARE] = 0;
         } else if (d + K >= ntiles && started == ntiles) {
             share = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_SHARE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a trip the wait below hides)
             if (share >= K - 1) share = 0xFFFFFFFFu;
         }
         s_tmp[5] = share;
+        s_tmp[6] = d + 1 == ntiles;
     }
     __syncthreads();
-    if (s_tmp[5] == 0xFFFFFFFFu) return;
+    uint32_t share = s_tmp[5];
+    if (share == 0xFFFFFFFFu) return;
     GJ_TRACE_E(14);
-    if (i == 0)
+    if (s_tmp[6]) gj_tail_reset_next(T, i);
+    else if (i == 0)
         while (__hip_atomic_load(&T.ctr[GJ_TAIL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ntiles) __builtin_amdgcn_s_sleep(8);
     __syncthreads();
-    uint32_t share = s_tmp[5];
     while (share < K) {
-        const uint32_t pa = (uint32_t)((uint64_t)share * P / K), pb = (uint32_t)((uint64_t)(share + 1) * P / K);
-        // all tile sizes in one trip (eight loads in flight per lane and round), starting with the share's own tiles (lane i: tile
-        // pa + i): the bytes in front of the share and the size of the whole stream
-        uint32_t before = 0, all = 0;
-        uint2 mine = make_uint2(0, 0);
-        for (uint32_t idx0 = 0; idx0 < P; idx0 += 2048) {
-            uint2 st[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t idx = idx0 + (uint32_t)u * 256u + (uint32_t)i;
-                uint32_t p = pa + idx;
-                if (p >= P) p -= P;
-                st[u] = idx < P ? gj_piece_get(T, p) : make_uint2(0, 0);
-            }
-            if (idx0 == 0) mine = st[0];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t idx = idx0 + (uint32_t)u * 256u + (uint32_t)i;
-                const uint32_t sz = st[u].x & 0x0FFFFFFFu;
-                all += sz;
-                before += pa + idx >= P ? sz : 0u; // (wrapped around: a tile in front of the share)
-            }
-        }
-        uint32_t done_bytes, all_bytes;
-        gj_wg256_incl_scan(before, s_tmp, &done_bytes);
-        gj_wg256_incl_scan(all, s_tmp, &all_bytes);
-        const uint32_t last_scan = gj_tail_scan_of(T, P - 1);
-        const uint64_t total = (uint64_t)T.main_hdr + gj_tail_hdr_end(T, last_scan) + all_bytes + 2u;
-        const bool overflow = total > T.capacity;
-        for (uint32_t p0 = pa; p0 < pb; p0 += 256) {
-            const uint32_t p = p0 + (uint32_t)i;
-            const bool have = p < pb;
-            uint2 st = make_uint2(0, 0);
-            if (have) st = p0 == pa ? mine : gj_piece_get(T, p);
-            const uint32_t size = st.x & 0x0FFFFFFFu, scan = gj_tail_scan_of(T, p);
-            uint32_t batch_bytes, C;
-            const uint32_t incl = gj_wg256_incl_scan(size, s_tmp, &batch_bytes);
-            const uint32_t F = T.main_hdr + gj_tail_hdr_end(T, scan) + done_bytes + incl - size;
-            const uint32_t nch = (size + 15u) >> 4; // 16-byte pieces of the tile stream (aligned in d_temp)
-            const uint32_t cincl = gj_wg256_incl_scan(nch, s_tmp, &C);
-            tF[i] = F;
-            tsrc[i] = st.y;
-            tsize[i] = size;
-            tcs[i] = cincl - nch; // (= C for the lanes behind the share's last tile)
-            if (have && !overflow) {
-                if (p == T.scan_first[0] || p == T.scan_first[1] || p == T.scan_first[2] || p == T.scan_first[3]) { // first tile of a scan: its header (APP13 placeholders + SOS) sits right in front
-                    const uint32_t h1 = gj_tail_hdr_end(T, scan), h0 = scan == 0 ? 0u : gj_tail_hdr_end(T, scan - 1);
-                    for (uint32_t b = 0; b < h1 - h0; b++) T.jpeg[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
-                }
-                if (p == P - 1) {
-                    T.jpeg[F + size] = 0xFF;
-                    T.jpeg[F + size + 1] = 0xD9;
-                }
-            }
-            if (have && p == P - 1) {
-                T.d_result[0] = (uint32_t)total;
-                T.d_result[1] = overflow ? 1u : 0u;
-                if (T.h_result) { // the host's (pinned, device-visible) copy: no copy launch behind the kernel
-                    T.h_result[0] = (uint32_t)total;
-                    T.h_result[1] = overflow ? 1u : 0u;
-                }
-            }
-            __syncthreads();
-            if (!overflow) {
-                const uint64_t* const src64 = reinterpret_cast<const uint64_t*>(T.temp);
-                for (uint32_t q0 = 0; q0 < C; q0 += 2048) { // (eight 16-byte pieces in flight per lane and round)
-                    uint64_t lo64[8], hi64[8];
-                    uint32_t dst[8], nbytes[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const uint32_t q = q0 + (uint32_t)u * 256u + (uint32_t)i;
-                        dst[u] = nbytes[u] = 0;
-                        lo64[u] = hi64[u] = 0;
-                        if (q < C) {
-                            uint32_t lo = 0;
-#pragma unroll
-                            for (uint32_t step = 128; step; step >>= 1)
-                                if (tcs[lo + step] <= q) lo += step;
-                            const uint32_t k = q - tcs[lo];
-                            dst[u] = tF[lo] + 16u * k;
-                            nbytes[u] = min(16u, tsize[lo] - 16u * k);
-                            const uint64_t* s8 = src64 + ((uint64_t)tsrc[lo] + k) * 2u;
-                            lo64[u] = __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            hi64[u] = __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (nbytes[u] == 16u) {
-                            gj_u4 v;
-                            v.x = (uint32_t)lo64[u]; v.y = (uint32_t)(lo64[u] >> 32); v.z = (uint32_t)hi64[u]; v.w = (uint32_t)(hi64[u] >> 32);
-                            *reinterpret_cast<gj_u4_unaligned*>(T.jpeg + dst[u]) = v;
-                        } else {
-                            for (uint32_t b = 0; b < nbytes[u]; b++) T.jpeg[dst[u] + b] = (uint8_t)((b < 8 ? lo64[u] : hi64[u]) >> (8 * (b & 7)));
-                        }
-                    }
-                }
-            }
-            done_bytes += batch_bytes;
-            __syncthreads();
-        }
+        gj_gather_share<true>(T, s_mem, i, share);
         // more shares than gathering workgroups? (the counter hands out 0 .. K - 2)
         if (i == 0) {
             const uint32_t t = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_SHARE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1242,6 +1275,14 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
         __syncthreads();
     }
     GJ_TRACE_E(15);
+}
+
+// the gathering as a launch of its own (GJ_ENC_TAIL < 0: A/B against the tail inside the encoder kernel): one workgroup per share
+__global__ __launch_bounds__(256) void k_gather(const GjTail T)
+{
+    __shared__ uint32_t s_mem[1104];
+    if (blockIdx.x == 0) gj_tail_reset_next(T, threadIdx.x);
+    gj_gather_share<false>(T, s_mem, threadIdx.x, blockIdx.x);
 }
 
 // the workgroup's Huffman tables in the layout of GjCoderLds::lut, from the host's (code << 8 | size) tables [type * 2 + is_ac][symbol]
@@ -1817,7 +1858,6 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
 typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail);
 
-#define GJ_TAIL_WORDS (2 * GJ_TAIL_CTR_WORDS) // counters in front of the tile list in d_tail
 #define GJ_TAIL_SHARES 256 // default number of parts the gathering tail cuts the tile list into (GJ_ENC_TAIL overrides)
 // the tail's arguments for a launch that leaves `pieces` tile streams, scan s beginning with stream scan_first[s]
 static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const unsigned (&scan_first)[GJ_MAX_COMP])
@@ -1826,7 +1866,11 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     for (int s = 0; s < GJ_MAX_COMP; s++) T.scan_first[s] = scan_first[s];
     T.ctr = job->d_tail + (job->tail_set & 1) * GJ_TAIL_CTR_WORDS;
     T.ctr_other = job->d_tail + ((job->tail_set + 1) & 1) * GJ_TAIL_CTR_WORDS;
-    T.piece = reinterpret_cast<uint2*>(job->d_tail + GJ_TAIL_WORDS);
+    const unsigned ngcap = GJ_TAIL_GROUPS_CAP(job->g.segment_count); // (one tile stream per segment at most)
+    T.group = job->d_tail + GJ_TAIL_HEAD_WORDS + (job->tail_set & 1) * ngcap;
+    T.group_other = job->d_tail + GJ_TAIL_HEAD_WORDS + ((job->tail_set + 1) & 1) * ngcap;
+    T.ngroups = (pieces + 31) / 32;
+    T.piece = reinterpret_cast<uint2*>(job->d_tail + GJ_TAIL_HEAD_WORDS + 2 * ngcap);
     T.temp = job->d_temp;
     T.jpeg = job->d_jpeg;
     T.capacity = job->jpeg_capacity;
@@ -1834,11 +1878,19 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     for (int s = 0; s < GJ_MAX_COMP; s++) T.hdr_end[s] = job->scan_hdr_offset[s + 1];
     T.main_hdr = job->main_hdr_size;
     T.npieces = pieces;
-    const unsigned want = job->tune.enc_tail_shares > 0 ? (unsigned)job->tune.enc_tail_shares : (unsigned)GJ_TAIL_SHARES;
+    const int ts = job->tune.enc_tail_shares;
+    const unsigned want = ts > 0 ? (unsigned)ts : ts < 0 ? (unsigned)-ts : (unsigned)GJ_TAIL_SHARES;
     T.shares = want < pieces ? want : pieces;
     T.d_result = job->d_result;
     T.h_result = job->h_result;
     T.seg_sizes = job->segment_info && job->g.restart_interval > 0;
+    return T;
+}
+
+// what the encoder kernel itself gets: no shares when the gathering is a launch of its own
+static GjTail gj_kernel_tail(GjTail T, const bool own_gather)
+{
+    if (own_gather) T.shares = 0;
     return T;
 }
 
@@ -1895,6 +1947,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         hipLaunchKernelGGL(k_channel_remap, dim3((n + 255) / 256), dim3(256), 0, st, g, const_cast<uint8_t*>(job->d_raw), job->channel_remap & 0xFFFFu);
     }
     bool one_launch = true; // k_encode_*: the stream is complete when the kernel ends
+    GjTail tail_for_gather;   // (GJ_ENC_TAIL < 0: what k_gather gets; the encoder kernel is told not to gather)
+    tail_for_gather.shares = 0;
+    const bool own_gather = job->tune.enc_tail_shares < 0;
     gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
     if (whole && job->tune.enc_by_blocks > 0 && gj_blocks_kernel_mode(g) == 0) whole = nullptr; // (k_encode_blocks below)
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
@@ -1909,8 +1964,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
+        tail_for_gather = gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u});
         hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u}));
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
     } else if (!whole && job->use_fused && !job->keep_coefs && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT &&
                gj_blocks_kernel_mode(g) >= 0) {
         // every other layout with short restart segments: one lane per block in coding order (k_encode_blocks)
@@ -1924,15 +1980,17 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                 scan_first[c] = wgs;
                 wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
             }
+        tail_for_gather = gj_make_tail(job, wgs, scan_first);
         hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
-                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, wgs, scan_first));
+                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
+        tail_for_gather = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u});
         hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
-                           job->d_seg_bytes, job->d_seg_ff, gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}));
+                           job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
     } else {
     one_launch = false;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU
@@ -1964,6 +2022,8 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                        job->d_seg_ff);
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
+    if (one_launch && own_gather) // (A/B: the tile streams gathered by a launch of their own)
+        hipLaunchKernelGGL(k_gather, dim3(tail_for_gather.shares), dim3(256), 0, st, tail_for_gather);
     const bool seg_info = job->segment_info && g.restart_interval > 0;
     // (the one-launch encoders need the segment offsets only for the APP13 index)
     const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;

@@ -164,8 +164,8 @@ static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_par
     if (gj_hip_memset(c->d_planes, 0, g->data_size, c->stream) != 0) return -1;
     if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_STAGE_BYTES_PER_BLOCK + 256) != 0) return -1;
     /* the tail's counters are zero between calls (the kernel leaves them so); cleared here in case a failed launch did not */
-    if (gj_ensure_device_buffer((void**)&e->d_tail, &e->d_tail_cap, (GJ_TAIL_HEAD_WORDS + 2 * ((size_t)g->segment_count + 1)) * sizeof(uint32_t)) != 0) return -1;
-    if (gj_hip_memset(e->d_tail, 0, GJ_TAIL_HEAD_WORDS * sizeof(uint32_t), c->stream) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&e->d_tail, &e->d_tail_cap, (size_t)GJ_TAIL_WORDS(g->segment_count) * sizeof(uint32_t)) != 0) return -1;
+    if (gj_hip_memset(e->d_tail, 0, (GJ_TAIL_HEAD_WORDS + 2 * (size_t)GJ_TAIL_GROUPS_CAP(g->segment_count)) * sizeof(uint32_t), c->stream) != 0) return -1;
     e->tail_set = 0;
     {
         const size_t need = (((size_t)g->segment_count + 1023) / 1024 + 1) * sizeof(uint64_t);

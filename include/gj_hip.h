@@ -64,7 +64,10 @@ GJ_HIP_API float gj_hip_event_elapsed_ms(gj_event_t start, gj_event_t stop); /* 
  * of >= 4 blocks < 416 B per block --, and block i's private spill slot is the upper half of its own 416 bytes, which the stream cannot
  * reach before block i has been merged into it */
 #define GJ_STAGE_BYTES_PER_BLOCK 416
-#define GJ_TAIL_HEAD_WORDS 192 /* words of gj_enc_job.d_tail in front of the tile list (the gathering tail's counters) */
+#define GJ_TAIL_HEAD_WORDS 192 /* gj_enc_job.d_tail: the gathering tail's counters (two sets), then two sets of GJ_TAIL_GROUPS_CAP(segments) group
+                                  totals, then the tile list (two words per tile stream, at most one stream per segment) */
+#define GJ_TAIL_GROUPS_CAP(segments) (((unsigned)(segments) + 32u) / 32u + 1u)
+#define GJ_TAIL_WORDS(segments) (GJ_TAIL_HEAD_WORDS + 2u * GJ_TAIL_GROUPS_CAP(segments) + 2u * ((unsigned)(segments) + 1u))
 
 enum { GJ_PF_U8 = 0, GJ_PF_444_P012 = 1, GJ_PF_444_P0P1P2 = 2, GJ_PF_422_P1020 = 3, GJ_PF_422_P0P1P2 = 4,
        GJ_PF_420_P0P1P2 = 5, GJ_PF_4444_P0123 = 6 };

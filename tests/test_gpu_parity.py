@@ -376,13 +376,14 @@ TAIL_CASES = [
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shares", [0, 1, 3, 100000], ids=lambda s: f"shares{s}")
+@pytest.mark.parametrize("shares", [0, 1, 3, 100000, -5], ids=lambda s: f"shares{s}")
 @pytest.mark.parametrize("tc", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
 def test_one_launch_encoder_tail(O, G, gpu_lib, tc, shares, monkeypatch):
     """The one-launch encoders (k_encode_*): every workgroup leaves its tile's finished stream (stuffed, RSTn in place) in d_temp, the
     last workgroups gather them into the file (scan headers, EOI, size). Replaces src/gpujpeg_huffman_gpu_encoder.cu:417-613 and the
     host stitching of src/gpujpeg_encoder.c:567-629; the bytes must be the oracle's whatever the number of shares the tail cuts the
-    tile list into (GJ_ENC_TAIL: 1 = one workgroup gathers everything, more shares than tiles = one tile stream per share), with
+    tile list into (GJ_ENC_TAIL: 1 = one workgroup gathers everything, more shares than tiles = one tile stream per share, negative = the
+    same gathering as a launch of its own, k_gather), with
     and without the APP13 index, twice in a row on the same coder (the tail's counters alternate between two sets)."""
     name, w, h, pf, cs, q, restart, il, sub, noisy = tc
     if shares:

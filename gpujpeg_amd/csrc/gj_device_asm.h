@@ -61,5 +61,8 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
 typedef uint32_t gj_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gj_store16_agent(void* p, gj_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void gj_store1_agent(uint8_t* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void gj_store2_agent(uint8_t* p, uint32_t v) { asm volatile("global_store_short %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void gj_store4_agent(uint8_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void gj_store8_agent(uint8_t* p, uint64_t v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 // every store this wave has issued is complete
 __device__ __forceinline__ void gj_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }

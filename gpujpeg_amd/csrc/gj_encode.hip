@@ -951,10 +951,18 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         const uint32_t O = wave == 0 ? 0u : wave == 1 ? n0 : wave == 2 ? n0 + n1 : n0 + n1 + n2, n = run - R;
         piece_size = n0 + n1 + n2 + n3;
         for (uint32_t q = (uint32_t)lane * 16u; q < n; q += 1024) {
+            const gj_u4 v = *reinterpret_cast<const gj_u4*>(stage + R + q); // (whole 16 bytes: the stage is larger than any wave's bytes)
+            uint8_t* const dst = region + O + q;
             if (q + 16u <= n) {
-                gj_store16_agent(region + O + q, *reinterpret_cast<const gj_u4*>(stage + R + q));
-            } else {
-                for (uint32_t b = q; b < n; b++) gj_store1_agent(region + O + b, stage[R + b]);
+                gj_store16_agent(dst, v);
+            } else { // the wave's last 1 .. 15 bytes: 8 + 4 + 2 + 1
+                const uint32_t nb = n - q;
+                uint64_t cur = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                uint32_t off = 0;
+                if (nb & 8u) { gj_store8_agent(dst, cur); cur = (uint64_t)v.z | ((uint64_t)v.w << 32); off = 8; }
+                if (nb & 4u) { gj_store4_agent(dst + off, (uint32_t)cur); cur >>= 32; off += 4; }
+                if (nb & 2u) { gj_store2_agent(dst + off, (uint32_t)cur); cur >>= 16; off += 2; }
+                if (nb & 1u) gj_store1_agent(dst + off, (uint32_t)cur);
             }
         }
     } else {
@@ -1053,6 +1061,9 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
 // Counters: two sets that alternate with the call's epoch; the last finisher clears the other set for the next call.
 // ================================================================================================
 typedef gj_u4 __attribute__((aligned(1))) gj_u4_unaligned; // a 16-byte global store to any address (one instruction on gfx950)
+typedef uint64_t __attribute__((aligned(1))) gj_u64_unaligned;
+typedef uint32_t __attribute__((aligned(1))) gj_u32_unaligned;
+typedef uint16_t __attribute__((aligned(1))) gj_u16_unaligned;
 #define GJ_TAIL_STARTED 0   // workgroups that have started
 #define GJ_TAIL_DONE 32     // workgroups whose tile streams are complete
 #define GJ_TAIL_SHARE 64    // next share of the tile list
@@ -1110,7 +1121,7 @@ __device__ __forceinline__ uint2 gj_piece_get(const GjTail& T, const uint32_t p)
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
-// One share of the tile list -> its place in the file. s_mem: >= 1100 words of LDS nothing else uses any more; all 256 threads.
+// One share of the tile list -> its place in the file. s_mem: >= 1120 words of LDS nothing else uses any more; all 256 threads.
 template <bool COHERENT>
 __device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem, const int i, const uint32_t share)
 {
@@ -1119,6 +1130,7 @@ __device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem
     uint32_t* const tsrc = tF + 256;    // [256] offset in d_temp / 16
     uint32_t* const tsize = tsrc + 256; // [256]
     uint32_t* const tcs = tsize + 256;  // [256] first 16-byte piece (in the batch's numbering)
+    uint32_t* const tcoarse = tcs + 256; // [65] tile of every 32nd piece of a round
     const uint32_t P = T.npieces, K = T.shares, NG = T.ngroups;
     const uint64_t* const piece64 = reinterpret_cast<const uint64_t*>(T.piece);
     const uint32_t pa = (uint32_t)((uint64_t)share * P / K), pb = (uint32_t)((uint64_t)(share + 1) * P / K);
@@ -1186,6 +1198,16 @@ __device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem
         if (!overflow) {
             const uint64_t* const src64 = reinterpret_cast<const uint64_t*>(T.temp);
             for (uint32_t q0 = 0; q0 < C; q0 += 2048) { // (eight 16-byte pieces in flight per lane and round)
+                // the tile of every 32nd piece of the round: one search per lane here, a short walk per piece below
+                if (i <= 64) {
+                    const uint32_t q = q0 + 32u * (uint32_t)i;
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t step = 128; step; step >>= 1)
+                        if (tcs[lo + step] <= q) lo += step;
+                    tcoarse[i] = lo;
+                }
+                __syncthreads();
                 uint64_t lo64[8], hi64[8];
                 uint32_t dst[8], nbytes[8];
 #pragma unroll
@@ -1194,10 +1216,8 @@ __device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem
                     dst[u] = nbytes[u] = 0;
                     lo64[u] = hi64[u] = 0;
                     if (q < C) {
-                        uint32_t lo = 0;
-#pragma unroll
-                        for (uint32_t step = 128; step; step >>= 1)
-                            if (tcs[lo + step] <= q) lo += step;
+                        uint32_t lo = tcoarse[(q - q0) >> 5];
+                        while (lo < 255u && tcs[lo + 1] <= q) lo++;
                         const uint32_t k = q - tcs[lo];
                         dst[u] = tF[lo] + 16u * k;
                         nbytes[u] = min(16u, tsize[lo] - 16u * k);
@@ -1208,14 +1228,21 @@ __device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
+                    uint8_t* const d = T.jpeg + dst[u];
                     if (nbytes[u] == 16u) {
                         gj_u4 v;
                         v.x = (uint32_t)lo64[u]; v.y = (uint32_t)(lo64[u] >> 32); v.z = (uint32_t)hi64[u]; v.w = (uint32_t)(hi64[u] >> 32);
-                        *reinterpret_cast<gj_u4_unaligned*>(T.jpeg + dst[u]) = v;
-                    } else {
-                        for (uint32_t b = 0; b < nbytes[u]; b++) T.jpeg[dst[u] + b] = (uint8_t)((b < 8 ? lo64[u] : hi64[u]) >> (8 * (b & 7)));
+                        *reinterpret_cast<gj_u4_unaligned*>(d) = v;
+                    } else if (nbytes[u]) { // the last 1 .. 15 bytes of a tile stream: 8 + 4 + 2 + 1
+                        uint64_t cur = lo64[u];
+                        uint32_t off = 0;
+                        if (nbytes[u] & 8u) { *reinterpret_cast<gj_u64_unaligned*>(d) = cur; cur = hi64[u]; off = 8; }
+                        if (nbytes[u] & 4u) { *reinterpret_cast<gj_u32_unaligned*>(d + off) = (uint32_t)cur; cur >>= 32; off += 4; }
+                        if (nbytes[u] & 2u) { *reinterpret_cast<gj_u16_unaligned*>(d + off) = (uint16_t)cur; cur >>= 16; off += 2; }
+                        if (nbytes[u] & 1u) d[off] = (uint8_t)cur;
                     }
                 }
+                __syncthreads(); // (tcoarse is rewritten by the next round)
             }
         }
         done_bytes += batch_bytes;
@@ -1280,7 +1307,7 @@ __device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem,
 // the gathering as a launch of its own (GJ_ENC_TAIL < 0: A/B against the tail inside the encoder kernel): one workgroup per share
 __global__ __launch_bounds__(256) void k_gather(const GjTail T)
 {
-    __shared__ uint32_t s_mem[1104];
+    __shared__ uint32_t s_mem[1120];
     if (blockIdx.x == 0) gj_tail_reset_next(T, threadIdx.x);
     gj_gather_share<false>(T, s_mem, threadIdx.x, blockIdx.x);
 }

@@ -25,8 +25,10 @@
 static __device__ unsigned long long* gj_trace_buf_e;
 extern "C" GJ_HIP_API int gj_hip_trace_set_encoder(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(gj_trace_buf_e), &p, sizeof p) == hipSuccess ? 0 : -1; }
 #define GJ_TRACE_E(slot) do { if (threadIdx.x == 0 && gj_trace_buf_e) gj_trace_buf_e[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GJ_TRACE_T(tile, slot) do { if (threadIdx.x == 0 && gj_trace_buf_e) gj_trace_buf_e[(size_t)(tile) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GJ_TRACE_E(slot) ((void)0)
+#define GJ_TRACE_T(tile, slot) ((void)0)
 #endif
 
 // ================================================================================================
@@ -152,31 +154,31 @@ __device__ __forceinline__ void gj_color_static(int& a, int& b, int& c)
 }
 
 // Pixels of one 8x8 block position (packed 4:4:4, 3 B/pixel) -> the three component blocks, one byte per sample.
-// All 24 loads are issued before the first use (the wave waits for HBM once); the colour transform runs in fp32 on
-// pixel pairs (gj_color_row). Samples outside the image are zero *component* values (src/gpujpeg_common.c:941-944).
-template <int CS_FROM, int CS_TO>
-__device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by,
-                                                  const bool exists, uint32_t (&pk)[3][16])
+// gj_load_444 issues all 24 loads (the wave waits for HBM once; the persistent encoder issues them for its NEXT tile while it codes the
+// last component of this one), gj_color_444 is the colour transform in fp32 on pixel pairs (gj_color_row). Samples outside the image
+// are zero *component* values (src/gpujpeg_common.c:941-944).
+template <int R0 = 0, int R1 = 8> // rows [R0, R1) of the block position
+__device__ __forceinline__ void gj_load_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by, const bool exists,
+                                            uint32_t (&px)[8][6])
 {
     const size_t pitch = (size_t)g.width * 3 + g.width_padding;
     const bool interior = exists && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
-    uint32_t px[8][6]; // 8 rows x 24 bytes
     if (!exists) { // a lane without a block (tile slack, past the last block): zeros, and none of the per-byte branches below
 #pragma unroll
-        for (int r = 0; r < 8; r++)
+        for (int r = R0; r < R1; r++)
 #pragma unroll
             for (int w = 0; w < 6; w++) px[r][w] = 0;
     } else if (interior && aligned) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = R0; r < R1; r++) {
             const uint2* p = reinterpret_cast<const uint2*>(raw + (size_t)(by * 8 + r) * pitch + (size_t)bx * 24);
             const uint2 a = p[0], b = p[1], c = p[2];
             px[r][0] = a.x; px[r][1] = a.y; px[r][2] = b.x; px[r][3] = b.y; px[r][4] = c.x; px[r][5] = c.y;
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = R0; r < R1; r++) {
             const unsigned y = by * 8 + r;
 #pragma unroll
             for (int w = 0; w < 6; w++) {
@@ -190,6 +192,13 @@ __device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_
             }
         }
     }
+}
+
+template <int CS_FROM, int CS_TO>
+__device__ __forceinline__ void gj_color_444(const gj_geom& g, const unsigned bx, const unsigned by, const bool exists, const uint32_t (&px)[8][6],
+                                             uint32_t (&pk)[3][16])
+{
+    const bool interior = exists && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     // byte masks of the samples that lie inside the image (all ones for interior blocks)
     const int cols = exists ? min(8, max(0, g.width - (int)(bx * 8))) : 0, rows = exists ? min(8, max(0, g.height - (int)(by * 8))) : 0;
     const uint32_t m_lo = cols >= 4 ? 0xFFFFFFFFu : (1u << (8 * cols)) - 1u;
@@ -208,6 +217,15 @@ __device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_
         // pin the colour transform of this row here (keeps the raw pixels from staying alive into the transforms)
         GJ_KEEP6(pk[0][r * 2], pk[0][r * 2 + 1], pk[1][r * 2], pk[1][r * 2 + 1], pk[2][r * 2], pk[2][r * 2 + 1]);
     }
+}
+
+template <int CS_FROM, int CS_TO>
+__device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by,
+                                                  const bool exists, uint32_t (&pk)[3][16])
+{
+    uint32_t px[8][6]; // 8 rows x 24 bytes
+    gj_load_444(g, raw, bx, by, exists, px);
+    gj_color_444<CS_FROM, CS_TO>(g, bx, by, exists, px, pk);
 }
 
 template <int CS_FROM, int CS_TO>
@@ -789,9 +807,10 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
                                                  const int nblocks, const int table, const int dc_dist, const int seg_count_left,
                                                  uint8_t* __restrict__ region, const int index0, const bool seg_sizes,
                                                  uint32_t* __restrict__ seg_bytes, uint32_t* __restrict__ seg_ff, const uint32_t first_segment,
-                                                 const int trace0 = -1)
+                                                 const uint32_t trace_tile = 0, const int trace0 = -1)
 {
     (void)trace0;
+    (void)trace_tile;
     const int lane = i & 63, wave = i >> 6;
     uint8_t* const col = reinterpret_cast<uint8_t*>(L.coef) + i * 4;
     uint32_t* const s_bits = L.coef + GJ_ENC_PRIV_ROWS * 256;
@@ -843,7 +862,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
     }
     const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill;
 
-    if (trace0 >= 0) GJ_TRACE_E(trace0 + 1); // walk done (this wave)
+    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 1); // walk done (this wave)
     // ---- 4. bit positions
     const uint32_t winc = gj_wave_incl_scan(len);
     if (lane == 63) L.wsum[wave] = winc;
@@ -862,7 +881,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         z[1] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads(); // B3: segment ends visible, window cleared
-    if (trace0 >= 0) GJ_TRACE_E(trace0 + 2); // positions known
+    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 2); // positions known
     // segment books, redundantly in every wave (lane l keeps local segment l): bits with ones-padding to a byte, dword base
     uint32_t sbits = 0, sdw = 0;
     if (lane < spt && lane < seg_count_left) {
@@ -1042,7 +1061,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         }
     }
     __syncthreads(); // B7: the coefficient area may be overwritten by the next component
-    if (trace0 >= 0) GJ_TRACE_E(trace0 + 3); // merged, stuffed and stored
+    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 3); // merged, stuffed and stored
     return piece_size;
 }
 
@@ -1067,7 +1086,8 @@ typedef uint16_t __attribute__((aligned(1))) gj_u16_unaligned;
 #define GJ_TAIL_STARTED 0   // workgroups that have started
 #define GJ_TAIL_DONE 32     // workgroups whose tile streams are complete
 #define GJ_TAIL_SHARE 64    // next share of the tile list
-#define GJ_TAIL_CTR_WORDS 96 // (every counter on a 128-byte line of its own: the waiting workgroups poll one of them)
+#define GJ_TAIL_TICKET 96   // persistent encoders: next tile (behind the first gridDim.x ones)
+#define GJ_TAIL_CTR_WORDS 128 // (every counter on a 128-byte line of its own: the waiting workgroups poll one of them)
 struct GjTail {
     uint32_t* ctr;        // this call's counters (GJ_TAIL_*), zero when the kernel starts
     uint32_t* ctr_other;  // the next call's set
@@ -1256,6 +1276,7 @@ __device__ __forceinline__ void gj_tail_reset_next(const GjTail& T, const int i)
     if (i == 0) T.ctr_other[GJ_TAIL_STARTED] = 0;
     if (i == 1) T.ctr_other[GJ_TAIL_DONE] = 0;
     if (i == 2) T.ctr_other[GJ_TAIL_SHARE] = 0;
+    if (i == 3) T.ctr_other[GJ_TAIL_TICKET] = 0;
     for (uint32_t g = i; g < T.ngroups; g += 256) T.group_other[g] = 0;
 }
 
@@ -1335,11 +1356,14 @@ __device__ __forceinline__ void gj_load_coder_lut(uint32_t* s_lut, const uint32_
 // (unstuffed bytes in d_temp, byte and 0xFF counts) is exactly what k_scan_segments / k_assemble expect.
 // Used for non-interleaved 4:4:4 with restart intervals of 4 .. 256 blocks.
 // ================================================================================================
+#ifndef GJ_ENC_PREFETCH_ROWS
+#define GJ_ENC_PREFETCH_ROWS 4 // pixel rows of the NEXT tile asked for while a tile's last component is coded (6 registers each)
+#endif
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                          uint32_t* __restrict__ seg_ff, const GjTail T)
+                                                          uint32_t* __restrict__ seg_ff, const GjTail T, const uint32_t ntiles)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
@@ -1347,48 +1371,90 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     __shared__ uint32_t s_wsum[4];
     __shared__ int s_edge[64];
     __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
+    __shared__ uint32_t s_next;
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
-    GJ_TRACE_E(0);
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
 
     const gj_comp_geom& k0 = g.comp[0];
     const int B = g.seg_blocks;
-    const int spt = 256 / B;       // segments per workgroup (per component)
+    const int spt = 256 / B;       // segments per tile (per component)
     const int tile_blocks = spt * B;
-    const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
-    const int j = min((int)(((uint32_t)i * recip) >> 16), GJ_ENC_MAX_SPT - 1);
-    const int k = i - j * B;       // block inside its segment
-    const int seg0 = blockIdx.x * spt; // first segment (inside each component's scan)
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
-    const unsigned lb = (unsigned)blockIdx.x * (unsigned)tile_blocks + (unsigned)i;
-    const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
-    const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
 
-    // ---- pixels -> three byte-packed component blocks
-    uint32_t pk[3][16];
-    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, active, pk);
-    __syncthreads(); // tables are in LDS
-    GJ_TRACE_E(1); // pixels loaded and converted
-    // "started", for the tail. Behind the pixel loads: memory operations complete in order, and this one queues up with everybody else's
-    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
+    // A workgroup codes tile after tile: its first one is its index, the others come from a counter (asked for a whole tile ahead).
+    // Nothing but the tile number (a scalar) and the pixels on their way is carried from tile to tile: whatever a lane derives from its
+    // index is derived again where it is needed (GJ_KEEP hides the index from the optimiser, which would otherwise keep two dozen
+    // such values alive across the transforms -- in scratch memory, whose loads queue up behind the pixel loads).
+    uint32_t tile = blockIdx.x;
+    uint32_t px[8][6]; // the raw pixels of the lane's block position
+    {
+        const unsigned lb = tile * (unsigned)tile_blocks + (unsigned)i;
+        const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
+        gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, i < tile_blocks && lb < nb, px);
+    }
+    for (bool first = true;; first = false) {
+        GJ_TRACE_T(tile, 0);
+        const int seg0 = (int)tile * spt; // the tile's first segment (inside each component's scan)
+        uint32_t pk[3][16];
+        {   // ---- pixels -> three byte-packed component blocks
+            int t = threadIdx.x;
+            GJ_KEEP(t);
+            const unsigned lb = tile * (unsigned)tile_blocks + (unsigned)t;
+            const bool active = t < tile_blocks && lb < nb; // (every component has the same geometry)
+            const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
+            gj_load_444<GJ_ENC_PREFETCH_ROWS, 8>(g, raw, bx, by, active, px); // (the rows the registers had no room for while the last tile was coded)
+            gj_color_444<CS_FROM, CS_TO>(g, bx, by, active, px, pk);
+        }
+        uint32_t ticket = 0;
+        if (first) {
+            __syncthreads(); // tables are in LDS
+            // "started", for the tail. Behind the pixel loads: memory operations complete in order, and this one queues up with everybody else's
+            if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (used two components later)
+        GJ_TRACE_T(tile, 1); // pixels loaded and converted
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const gj_comp_geom& kc = g.comp[c];
-        // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
+        for (int c = 0; c < 3; c++) {
+            const gj_comp_geom& kc = g.comp[c];
+            // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
 #pragma unroll
-        for (int t = 0; t < 16; t++) GJ_KEEP(pk[c][t]);
-        gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
-        GJ_TRACE_E(2 + 4 * c); // transformed (this wave)
-        const uint64_t first_block = kc.data_offset / 64 + (uint64_t)seg0 * B; // coding-order index of the tile's first block of this component
-        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
-                                           temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
-                                           (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
-        // file order: the luminance scan's tiles, then the two chrominance scans'
-        if (i == 0) gj_piece_put(T, (uint32_t)c * gridDim.x + blockIdx.x, size | ((uint32_t)c << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+            for (int t = 0; t < 16; t++) GJ_KEEP(pk[c][t]);
+            {
+                int t = threadIdx.x;
+                GJ_KEEP(t);
+                gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + t * 4);
+            }
+            GJ_TRACE_T(tile, 2 + 4 * c); // transformed (this wave)
+            if (c == 2) {
+                // the next tile: its number, and its pixels on their way while this tile's last component is coded (the registers of
+                // the transforms are free now)
+                if (threadIdx.x == 0) s_next = gridDim.x + ticket;
+                __syncthreads();
+                const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
+                int t = threadIdx.x;
+                GJ_KEEP(t);
+                const unsigned lb = next * (unsigned)tile_blocks + (unsigned)t;
+                const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
+                gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, next < ntiles && t < tile_blocks && lb < nb, px);
+            }
+            int t = threadIdx.x;
+            GJ_KEEP(t);
+            const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = t / B through a 16.16 reciprocal (exact for t < 256, B <= 256)
+            const int j = min((int)(((uint32_t)t * recip) >> 16), GJ_ENC_MAX_SPT - 1);
+            const int k = t - j * B; // block inside its segment
+            const bool active = t < tile_blocks && tile * (unsigned)tile_blocks + (unsigned)t < nb;
+            const uint64_t first_block = kc.data_offset / 64 + (uint64_t)seg0 * B; // coding-order index of the tile's first block of this component
+            const uint32_t size = gj_code_tile(L, t, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
+                                               temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
+                                               (uint32_t)(kc.first_segment + seg0), tile, 2 + 4 * c);
+            // file order: the luminance scan's tiles, then the two chrominance scans'
+            if (threadIdx.x == 0) gj_piece_put(T, (uint32_t)c * ntiles + tile, size | ((uint32_t)c << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+        }
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next); // (stable until the next tile's third component)
+        if (tile >= ntiles) break;
     }
     gj_encode_tail(T, s_coef, i);
 }
@@ -1883,7 +1949,7 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // Launcher
 // ================================================================================================
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
-typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail);
+typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail, uint32_t);
 
 #define GJ_TAIL_SHARES 256 // default number of parts the gathering tail cuts the tile list into (GJ_ENC_TAIL overrides)
 // the tail's arguments for a launch that leaves `pieces` tile streams, scan s beginning with stream scan_first[s]
@@ -1912,6 +1978,19 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     T.h_result = job->h_result;
     T.seg_sizes = job->segment_info && job->g.restart_interval > 0;
     return T;
+}
+
+// compute units of the current device (asked once per device)
+static int gj_cu_count()
+{
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t p;
+        cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    return cus[dev];
 }
 
 // what the encoder kernel itself gets: no shares when the gathering is a launch of its own
@@ -2016,8 +2095,10 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         tail_for_gather = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u});
-        hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
-                           job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
+        // persistent: as many workgroups as the device holds at once (four per CU), each codes tile after tile
+        const unsigned resident = job->tune.enc_resident > 0 ? (unsigned)job->tune.enc_resident : 4u * (unsigned)gj_cu_count();
+        hipLaunchKernelGGL(whole, dim3(wgs < resident ? wgs : resident), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather), wgs);
     } else {
     one_launch = false;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU

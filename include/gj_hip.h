@@ -64,7 +64,7 @@ GJ_HIP_API float gj_hip_event_elapsed_ms(gj_event_t start, gj_event_t stop); /* 
  * of >= 4 blocks < 416 B per block --, and block i's private spill slot is the upper half of its own 416 bytes, which the stream cannot
  * reach before block i has been merged into it */
 #define GJ_STAGE_BYTES_PER_BLOCK 416
-#define GJ_TAIL_HEAD_WORDS 192 /* gj_enc_job.d_tail: the gathering tail's counters (two sets), then two sets of GJ_TAIL_GROUPS_CAP(segments) group
+#define GJ_TAIL_HEAD_WORDS 256 /* gj_enc_job.d_tail: the gathering tail's counters (two sets), then two sets of GJ_TAIL_GROUPS_CAP(segments) group
                                   totals, then the tile list (two words per tile stream, at most one stream per segment) */
 #define GJ_TAIL_GROUPS_CAP(segments) (((unsigned)(segments) + 32u) / 32u + 1u)
 #define GJ_TAIL_WORDS(segments) (GJ_TAIL_HEAD_WORDS + 2u * GJ_TAIL_GROUPS_CAP(segments) + 2u * ((unsigned)(segments) + 1u))
@@ -128,6 +128,7 @@ typedef struct gj_tuning {
     int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
     int enc_by_blocks;   /* GJ_ENC_BLOCKS: packed RGB 4:4:4 through k_encode_blocks (a workgroup codes one component of its tile: three times the
                             workgroups, a third of the work each) 1 = always, -1 = never, 0 = small frames only */
+    int enc_resident;    /* GJ_ENC_RESIDENT: workgroups of the persistent encoder kernel (0 = four per compute unit) */
     int enc_tail_shares; /* GJ_ENC_TAIL: parts the gathering tail of the one-launch encoders cuts the stream into (0 = default) */
     int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that
                             does not fit (overflow flag) -- this call uses the kernels without that limit */

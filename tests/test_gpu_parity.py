@@ -376,16 +376,25 @@ TAIL_CASES = [
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("resident", [0, 1, 5], ids=lambda r: f"resident{r}")
 @pytest.mark.parametrize("shares", [0, 1, 3, 100000, -5], ids=lambda s: f"shares{s}")
 @pytest.mark.parametrize("tc", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
-def test_one_launch_encoder_tail(O, G, gpu_lib, tc, shares, monkeypatch):
+def test_one_launch_encoder_tail(O, G, gpu_lib, tc, shares, resident, monkeypatch):
     """The one-launch encoders (k_encode_*): every workgroup leaves its tile's finished stream (stuffed, RSTn in place) in d_temp, the
     last workgroups gather them into the file (scan headers, EOI, size). Replaces src/gpujpeg_huffman_gpu_encoder.cu:417-613 and the
     host stitching of src/gpujpeg_encoder.c:567-629; the bytes must be the oracle's whatever the number of shares the tail cuts the
     tile list into (GJ_ENC_TAIL: 1 = one workgroup gathers everything, more shares than tiles = one tile stream per share, negative = the
     same gathering as a launch of its own, k_gather), with
-    and without the APP13 index, twice in a row on the same coder (the tail's counters alternate between two sets)."""
+    and without the APP13 index, twice in a row on the same coder (the tail's counters alternate between two sets). GJ_ENC_RESIDENT
+    limits the workgroups of the persistent kernel (k_encode_rgb444): 1 = one workgroup codes every tile, 5 = tiles handed out by the
+    counter to five of them."""
     name, w, h, pf, cs, q, restart, il, sub, noisy = tc
+    if resident:
+        if pf != 1 or il or sub is not None:
+            pytest.skip("only k_encode_rgb444 is persistent")
+        monkeypatch.setenv("GJ_ENC_RESIDENT", str(resident))
+    else:
+        monkeypatch.delenv("GJ_ENC_RESIDENT", raising=False)
     if shares:
         monkeypatch.setenv("GJ_ENC_TAIL", str(shares))
     else:

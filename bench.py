@@ -285,7 +285,9 @@ class Lanes:
 def kernel_names(spec, enc_ms, token_mode):
     whole = enc_ms[1] < 0.02 * max(1.0, spec.pixels / 33e6)  # fully fused encoder: pixels -> segment streams in one kernel (slots 0/1 empty)
     fmt = "uyvy422" if spec.is422 else "rgb444"
-    return ["enc:k_preprocess", f"enc:k_fused_{fmt}", f"enc:k_encode_{fmt}" if whole else "enc:k_huffman", "enc:k_scan_segments", "enc:k_assemble",
+    # (round 4: the k_encode_* kernels leave the finished stream themselves or, for frames of more tiles than the device holds at once,
+    # through k_gather; k_scan_segments + k_assemble follow k_huffman only)
+    return ["enc:k_preprocess", f"enc:k_fused_{fmt}", f"enc:k_encode_{fmt}" if whole else "enc:k_huffman", "enc:k_gather" if whole else "enc:k_scan_segments", "enc:k_assemble",
             ("dec:k_huffman_decode_win" if token_mode else "dec:k_huffman_decode_seq") if spec.is422 and spec.pixels > 3e7 else ("dec:k_huffman_decode_tok" if token_mode else "dec:k_huffman_decode_par"),
             f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}", "dec:k_postprocess"]
 

@@ -1951,9 +1951,14 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
 typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail, uint32_t);
 
-#define GJ_TAIL_SHARES 256 // default number of parts the gathering tail cuts the tile list into (GJ_ENC_TAIL overrides)
+// Who gathers the tile streams (measured, profiles/r4_03_*): a device-scope round trip costs ~2 us on this part and the tail inside the
+// encoder kernel needs four in a row after the last tile (finished-counter, its observation, sizes, data) where a launch of its own
+// reads through its L2 -- k_gather is faster from ~1000 tiles on (8K: 8 against 16 us) and the tail inside wins for frames whose tiles
+// are all resident at once (HD: one launch less, 38 against 42 us). GJ_ENC_TAIL > 0 / < 0 forces one or the other with that many shares.
+#define GJ_TAIL_SHARES 64    // parts of the tile list for the tail inside the kernel
+#define GJ_GATHER_SHARES 512 // ... for k_gather
 // the tail's arguments for a launch that leaves `pieces` tile streams, scan s beginning with stream scan_first[s]
-static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const unsigned (&scan_first)[GJ_MAX_COMP])
+static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const unsigned (&scan_first)[GJ_MAX_COMP], const bool own_gather)
 {
     GjTail T;
     for (int s = 0; s < GJ_MAX_COMP; s++) T.scan_first[s] = scan_first[s];
@@ -1972,7 +1977,7 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     T.main_hdr = job->main_hdr_size;
     T.npieces = pieces;
     const int ts = job->tune.enc_tail_shares;
-    const unsigned want = ts > 0 ? (unsigned)ts : ts < 0 ? (unsigned)-ts : (unsigned)GJ_TAIL_SHARES;
+    const unsigned want = ts > 0 ? (unsigned)ts : ts < 0 ? (unsigned)-ts : own_gather ? (unsigned)GJ_GATHER_SHARES : (unsigned)GJ_TAIL_SHARES;
     T.shares = want < pieces ? want : pieces;
     T.d_result = job->d_result;
     T.h_result = job->h_result;
@@ -2055,7 +2060,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     bool one_launch = true; // k_encode_*: the stream is complete when the kernel ends
     GjTail tail_for_gather;   // (GJ_ENC_TAIL < 0: what k_gather gets; the encoder kernel is told not to gather)
     tail_for_gather.shares = 0;
-    const bool own_gather = job->tune.enc_tail_shares < 0;
+    bool own_gather = job->tune.enc_tail_shares < 0;
     gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
     if (whole && job->tune.enc_by_blocks > 0 && gj_blocks_kernel_mode(g) == 0) whole = nullptr; // (k_encode_blocks below)
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
@@ -2070,7 +2075,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
-        tail_for_gather = gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u});
+        // (not persistent: a finished-counter trip per tile, which 17 000 tiles of a 16K frame queue up for -- k_gather unless they are few)
+        if (job->tune.enc_tail_shares == 0) own_gather = wgs > 4u * (unsigned)gj_cu_count();
+        tail_for_gather = gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u}, own_gather);
         hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
                            job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
     } else if (!whole && job->use_fused && !job->keep_coefs && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT &&
@@ -2086,7 +2093,8 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                 scan_first[c] = wgs;
                 wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
             }
-        tail_for_gather = gj_make_tail(job, wgs, scan_first);
+        if (job->tune.enc_tail_shares == 0) own_gather = wgs > 4u * (unsigned)gj_cu_count();
+        tail_for_gather = gj_make_tail(job, wgs, scan_first, own_gather);
         hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
                            job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
@@ -2094,9 +2102,10 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
-        tail_for_gather = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u});
         // persistent: as many workgroups as the device holds at once (four per CU), each codes tile after tile
         const unsigned resident = job->tune.enc_resident > 0 ? (unsigned)job->tune.enc_resident : 4u * (unsigned)gj_cu_count();
+        if (job->tune.enc_tail_shares == 0) own_gather = wgs > resident;
+        tail_for_gather = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, own_gather);
         hipLaunchKernelGGL(whole, dim3(wgs < resident ? wgs : resident), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
                            job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather), wgs);
     } else {

@@ -796,16 +796,16 @@ __device__ __forceinline__ void gj_merge_stream(const GjWalk& w, const uint8_t* 
     }
 }
 
-// Steps 2-6 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
+// Steps 2-5 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
 // nblocks = blocks of that segment, table = 0 luminance / 1 chrominance tables, dc_dist = lanes back to the previous block of the
-// same component; region = the tile's area of d_temp (GJ_STAGE_BYTES_PER_BLOCK per block: the finished stream from its start, block
-// i's spill slot in the upper half of its own bytes), seg_count_left = segments of the scan from the tile's first one on (the last one
-// of a scan gets no restart marker), index0 = index of the tile's first segment in its scan (restart marker numbers);
-// seg_bytes / seg_ff (only with `seg_sizes`: the APP13 index wants them) = unstuffed size and 0xFF count per segment.
-// Returns the size of the tile's finished stream (the same in every thread).
+// same component; region = the tile's area of d_temp (GJ_TEMP_BYTES_PER_BLOCK per block: the tile's UNSTUFFED stream from its start --
+// every segment on a dword boundary, in the order of the scan --, block i's spill slot at i * GJ_TEMP_BYTES_PER_BLOCK, which the stream
+// reaches only after block i has been merged into it), seg_count_left = segments of the scan from the tile's first one on (the last
+// one of a scan gets no restart marker); seg_bytes / seg_ff = unstuffed size and 0xFF count per segment (k_gather stuffs).
+// Returns the size of the tile's FINISHED stream (stuffed, restart markers included; the same in every thread).
 __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int i, const int j, const int k, const bool active, const int spt,
                                                  const int nblocks, const int table, const int dc_dist, const int seg_count_left,
-                                                 uint8_t* __restrict__ region, const int index0, const bool seg_sizes,
+                                                 uint8_t* __restrict__ region,
                                                  uint32_t* __restrict__ seg_bytes, uint32_t* __restrict__ seg_ff, const uint32_t first_segment,
                                                  const uint32_t trace_tile = 0, const int trace0 = -1)
 {
@@ -842,7 +842,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
 
     // ---- 3. the walk
     GjWalk w = {0, 0, 0, 0, 1};
-    uint32_t* const spill = reinterpret_cast<uint32_t*>(region + (size_t)i * GJ_STAGE_BYTES_PER_BLOCK + GJ_STAGE_BYTES_PER_BLOCK / 2); // (lane i = block i of the tile)
+    uint32_t* const spill = reinterpret_cast<uint32_t*>(region + (size_t)i * GJ_TEMP_BYTES_PER_BLOCK); // (lane i = block i of the tile)
     int dc_diff = 0;
     {
         // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342)
@@ -905,265 +905,143 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         if (active && k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
     }
 
-    // ---- 5. merge into the window
+    // ---- 5. merge into the window, drain the window to HBM
     // The lane's stream is its `produced` completed dwords, then the accumulator and the ones-padding of a segment's last block as
     // one 64-bit tail; it lands `start_bit & 31` bits into dword `start_bit >> 5` of the tile stream, so every output dword is
     // one funnel shift (v_alignbit_b32) of two neighbouring stream dwords and one ds_or_b32.
-    // ---- 6. the window's streams -> the tile's FINISHED stream: 0x00 behind every 0xFF, RSTn behind every segment but a scan's last
-    // (src/gpujpeg_huffman_gpu_encoder.cu:417-503 serialisation + :563-613 compaction + the host's stitching, src/gpujpeg_encoder.c:567-629).
     const uint32_t sh = start_bit & 31u, d0 = start_bit >> 5;
     uint64_t tail = (uint64_t)w.hi << 32;
     if (pad_bits) tail |= (uint64_t)((1u << pad_bits) - 1u) << (64 - w.fill - pad_bits);
     const int ndw = w.produced + (w.fill + pad_bits > 32 ? 2 : (w.fill + pad_bits > 0 ? 1 : 0)); // stream dwords incl. the tail
     const int nseg = min(spt, seg_count_left);
-    uint8_t* const stage = reinterpret_cast<uint8_t*>(L.coef); // rows 0 .. GJ_ENC_PRIV_ROWS - 1: 24 KB >= 2 x the window + the markers
-    uint32_t piece_size = 0;
-    if (total_dw <= (uint32_t)GJ_ENC_WIN_DW) {
-        // A tile whose streams fit one window (all but noise-like content): ONE pass. A wave takes a quarter of the segments, one after
-        // the other; a lane takes a dword, the wave's prefix sum of the byte counts places its bytes. The wave's bytes go to a place of
-        // their own in the dead private rows of the coefficient area (twice the unstuffed bytes in front of them is an upper bound of
-        // what the waves before it write), then leave as whole 16-byte pieces behind those of the waves before it.
-        if (active) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, 0u, total_dw);
-        __syncthreads(); // B4: window complete; the private streams are dead
-        const int sa = (wave * nseg) >> 2, sz = ((wave + 1) * nseg) >> 2; // this wave's segments
-        const uint32_t R = sa < nseg ? ((8u * L.segbase[sa] + 2u * (uint32_t)sa + 15u) & ~15u) + 16u * (uint32_t)wave : 0u;
-        uint32_t run = R;
-        for (int sl = sa; sl < sz; sl++) {
-            const uint32_t sb = L.segbase[sl], nb = L.segbits[sl] >> 3, nfl = (nb + 3u) >> 2;
-            const uint32_t run0 = run;
-            for (uint32_t c0 = 0; c0 < nfl; c0 += 64) {
-                const uint32_t d = c0 + (uint32_t)lane;
-                uint32_t v = 0;
-                int vb = 0;
-                if (d < nfl) {
-                    v = s_bits[sb + d];
-                    vb = (int)min(4u, nb - 4u * d);
-                }
+    uint32_t* const dst = reinterpret_cast<uint32_t*>(region); // dword d of the tile stream
+    for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {
+        const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_ENC_WIN_DW);
+        if (wbase) {
+            __syncthreads(); // previous window drained
+            for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
+            __syncthreads();
+        }
+        if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, wbase, wend);
+        __syncthreads(); // B4: window complete
+        // every wave drains whole segments: no search for the owner of a dword, the 0xFF count of a segment is one wave reduction
+        for (int sl = wave; sl < nseg; sl += 4) {
+            const uint32_t sb = L.segbase[sl], nfl = (L.segbits[sl] + 31u) >> 5;
+            const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
+            uint32_t ffc = 0;
+            for (uint32_t d = lo + (uint32_t)lane; d < hi; d += 64) {
+                const uint32_t v = s_bits[d - wbase];
                 // 0xFF bytes (the unused low bytes of a segment's last dword are zero)
-                const uint32_t cnt = (uint32_t)vb + (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
-                const uint32_t inc = gj_wave_incl_scan(cnt);
-                uint32_t p = run + inc - cnt;
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (b < vb) {
-                        const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
-                        stage[p++] = (uint8_t)byte;
-                        if (byte == 0xFFu) stage[p++] = 0;
-                    }
-                run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                ffc += (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
+                dst[d] = __builtin_bswap32(v);
             }
-            if (seg_sizes && lane == 0) {
-                seg_bytes[first_segment + sl] = nb;
-                seg_ff[first_segment + sl] = run - run0 - nb;
-            }
-            if (sl != seg_count_left - 1) { // RSTn (src/gpujpeg_huffman_gpu_encoder.cu:497-502)
-                if (lane == 0) {
-                    stage[run] = 0xFF;
-                    stage[run + 1] = (uint8_t)(0xD0 + ((index0 + sl) & 7));
-                }
-                run += 2;
-            }
-        }
-        if (lane == 0) L.wsum[wave] = run - R;
-        __syncthreads(); // B5: every wave's bytes and their count
-        const uint32_t n0 = L.wsum[0], n1 = L.wsum[1], n2 = L.wsum[2], n3 = L.wsum[3];
-        const uint32_t O = wave == 0 ? 0u : wave == 1 ? n0 : wave == 2 ? n0 + n1 : n0 + n1 + n2, n = run - R;
-        piece_size = n0 + n1 + n2 + n3;
-        for (uint32_t q = (uint32_t)lane * 16u; q < n; q += 1024) {
-            const gj_u4 v = *reinterpret_cast<const gj_u4*>(stage + R + q); // (whole 16 bytes: the stage is larger than any wave's bytes)
-            uint8_t* const dst = region + O + q;
-            if (q + 16u <= n) {
-                gj_store16_agent(dst, v);
-            } else { // the wave's last 1 .. 15 bytes: 8 + 4 + 2 + 1
-                const uint32_t nb = n - q;
-                uint64_t cur = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                uint32_t off = 0;
-                if (nb & 8u) { gj_store8_agent(dst, cur); cur = (uint64_t)v.z | ((uint64_t)v.w << 32); off = 8; }
-                if (nb & 4u) { gj_store4_agent(dst + off, (uint32_t)cur); cur >>= 32; off += 4; }
-                if (nb & 2u) { gj_store2_agent(dst + off, (uint32_t)cur); cur >>= 16; off += 2; }
-                if (nb & 1u) gj_store1_agent(dst + off, (uint32_t)cur);
-            }
-        }
-    } else {
-        // noise-like content: window after window; the bytes are counted first (6a, 6b), then stored one by one (6c)
-        uint32_t ff_total = 0;
-        for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {
-            const uint32_t wend = min(total_dw, wbase + (uint32_t)GJ_ENC_WIN_DW);
-            if (wbase) {
-                __syncthreads(); // previous window consumed
-                for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
-                __syncthreads();
-            }
-            if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, wbase, wend);
-            __syncthreads(); // B4: window complete
-            // 6a. every wave takes whole segments: the 0xFF bytes of a segment's part of this window are one wave reduction
-            for (int sl = wave; sl < nseg; sl += 4) {
-                const uint32_t sb = L.segbase[sl], nfl = (L.segbits[sl] + 31u) >> 5;
-                const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
-                uint32_t ffc = 0;
-                for (uint32_t d = lo + (uint32_t)lane; d < hi; d += 64) {
-                    const uint32_t v = s_bits[d - wbase];
-                    ffc += (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
-                }
-                ffc = gj_wave_incl_scan(ffc);
-                if (lane == 63) L.segff[sl] = ffc;
-            }
-            __syncthreads(); // B5: 0xFF counts
-            // 6b. sizes and places of the parts, redundantly in every wave (lane l keeps local segment l)
-            uint32_t psz = 0;
-            if (lane < nseg) {
-                const uint32_t sb = L.segbase[lane], nb = L.segbits[lane] >> 3, nfl = (nb + 3u) >> 2;
-                const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
-                if (hi > lo) {
-                    const bool ends = hi == sb + nfl;
-                    const uint32_t ff = L.segff[lane];
-                    ff_total += ff;
-                    psz = (ends ? nb - 4u * (lo - sb) : 4u * (hi - lo)) + ff + (ends && lane != seg_count_left - 1 ? 2u : 0u);
-                }
-            }
-            const uint32_t pincl = gj_wave_incl_scan(psz);
-            const uint32_t poff = pincl - psz;
-            // 6c. stuffing: a lane takes a dword, the wave's prefix sum of the byte counts places it
-            for (int sl = wave; sl < nseg; sl += 4) {
-                const uint32_t sb = L.segbase[sl], nb = L.segbits[sl] >> 3, nfl = (nb + 3u) >> 2;
-                const uint32_t lo = max(sb, wbase), hi = min(sb + nfl, wend);
-                uint32_t run = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)poff) + piece_size;
-                for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
-                    const uint32_t d = c0 + (uint32_t)lane;
-                    uint32_t v = 0;
-                    int vb = 0;
-                    if (d < hi) {
-                        v = s_bits[d - wbase];
-                        vb = (int)min(4u, nb - 4u * (d - sb));
-                    }
-                    const uint32_t cnt = (uint32_t)vb + (uint32_t)__builtin_popcount(((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u);
-                    const uint32_t inc = gj_wave_incl_scan(cnt);
-                    uint32_t p = run + inc - cnt;
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (b < vb) {
-                            const uint32_t byte = (v >> (24 - 8 * b)) & 0xFFu;
-                            gj_store1_agent(region + p++, byte);
-                            if (byte == 0xFFu) gj_store1_agent(region + p++, 0u);
-                        }
-                    run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                }
-                if (hi > lo && hi == sb + nfl && sl != seg_count_left - 1 && lane == 0) { // the segment ends here: RSTn
-                    gj_store1_agent(region + run, 0xFFu);
-                    gj_store1_agent(region + run + 1, 0xD0u + (uint32_t)((index0 + sl) & 7));
-                }
-            }
-            piece_size += (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
-        }
-        if (seg_sizes && wave == 0 && lane < nseg) {
-            seg_bytes[first_segment + lane] = L.segbits[lane] >> 3;
-            seg_ff[first_segment + lane] = ff_total;
+            ffc = gj_wave_incl_scan(ffc);
+            if (lane == 63 && ffc) L.segff[sl] += ffc;
         }
     }
-    __syncthreads(); // B7: the coefficient area may be overwritten by the next component
-    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 3); // merged, stuffed and stored
-    return piece_size;
+    __syncthreads(); // B5: 0xFF counts complete; the coefficient area may be overwritten by the next component
+    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 3); // merged and drained
+    // the segments' sizes for k_gather, and what the tile's stream will measure once it is stuffed
+    uint32_t out = 0;
+    if (lane < nseg) {
+        const uint32_t nb = (L.segbits[lane] + 7u) >> 3, ff = L.segff[lane];
+        out = nb + ff + (lane != seg_count_left - 1 ? 2u : 0u);
+        if (wave == 0) {
+            seg_bytes[first_segment + lane] = nb;
+            seg_ff[first_segment + lane] = ff;
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readlane((int)gj_wave_incl_scan(out), 63);
 }
 
 // ================================================================================================
-// The gathering tail of the one-launch encoders (replaces k_scan_segments + k_assemble and their two launches for k_encode_*).
+// k_gather: the tile streams -> the file. Replaces k_scan_segments + k_assemble behind the k_encode_* kernels (the reference:
+// serialisation + compaction kernels and the host's stitching, src/gpujpeg_huffman_gpu_encoder.cu:417-613, src/gpujpeg_encoder.c:567-629).
 //
-// A workgroup leaves the FINISHED stream of its tile (stuffed, restart markers in place) at the start of the tile's area of d_temp
-// and notes its size. Where a tile's bytes go in the file depends on the sizes of all tiles in front of it -- for the chrominance
-// scans of k_encode_rgb444 on tiles that have not even started --, so nobody waits for a position: the workgroups that finish
-// LAST gather. A workgroup that is among the last `shares` to finish, and finds that every workgroup of the launch has started
-// (then everything unfinished is running and will finish: waiting cannot deadlock, whatever else occupies the device), waits for
-// the last tile and takes shares of the tile list from a counter: it reads all tile sizes (one trip: the place of its share in the
-// file and the size of the stream), then every lane copies whole 16-byte pieces of the file -- found by a search over the share's
-// tiles in LDS, all loads of a round in flight together --, the ends of a tile byte by byte; scan headers and EOI come from the
-// share that meets them. The workgroup that finishes last always gathers, so the list is always emptied.
-// Counters: two sets that alternate with the call's epoch; the last finisher clears the other set for the next call.
+// An encoder workgroup leaves the UNSTUFFED stream of its tile in the tile's area of d_temp (segments on dword boundaries), the
+// segments' byte and 0xFF counts, the size the tile's stream will have in the file, and adds that size to the total of its group of
+// 32 tiles (one atomic, nobody waits for it). Here ONE WAVE takes one tile stream, ~6000 waves at once for an 8K frame, and everything
+// it needs is asked for in one trip: the group totals and the sizes of its group's tiles in front of it (its place in the file), its
+// segments' counts, and the first 2 KB of its stream (where those are follows from the launch's geometry, not from loaded values).
+// Then the stream is stuffed in flight: a lane takes a dword, finds its segment (a bit mask of the segment starts in the 64 dwords
+// of the round + popcount), counts its 0xFF bytes; a wave prefix sum places it; a dword without 0xFF leaves as one unaligned 4-byte
+// store, restart markers follow the last dword of a segment. Round 3 needed a launch for the offsets (5 us), a wave per four
+// segments with two dependent trips and byte stores (16 us), and 19 MB of traffic for the same.
 // ================================================================================================
-typedef gj_u4 __attribute__((aligned(1))) gj_u4_unaligned; // a 16-byte global store to any address (one instruction on gfx950)
-typedef uint64_t __attribute__((aligned(1))) gj_u64_unaligned;
 typedef uint32_t __attribute__((aligned(1))) gj_u32_unaligned;
-typedef uint16_t __attribute__((aligned(1))) gj_u16_unaligned;
-#define GJ_TAIL_STARTED 0   // workgroups that have started
-#define GJ_TAIL_DONE 32     // workgroups whose tile streams are complete
-#define GJ_TAIL_SHARE 64    // next share of the tile list
-#define GJ_TAIL_TICKET 96   // persistent encoders: next tile (behind the first gridDim.x ones)
-#define GJ_TAIL_CTR_WORDS 128 // (every counter on a 128-byte line of its own: the waiting workgroups poll one of them)
+#define GJ_TAIL_TICKET 0     // persistent encoders: next tile (behind the first gridDim.x ones)
+#define GJ_TAIL_CTR_WORDS 32 // (a 128-byte line per call parity)
 struct GjTail {
-    uint32_t* ctr;        // this call's counters (GJ_TAIL_*), zero when the kernel starts
-    uint32_t* ctr_other;  // the next call's set
-    uint2* piece;         // [npieces] tile streams in FILE order: x = size | scan << 28, y = offset in d_temp / 16
-    uint32_t* group;      // [ngroups] bytes of the tile streams 32 g .. 32 g + 31, added up by the tiles themselves; zero when the kernel starts
+    uint32_t* ctr;         // this call's counters (GJ_TAIL_*), zero when the encoder kernel starts
+    uint32_t* ctr_other;   // the next call's: cleared by k_gather
+    uint32_t* piece;       // [npieces] size in the file of every tile stream, in FILE order
+    uint32_t* group;       // [ngroups] bytes of the tile streams 32 g .. 32 g + 31, added up by the tiles themselves; zero when the encoder kernel starts
     uint32_t* group_other; // the next call's
-    uint32_t ngroups;
+    uint32_t ngroups, npieces;
     const uint8_t* temp;
+    const uint32_t* seg_bytes;
+    const uint32_t* seg_ff;
     uint8_t* jpeg;
     uint64_t capacity;
     const uint8_t* scan_hdr;
-    uint32_t hdr_end[GJ_MAX_COMP]; // bytes of the scan headers up to and including scan s
-    uint32_t scan_first[GJ_MAX_COMP]; // index in the list of the first tile stream of scan s (0xFFFFFFFF behind the last scan)
+    uint32_t hdr_end[GJ_MAX_COMP];     // bytes of the scan headers up to and including scan s
+    uint32_t scan_first[GJ_MAX_COMP];  // index in the list of the first tile stream of scan s (0xFFFFFFFF behind the last scan)
+    uint32_t seg_first[GJ_MAX_COMP];   // global index of the scan's first segment
+    uint32_t segs[GJ_MAX_COMP];        // segments of the scan
+    uint32_t block_first[GJ_MAX_COMP]; // coding-order index of the scan's first block (addresses d_temp)
+    uint32_t spt, seg_blocks;          // segments per tile, blocks per full segment
     uint32_t main_hdr;
-    uint32_t npieces, shares;
     uint32_t* d_result;
     uint32_t* h_result;
-    int seg_sizes;        // the APP13 index is wanted: per-segment sizes to d_seg_bytes / d_seg_ff
 };
 
-__device__ __forceinline__ uint32_t gj_tail_hdr_end(const GjTail& T, const uint32_t scan)
+__device__ __forceinline__ uint32_t gj_pick4(const uint32_t (&a)[GJ_MAX_COMP], const uint32_t s)
 {
-    return scan == 0 ? T.hdr_end[0] : scan == 1 ? T.hdr_end[1] : scan == 2 ? T.hdr_end[2] : T.hdr_end[3];
+    return s == 0 ? a[0] : s == 1 ? a[1] : s == 2 ? a[2] : a[3];
 }
 // the scan tile stream p belongs to
 __device__ __forceinline__ uint32_t gj_tail_scan_of(const GjTail& T, const uint32_t p)
 {
     return (p >= T.scan_first[1] ? 1u : 0u) + (p >= T.scan_first[2] ? 1u : 0u) + (p >= T.scan_first[3] ? 1u : 0u);
 }
-
-// one entry of the tile list (written and read with device scope, see gj_store16_agent)
-__device__ __forceinline__ void gj_piece_put(const GjTail& T, const uint32_t p, const uint32_t size_scan, const uint32_t off16)
+// an encoder workgroup's entry for tile stream p
+__device__ __forceinline__ void gj_piece_put(const GjTail& T, const uint32_t p, const uint32_t size)
 {
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(T.piece) + p, (uint64_t)size_scan | ((uint64_t)off16 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (a gathering workgroup reads these totals and the few list entries around its share, not the whole list: 256 workgroups reading
-    // the same 50 KB past their L2s kept a dozen memory channels busy for 10 us, profiles/r4_02_*)
-    (void)__hip_atomic_fetch_add(&T.group[p >> 5], size_scan & 0x0FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// loads of what other workgroups of the same launch have written (device scope), or plain ones (a launch of its own)
-template <bool COHERENT> __device__ __forceinline__ uint32_t gj_tail_ld32(const uint32_t* p)
-{
-    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool COHERENT> __device__ __forceinline__ uint64_t gj_tail_ld64(const uint64_t* p)
-{
-    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-__device__ __forceinline__ uint2 gj_piece_get(const GjTail& T, const uint32_t p)
-{
-    const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(T.piece) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    T.piece[p] = size;
+    (void)__hip_atomic_fetch_add(&T.group[p >> 5], size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One share of the tile list -> its place in the file. s_mem: >= 1120 words of LDS nothing else uses any more; all 256 threads.
-template <bool COHERENT>
-__device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem, const int i, const uint32_t share)
+#define GJ_GATHER_PRELOAD 8 // rounds of 64 dwords whose loads are issued before anything is known about the tile stream
+__global__ __launch_bounds__(256) void k_gather(const GjTail T)
 {
-    uint32_t* const s_tmp = s_mem;      // [4] scans
-    uint32_t* const tF = s_mem + 16;    // [256] file offset of the tile stream
-    uint32_t* const tsrc = tF + 256;    // [256] offset in d_temp / 16
-    uint32_t* const tsize = tsrc + 256; // [256]
-    uint32_t* const tcs = tsize + 256;  // [256] first 16-byte piece (in the batch's numbering)
-    uint32_t* const tcoarse = tcs + 256; // [65] tile of every 32nd piece of a round
-    const uint32_t P = T.npieces, K = T.shares, NG = T.ngroups;
-    const uint64_t* const piece64 = reinterpret_cast<const uint64_t*>(T.piece);
-    const uint32_t pa = (uint32_t)((uint64_t)share * P / K), pb = (uint32_t)((uint64_t)(share + 1) * P / K);
-    // one trip: the group totals (the bytes of the groups in front of the share's first one, and of the whole stream), the tiles of that
-    // first group in front of the share, the share's own tiles (lane i: tile pa + i)
-    const uint32_t ga = pa >> 5;
+    __shared__ uint32_t s_tmp[4];
+    __shared__ unsigned long long s_mask[4];
+    __shared__ uint32_t s_ffstart[4][GJ_ENC_MAX_SPT];
+    const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    const uint32_t P = T.npieces, NG = T.ngroups;
+    const uint32_t p0 = blockIdx.x * 4u, p = p0 + (uint32_t)wave;
+    const bool have = p < P;
+    if (blockIdx.x == 0) { // the next call's counters and group totals
+        if (i == 0) T.ctr_other[GJ_TAIL_TICKET] = 0;
+        for (uint32_t g = i; g < NG; g += 256) T.group_other[g] = 0;
+    }
+    // ---- this wave's tile stream: where its segments and its bytes are (no loaded value needed)
+    const uint32_t scan = gj_tail_scan_of(T, have ? p : 0u);
+    const uint32_t t = (have ? p : 0u) - gj_pick4(T.scan_first, scan), seg0 = t * T.spt, scan_segs = gj_pick4(T.segs, scan);
+    const uint32_t nseg = have ? min(T.spt, scan_segs - seg0) : 0u;
+    const uint32_t s0 = gj_pick4(T.seg_first, scan) + seg0;
+    const uint32_t* const src = reinterpret_cast<const uint32_t*>(T.temp + ((uint64_t)gj_pick4(T.block_first, scan) + (uint64_t)seg0 * T.seg_blocks) * GJ_TEMP_BYTES_PER_BLOCK);
+    const uint32_t src_dw = nseg * T.seg_blocks * (GJ_TEMP_BYTES_PER_BLOCK / 4u); // (dwords of the tile's area: nothing is read behind them)
+    // ---- one trip: group totals, the sizes of the tiles of the group in front of the workgroup's first one and of the workgroup's
+    // own, the segments' counts, the first rounds of the stream
+    const uint32_t ga = p0 >> 5;
     uint32_t before = 0, all = 0;
     for (uint32_t g0 = 0; g0 < NG; g0 += 1024) {
         uint32_t v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t g = g0 + (uint32_t)u * 256u + (uint32_t)i;
-            v[u] = g < NG ? gj_tail_ld32<COHERENT>(&T.group[g]) : 0u;
+            v[u] = g < NG ? T.group[g] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1172,165 +1050,105 @@ __device__ __forceinline__ void gj_gather_share(const GjTail& T, uint32_t* s_mem
             before += g < ga ? v[u] : 0u;
         }
     }
-    if ((uint32_t)i < (pa & 31u)) before += (uint32_t)gj_tail_ld64<COHERENT>(piece64 + (ga << 5) + i) & 0x0FFFFFFFu;
-    uint64_t mine = 0;
-    if (pa + (uint32_t)i < pb) mine = gj_tail_ld64<COHERENT>(piece64 + pa + i);
+    if ((uint32_t)i < (p0 & 31u)) before += T.piece[(ga << 5) + i];
+    uint32_t in_front = 0; // of this wave's tile inside the workgroup
+    if (wave > 0 && have) in_front += T.piece[p0];
+    if (wave > 1 && have) in_front += T.piece[p0 + 1];
+    if (wave > 2 && have) in_front += T.piece[p0 + 2];
+    uint32_t nb = 0, ff = 0;
+    if ((uint32_t)lane < nseg) {
+        nb = T.seg_bytes[s0 + lane];
+        ff = T.seg_ff[s0 + lane];
+    }
+    uint32_t pre[GJ_GATHER_PRELOAD];
+#pragma unroll
+    for (int m = 0; m < GJ_GATHER_PRELOAD; m++) {
+        const uint32_t d = (uint32_t)m * 64u + (uint32_t)lane;
+        pre[m] = d < src_dw ? src[d] : 0u;
+    }
     uint32_t done_bytes, all_bytes;
     gj_wg256_incl_scan(before, s_tmp, &done_bytes);
     gj_wg256_incl_scan(all, s_tmp, &all_bytes);
-    const uint64_t total = (uint64_t)T.main_hdr + gj_tail_hdr_end(T, gj_tail_scan_of(T, P - 1)) + all_bytes + 2u;
+    const uint64_t total = (uint64_t)T.main_hdr + gj_pick4(T.hdr_end, gj_tail_scan_of(T, P - 1)) + all_bytes + 2u;
     const bool overflow = total > T.capacity;
-    for (uint32_t p0 = pa; p0 < pb; p0 += 256) {
-        const uint32_t p = p0 + (uint32_t)i;
-        const bool have = p < pb;
-        uint64_t st = 0;
-        if (have) st = p0 == pa ? mine : gj_tail_ld64<COHERENT>(piece64 + p);
-        const uint32_t size = (uint32_t)st & 0x0FFFFFFFu, scan = gj_tail_scan_of(T, p);
-        uint32_t batch_bytes, C;
-        const uint32_t incl = gj_wg256_incl_scan(size, s_tmp, &batch_bytes);
-        const uint32_t F = T.main_hdr + gj_tail_hdr_end(T, scan) + done_bytes + incl - size;
-        const uint32_t nch = (size + 15u) >> 4; // 16-byte pieces of the tile stream (aligned in d_temp)
-        const uint32_t cincl = gj_wg256_incl_scan(nch, s_tmp, &C);
-        tF[i] = F;
-        tsrc[i] = (uint32_t)(st >> 32);
-        tsize[i] = size;
-        tcs[i] = cincl - nch; // (= C for the lanes behind the share's last tile)
-        if (have && !overflow) {
-            if (p == T.scan_first[0] || p == T.scan_first[1] || p == T.scan_first[2] || p == T.scan_first[3]) { // first tile of a scan:
-                // its header (APP13 placeholders + SOS) sits right in front
-                const uint32_t h1 = gj_tail_hdr_end(T, scan), h0 = scan == 0 ? 0u : gj_tail_hdr_end(T, scan - 1);
-                for (uint32_t b = 0; b < h1 - h0; b++) T.jpeg[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
-            }
-            if (p == P - 1) {
-                T.jpeg[F + size] = 0xFF;
-                T.jpeg[F + size + 1] = 0xD9;
-            }
+    if (p0 + 4 >= P && i == 0) { // (the workgroup of the last tile stream)
+        T.d_result[0] = (uint32_t)total;
+        T.d_result[1] = overflow ? 1u : 0u;
+        if (T.h_result) { // the host's (pinned, device-visible) copy: no copy launch behind the kernel
+            T.h_result[0] = (uint32_t)total;
+            T.h_result[1] = overflow ? 1u : 0u;
         }
-        if (have && p == P - 1) {
-            T.d_result[0] = (uint32_t)total;
-            T.d_result[1] = overflow ? 1u : 0u;
-            if (T.h_result) { // the host's (pinned, device-visible) copy: no copy launch behind the kernel
-                T.h_result[0] = (uint32_t)total;
-                T.h_result[1] = overflow ? 1u : 0u;
-            }
+    }
+    if (!have || overflow) return;
+    const uint32_t F = T.main_hdr + gj_pick4(T.hdr_end, scan) + done_bytes + in_front; // the tile stream's first byte in the file
+    uint8_t* const out = T.jpeg;
+    if (t == 0) { // first tile of a scan: its header (APP13 placeholders + SOS) sits right in front
+        const uint32_t h1 = gj_pick4(T.hdr_end, scan), h0 = scan == 0 ? 0u : gj_pick4(T.hdr_end, scan - 1);
+        for (uint32_t b = lane; b < h1 - h0; b += 64) out[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
+    }
+    // ---- lane sl keeps segment sl: its dwords, its first dword in the tile stream, its first byte in the file
+    const uint32_t last = scan_segs - seg0 - 1u; // (local index of the scan's last segment: no restart marker behind it)
+    const uint32_t ndw = (nb + 3u) >> 2, olen = nb + ff + ((uint32_t)lane < nseg && (uint32_t)lane != last ? 2u : 0u);
+    const uint32_t dwi = gj_wave_incl_scan(ndw), dwb = dwi - ndw;
+    const uint32_t oi = gj_wave_incl_scan(olen), ob = F + oi - olen;
+    const uint32_t total_dw = (uint32_t)__builtin_amdgcn_readlane((int)dwi, 63);
+    const uint32_t end = F + (uint32_t)__builtin_amdgcn_readlane((int)oi, 63);
+    if (p == P - 1 && lane == 0) { // EOI
+        out[end] = 0xFF;
+        out[end + 1] = 0xD9;
+    }
+    uint32_t ffrun = 0; // 0xFF bytes of the dwords of earlier rounds
+    for (uint32_t m = 0; m * 64u < total_dw; m++) {
+        const uint32_t d = m * 64u + (uint32_t)lane;
+        uint32_t v = 0;
+        if (m < GJ_GATHER_PRELOAD) {
+#pragma unroll
+            for (int q = 0; q < GJ_GATHER_PRELOAD; q++)
+                if (m == (uint32_t)q) v = pre[q];
+        } else if (d < total_dw) {
+            v = src[d];
         }
-        __syncthreads();
-        if (!overflow) {
-            const uint64_t* const src64 = reinterpret_cast<const uint64_t*>(T.temp);
-            for (uint32_t q0 = 0; q0 < C; q0 += 2048) { // (eight 16-byte pieces in flight per lane and round)
-                // the tile of every 32nd piece of the round: one search per lane here, a short walk per piece below
-                if (i <= 64) {
-                    const uint32_t q = q0 + 32u * (uint32_t)i;
-                    uint32_t lo = 0;
+        // the segment of dword d: the segments that start in front of this round, and a mask of the starts inside it
+        const uint32_t first_in_round = (uint32_t)__builtin_popcountll(__ballot((uint32_t)lane < nseg && dwb < m * 64u));
+        if (lane == 0) s_mask[wave] = 0;
+        gj_wave_sync();
+        if ((uint32_t)lane < nseg && dwb >= m * 64u && dwb < m * 64u + 64u) atomicOr(&s_mask[wave], 1ull << (dwb & 63u));
+        gj_wave_sync();
+        const unsigned long long starts = s_mask[wave];
+        const uint32_t seg = first_in_round + (uint32_t)__builtin_popcountll(starts & ((2ull << lane) - 1ull)) - 1u;
+        const bool live = d < total_dw;
+        const int sidx = (int)((live ? seg : 0u) << 2);
+        const uint32_t s_nb = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)nb), s_dwb = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)dwb);
+        const uint32_t s_ob = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)ob), s_ndw = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)ndw);
+        const uint32_t k = d - s_dwb; // dword inside its segment
+        const int vb = live ? (int)min(4u, s_nb - 4u * k) : 0;
+        const uint32_t ffm = live ? ((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u : 0u; // (the bytes behind a segment's end are zero)
+        const uint32_t ffc = (uint32_t)__builtin_popcount(ffm);
+        const uint32_t fi = gj_wave_incl_scan(ffc) + ffrun; // 0xFF bytes up to and including this dword
+        if (live && k == 0) s_ffstart[wave][seg] = fi - ffc; // ... in front of the segment
+        gj_wave_sync();
+        if (live) {
+            uint32_t q = s_ob + 4u * k + (fi - ffc - s_ffstart[wave][seg]);
+            if (ffc == 0 && vb == 4) {
+                *reinterpret_cast<gj_u32_unaligned*>(out + q) = v;
+                q += 4;
+            } else {
 #pragma unroll
-                    for (uint32_t step = 128; step; step >>= 1)
-                        if (tcs[lo + step] <= q) lo += step;
-                    tcoarse[i] = lo;
-                }
-                __syncthreads();
-                uint64_t lo64[8], hi64[8];
-                uint32_t dst[8], nbytes[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t q = q0 + (uint32_t)u * 256u + (uint32_t)i;
-                    dst[u] = nbytes[u] = 0;
-                    lo64[u] = hi64[u] = 0;
-                    if (q < C) {
-                        uint32_t lo = tcoarse[(q - q0) >> 5];
-                        while (lo < 255u && tcs[lo + 1] <= q) lo++;
-                        const uint32_t k = q - tcs[lo];
-                        dst[u] = tF[lo] + 16u * k;
-                        nbytes[u] = min(16u, tsize[lo] - 16u * k);
-                        const uint64_t* s8 = src64 + ((uint64_t)tsrc[lo] + k) * 2u;
-                        lo64[u] = gj_tail_ld64<COHERENT>(s8);
-                        hi64[u] = gj_tail_ld64<COHERENT>(s8 + 1);
+                for (int b = 0; b < 4; b++)
+                    if (b < vb) {
+                        const uint32_t byte = (v >> (8 * b)) & 0xFFu;
+                        out[q++] = (uint8_t)byte;
+                        if (byte == 0xFFu) out[q++] = 0;
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    uint8_t* const d = T.jpeg + dst[u];
-                    if (nbytes[u] == 16u) {
-                        gj_u4 v;
-                        v.x = (uint32_t)lo64[u]; v.y = (uint32_t)(lo64[u] >> 32); v.z = (uint32_t)hi64[u]; v.w = (uint32_t)(hi64[u] >> 32);
-                        *reinterpret_cast<gj_u4_unaligned*>(d) = v;
-                    } else if (nbytes[u]) { // the last 1 .. 15 bytes of a tile stream: 8 + 4 + 2 + 1
-                        uint64_t cur = lo64[u];
-                        uint32_t off = 0;
-                        if (nbytes[u] & 8u) { *reinterpret_cast<gj_u64_unaligned*>(d) = cur; cur = hi64[u]; off = 8; }
-                        if (nbytes[u] & 4u) { *reinterpret_cast<gj_u32_unaligned*>(d + off) = (uint32_t)cur; cur >>= 32; off += 4; }
-                        if (nbytes[u] & 2u) { *reinterpret_cast<gj_u16_unaligned*>(d + off) = (uint16_t)cur; cur >>= 16; off += 2; }
-                        if (nbytes[u] & 1u) d[off] = (uint8_t)cur;
-                    }
-                }
-                __syncthreads(); // (tcoarse is rewritten by the next round)
+            }
+            if (k == s_ndw - 1 && seg != last) { // RSTn (src/gpujpeg_huffman_gpu_encoder.cu:497-502)
+                out[q] = 0xFF;
+                out[q + 1] = (uint8_t)(0xD0 + ((seg0 + seg) & 7u));
             }
         }
-        done_bytes += batch_bytes;
-        __syncthreads();
+        ffrun = (uint32_t)__builtin_amdgcn_readlane((int)fi, 63);
+        gj_wave_sync(); // (s_mask, s_ffstart are rewritten by the next round)
     }
-}
-
-// the counters and group totals of the NEXT call (read by the next launch only): all 256 threads of one workgroup
-__device__ __forceinline__ void gj_tail_reset_next(const GjTail& T, const int i)
-{
-    if (i == 0) T.ctr_other[GJ_TAIL_STARTED] = 0;
-    if (i == 1) T.ctr_other[GJ_TAIL_DONE] = 0;
-    if (i == 2) T.ctr_other[GJ_TAIL_SHARE] = 0;
-    if (i == 3) T.ctr_other[GJ_TAIL_TICKET] = 0;
-    for (uint32_t g = i; g < T.ngroups; g += 256) T.group_other[g] = 0;
-}
-
-// the end of a one-launch encoder kernel: s_mem as for gj_gather_share
-__device__ __forceinline__ void gj_encode_tail(const GjTail& T, uint32_t* s_mem, const int i)
-{
-    const uint32_t ntiles = gridDim.x, K = T.shares;
-    if (K == 0) return; // (the gathering is a launch of its own: k_gather)
-    uint32_t* const s_tmp = s_mem;
-    // (asked for before the wait below, which hides the trip: has every workgroup of the launch started?)
-    uint32_t started = 0;
-    if (i == 0) started = __hip_atomic_load(&T.ctr[GJ_TAIL_STARTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gj_wait_stores(); // this wave's part of the tile streams (and the tile's list entries) is out: device-scope stores, no fence
-    __syncthreads();
-    if (i == 0) {
-        const uint32_t d = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t share = 0xFFFFFFFFu; // not gathering
-        if (d + 1 == ntiles) {
-            share = K - 1; // the last one to finish gathers whatever happens; its share is reserved (no trip to the counter on the critical path)
-        } else if (d + K >= ntiles && started == ntiles) {
-            share = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_SHARE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a trip the wait below hides)
-            if (share >= K - 1) share = 0xFFFFFFFFu;
-        }
-        s_tmp[5] = share;
-        s_tmp[6] = d + 1 == ntiles;
-    }
-    __syncthreads();
-    uint32_t share = s_tmp[5];
-    if (share == 0xFFFFFFFFu) return;
-    GJ_TRACE_E(14);
-    if (s_tmp[6]) gj_tail_reset_next(T, i);
-    else if (i == 0)
-        while (__hip_atomic_load(&T.ctr[GJ_TAIL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ntiles) __builtin_amdgcn_s_sleep(8);
-    __syncthreads();
-    while (share < K) {
-        gj_gather_share<true>(T, s_mem, i, share);
-        // more shares than gathering workgroups? (the counter hands out 0 .. K - 2)
-        if (i == 0) {
-            const uint32_t t = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_SHARE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_tmp[5] = t < K - 1 ? t : K;
-        }
-        __syncthreads();
-        share = s_tmp[5];
-        __syncthreads();
-    }
-    GJ_TRACE_E(15);
-}
-
-// the gathering as a launch of its own (GJ_ENC_TAIL < 0: A/B against the tail inside the encoder kernel): one workgroup per share
-__global__ __launch_bounds__(256) void k_gather(const GjTail T)
-{
-    __shared__ uint32_t s_mem[1120];
-    if (blockIdx.x == 0) gj_tail_reset_next(T, threadIdx.x);
-    gj_gather_share<false>(T, s_mem, threadIdx.x, blockIdx.x);
 }
 
 // the workgroup's Huffman tables in the layout of GjCoderLds::lut, from the host's (code << 8 | size) tables [type * 2 + is_ac][symbol]
@@ -1409,11 +1227,8 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
             gj_color_444<CS_FROM, CS_TO>(g, bx, by, active, px, pk);
         }
         uint32_t ticket = 0;
-        if (first) {
-            __syncthreads(); // tables are in LDS
-            // "started", for the tail. Behind the pixel loads: memory operations complete in order, and this one queues up with everybody else's
-            if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (first) __syncthreads(); // tables are in LDS
+        // (behind the pixel loads: memory operations complete in order, and this one queues up with everybody else's)
         if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (used two components later)
         GJ_TRACE_T(tile, 1); // pixels loaded and converted
 #pragma unroll
@@ -1448,15 +1263,13 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
             const bool active = t < tile_blocks && tile * (unsigned)tile_blocks + (unsigned)t < nb;
             const uint64_t first_block = kc.data_offset / 64 + (uint64_t)seg0 * B; // coding-order index of the tile's first block of this component
             const uint32_t size = gj_code_tile(L, t, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
-                                               temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
-                                               (uint32_t)(kc.first_segment + seg0), tile, 2 + 4 * c);
+                                               temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), tile, 2 + 4 * c);
             // file order: the luminance scan's tiles, then the two chrominance scans'
-            if (threadIdx.x == 0) gj_piece_put(T, (uint32_t)c * ntiles + tile, size | ((uint32_t)c << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+            if (threadIdx.x == 0) gj_piece_put(T, (uint32_t)c * ntiles + tile, size);
         }
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next); // (stable until the next tile's third component)
         if (tile >= ntiles) break;
     }
-    gj_encode_tail(T, s_coef, i);
 }
 
 // ================================================================================================
@@ -1555,7 +1368,6 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
         }
     }
     __syncthreads(); // tables are in LDS
-    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // "started" (behind the pixel loads, see k_encode_rgb444)
     {
         const int table = p < 2 ? g.comp[0].type : g.comp[1].type;
 #pragma unroll
@@ -1564,10 +1376,9 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
         const uint64_t first_block = (uint64_t)seg0 * B;
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
                                            p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0,
-                                           temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff, (uint32_t)seg0);
-        if (i == 0) gj_piece_put(T, blockIdx.x, size, (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)seg0);
+        if (i == 0) gj_piece_put(T, blockIdx.x, size);
     }
-    gj_encode_tail(T, s_coef, i);
 }
 
 // ================================================================================================
@@ -1753,7 +1564,6 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
         }
     }
     __syncthreads(); // tables are in LDS
-    if (i == 0) (void)__hip_atomic_fetch_add(&T.ctr[GJ_TAIL_STARTED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // "started" (behind the pixel loads, see k_encode_rgb444)
     {
         const int table = kc.type;
 #pragma unroll
@@ -1761,12 +1571,10 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         const uint64_t first_block = s_first_block;
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0,
-                                           temp + first_block * GJ_STAGE_BYTES_PER_BLOCK, seg0, T.seg_sizes != 0, seg_bytes, seg_ff,
-                                           (uint32_t)(scan_first + seg0));
+                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(scan_first + seg0));
         // (workgroups are numbered in file order: the tiles of scan 0, of scan 1, ...)
-        if (i == 0) gj_piece_put(T, blockIdx.x, size | ((uint32_t)scan << 28), (uint32_t)(first_block * (GJ_STAGE_BYTES_PER_BLOCK / 16)));
+        if (i == 0) gj_piece_put(T, blockIdx.x, size);
     }
-    gj_encode_tail(T, s_coef, i);
 }
 
 // ================================================================================================
@@ -1951,37 +1759,39 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
 typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail, uint32_t);
 
-// Who gathers the tile streams (measured, profiles/r4_03_*): a device-scope round trip costs ~2 us on this part and the tail inside the
-// encoder kernel needs four in a row after the last tile (finished-counter, its observation, sizes, data) where a launch of its own
-// reads through its L2 -- k_gather is faster from ~1000 tiles on (8K: 8 against 16 us) and the tail inside wins for frames whose tiles
-// are all resident at once (HD: one launch less, 38 against 42 us). GJ_ENC_TAIL > 0 / < 0 forces one or the other with that many shares.
-#define GJ_TAIL_SHARES 64    // parts of the tile list for the tail inside the kernel
-#define GJ_GATHER_SHARES 512 // ... for k_gather
-// the tail's arguments for a launch that leaves `pieces` tile streams, scan s beginning with stream scan_first[s]
-static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const unsigned (&scan_first)[GJ_MAX_COMP], const bool own_gather)
+// k_gather's arguments (and the encoder kernels': they use the tile list, the group totals and the ticket counter) for a launch that leaves
+// `pieces` tile streams of `spt` segments; scan s begins with stream scan_first[s]
+static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const unsigned (&scan_first)[GJ_MAX_COMP], const unsigned spt)
 {
+    const gj_geom& g = job->g;
     GjTail T;
-    for (int s = 0; s < GJ_MAX_COMP; s++) T.scan_first[s] = scan_first[s];
+    for (int s = 0; s < GJ_MAX_COMP; s++) {
+        T.scan_first[s] = scan_first[s];
+        T.hdr_end[s] = job->scan_hdr_offset[s + 1];
+        const bool own_scan = !g.interleaved && s < g.comp_count; // (one scan per component, or one for all)
+        T.seg_first[s] = own_scan ? (uint32_t)g.comp[s].first_segment : 0u;
+        T.segs[s] = own_scan ? (uint32_t)g.comp[s].segment_count : (uint32_t)g.segment_count;
+        T.block_first[s] = own_scan ? (uint32_t)(g.comp[s].data_offset / 64) : 0u;
+    }
+    T.spt = spt;
+    T.seg_blocks = (uint32_t)g.seg_blocks;
     T.ctr = job->d_tail + (job->tail_set & 1) * GJ_TAIL_CTR_WORDS;
     T.ctr_other = job->d_tail + ((job->tail_set + 1) & 1) * GJ_TAIL_CTR_WORDS;
-    const unsigned ngcap = GJ_TAIL_GROUPS_CAP(job->g.segment_count); // (one tile stream per segment at most)
+    const unsigned ngcap = GJ_TAIL_GROUPS_CAP(g.segment_count); // (one tile stream per segment at most)
     T.group = job->d_tail + GJ_TAIL_HEAD_WORDS + (job->tail_set & 1) * ngcap;
     T.group_other = job->d_tail + GJ_TAIL_HEAD_WORDS + ((job->tail_set + 1) & 1) * ngcap;
     T.ngroups = (pieces + 31) / 32;
-    T.piece = reinterpret_cast<uint2*>(job->d_tail + GJ_TAIL_HEAD_WORDS + 2 * ngcap);
+    T.piece = job->d_tail + GJ_TAIL_HEAD_WORDS + 2 * ngcap;
+    T.npieces = pieces;
     T.temp = job->d_temp;
+    T.seg_bytes = job->d_seg_bytes;
+    T.seg_ff = job->d_seg_ff;
     T.jpeg = job->d_jpeg;
     T.capacity = job->jpeg_capacity;
     T.scan_hdr = job->d_scan_hdr;
-    for (int s = 0; s < GJ_MAX_COMP; s++) T.hdr_end[s] = job->scan_hdr_offset[s + 1];
     T.main_hdr = job->main_hdr_size;
-    T.npieces = pieces;
-    const int ts = job->tune.enc_tail_shares;
-    const unsigned want = ts > 0 ? (unsigned)ts : ts < 0 ? (unsigned)-ts : own_gather ? (unsigned)GJ_GATHER_SHARES : (unsigned)GJ_TAIL_SHARES;
-    T.shares = want < pieces ? want : pieces;
     T.d_result = job->d_result;
     T.h_result = job->h_result;
-    T.seg_sizes = job->segment_info && job->g.restart_interval > 0;
     return T;
 }
 
@@ -1996,13 +1806,6 @@ static int gj_cu_count()
         cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
     return cus[dev];
-}
-
-// what the encoder kernel itself gets: no shares when the gathering is a launch of its own
-static GjTail gj_kernel_tail(GjTail T, const bool own_gather)
-{
-    if (own_gather) T.shares = 0;
-    return T;
 }
 
 // fused kernel for this configuration, or nullptr when the generic path has to be used
@@ -2057,10 +1860,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const unsigned n = (unsigned)g.width * (unsigned)g.height;
         hipLaunchKernelGGL(k_channel_remap, dim3((n + 255) / 256), dim3(256), 0, st, g, const_cast<uint8_t*>(job->d_raw), job->channel_remap & 0xFFFFu);
     }
-    bool one_launch = true; // k_encode_*: the stream is complete when the kernel ends
-    GjTail tail_for_gather;   // (GJ_ENC_TAIL < 0: what k_gather gets; the encoder kernel is told not to gather)
-    tail_for_gather.shares = 0;
-    bool own_gather = job->tune.enc_tail_shares < 0;
+    bool tiles = true; // k_encode_*: tile streams for k_gather
+    GjTail T;
+    T.npieces = 0;
     gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
     if (whole && job->tune.enc_by_blocks > 0 && gj_blocks_kernel_mode(g) == 0) whole = nullptr; // (k_encode_blocks below)
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
@@ -2075,11 +1877,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
-        // (not persistent: a finished-counter trip per tile, which 17 000 tiles of a 16K frame queue up for -- k_gather unless they are few)
-        if (job->tune.enc_tail_shares == 0) own_gather = wgs > 4u * (unsigned)gj_cu_count();
-        tail_for_gather = gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u}, own_gather);
+        T = gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u}, (unsigned)spt);
         hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, T);
     } else if (!whole && job->use_fused && !job->keep_coefs && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT &&
                gj_blocks_kernel_mode(g) >= 0) {
         // every other layout with short restart segments: one lane per block in coding order (k_encode_blocks)
@@ -2093,10 +1893,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                 scan_first[c] = wgs;
                 wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
             }
-        if (job->tune.enc_tail_shares == 0) own_gather = wgs > 4u * (unsigned)gj_cu_count();
-        tail_for_gather = gj_make_tail(job, wgs, scan_first, own_gather);
+        T = gj_make_tail(job, wgs, scan_first, (unsigned)spt);
         hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
-                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather));
+                           job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, T);
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
@@ -2104,12 +1903,11 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         // persistent: as many workgroups as the device holds at once (four per CU), each codes tile after tile
         const unsigned resident = job->tune.enc_resident > 0 ? (unsigned)job->tune.enc_resident : 4u * (unsigned)gj_cu_count();
-        if (job->tune.enc_tail_shares == 0) own_gather = wgs > resident;
-        tail_for_gather = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, own_gather);
+        T = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, (unsigned)spt);
         hipLaunchKernelGGL(whole, dim3(wgs < resident ? wgs : resident), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, gj_kernel_tail(tail_for_gather, own_gather), wgs);
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, T, wgs);
     } else {
-    one_launch = false;
+    tiles = false;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);
@@ -2139,15 +1937,15 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                        job->d_seg_ff);
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
-    if (one_launch && own_gather) // (A/B: the tile streams gathered by a launch of their own)
-        hipLaunchKernelGGL(k_gather, dim3(tail_for_gather.shares), dim3(256), 0, st, tail_for_gather);
+    if (tiles) // the tile streams -> the file: one wave each
+        hipLaunchKernelGGL(k_gather, dim3((T.npieces + 3) / 4), dim3(256), 0, st, T);
     const bool seg_info = job->segment_info && g.restart_interval > 0;
-    // (the one-launch encoders need the segment offsets only for the APP13 index)
+    // (behind k_gather the segment offsets are needed for the APP13 index only)
     const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;
-    if (!one_launch || seg_info)
+    if (!tiles || seg_info)
         hipLaunchKernelGGL(k_scan_segments, dim3(scan_wgs), dim3(1024), 0, st, *job, (unsigned long long*)job->d_scan_partial, job->epoch);
     if (ev) (void)hipEventRecord((hipEvent_t)ev[4], st);
-    if (!one_launch)
+    if (!tiles)
         hipLaunchKernelGGL(k_assemble, dim3(((unsigned)g.segment_count + 4 * GJ_ASM_SEGS - 1) / (4 * GJ_ASM_SEGS)), dim3(256), 0, st, *job);
     if (seg_info)
         hipLaunchKernelGGL(k_segment_info, dim3(((unsigned)g.segment_count + 255) / 256), dim3(256), 0, st, *job);

@@ -162,8 +162,8 @@ static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_par
     /* planes are needed by the generic path only; zero filled once, padding is never written (common.c:941-944) */
     if (gj_ensure_device_buffer((void**)&c->d_planes, &c->d_planes_cap, g->data_size) != 0) return -1;
     if (gj_hip_memset(c->d_planes, 0, g->data_size, c->stream) != 0) return -1;
-    if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_STAGE_BYTES_PER_BLOCK + 256) != 0) return -1;
-    /* the tail's counters are zero between calls (the kernel leaves them so); cleared here in case a failed launch did not */
+    if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_TEMP_BYTES_PER_BLOCK + 256) != 0) return -1;
+    /* k_gather's counters and group totals are zero between calls (the kernel leaves them so); cleared here in case a failed launch did not */
     if (gj_ensure_device_buffer((void**)&e->d_tail, &e->d_tail_cap, (size_t)GJ_TAIL_WORDS(g->segment_count) * sizeof(uint32_t)) != 0) return -1;
     if (gj_hip_memset(e->d_tail, 0, (GJ_TAIL_HEAD_WORDS + 2 * (size_t)GJ_TAIL_GROUPS_CAP(g->segment_count)) * sizeof(uint32_t), c->stream) != 0) return -1;
     e->tail_set = 0;
@@ -377,7 +377,7 @@ size_t gpujpeg_encoder_max_memory(struct gpujpeg_parameters* param, struct gpujp
     if (p.restart_interval == RESTART_AUTO) p.restart_interval = gpujpeg_encoder_suggest_restart_interval(&t, gj_make_sampling_factor(p.comp_count, p.sampling_factor), p.interleaved, -1);
     gj_geom g;
     if (gj_geom_init(&g, &p, &t, true) != 0) return 0;
-    size_t total = g.data_size * 3 + (size_t)g.block_count * GJ_STAGE_BYTES_PER_BLOCK + (size_t)g.segment_count * 20 +
+    size_t total = g.data_size * 3 + (size_t)g.block_count * GJ_TEMP_BYTES_PER_BLOCK + (size_t)g.segment_count * 20 +
                    1000 + (size_t)t.width * t.height * p.comp_count * 2;
     if (type == GPUJPEG_ENCODER_INPUT_IMAGE) total += g.raw_size;
     return total;

@@ -377,17 +377,13 @@ TAIL_CASES = [
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("resident", [0, 1, 5], ids=lambda r: f"resident{r}")
-@pytest.mark.parametrize("shares", [0, 1, 3, 100000, -5], ids=lambda s: f"shares{s}")
 @pytest.mark.parametrize("tc", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
-def test_one_launch_encoder_tail(O, G, gpu_lib, tc, shares, resident, monkeypatch):
-    """The one-launch encoders (k_encode_*): every workgroup leaves its tile's finished stream (stuffed, RSTn in place) in d_temp, the
-    last workgroups gather them into the file (scan headers, EOI, size). Replaces src/gpujpeg_huffman_gpu_encoder.cu:417-613 and the
-    host stitching of src/gpujpeg_encoder.c:567-629; the bytes must be the oracle's whatever the number of shares the tail cuts the
-    tile list into (GJ_ENC_TAIL: 1 = one workgroup gathers everything, more shares than tiles = one tile stream per share, negative = the
-    same gathering as a launch of its own, k_gather), with
-    and without the APP13 index, twice in a row on the same coder (the tail's counters alternate between two sets). GJ_ENC_RESIDENT
-    limits the workgroups of the persistent kernel (k_encode_rgb444): 1 = one workgroup codes every tile, 5 = tiles handed out by the
-    counter to five of them."""
+def test_encoder_tiles_and_gather(O, G, gpu_lib, tc, resident, monkeypatch):
+    """k_encode_* leave the unstuffed stream of every tile and its size in the file; k_gather (one wave per tile stream) places, stuffs
+    and marks them: the file's bytes must be the oracle's (replaces src/gpujpeg_huffman_gpu_encoder.cu:417-613 and the host stitching of
+    src/gpujpeg_encoder.c:567-629), with and without the APP13 index, three times in a row on the same coder (the counters and group
+    totals alternate between two sets that k_gather clears). GJ_ENC_RESIDENT limits the workgroups of the persistent kernel
+    (k_encode_rgb444): 1 = one workgroup codes every tile, 5 = tiles handed out by the counter to five of them."""
     name, w, h, pf, cs, q, restart, il, sub, noisy = tc
     if resident:
         if pf != 1 or il or sub is not None:
@@ -395,10 +391,6 @@ def test_one_launch_encoder_tail(O, G, gpu_lib, tc, shares, resident, monkeypatc
         monkeypatch.setenv("GJ_ENC_RESIDENT", str(resident))
     else:
         monkeypatch.delenv("GJ_ENC_RESIDENT", raising=False)
-    if shares:
-        monkeypatch.setenv("GJ_ENC_TAIL", str(shares))
-    else:
-        monkeypatch.delenv("GJ_ENC_TAIL", raising=False)
     case = (name, w, h, pf, cs, q, restart, il, sub, 3)
     comps = {0: 1, 1: 3}.get(pf)
     raw = natural_image(w, h, comps, seed=w) if comps and not noisy else O.noise(O.raw_size(w, h, pf), seed=w * 7 + h)
@@ -407,7 +399,7 @@ def test_one_launch_encoder_tail(O, G, gpu_lib, tc, shares, resident, monkeypatc
         want = O.encode(oracle_image(O, case, segment_info=seg_info), raw)
         p, pi = api_params(gpu_lib, G, case, segment_info=seg_info)
         got = enc.encode(p, pi, raw)
-        assert got.size == want.size and np.array_equal(got, want), (name, shares, seg_info, got.size, want.size)
+        assert got.size == want.size and np.array_equal(got, want), (name, resident, seg_info, got.size, want.size)
     enc.close()
 
 

@@ -963,9 +963,9 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
 // 32 tiles (one atomic, nobody waits for it). Here ONE WAVE takes one tile stream, ~6000 waves at once for an 8K frame, and everything
 // it needs is asked for in one trip: the group totals and the sizes of its group's tiles in front of it (its place in the file), its
 // segments' counts, and the first 2 KB of its stream (where those are follows from the launch's geometry, not from loaded values).
-// Then the stream is stuffed in flight: a lane takes a dword, finds its segment (a bit mask of the segment starts in the 64 dwords
-// of the round + popcount), counts its 0xFF bytes; a wave prefix sum places it; a dword without 0xFF leaves as one unaligned 4-byte
-// store, restart markers follow the last dword of a segment. Round 3 needed a launch for the offsets (5 us), a wave per four
+// Then the stream is stuffed in flight: a lane takes a dword, finds its segment (the segment starts are marked in LDS: a wave prefix
+// sum of the marks), counts its 0xFF bytes; a second prefix sum places it; a dword without 0xFF leaves as one unaligned 4-byte store,
+// restart markers follow the last dword of a segment. Round 3 needed a launch for the offsets (5 us), a wave per four
 // segments with two dependent trips and byte stores (16 us), and 19 MB of traffic for the same.
 // ================================================================================================
 typedef uint32_t __attribute__((aligned(1))) gj_u32_unaligned;
@@ -1012,11 +1012,11 @@ __device__ __forceinline__ void gj_piece_put(const GjTail& T, const uint32_t p, 
 }
 
 #define GJ_GATHER_PRELOAD 8 // rounds of 64 dwords whose loads are issued before anything is known about the tile stream
+#define GJ_GATHER_MARK_DW 2048 // dwords of a tile stream whose segment starts are marked in LDS at a time
 __global__ __launch_bounds__(256) void k_gather(const GjTail T)
 {
     __shared__ uint32_t s_tmp[4];
-    __shared__ unsigned long long s_mask[4];
-    __shared__ uint32_t s_ffstart[4][GJ_ENC_MAX_SPT];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mark[4][GJ_GATHER_MARK_DW];
     const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
     const uint32_t P = T.npieces, NG = T.ngroups;
     const uint32_t p0 = blockIdx.x * 4u, p = p0 + (uint32_t)wave;
@@ -1086,68 +1086,74 @@ __global__ __launch_bounds__(256) void k_gather(const GjTail T)
         const uint32_t h1 = gj_pick4(T.hdr_end, scan), h0 = scan == 0 ? 0u : gj_pick4(T.hdr_end, scan - 1);
         for (uint32_t b = lane; b < h1 - h0; b += 64) out[F - (h1 - h0) + b] = T.scan_hdr[h0 + b];
     }
-    // ---- lane sl keeps segment sl: its dwords, its first dword in the tile stream, its first byte in the file
+    // ---- lane sl keeps segment sl: its dwords, its first dword in the tile stream, its first byte in the file, the 0xFF bytes in front
+    // of it. Everything a dword needs to know about its segment is two words: where its bytes go if none of the tile's dwords held a
+    // 0xFF (minus 4 x its index), and the segment's last dword with the bytes that count in it.
     const uint32_t last = scan_segs - seg0 - 1u; // (local index of the scan's last segment: no restart marker behind it)
     const uint32_t ndw = (nb + 3u) >> 2, olen = nb + ff + ((uint32_t)lane < nseg && (uint32_t)lane != last ? 2u : 0u);
     const uint32_t dwi = gj_wave_incl_scan(ndw), dwb = dwi - ndw;
     const uint32_t oi = gj_wave_incl_scan(olen), ob = F + oi - olen;
+    const uint32_t ffi = gj_wave_incl_scan(ff);
     const uint32_t total_dw = (uint32_t)__builtin_amdgcn_readlane((int)dwi, 63);
     const uint32_t end = F + (uint32_t)__builtin_amdgcn_readlane((int)oi, 63);
     if (p == P - 1 && lane == 0) { // EOI
         out[end] = 0xFF;
         out[end + 1] = 0xD9;
     }
-    uint32_t ffrun = 0; // 0xFF bytes of the dwords of earlier rounds
-    for (uint32_t m = 0; m * 64u < total_dw; m++) {
-        const uint32_t d = m * 64u + (uint32_t)lane;
-        uint32_t v = 0;
-        if (m < GJ_GATHER_PRELOAD) {
+    const uint32_t seg_a = ob - 4u * dwb - (ffi - ff);                               // byte q of dword d: seg_a + 4 d + 0xFF bytes in front of d
+    const uint32_t seg_e = (dwi - 1u) | ((nb - 4u * (ndw - 1u)) << 28);              // last dword | its bytes (1 .. 4) << 28
+    // which dwords begin a segment: a byte per dword in LDS (tile streams of more dwords take several passes)
+    uint8_t* const mark = s_mark[wave];
+    uint32_t ffrun = 0, segs_before = 0; // 0xFF bytes / segment starts of the dwords of earlier rounds
+    for (uint32_t c0 = 0; c0 < total_dw; c0 += GJ_GATHER_MARK_DW) {
+        const uint32_t c1 = min(total_dw, c0 + (uint32_t)GJ_GATHER_MARK_DW);
+        gj_wave_sync();
 #pragma unroll
-            for (int q = 0; q < GJ_GATHER_PRELOAD; q++)
-                if (m == (uint32_t)q) v = pre[q];
-        } else if (d < total_dw) {
-            v = src[d];
-        }
-        // the segment of dword d: the segments that start in front of this round, and a mask of the starts inside it
-        const uint32_t first_in_round = (uint32_t)__builtin_popcountll(__ballot((uint32_t)lane < nseg && dwb < m * 64u));
-        if (lane == 0) s_mask[wave] = 0;
+        for (int z = 0; z < GJ_GATHER_MARK_DW / 256; z++) reinterpret_cast<uint32_t*>(mark)[z * 64 + lane] = 0;
         gj_wave_sync();
-        if ((uint32_t)lane < nseg && dwb >= m * 64u && dwb < m * 64u + 64u) atomicOr(&s_mask[wave], 1ull << (dwb & 63u));
+        if ((uint32_t)lane < nseg && dwb >= c0 && dwb < c1) mark[dwb - c0] = 1;
         gj_wave_sync();
-        const unsigned long long starts = s_mask[wave];
-        const uint32_t seg = first_in_round + (uint32_t)__builtin_popcountll(starts & ((2ull << lane) - 1ull)) - 1u;
-        const bool live = d < total_dw;
-        const int sidx = (int)((live ? seg : 0u) << 2);
-        const uint32_t s_nb = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)nb), s_dwb = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)dwb);
-        const uint32_t s_ob = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)ob), s_ndw = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)ndw);
-        const uint32_t k = d - s_dwb; // dword inside its segment
-        const int vb = live ? (int)min(4u, s_nb - 4u * k) : 0;
-        const uint32_t ffm = live ? ((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u : 0u; // (the bytes behind a segment's end are zero)
-        const uint32_t ffc = (uint32_t)__builtin_popcount(ffm);
-        const uint32_t fi = gj_wave_incl_scan(ffc) + ffrun; // 0xFF bytes up to and including this dword
-        if (live && k == 0) s_ffstart[wave][seg] = fi - ffc; // ... in front of the segment
-        gj_wave_sync();
-        if (live) {
-            uint32_t q = s_ob + 4u * k + (fi - ffc - s_ffstart[wave][seg]);
-            if (ffc == 0 && vb == 4) {
-                *reinterpret_cast<gj_u32_unaligned*>(out + q) = v;
-                q += 4;
-            } else {
+        for (uint32_t m = c0 >> 6; m * 64u < c1; m++) {
+            const uint32_t d = m * 64u + (uint32_t)lane;
+            const bool live = d < total_dw;
+            uint32_t v = 0;
+            if (m < GJ_GATHER_PRELOAD) {
 #pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (b < vb) {
-                        const uint32_t byte = (v >> (8 * b)) & 0xFFu;
-                        out[q++] = (uint8_t)byte;
-                        if (byte == 0xFFu) out[q++] = 0;
-                    }
+                for (int q = 0; q < GJ_GATHER_PRELOAD; q++)
+                    if (m == (uint32_t)q) v = pre[q];
+            } else if (live) {
+                v = src[d];
             }
-            if (k == s_ndw - 1 && seg != last) { // RSTn (src/gpujpeg_huffman_gpu_encoder.cu:497-502)
-                out[q] = 0xFF;
-                out[q + 1] = (uint8_t)(0xD0 + ((seg0 + seg) & 7u));
+            const uint32_t seg = gj_wave_incl_scan(live ? mark[d - c0] : 0u) + segs_before - 1u; // the segment of dword d
+            const int sidx = (int)((live ? seg : 0u) << 2);
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)seg_a), e = (uint32_t)__builtin_amdgcn_ds_bpermute(sidx, (int)seg_e);
+            const bool ends = live && d == (e & 0x0FFFFFFFu);
+            const int vb = live ? (ends ? (int)(e >> 28) : 4) : 0;
+            const uint32_t ffm = live ? ((v & 0x7F7F7F7Fu) + 0x01010101u) & v & 0x80808080u : 0u; // (the bytes behind a segment's end are zero)
+            const uint32_t ffc = (uint32_t)__builtin_popcount(ffm);
+            const uint32_t fi = gj_wave_incl_scan(ffc) + ffrun; // 0xFF bytes up to and including this dword
+            if (live) {
+                uint32_t q = a + 4u * d + (fi - ffc);
+                if (ffc == 0 && vb == 4) {
+                    *reinterpret_cast<gj_u32_unaligned*>(out + q) = v;
+                    q += 4;
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (b < vb) {
+                            const uint32_t byte = (v >> (8 * b)) & 0xFFu;
+                            out[q++] = (uint8_t)byte;
+                            if (byte == 0xFFu) out[q++] = 0;
+                        }
+                }
+                if (ends && seg != last) { // RSTn (src/gpujpeg_huffman_gpu_encoder.cu:497-502)
+                    out[q] = 0xFF;
+                    out[q + 1] = (uint8_t)(0xD0 + ((seg0 + seg) & 7u));
+                }
             }
+            ffrun = (uint32_t)__builtin_amdgcn_readlane((int)fi, 63);
+            segs_before = (uint32_t)__builtin_amdgcn_readlane((int)seg, 63) + 1u;
         }
-        ffrun = (uint32_t)__builtin_amdgcn_readlane((int)fi, 63);
-        gj_wave_sync(); // (s_mask, s_ffstart are rewritten by the next round)
     }
 }
 
@@ -1181,7 +1187,7 @@ template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                          uint32_t* __restrict__ seg_ff, const GjTail T, const uint32_t ntiles)
+                                                          uint32_t* __restrict__ seg_ff, const GjTail T, const uint32_t ntiles, const uint32_t stagger)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
@@ -1192,6 +1198,9 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     __shared__ uint32_t s_next;
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
+    // the workgroups that share a compute unit ask for their first pixels one after the other (they are dispatched 256 at a time, one
+    // per unit): the first ones have theirs while the memory system is still busy with the others', instead of all waiting to the end
+    for (uint32_t n = (blockIdx.x >> 8) * stagger; n; n--) __builtin_amdgcn_s_sleep(32);
     const int i = threadIdx.x;
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
@@ -1757,7 +1766,7 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // Launcher
 // ================================================================================================
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
-typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail, uint32_t);
+typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail, uint32_t, uint32_t);
 
 // k_gather's arguments (and the encoder kernels': they use the tile list, the group totals and the ticket counter) for a launch that leaves
 // `pieces` tile streams of `spt` segments; scan s begins with stream scan_first[s]
@@ -1905,7 +1914,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const unsigned resident = job->tune.enc_resident > 0 ? (unsigned)job->tune.enc_resident : 4u * (unsigned)gj_cu_count();
         T = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, (unsigned)spt);
         hipLaunchKernelGGL(whole, dim3(wgs < resident ? wgs : resident), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, T, wgs);
+                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, T, wgs, (uint32_t)job->tune.enc_stagger);
     } else {
     tiles = false;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU

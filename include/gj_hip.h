@@ -123,6 +123,7 @@ typedef struct gj_tuning {
     int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
     int enc_by_blocks;   /* GJ_ENC_BLOCKS: packed RGB 4:4:4 through k_encode_blocks (a workgroup codes one component of its tile: three times the
                             workgroups, a third of the work each) 1 = always, -1 = never, 0 = small frames only */
+    int enc_stagger;     /* GJ_ENC_STAGGER: the persistent encoder's workgroup n starts (n / 256) x this many 0.85 us late (0 = all at once) */
     int enc_resident;    /* GJ_ENC_RESIDENT: workgroups of the persistent encoder kernel (0 = four per compute unit) */
     int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that
                             does not fit (overflow flag) -- this call uses the kernels without that limit */

@@ -969,8 +969,11 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
 // segments with two dependent trips and byte stores (16 us), and 19 MB of traffic for the same.
 // ================================================================================================
 typedef uint32_t __attribute__((aligned(1))) gj_u32_unaligned;
-#define GJ_TAIL_TICKET 0     // persistent encoders: next tile (behind the first gridDim.x ones)
-#define GJ_TAIL_CTR_WORDS 32 // (a 128-byte line per call parity)
+// persistent encoders: the next tile (behind the first gridDim.x ones) comes from one of 16 counters, each on a 128-byte line of its own
+// -- a device-scope atomic on ONE address takes ~30 ns and they queue: a thousand workgroups asking at the same moment would wait
+// up to 30 us for their number. Counter r hands out the tiles gridDim.x + 16 n + r to the workgroups with index = r (mod 16) (fewer counters for fewer workgroups).
+#define GJ_TAIL_TICKET_SHARDS 16
+#define GJ_TAIL_CTR_WORDS (32 * GJ_TAIL_TICKET_SHARDS)
 struct GjTail {
     uint32_t* ctr;         // this call's counters (GJ_TAIL_*), zero when the encoder kernel starts
     uint32_t* ctr_other;   // the next call's: cleared by k_gather
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_gather(const GjTail T)
     const uint32_t p0 = blockIdx.x * 4u, p = p0 + (uint32_t)wave;
     const bool have = p < P;
     if (blockIdx.x == 0) { // the next call's counters and group totals
-        if (i == 0) T.ctr_other[GJ_TAIL_TICKET] = 0;
+        if (i < GJ_TAIL_TICKET_SHARDS) T.ctr_other[32 * i] = 0;
         for (uint32_t g = i; g < NG; g += 256) T.group_other[g] = 0;
     }
     // ---- this wave's tile stream: where its segments and its bytes are (no loaded value needed)
@@ -1216,6 +1219,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     // index is derived again where it is needed (GJ_KEEP hides the index from the optimiser, which would otherwise keep two dozen
     // such values alive across the transforms -- in scratch memory, whose loads queue up behind the pixel loads).
     uint32_t tile = blockIdx.x;
+    const uint32_t shards = min((uint32_t)GJ_TAIL_TICKET_SHARDS, gridDim.x); // (see GJ_TAIL_TICKET_SHARDS)
     uint32_t px[8][6]; // the raw pixels of the lane's block position
     {
         const unsigned lb = tile * (unsigned)tile_blocks + (unsigned)i;
@@ -1238,7 +1242,8 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
         uint32_t ticket = 0;
         if (first) __syncthreads(); // tables are in LDS
         // (behind the pixel loads: memory operations complete in order, and this one queues up with everybody else's)
-        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&T.ctr[GJ_TAIL_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (used two components later)
+        if (threadIdx.x == 0) // (used two components later)
+            ticket = __hip_atomic_fetch_add(&T.ctr[32u * (blockIdx.x % shards)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         GJ_TRACE_T(tile, 1); // pixels loaded and converted
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -1255,7 +1260,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
             if (c == 2) {
                 // the next tile: its number, and its pixels on their way while this tile's last component is coded (the registers of
                 // the transforms are free now)
-                if (threadIdx.x == 0) s_next = gridDim.x + ticket;
+                if (threadIdx.x == 0) s_next = gridDim.x + ticket * shards + blockIdx.x % shards;
                 __syncthreads();
                 const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
                 int t = threadIdx.x;

@@ -59,7 +59,7 @@ GJ_HIP_API float gj_hip_event_elapsed_ms(gj_event_t start, gj_event_t stop); /* 
 #define GJ_MAX_COMP 4
 #define GJ_MAX_MCU_BLOCKS 16     /* blocks per interleaved MCU we accept (JPEG itself allows 10) */
 #define GJ_TEMP_BYTES_PER_BLOCK 208 /* >= worst case 1658 bits of an 8x8 block before byte stuffing, 16 B multiple */
-#define GJ_TAIL_HEAD_WORDS 64 /* gj_enc_job.d_tail (k_encode_* -> k_gather): the tile counter of the persistent encoder (two sets), then two sets of
+#define GJ_TAIL_HEAD_WORDS 1024 /* gj_enc_job.d_tail (k_encode_* -> k_gather): the tile counters of the persistent encoder (two sets of 16, a 128-byte line each), then two sets of
                                  GJ_TAIL_GROUPS_CAP(segments) group totals, then the tile list (one word per tile stream, at most one stream per segment) */
 #define GJ_TAIL_GROUPS_CAP(segments) (((unsigned)(segments) + 32u) / 32u + 1u)
 #define GJ_TAIL_WORDS(segments) (GJ_TAIL_HEAD_WORDS + 2u * GJ_TAIL_GROUPS_CAP(segments) + ((unsigned)(segments) + 1u))

@@ -1221,21 +1221,21 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     uint32_t tile = blockIdx.x;
     const uint32_t shards = min((uint32_t)GJ_TAIL_TICKET_SHARDS, gridDim.x); // (see GJ_TAIL_TICKET_SHARDS)
     uint32_t px[8][6]; // the raw pixels of the lane's block position
+    uint32_t pos;      // that position: bx | by << 15 | exists << 30 (an integer division to get it: done once per tile)
     {
         const unsigned lb = tile * (unsigned)tile_blocks + (unsigned)i;
         const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
-        gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, i < tile_blocks && lb < nb, px);
+        const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
+        pos = bx | (by << 15) | ((uint32_t)active << 30);
+        gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, active, px);
     }
     for (bool first = true;; first = false) {
         GJ_TRACE_T(tile, 0);
         const int seg0 = (int)tile * spt; // the tile's first segment (inside each component's scan)
         uint32_t pk[3][16];
         {   // ---- pixels -> three byte-packed component blocks
-            int t = threadIdx.x;
-            GJ_KEEP(t);
-            const unsigned lb = tile * (unsigned)tile_blocks + (unsigned)t;
-            const bool active = t < tile_blocks && lb < nb; // (every component has the same geometry)
-            const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
+            const unsigned bx = pos & 0x7FFFu, by = (pos >> 15) & 0x7FFFu;
+            const bool active = (pos >> 30) != 0;
             gj_load_444<GJ_ENC_PREFETCH_ROWS, 8>(g, raw, bx, by, active, px); // (the rows the registers had no room for while the last tile was coded)
             gj_color_444<CS_FROM, CS_TO>(g, bx, by, active, px, pk);
         }
@@ -1267,7 +1267,9 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
                 GJ_KEEP(t);
                 const unsigned lb = next * (unsigned)tile_blocks + (unsigned)t;
                 const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
-                gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, next < ntiles && t < tile_blocks && lb < nb, px);
+                const bool next_active = next < ntiles && t < tile_blocks && lb < nb;
+                pos = bx | (by << 15) | ((uint32_t)next_active << 30);
+                gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, next_active, px);
             }
             int t = threadIdx.x;
             GJ_KEEP(t);

@@ -22,3 +22,18 @@ f = glob.glob("gpurun_out/prof_stats/**/*kernel_stats.csv", recursive=True)
 for r in list(csv.DictReader(open(f[0])))[:6]:
     print(r["Name"][:60], r["Calls"], r["AverageNs"])
 PY
+rm -rf gpurun_out/prof_sq
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/prof_sq -- python bench.py --steps 3 --warmup 1 --min-seconds 0 --workload 8k --streams 1 --lean > gpurun_out/${T}_prof_sq.log 2>&1
+python - <<'PY'
+import csv, glob, collections
+f = glob.glob("gpurun_out/prof_sq/**/*counter_collection.csv", recursive=True)
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for r in csv.DictReader(open(f[0])):
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:40]
+    if not k.startswith("k_"): continue
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Counter_Name"] == "SQ_WAVES": cnt[k] += 1
+for k, v in acc.items():
+    n = max(cnt[k], 1)
+    print(k, "dispatches", n, " ".join(f"{c}={x / n:.4g}" for c, x in sorted(v.items())))
+PY

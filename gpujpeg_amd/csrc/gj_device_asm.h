@@ -54,15 +54,3 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
     return v + d;
 }
 
-// ---- memory that other workgroups of the SAME launch read (the one-launch encoders' tile streams). Each XCD has its own L2, which is
-// not coherent with the others': a plain store stays there until a release fence writes the whole L2 back (buffer_wbl2: ~10 us on this
-// part, and everybody's memory operations queue behind it -- profiles/r4_01_threadfence_version.txt). Stores of DEVICE scope (sc1) are
-// written through instead; their completion (vmcnt) is their visibility, so no fence is needed, only the wait.
-typedef uint32_t gj_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void gj_store16_agent(void* p, gj_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void gj_store1_agent(uint8_t* p, uint32_t v) { asm volatile("global_store_byte %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void gj_store2_agent(uint8_t* p, uint32_t v) { asm volatile("global_store_short %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void gj_store4_agent(uint8_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void gj_store8_agent(uint8_t* p, uint64_t v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
-// every store this wave has issued is complete
-__device__ __forceinline__ void gj_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }

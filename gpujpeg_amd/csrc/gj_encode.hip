@@ -25,10 +25,8 @@
 static __device__ unsigned long long* gj_trace_buf_e;
 extern "C" GJ_HIP_API int gj_hip_trace_set_encoder(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(gj_trace_buf_e), &p, sizeof p) == hipSuccess ? 0 : -1; }
 #define GJ_TRACE_E(slot) do { if (threadIdx.x == 0 && gj_trace_buf_e) gj_trace_buf_e[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define GJ_TRACE_T(tile, slot) do { if (threadIdx.x == 0 && gj_trace_buf_e) gj_trace_buf_e[(size_t)(tile) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GJ_TRACE_E(slot) ((void)0)
-#define GJ_TRACE_T(tile, slot) ((void)0)
 #endif
 
 // ================================================================================================
@@ -807,10 +805,9 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
                                                  const int nblocks, const int table, const int dc_dist, const int seg_count_left,
                                                  uint8_t* __restrict__ region,
                                                  uint32_t* __restrict__ seg_bytes, uint32_t* __restrict__ seg_ff, const uint32_t first_segment,
-                                                 const uint32_t trace_tile = 0, const int trace0 = -1)
+                                                 const int trace0 = -1)
 {
     (void)trace0;
-    (void)trace_tile;
     const int lane = i & 63, wave = i >> 6;
     uint8_t* const col = reinterpret_cast<uint8_t*>(L.coef) + i * 4;
     uint32_t* const s_bits = L.coef + GJ_ENC_PRIV_ROWS * 256;
@@ -862,7 +859,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
     }
     const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill;
 
-    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 1); // walk done (this wave)
+    if (trace0 >= 0) GJ_TRACE_E(trace0 + 1); // walk done (this wave)
     // ---- 4. bit positions
     const uint32_t winc = gj_wave_incl_scan(len);
     if (lane == 63) L.wsum[wave] = winc;
@@ -881,7 +878,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         z[1] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads(); // B3: segment ends visible, window cleared
-    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 2); // positions known
+    if (trace0 >= 0) GJ_TRACE_E(trace0 + 2); // positions known
     // segment books, redundantly in every wave (lane l keeps local segment l): bits with ones-padding to a byte, dword base
     uint32_t sbits = 0, sdw = 0;
     if (lane < spt && lane < seg_count_left) {
@@ -940,7 +937,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         }
     }
     __syncthreads(); // B5: 0xFF counts complete; the coefficient area may be overwritten by the next component
-    if (trace0 >= 0) GJ_TRACE_T(trace_tile, trace0 + 3); // merged and drained
+    if (trace0 >= 0) GJ_TRACE_E(trace0 + 3); // merged and drained
     // the segments' sizes for k_gather, and what the tile's stream will measure once it is stuffed
     uint32_t out = 0;
     if (lane < nseg) {
@@ -969,14 +966,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
 // segments with two dependent trips and byte stores (16 us), and 19 MB of traffic for the same.
 // ================================================================================================
 typedef uint32_t __attribute__((aligned(1))) gj_u32_unaligned;
-// persistent encoders: the next tile (behind the first gridDim.x ones) comes from one of 16 counters, each on a 128-byte line of its own
-// -- a device-scope atomic on ONE address takes ~30 ns and they queue: a thousand workgroups asking at the same moment would wait
-// up to 30 us for their number. Counter r hands out the tiles gridDim.x + 16 n + r to the workgroups with index = r (mod 16) (fewer counters for fewer workgroups).
-#define GJ_TAIL_TICKET_SHARDS 16
-#define GJ_TAIL_CTR_WORDS (32 * GJ_TAIL_TICKET_SHARDS)
 struct GjTail {
-    uint32_t* ctr;         // this call's counters (GJ_TAIL_*), zero when the encoder kernel starts
-    uint32_t* ctr_other;   // the next call's: cleared by k_gather
     uint32_t* piece;       // [npieces] size in the file of every tile stream, in FILE order
     uint32_t* group;       // [ngroups] bytes of the tile streams 32 g .. 32 g + 31, added up by the tiles themselves; zero when the encoder kernel starts
     uint32_t* group_other; // the next call's
@@ -1024,10 +1014,8 @@ __global__ __launch_bounds__(256) void k_gather(const GjTail T)
     const uint32_t P = T.npieces, NG = T.ngroups;
     const uint32_t p0 = blockIdx.x * 4u, p = p0 + (uint32_t)wave;
     const bool have = p < P;
-    if (blockIdx.x == 0) { // the next call's counters and group totals
-        if (i < GJ_TAIL_TICKET_SHARDS) T.ctr_other[32 * i] = 0;
+    if (blockIdx.x == 0) // the next call's group totals
         for (uint32_t g = i; g < NG; g += 256) T.group_other[g] = 0;
-    }
     // ---- this wave's tile stream: where its segments and its bytes are (no loaded value needed)
     const uint32_t scan = gj_tail_scan_of(T, have ? p : 0u);
     const uint32_t t = (have ? p : 0u) - gj_pick4(T.scan_first, scan), seg0 = t * T.spt, scan_segs = gj_pick4(T.segs, scan);
@@ -1179,18 +1167,15 @@ __device__ __forceinline__ void gj_load_coder_lut(uint32_t* s_lut, const uint32_
 // alone costs as much as all arithmetic of the kernel. Both kernels already give one thread one 8x8 block, so the
 // quantised block can stay with that thread: a workgroup takes spt = 256 / B whole restart segments (B blocks
 // each, e.g. 7 x 36 = 252 block positions) of ALL THREE component scans, colour-converts its pixels once, then for one
-// component after the other transforms the block into its LDS column and runs the coder above on it. The per-segment output
-// (unstuffed bytes in d_temp, byte and 0xFF counts) is exactly what k_scan_segments / k_assemble expect.
+// component after the other transforms the block into its LDS column and runs the coder above on it. The output (the tile's unstuffed
+// stream in d_temp, byte and 0xFF counts per segment, the stream's size in the file) is what k_gather turns into the file.
 // Used for non-interleaved 4:4:4 with restart intervals of 4 .. 256 blocks.
 // ================================================================================================
-#ifndef GJ_ENC_PREFETCH_ROWS
-#define GJ_ENC_PREFETCH_ROWS 4 // pixel rows of the NEXT tile asked for while a tile's last component is coded (6 registers each)
-#endif
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
-                                                          uint32_t* __restrict__ seg_ff, const GjTail T, const uint32_t ntiles, const uint32_t stagger)
+                                                          uint32_t* __restrict__ seg_ff, const GjTail T)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
@@ -1198,93 +1183,45 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     __shared__ uint32_t s_wsum[4];
     __shared__ int s_edge[64];
     __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
-    __shared__ uint32_t s_next;
     const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
-    // the workgroups that share a compute unit ask for their first pixels one after the other (they are dispatched 256 at a time, one
-    // per unit): the first ones have theirs while the memory system is still busy with the others', instead of all waiting to the end
-    for (uint32_t n = (blockIdx.x >> 8) * stagger; n; n--) __builtin_amdgcn_s_sleep(32);
     const int i = threadIdx.x;
+    GJ_TRACE_E(0);
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
 
     const gj_comp_geom& k0 = g.comp[0];
     const int B = g.seg_blocks;
-    const int spt = 256 / B;       // segments per tile (per component)
+    const int spt = 256 / B;       // segments per workgroup (per component)
     const int tile_blocks = spt * B;
+    const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
+    const int j = min((int)(((uint32_t)i * recip) >> 16), GJ_ENC_MAX_SPT - 1);
+    const int k = i - j * B;       // block inside its segment
+    const int seg0 = blockIdx.x * spt; // first segment (inside each component's scan)
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
+    const unsigned lb = (unsigned)blockIdx.x * (unsigned)tile_blocks + (unsigned)i;
+    const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
+    const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
 
-    // A workgroup codes tile after tile: its first one is its index, the others come from a counter (asked for a whole tile ahead).
-    // Nothing but the tile number (a scalar) and the pixels on their way is carried from tile to tile: whatever a lane derives from its
-    // index is derived again where it is needed (GJ_KEEP hides the index from the optimiser, which would otherwise keep two dozen
-    // such values alive across the transforms -- in scratch memory, whose loads queue up behind the pixel loads).
-    uint32_t tile = blockIdx.x;
-    const uint32_t shards = min((uint32_t)GJ_TAIL_TICKET_SHARDS, gridDim.x); // (see GJ_TAIL_TICKET_SHARDS)
-    uint32_t px[8][6]; // the raw pixels of the lane's block position
-    uint32_t pos;      // that position: bx | by << 15 | exists << 30 (an integer division to get it: done once per tile)
-    {
-        const unsigned lb = tile * (unsigned)tile_blocks + (unsigned)i;
-        const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
-        const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
-        pos = bx | (by << 15) | ((uint32_t)active << 30);
-        gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, active, px);
-    }
-    for (bool first = true;; first = false) {
-        GJ_TRACE_T(tile, 0);
-        const int seg0 = (int)tile * spt; // the tile's first segment (inside each component's scan)
-        uint32_t pk[3][16];
-        {   // ---- pixels -> three byte-packed component blocks
-            const unsigned bx = pos & 0x7FFFu, by = (pos >> 15) & 0x7FFFu;
-            const bool active = (pos >> 30) != 0;
-            gj_load_444<GJ_ENC_PREFETCH_ROWS, 8>(g, raw, bx, by, active, px); // (the rows the registers had no room for while the last tile was coded)
-            gj_color_444<CS_FROM, CS_TO>(g, bx, by, active, px, pk);
-        }
-        uint32_t ticket = 0;
-        if (first) __syncthreads(); // tables are in LDS
-        // (behind the pixel loads: memory operations complete in order, and this one queues up with everybody else's)
-        if (threadIdx.x == 0) // (used two components later)
-            ticket = __hip_atomic_fetch_add(&T.ctr[32u * (blockIdx.x % shards)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        GJ_TRACE_T(tile, 1); // pixels loaded and converted
+    // ---- pixels -> three byte-packed component blocks
+    uint32_t pk[3][16];
+    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, active, pk);
+    __syncthreads(); // tables are in LDS
+    GJ_TRACE_E(1); // pixels loaded and converted
+
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const gj_comp_geom& kc = g.comp[c];
-            // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
+    for (int c = 0; c < 3; c++) {
+        const gj_comp_geom& kc = g.comp[c];
+        // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
 #pragma unroll
-            for (int t = 0; t < 16; t++) GJ_KEEP(pk[c][t]);
-            {
-                int t = threadIdx.x;
-                GJ_KEEP(t);
-                gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + t * 4);
-            }
-            GJ_TRACE_T(tile, 2 + 4 * c); // transformed (this wave)
-            if (c == 2) {
-                // the next tile: its number, and its pixels on their way while this tile's last component is coded (the registers of
-                // the transforms are free now)
-                if (threadIdx.x == 0) s_next = gridDim.x + ticket * shards + blockIdx.x % shards;
-                __syncthreads();
-                const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
-                int t = threadIdx.x;
-                GJ_KEEP(t);
-                const unsigned lb = next * (unsigned)tile_blocks + (unsigned)t;
-                const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
-                const bool next_active = next < ntiles && t < tile_blocks && lb < nb;
-                pos = bx | (by << 15) | ((uint32_t)next_active << 30);
-                gj_load_444<0, GJ_ENC_PREFETCH_ROWS>(g, raw, bx, by, next_active, px);
-            }
-            int t = threadIdx.x;
-            GJ_KEEP(t);
-            const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = t / B through a 16.16 reciprocal (exact for t < 256, B <= 256)
-            const int j = min((int)(((uint32_t)t * recip) >> 16), GJ_ENC_MAX_SPT - 1);
-            const int k = t - j * B; // block inside its segment
-            const bool active = t < tile_blocks && tile * (unsigned)tile_blocks + (unsigned)t < nb;
-            const uint64_t first_block = kc.data_offset / 64 + (uint64_t)seg0 * B; // coding-order index of the tile's first block of this component
-            const uint32_t size = gj_code_tile(L, t, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
-                                               temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), tile, 2 + 4 * c);
-            // file order: the luminance scan's tiles, then the two chrominance scans'
-            if (threadIdx.x == 0) gj_piece_put(T, (uint32_t)c * ntiles + tile, size);
-        }
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next); // (stable until the next tile's third component)
-        if (tile >= ntiles) break;
+        for (int t = 0; t < 16; t++) GJ_KEEP(pk[c][t]);
+        gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
+        GJ_TRACE_E(2 + 4 * c); // transformed (this wave)
+        const uint64_t first_block = kc.data_offset / 64 + (uint64_t)seg0 * B; // coding-order index of the tile's first block of this component
+        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
+                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
+        // file order: the luminance scan's tiles, then the two chrominance scans'
+        if (i == 0) gj_piece_put(T, (uint32_t)c * gridDim.x + blockIdx.x, size);
     }
 }
 
@@ -1773,9 +1710,9 @@ __global__ __launch_bounds__(256) void k_segment_info(const gj_enc_job J)
 // Launcher
 // ================================================================================================
 typedef void (*gj_fused_kernel_t)(const gj_geom, const uint8_t*, int16_t*, const float*, const float*);
-typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail, uint32_t, uint32_t);
+typedef void (*gj_encode_kernel_t)(const gj_geom, const uint8_t*, const float*, const float*, const uint32_t*, uint8_t*, uint32_t*, uint32_t*, const GjTail);
 
-// k_gather's arguments (and the encoder kernels': they use the tile list, the group totals and the ticket counter) for a launch that leaves
+// k_gather's arguments (and the encoder kernels': they use the tile list and the group totals) for a launch that leaves
 // `pieces` tile streams of `spt` segments; scan s begins with stream scan_first[s]
 static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const unsigned (&scan_first)[GJ_MAX_COMP], const unsigned spt)
 {
@@ -1791,13 +1728,11 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     }
     T.spt = spt;
     T.seg_blocks = (uint32_t)g.seg_blocks;
-    T.ctr = job->d_tail + (job->tail_set & 1) * GJ_TAIL_CTR_WORDS;
-    T.ctr_other = job->d_tail + ((job->tail_set + 1) & 1) * GJ_TAIL_CTR_WORDS;
     const unsigned ngcap = GJ_TAIL_GROUPS_CAP(g.segment_count); // (one tile stream per segment at most)
-    T.group = job->d_tail + GJ_TAIL_HEAD_WORDS + (job->tail_set & 1) * ngcap;
-    T.group_other = job->d_tail + GJ_TAIL_HEAD_WORDS + ((job->tail_set + 1) & 1) * ngcap;
+    T.group = job->d_tail + (job->tail_set & 1) * ngcap;
+    T.group_other = job->d_tail + ((job->tail_set + 1) & 1) * ngcap;
     T.ngroups = (pieces + 31) / 32;
-    T.piece = job->d_tail + GJ_TAIL_HEAD_WORDS + 2 * ngcap;
+    T.piece = job->d_tail + 2 * ngcap;
     T.npieces = pieces;
     T.temp = job->d_temp;
     T.seg_bytes = job->d_seg_bytes;
@@ -1809,19 +1744,6 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     T.d_result = job->d_result;
     T.h_result = job->h_result;
     return T;
-}
-
-// compute units of the current device (asked once per device)
-static int gj_cu_count()
-{
-    static int cus[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!cus[dev]) {
-        hipDeviceProp_t p;
-        cus[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    }
-    return cus[dev];
 }
 
 // fused kernel for this configuration, or nullptr when the generic path has to be used
@@ -1917,11 +1839,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
-        // persistent: as many workgroups as the device holds at once (four per CU), each codes tile after tile
-        const unsigned resident = job->tune.enc_resident > 0 ? (unsigned)job->tune.enc_resident : 4u * (unsigned)gj_cu_count();
         T = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, (unsigned)spt);
-        hipLaunchKernelGGL(whole, dim3(wgs < resident ? wgs : resident), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
-                           job->d_temp, job->d_seg_bytes, job->d_seg_ff, T, wgs, (uint32_t)job->tune.enc_stagger);
+        hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
+                           job->d_seg_bytes, job->d_seg_ff, T);
     } else {
     tiles = false;
     if (uyvy) { // packed 4:2:2 without colour transform: pixels -> coefficients, one thread per MCU

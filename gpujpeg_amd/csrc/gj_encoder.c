@@ -32,8 +32,8 @@ struct gpujpeg_encoder {
     uint8_t* d_jpeg; size_t d_jpeg_cap;
     uint32_t* d_result;
     uint64_t* d_scan_partial; size_t d_scan_partial_cap;
-    uint32_t* d_tail; size_t d_tail_cap; /* the gathering tail of the one-launch kernels: two counter sets + one entry per tile stream */
-    int tail_set;                        /* the counter set the next call uses */
+    uint32_t* d_tail; size_t d_tail_cap; /* k_encode_* -> k_gather: two sets of group totals + one entry per tile stream (GJ_TAIL_WORDS) */
+    int tail_set;                        /* the set the next call uses */
     uint32_t epoch;
     uint8_t* d_scan_hdr; size_t d_scan_hdr_cap;
     struct gj_scan_headers scan_hdrs;
@@ -165,7 +165,7 @@ static int encoder_configure(struct gpujpeg_encoder* e, const struct gpujpeg_par
     if (gj_ensure_device_buffer((void**)&e->d_temp, &e->d_temp_cap, (size_t)g->block_count * GJ_TEMP_BYTES_PER_BLOCK + 256) != 0) return -1;
     /* k_gather's counters and group totals are zero between calls (the kernel leaves them so); cleared here in case a failed launch did not */
     if (gj_ensure_device_buffer((void**)&e->d_tail, &e->d_tail_cap, (size_t)GJ_TAIL_WORDS(g->segment_count) * sizeof(uint32_t)) != 0) return -1;
-    if (gj_hip_memset(e->d_tail, 0, (GJ_TAIL_HEAD_WORDS + 2 * (size_t)GJ_TAIL_GROUPS_CAP(g->segment_count)) * sizeof(uint32_t), c->stream) != 0) return -1;
+    if (gj_hip_memset(e->d_tail, 0, 2 * (size_t)GJ_TAIL_GROUPS_CAP(g->segment_count) * sizeof(uint32_t), c->stream) != 0) return -1;
     e->tail_set = 0;
     {
         const size_t need = (((size_t)g->segment_count + 1023) / 1024 + 1) * sizeof(uint64_t);

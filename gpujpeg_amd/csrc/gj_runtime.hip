@@ -141,6 +141,4 @@ extern "C" void gj_hip_tuning_from_env(gj_tuning* t)
     t->scan_tb = (e = getenv("GJ_SCAN_TB")) ? atoi(e) : 0;
     t->dec_tok_nocoop = (e = getenv("GJ_DEC_TOK_NOCOOP")) && e[0] == '1';
     t->enc_by_blocks = (e = getenv("GJ_ENC_BLOCKS")) ? atoi(e) : 0;
-    t->enc_resident = (e = getenv("GJ_ENC_RESIDENT")) ? atoi(e) : 0;
-    t->enc_stagger = (e = getenv("GJ_ENC_STAGGER")) ? atoi(e) : 0;
 }

@@ -59,10 +59,10 @@ GJ_HIP_API float gj_hip_event_elapsed_ms(gj_event_t start, gj_event_t stop); /* 
 #define GJ_MAX_COMP 4
 #define GJ_MAX_MCU_BLOCKS 16     /* blocks per interleaved MCU we accept (JPEG itself allows 10) */
 #define GJ_TEMP_BYTES_PER_BLOCK 208 /* >= worst case 1658 bits of an 8x8 block before byte stuffing, 16 B multiple */
-#define GJ_TAIL_HEAD_WORDS 1024 /* gj_enc_job.d_tail (k_encode_* -> k_gather): the tile counters of the persistent encoder (two sets of 16, a 128-byte line each), then two sets of
-                                 GJ_TAIL_GROUPS_CAP(segments) group totals, then the tile list (one word per tile stream, at most one stream per segment) */
+/* gj_enc_job.d_tail (k_encode_* -> k_gather): two sets of GJ_TAIL_GROUPS_CAP(segments) group totals, used alternately, then the tile list
+ * (one word per tile stream, at most one stream per segment) */
 #define GJ_TAIL_GROUPS_CAP(segments) (((unsigned)(segments) + 32u) / 32u + 1u)
-#define GJ_TAIL_WORDS(segments) (GJ_TAIL_HEAD_WORDS + 2u * GJ_TAIL_GROUPS_CAP(segments) + ((unsigned)(segments) + 1u))
+#define GJ_TAIL_WORDS(segments) (2u * GJ_TAIL_GROUPS_CAP(segments) + ((unsigned)(segments) + 1u))
 
 enum { GJ_PF_U8 = 0, GJ_PF_444_P012 = 1, GJ_PF_444_P0P1P2 = 2, GJ_PF_422_P1020 = 3, GJ_PF_422_P0P1P2 = 4,
        GJ_PF_420_P0P1P2 = 5, GJ_PF_4444_P0123 = 6 };
@@ -123,8 +123,6 @@ typedef struct gj_tuning {
     int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
     int enc_by_blocks;   /* GJ_ENC_BLOCKS: packed RGB 4:4:4 through k_encode_blocks (a workgroup codes one component of its tile: three times the
                             workgroups, a third of the work each) 1 = always, -1 = never, 0 = small frames only */
-    int enc_stagger;     /* GJ_ENC_STAGGER: the persistent encoder's workgroup n starts (n / 256) x this many 0.85 us late (0 = all at once) */
-    int enc_resident;    /* GJ_ENC_RESIDENT: workgroups of the persistent encoder kernel (0 = four per compute unit) */
     int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that
                             does not fit (overflow flag) -- this call uses the kernels without that limit */
 } gj_tuning;
@@ -145,9 +143,9 @@ typedef struct gj_enc_job {
     uint64_t jpeg_capacity;
     uint32_t* d_result;            /* [0] total JPEG size, [1] overflow flag */
     uint32_t* h_result;            /* optional: the same two words in pinned host memory, written by the kernel that computes them */
-    uint32_t* d_tail;              /* k_encode_* -> k_gather: GJ_TAIL_WORDS(segment_count) words, see there; the counters and group totals are zero
-                                      at allocation and after every call (two sets, used alternately) */
-    int tail_set;                  /* which of d_tail's two counter sets this call uses: alternates from call to call */
+    uint32_t* d_tail;              /* k_encode_* -> k_gather: GJ_TAIL_WORDS(segment_count) words, see there; the group totals are zero at allocation
+                                      and after every call (two sets, used alternately) */
+    int tail_set;                  /* which of d_tail's two sets of group totals this call uses: alternates from call to call */
     uint64_t* d_scan_partial;      /* [ceil(segment_count / 1024)] epoch-tagged workgroup totals of the offset scan; zero at allocation */
     uint32_t epoch;                /* differs from the previous call's (and is never 0) */
     gj_tuning tune;

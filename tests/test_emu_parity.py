@@ -80,10 +80,9 @@ def test_emu_packed_422_whole_frame_encoder(O, G, emu_lib, w, h, restart):
     T.test_packed_422_whole_frame_encoder(O, G, emu_lib, w, h, restart)
 
 
-@pytest.mark.parametrize("resident", [0, 1, 5], ids=lambda r: f"resident{r}")
 @pytest.mark.parametrize("tc", T.TAIL_CASES, ids=[c[0] for c in T.TAIL_CASES])
-def test_emu_encoder_tiles_and_gather(O, G, emu_lib, tc, resident, monkeypatch):
-    T.test_encoder_tiles_and_gather(O, G, emu_lib, tc, resident, monkeypatch)
+def test_emu_encoder_tiles_and_gather(O, G, emu_lib, tc):
+    T.test_encoder_tiles_and_gather(O, G, emu_lib, tc)
 
 
 def test_emu_reuse_padding_and_reconfiguration(O, G, emu_lib):

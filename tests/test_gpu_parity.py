@@ -376,21 +376,13 @@ TAIL_CASES = [
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("resident", [0, 1, 5], ids=lambda r: f"resident{r}")
 @pytest.mark.parametrize("tc", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
-def test_encoder_tiles_and_gather(O, G, gpu_lib, tc, resident, monkeypatch):
+def test_encoder_tiles_and_gather(O, G, gpu_lib, tc):
     """k_encode_* leave the unstuffed stream of every tile and its size in the file; k_gather (one wave per tile stream) places, stuffs
     and marks them: the file's bytes must be the oracle's (replaces src/gpujpeg_huffman_gpu_encoder.cu:417-613 and the host stitching of
-    src/gpujpeg_encoder.c:567-629), with and without the APP13 index, three times in a row on the same coder (the counters and group
-    totals alternate between two sets that k_gather clears). GJ_ENC_RESIDENT limits the workgroups of the persistent kernel
-    (k_encode_rgb444): 1 = one workgroup codes every tile, 5 = tiles handed out by the counter to five of them."""
+    src/gpujpeg_encoder.c:567-629), with and without the APP13 index, three times in a row on the same coder (the group totals
+    alternate between two sets that k_gather clears)."""
     name, w, h, pf, cs, q, restart, il, sub, noisy = tc
-    if resident:
-        if pf != 1 or il or sub is not None:
-            pytest.skip("only k_encode_rgb444 is persistent")
-        monkeypatch.setenv("GJ_ENC_RESIDENT", str(resident))
-    else:
-        monkeypatch.delenv("GJ_ENC_RESIDENT", raising=False)
     case = (name, w, h, pf, cs, q, restart, il, sub, 3)
     comps = {0: 1, 1: 3}.get(pf)
     raw = natural_image(w, h, comps, seed=w) if comps and not noisy else O.noise(O.raw_size(w, h, pf), seed=w * 7 + h)
@@ -399,7 +391,7 @@ def test_encoder_tiles_and_gather(O, G, gpu_lib, tc, resident, monkeypatch):
         want = O.encode(oracle_image(O, case, segment_info=seg_info), raw)
         p, pi = api_params(gpu_lib, G, case, segment_info=seg_info)
         got = enc.encode(p, pi, raw)
-        assert got.size == want.size and np.array_equal(got, want), (name, resident, seg_info, got.size, want.size)
+        assert got.size == want.size and np.array_equal(got, want), (name, seg_info, got.size, want.size)
     enc.close()
 
 

@@ -50,11 +50,6 @@ tot = (t[:, n - 1] - t[:, 0]) / 100.0
 end = (t[:, n - 1] - t0) / 100.0
 print("  workgroup total: mean %.1f p50 %.1f p90 %.1f max %.1f; kernel span %.1f; workgroups that start after 40 us: %d, their mean total %.1f" %
       (tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max(), end.max(), int((x > 40).sum()), float(tot[x > 40].mean()) if (x > 40).any() else 0.0))
-part = t[t[:, 14] > 0]
-if len(part):  # the gathering tail: slot 14 = a workgroup that gathers has finished its tile, 15 = it has emptied the share list
-    a, b = (part[:, 14] - t0) / 100.0, (part[:, 15] - t0) / 100.0
-    print("  gathering workgroups: %d; finish their tile at %.1f .. %.1f us, wait + gather mean %.1f max %.1f us, last tile done at %.1f, kernel ends at %.1f us" %
-          (len(part), a.min(), a.max(), (b - a).mean(), (b - a).max(), end.max(), b.max()))
 busy = np.zeros(int(end.max()) + 2)
 for a, b in zip(x.astype(int), end.astype(int)):
     busy[a:b + 1] += 1

@@ -226,7 +226,7 @@ class Lanes:
     def solo_kernel_ms(self, iters=10):
         """per-kernel hipEvent durations (events on the coder's stream) with one pipeline and the GPU otherwise idle"""
         ln = self.lanes[0]
-        acc = np.zeros(8)
+        acc = np.zeros(9)
         for _ in range(iters):
             jp, js = self.encode(ln)
             torch.cuda.synchronize()
@@ -240,7 +240,7 @@ class Lanes:
         mean contended kernel ms of lane 0)"""
         go = threading.Event()
         walls = [0.0, 0.0]
-        kms = np.zeros(8)
+        kms = np.zeros(9)
 
         def worker(idx):
             torch.cuda.set_device(local_rank)  # the HIP device is per host thread
@@ -289,7 +289,7 @@ def kernel_names(spec, enc_ms, token_mode):
     # through k_gather; k_scan_segments + k_assemble follow k_huffman only)
     return ["enc:k_preprocess", f"enc:k_fused_{fmt}", f"enc:k_encode_{fmt}" if whole else "enc:k_huffman", "enc:k_gather" if whole else "enc:k_scan_segments", "enc:k_assemble",
             ("dec:k_huffman_decode_win" if token_mode else "dec:k_huffman_decode_seq") if spec.is422 and spec.pixels > 3e7 else ("dec:k_huffman_decode_tok" if token_mode else "dec:k_huffman_decode_par"),
-            f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}", "dec:k_postprocess"]
+            f"dec:k_idct_{'tok' if token_mode else 'fused'}_{fmt}", "dec:k_postprocess", "dec:k_markers"]
 
 
 def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, steps=20, warmup=3, min_seconds=0.5, host_io=False, keep_coefs=False,
@@ -633,7 +633,7 @@ def main():
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             return {"kernel": name, "ms": round(float(ms), 4), "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
 
-        live = [i for i in range(8) if solo[i] > 0.006]  # (event slots of kernels this configuration does not launch hold only the gap between two events)
+        live = [i for i in range(9) if solo[i] > 0.006]  # (event slots of kernels this configuration does not launch hold only the gap between two events)
         dom = max(live, key=lambda i: solo[i])
         valu = load_traffic("valu_insts", args.workload) if traffic else {}
 
@@ -742,7 +742,7 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
             tokm = nblk >= (900000 if sp.is422 else 300000) and m["jpeg_bytes"] <= (12 if sp.is422 else 8) * nblk and not os.environ.get("GJ_DEC_NO_TOKENS")
             nm = kernel_names(sp, m["solo_ms"], tokm)
             solo_ = m["solo_ms"]
-            live_ = [i for i in range(8) if solo_[i] > 0.006]
+            live_ = [i for i in range(9) if solo_[i] > 0.006]
             dom_ = max(live_, key=lambda i: solo_[i])
             tr_ = load_traffic("kernels", name)
             fr = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None  # noqa: E731

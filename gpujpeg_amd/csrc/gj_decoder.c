@@ -39,8 +39,9 @@ struct gpujpeg_decoder {
     /* device-side segment discovery */
     uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
     uint32_t* d_scan_scratch; size_t d_scan_scratch_cap;
-    gj_scan_summary* d_summary;   /* [2]: the marker scan of a call uses one and clears the other for the next call */
-    int sum_idx;
+    gj_scan_summary* d_summary;   /* the device's copy: only segment_count is used (speculative launches read it) */
+    uint32_t scan_epoch;          /* number of the marker scan's call: tags the records of its workgroups */
+    bool scan_timed;              /* this call's marker scan ran on the device between events 4 and 5 */
     uint32_t last_max_seg_len;    /* longest segment of the last frame decoded with this header (speculative path) */
     uint32_t last_scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes per scan of the last frame decoded with this header (speculative path) */
     gj_scan_summary* h_summary;   /* pinned */
@@ -89,10 +90,10 @@ struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
     if (!d->d_huff_tab || !d->h_tabs) goto fail;
     d->d_qtab = d->d_huff_tab + 8 * GJ_DEC_TAB_WORDS;
     d->h_hdr = gj_hip_host_alloc(GJ_HDR_WINDOW);
-    d->d_summary = gj_hip_malloc(2 * sizeof(gj_scan_summary));
+    d->d_summary = gj_hip_malloc(sizeof(gj_scan_summary));
     d->h_summary = gj_hip_host_alloc(sizeof(gj_scan_summary));
     if (!d->h_hdr || !d->d_summary || !d->h_summary) goto fail;
-    if (gj_hip_memset(d->d_summary, 0, 2 * sizeof(gj_scan_summary), d->coder.stream) != 0 || gj_hip_stream_sync(d->coder.stream) != 0) goto fail;
+    if (gj_hip_memset(d->d_summary, 0, sizeof(gj_scan_summary), d->coder.stream) != 0 || gj_hip_stream_sync(d->coder.stream) != 0) goto fail;
     d->host_scan = d->tune.host_scan;
     return d;
 fail:
@@ -292,12 +293,16 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     /* ---- 3. segment table ---- */
     int seg_count = 0;
     const uint32_t* d_seg_count = NULL;
-    gj_scan_summary *sum_cur = d->d_summary + d->sum_idx, *sum_next = d->d_summary + (d->sum_idx ^ 1);
+    gj_scan_summary* sum_cur = d->d_summary;
     const size_t S = (size_t)g->segment_count + GJ_MAX_COMP;
     if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 4 + 8) * sizeof(uint32_t)) != 0) goto out;
     if (device_scan) {
         const size_t words = gj_hip_find_segments_scratch_words(r.scan_begin[0], image_size, (uint32_t)g->segment_count);
-        if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
+        {   /* (the records in it are told apart by the call's number: a fresh buffer starts without any) */
+            const size_t had = d->d_scan_scratch_cap;
+            if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
+            if (d->d_scan_scratch_cap != had && gj_hip_memset(d->d_scan_scratch, 0, d->d_scan_scratch_cap, c->stream) != 0) goto out;
+        }
         /* (a speculative launch on a device-resident stream has its header compared with the cached one by the scan's first kernel) */
         const bool cmp = spec && jpeg_on_device;
         /* the kernels write what the host validates straight into pinned host memory */
@@ -311,11 +316,15 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         }
         d->h_summary->rst_irregular = 0;
         d->h_summary->seq_overflow = 0;
+        d->h_summary->header_differs = 0;
+        if (stats) gj_hip_event_record(c->timers.ev[4], c->stream); /* (the marker scan is GPU time of this call: events 4 and 5 bracket it) */
+        if ((++d->scan_epoch & 0xFFFFu) == 0) d->scan_epoch++; /* (never 0 in the low 16 bits: what a cleared buffer holds) */
         if (frc == 0)
             frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
-                                       d->d_scan_scratch, sum_cur, sum_next, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, d->h_summary,
-                                       d->h_maxlen, (uint32_t)(d->h_maxlen_cap / sizeof(uint32_t)), &d->maxlen_parts, c->stream, &d->tune);
-        if (frc == 0) d->sum_idx ^= 1; /* (sum_next is clean once this call's kernels have run: it serves the next call) */
+                                       d->d_scan_scratch, sum_cur, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, d->h_summary,
+                                       d->h_maxlen, (uint32_t)(d->h_maxlen_cap / sizeof(uint32_t)), &d->maxlen_parts, d->scan_epoch, c->stream, &d->tune);
+        if (stats) gj_hip_event_record(c->timers.ev[5], c->stream);
+        d->scan_timed = stats;
         if (frc != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {
             GJ_ERROR("Marker scan failed: %s\n", gj_hip_last_error());
             goto out;
@@ -590,6 +599,8 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         s->duration_preprocessor = gj_hip_event_elapsed_ms(c->timers.ev[2], c->timers.ev[3]);
         s->duration_in_gpu = gj_hip_event_elapsed_ms(c->timers.ev[0], c->timers.ev[3]);
         for (int k = 0; k < GJ_DEC_EVENTS - 1; k++) c->kernel_ms[k] = gj_hip_event_elapsed_ms(c->timers.ev[k], c->timers.ev[k + 1]);
+        c->kernel_ms[3] = d->scan_timed ? gj_hip_event_elapsed_ms(c->timers.ev[4], c->timers.ev[5]) : 0.0f; /* the marker scan, when the device did it */
+        s->duration_in_gpu += c->kernel_ms[3];
         c->timers.valid = true;
         s->duration_memory_to = gj_hip_event_elapsed_ms(c->timers.copy_in[0], c->timers.copy_in[1]);
         if (output->type == GPUJPEG_DECODER_OUTPUT_INTERNAL_BUFFER || output->type == GPUJPEG_DECODER_OUTPUT_CUSTOM_BUFFER)

@@ -268,7 +268,7 @@ class Decoder:
         ms = (C.c_float * 8)()
         if self.lib.L.gpujpeg_amd_decoder_get_kernel_times(self.h, ms) != 0:
             return None
-        return list(ms)[:3]
+        return list(ms)[:4]
 
     def coefficients(self, count):
         a = np.empty(count, np.int16)

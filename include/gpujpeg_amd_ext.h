@@ -64,8 +64,9 @@ GPUJPEG_API int gpujpeg_amd_host_geometry(const struct gpujpeg_parameters* param
 GPUJPEG_API int gpujpeg_amd_host_huffman_table_check(const uint8_t bits[17], const uint8_t* vals, int is_ac);
 
 /* per-kernel durations (ms, hipEvents on the coder's stream) of the last call made with perf_stats != 0:
- * encoder: [0] preprocess, [1] DCT+quant (fused path: preprocess included), [2] k_huffman, [3] k_scan_segments, [4] k_assemble
- * decoder: [0] k_huffman_decode, [1] IDCT (fused path: postprocess included), [2] postprocess */
+ * encoder: [0] preprocess, [1] DCT+quant (fused path: preprocess included), [2] k_huffman or k_encode_*, [3] k_gather (behind k_huffman:
+ *          k_scan_segments), [4] k_assemble (behind k_huffman only)
+ * decoder: [0] entropy decoder, [1] IDCT (fused path: postprocess included), [2] postprocess, [3] marker scan (k_markers; 0 when the host walked the stream) */
 GPUJPEG_API int gpujpeg_amd_encoder_get_kernel_times(struct gpujpeg_encoder* encoder, float ms[8]);
 GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* decoder, float ms[8]);
 

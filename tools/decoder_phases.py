@@ -58,7 +58,7 @@ for q in range(0, n, max(1, n // 8)):
     sel = np.arange(q, min(n, q + max(1, n // 8)))
     d = np.diff(t[sel][:, :9], axis=1).mean(0) / 100.0
     print(f"  wg {q:5d}..: start {((t[sel, 0] - t0) / 100).mean():6.1f} phases " + " ".join(f"{x:5.1f}" for x in d) + f" total {d.sum():6.1f}")
-# ---- the same for k_marker_segments
+# ---- the same for the marker scan (k_markers)
 mb = torch.zeros(16384 * SLOTS, dtype=torch.int64, device=dev)
 lib.L.gj_hip_trace_set_markers.argtypes = [C.c_void_p]
 assert lib.L.gj_hip_trace_set_markers(mb.data_ptr()) == 0
@@ -68,8 +68,8 @@ assert lib.L.gj_hip_trace_set_markers(None) == 0
 m = mb.cpu().numpy().reshape(-1, SLOTS)
 m = m[m[:, 0] > 0]
 m0 = m[:, 0].min()
-mn = ["start", "loads asked / scans derived", "after barrier", "counts reduced", "list built", "entries written", "summary out"]
-print(f"k_marker_segments: workgroups {len(m)}")
+mn = ["start", "bytes read, markers found", "marker list built", "records read", "scans derived", "entries written", "summary out"]
+print(f"k_markers: workgroups {len(m)}")
 for i in range(7):
     x = (m[:, i] - m0) / 100.0
     print(f"  at {mn[i]:28s}: min {x.min():6.1f} mean {x.mean():6.1f} p90 {np.percentile(x, 90):6.1f} max {x.max():6.1f}")

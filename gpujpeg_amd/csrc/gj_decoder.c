@@ -40,7 +40,6 @@ struct gpujpeg_decoder {
     uint8_t* h_hdr;               /* pinned: first bytes of a device-resident stream, for header parsing */
     uint32_t* d_scan_scratch; size_t d_scan_scratch_cap;
     gj_scan_summary* d_summary;   /* the device's copy: only segment_count is used (speculative launches read it) */
-    uint32_t scan_epoch;          /* number of the marker scan's call: tags the records of its workgroups */
     bool scan_timed;              /* this call's marker scan ran on the device between events 4 and 5 */
     uint32_t last_max_seg_len;    /* longest segment of the last frame decoded with this header (speculative path) */
     uint32_t last_scan_bytes[GJ_MAX_COMP]; /* entropy-coded bytes per scan of the last frame decoded with this header (speculative path) */
@@ -298,11 +297,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 4 + 8) * sizeof(uint32_t)) != 0) goto out;
     if (device_scan) {
         const size_t words = gj_hip_find_segments_scratch_words(r.scan_begin[0], image_size, (uint32_t)g->segment_count);
-        {   /* (the records in it are told apart by the call's number: a fresh buffer starts without any) */
-            const size_t had = d->d_scan_scratch_cap;
-            if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
-            if (d->d_scan_scratch_cap != had && gj_hip_memset(d->d_scan_scratch, 0, d->d_scan_scratch_cap, c->stream) != 0) goto out;
-        }
+        if (gj_ensure_device_buffer((void**)&d->d_scan_scratch, &d->d_scan_scratch_cap, words * sizeof(uint32_t)) != 0) goto out;
         /* (a speculative launch on a device-resident stream has its header compared with the cached one by the scan's first kernel) */
         const bool cmp = spec && jpeg_on_device;
         /* the kernels write what the host validates straight into pinned host memory */
@@ -318,11 +313,10 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         d->h_summary->seq_overflow = 0;
         d->h_summary->header_differs = 0;
         if (stats) gj_hip_event_record(c->timers.ev[4], c->stream); /* (the marker scan is GPU time of this call: events 4 and 5 bracket it) */
-        if ((++d->scan_epoch & 0xFFFFu) == 0) d->scan_epoch++; /* (never 0 in the low 16 bits: what a cleared buffer holds) */
         if (frc == 0)
             frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
                                        d->d_scan_scratch, sum_cur, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, d->h_summary,
-                                       d->h_maxlen, (uint32_t)(d->h_maxlen_cap / sizeof(uint32_t)), &d->maxlen_parts, d->scan_epoch, c->stream, &d->tune);
+                                       d->h_maxlen, (uint32_t)(d->h_maxlen_cap / sizeof(uint32_t)), &d->maxlen_parts, c->stream, &d->tune);
         if (stats) gj_hip_event_record(c->timers.ev[5], c->stream);
         d->scan_timed = stats;
         if (frc != 0 || (!spec && gj_hip_stream_sync(c->stream) != 0)) {

@@ -139,5 +139,6 @@ extern "C" void gj_hip_tuning_from_env(gj_tuning* t)
     if ((e = getenv("GJ_DEC_SEQ"))) t->dec_seq = e[0] == '1' ? 1 : 2;
     t->debug_sync = (e = getenv("GJ_DEC_DEBUG_SYNC")) && e[0] == '1';
     t->dec_tok_nocoop = (e = getenv("GJ_DEC_TOK_NOCOOP")) && e[0] == '1';
+    t->scan_shape = (e = getenv("GJ_SCAN_SHAPE")) ? atoi(e) : 0;
     t->enc_by_blocks = (e = getenv("GJ_ENC_BLOCKS")) ? atoi(e) : 0;
 }

@@ -119,6 +119,8 @@ typedef struct gj_tuning {
     int dec_no_spec;     /* GJ_DEC_NO_SPEC: no speculative launch on a cached header */
     int dec_seq;         /* GJ_DEC_SEQ: 1 = always the lane-per-segment entropy decoder in plane mode, 2 (GJ_DEC_SEQ=0) = never, 0 = by the frame */
     int debug_sync;      /* GJ_DEC_DEBUG_SYNC=1: wait after every decoder stage and name it on stderr */
+    int scan_shape;      /* GJ_SCAN_SHAPE=<pieces * 100 + rounds>: 4 KB pieces per round (1, 2, 4, 8, 16) and rounds (1 .. 4) of a workgroup of the marker scan
+                            instead of the choice by the stream's size (tests: every shape on small streams) */
     int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
     int enc_by_blocks;   /* GJ_ENC_BLOCKS: packed RGB 4:4:4 through k_encode_blocks (a workgroup codes one component of its tile: three times the
                             workgroups, a third of the work each) 1 = always, -1 = never, 0 = small frames only */
@@ -249,18 +251,18 @@ typedef struct gj_scan_summary {
 } gj_scan_summary;
 
 GJ_HIP_API size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t size, uint32_t max_segments);
-/* d_scratch: gj_hip_find_segments_scratch_words() words that keep their contents from call to call (the workgroups' records carry the call's
- * number `epoch`: any value that differs from the previous calls' in its low 16 bits, e.g. a counter); d_summary: the device's copy, of which
- * only segment_count is written (speculative launches read it).
+/* d_scratch: gj_hip_find_segments_scratch_words() words (the workgroups' records and marker lists between the two launches);
+ * d_summary: the device's copy, of which only segment_count is written (speculative launches read it).
  * d_hdr_ref (may be NULL): the cached header of a speculative launch; sets h_summary->header_differs = (d_jpeg[0..hdr_n) != d_hdr_ref[0..hdr_n))
- * h_summary, h_maxlen_parts: PINNED HOST memory the kernel writes directly (no copy launches behind it): the summary the host validates
- * once the stream has been waited for (the host clears rst_irregular and seq_overflow in it before the launch; max_seg_len is not written
- * by the device: the longest segment of the table is the maximum over *maxlen_part_count words of h_maxlen_parts, one per workgroup) */
+ * h_summary, h_maxlen_parts: PINNED HOST memory the kernels write directly (no copy launches behind them): the summary the host validates
+ * once the stream has been waited for (the host clears rst_irregular, seq_overflow and header_differs in it before the launch; max_seg_len
+ * is not written by the device: the longest segment of the table is the maximum over *maxlen_part_count words of h_maxlen_parts, one per
+ * workgroup) */
 GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                     uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
                                     gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
-                                    uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, uint32_t epoch,
-                                    gj_stream_t stream, const gj_tuning* tune);
+                                    uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
+                                    const gj_tuning* tune);
 /* workgroups the marker scan cuts [begin, size) into at most (capacity of h_maxlen_parts) */
 GJ_HIP_API size_t gj_hip_find_segments_max_chunks(uint64_t begin, uint64_t size);
 

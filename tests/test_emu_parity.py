@@ -85,6 +85,11 @@ def test_emu_encoder_tiles_and_gather(O, G, emu_lib, tc):
     T.test_encoder_tiles_and_gather(O, G, emu_lib, tc)
 
 
+@pytest.mark.parametrize("shape", [101, 103, 204, 401, 802, 1601, 1604])
+def test_emu_marker_scan_shapes(O, G, emu_lib, shape, monkeypatch):
+    T.test_marker_scan_shapes(O, G, emu_lib, shape, monkeypatch)
+
+
 def test_emu_reuse_padding_and_reconfiguration(O, G, emu_lib):
     T.test_width_padding(O, G, emu_lib)
     T.test_decoder_reuse_without_clearing(O, G, emu_lib)

@@ -395,6 +395,27 @@ def test_encoder_tiles_and_gather(O, G, gpu_lib, tc):
     enc.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [101, 103, 204, 401, 802, 1601, 1604])
+def test_marker_scan_shapes(O, G, gpu_lib, shape, monkeypatch):
+    """The device's segment table (k_marker_scan + k_marker_table, replaces the host walk of src/gpujpeg_reader.c:1039-1155) for every
+    shape of the scan's workgroups -- 4 KB pieces per round x rounds, GJ_SCAN_SHAPE --, which the stream's size chooses otherwise (an 8K
+    frame: 8 pieces, config 4: 16 pieces x 3 rounds): three scans whose SOS markers fall into different workgroups, one interleaved
+    scan, segments of a few bytes (several restart markers in a lane's 16 bytes), a stream without restart markers."""
+    monkeypatch.setenv("GJ_SCAN_SHAPE", str(shape))
+    cases = [("a", 640, 368, 1, 1, 90, -1, 0, None, 3), ("b", 322, 250, 3, 3, 90, -1, 1, None, 3), ("c", 320, 64, 1, 1, 30, 1, 0, None, 3),
+             ("d", 200, 120, 1, 1, 75, 0, 0, None, 3), ("e", 1024, 520, 1, 1, 95, 5, 0, None, 3)]
+    dec = G.Decoder(gpu_lib)  # (reads the switch)
+    for case in cases:
+        raw = O.noise(O.raw_size(case[1], case[2], case[3]), seed=case[1])
+        jpeg = O.encode(oracle_image(O, case), raw)
+        want = O.decode(jpeg, 3, 3)[0] if case[3] == 3 else O.decode(jpeg)[0]
+        dec.set_output_format(3, 3) if case[3] == 3 else dec.set_output_format(1, 1)  # (colour space, pixel format)
+        px, _ = dec.decode(jpeg)
+        assert np.array_equal(px, want), (shape, case[0])
+    dec.close()
+
+
 TOKEN_CASES = [
     # name, w, h, quality, restart, noise? (non-interleaved RGB 4:4:4: the configurations the token-fed IDCT serves)
     ("natural_auto", 1920, 136, 75, -1, False),

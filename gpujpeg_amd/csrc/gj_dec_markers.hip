@@ -76,34 +76,51 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
             if (lane == 63 && b + 16u < size) nx[it] = *reinterpret_cast<const uint32_t*>(jpeg + b + 16u);
         }
         __syncthreads(); // (s_blk, s_own_q of the round before are no longer read)
-        // ---- markers: bit b of rst[it] = byte b of the lane's 16 of piece it starts a restart marker; the restart markers' codes, 3 bits each
+        // ---- markers: bit b of rst[it] = byte b of the lane's 16 of piece it starts a restart marker; the restart markers' codes, 3 bits each.
+        // Byte classes for four bytes at a time, without a branch (a wave nearly always holds a 0xFF somewhere, so a "rare" path is taken
+        // for every dword): bit 7 of a byte of the masks below says "this byte is 0xFF / 0x00 / 0xD0..0xD7"; a marker is a 0xFF whose NEXT
+        // byte is neither 0x00 nor 0xFF (the masks of the next bytes: the same masks moved down by a byte, v_alignbit_b32).
         uint32_t rst[ITERS], num[ITERS], winc[ITERS];
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
-            const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)nx[it], (int)v[it].x, 0x130, 0xF, 0xF, false); // wave_shl:1: the next lane's first dword
-            const uint32_t w[5] = {v[it].x, v[it].y, v[it].z, v[it].w, lane == 63 ? nx[it] : next};
             const uint64_t b0 = round0 + 4096u * it + 16u * tid;
-            uint32_t r = 0, o = 0, nm = 0, nn = 0;
+            const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)nx[it], (int)v[it].x, 0x130, 0xF, 0xF, false); // wave_shl:1: the next lane's first dword
+            uint32_t w[5] = {v[it].x, v[it].y, v[it].z, v[it].w, lane == 63 ? nx[it] : next};
+            if (b0 < begin || b0 + 20u > size) { // the stream's first and last bytes: what lies outside is no 0xFF and follows none
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t x = w[q], xn = w[q + 1];
-                if ((~x - 0x01010101u) & x & 0x80808080u) { // 0xFF bytes are rare: one test for the four (a zero byte in ~x; a borrow can only add a false alarm)
+                for (int q = 0; q < 5; q++) {
+                    uint32_t keep = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const uint32_t b = (x >> (8 * k)) & 0xFFu;
-                        const uint32_t nb = k < 3 ? (x >> (8 * k + 8)) & 0xFFu : xn & 0xFFu;
                         const uint64_t p = b0 + (uint64_t)(4 * q + k);
-                        if (b == 0xFFu && nb != 0u && nb != 0xFFu && p >= begin && p + 1 < size) {
-                            if ((nb & 0xF8u) == 0xD0u) {
-                                r |= 1u << (4 * q + k);
-                                nm |= (nb & 7u) << (3u * nn);
-                                nn++;
-                            } else {
-                                o |= 1u << (4 * q + k);
-                            }
-                        }
+                        if (p >= begin && p < size) keep |= 0xFFu << (8 * k);
                     }
+                    w[q] &= keep;
                 }
+            }
+            uint32_t ff[5], zero[5], rc[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const uint32_t x = w[q], y = (x ^ 0xD0D0D0D0u) & 0xF8F8F8F8u;
+                ff[q] = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;
+                zero[q] = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+                rc[q] = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+            }
+            uint32_t r = 0, o = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t nplain = __builtin_amdgcn_alignbit(ff[q + 1] | zero[q + 1], ff[q] | zero[q], 8); // the next byte is 0x00 or 0xFF
+                const uint32_t nrst = __builtin_amdgcn_alignbit(rc[q + 1], rc[q], 8);                           // the next byte is 0xD0..0xD7
+                const uint32_t mk = ff[q] & ~nplain, mr = mk & nrst, mo = mk & ~nrst;
+                // bits 7, 15, 23, 31 -> 0 .. 3
+                r |= (((mr >> 7) | (mr >> 14) | (mr >> 21) | (mr >> 28)) & 0xFu) << (4 * q);
+                o |= (((mo >> 7) | (mo >> 14) | (mo >> 21) | (mo >> 28)) & 0xFu) << (4 * q);
+            }
+            uint32_t nm = 0, nn = 0;
+            for (uint32_t m = r; m; m &= m - 1, nn++) { // (a restart marker per ~170 bytes)
+                const uint32_t bit = (uint32_t)__builtin_ctz(m) + 1u, q = bit >> 2;
+                const uint32_t x = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : q == 3 ? w[3] : w[4];
+                nm |= ((x >> (8u * (bit & 3u))) & 7u) << (3u * nn);
             }
             rst[it] = r;
             num[it] = nm;
@@ -328,7 +345,10 @@ __global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uin
         // what the host validates about it
         hsum->other_pos[slot] = p;
         hsum->other_code[slot] = (uint8_t)s_ocode[slot];
-        for (int b = 0; b < 16; b++) hsum->other_bytes[slot][b] = (uint64_t)p + 2 + b < size ? jpeg[p + 2 + b] : 0;
+        uint32_t ob[4] = {0, 0, 0, 0}; // (whole words to the host's memory)
+        for (int b = 0; b < 16; b++)
+            if ((uint64_t)p + 2 + b < size) ob[b >> 2] |= (uint32_t)jpeg[p + 2 + b] << (8 * (b & 3));
+        for (int q = 0; q < 4; q++) reinterpret_cast<uint32_t*>(hsum->other_bytes[slot])[q] = ob[q];
         hsum->other_after[slot] = s_own_after[tid];
     }
     if (maxlen) atomicMax(&s_maxlen, maxlen);

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
         for (int t = tid; t < 4 * GJ_DEC2_WORDS / 8; t += 256) dst[t] = src[t];
     }
-    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 0; // (behind a block's end, damaged streams only: a token there lands on position 0, which the IDCT overwrites
+                                                          //  with the DC term, i.e. it is dropped like in the plane kernels; the plane path below asks pos < 64)
     const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
     const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
     const int si0 = blockIdx.x * NS;
@@ -300,11 +301,14 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
     __shared__ uint32_t s_pcomp[GJ_MAX_MCU_BLOCKS];
     __shared__ uint32_t s_sel[16];
     const int tid = threadIdx.x;
+    static_assert(GJ_MAX_MCU_BLOCKS >= 16, "the sixteen byte selectors below are set up by the lanes that set up the MCU's blocks");
     if (tid < GJ_MAX_MCU_BLOCKS) {
         const int pp = tid < g.blocks_per_mcu ? tid : 0;
         const int c = INTERLEAVED ? g.mcu_comp[pp] : 0;
         s_ptab[tid] = (uint32_t)((g.comp[c].dc_table * 2 + 0) * GJ_DEC2_WORDS) | ((uint32_t)((g.comp[c].ac_table * 2 + 1) * GJ_DEC2_WORDS) << 16);
         s_pcomp[tid] = (uint32_t)c;
+    }
+    if (tid < 16) {
         uint32_t sel = 0x0C0C0C0Cu; // (0x0C selects a zero byte)
         int at = 3;
         for (int k = 0; k < 4; k++)
@@ -316,7 +320,8 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
         uint4* dst = reinterpret_cast<uint4*>(s_tab);
         for (int t = tid; t < 4 * GJ_DEC2_WORDS / 8; t += 256) dst[t] = src[t];
     }
-    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    if (tid < 128) s_zz[tid] = tid < 64 ? GJ_ZZ[tid] : 0; // (behind a block's end, damaged streams only: a token there lands on position 0, which the IDCT overwrites
+                                                          //  with the DC term, i.e. it is dropped like in the plane kernels; the plane path below asks pos < 64)
     const uint32_t* const end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
     const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
     const int s = (int)blockIdx.x * 256 + tid;
@@ -439,7 +444,11 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
     // aligned 32-byte pieces -- 8-byte stores from 172 800 lanes at once kept two partial lines per lane open in the L2 and wrote 670 MB
     // for 86 MB of tokens and records. (A segment too short to leave room for the alignment keeps the 8-byte boundary it starts on.)
     const uint32_t tbase = len >= 6u ? (4u * pos + 15u) & ~15u : 4u * pos;
-    const bool tok_ok = 4u * pos <= tok_cap && 4u * len + 8u <= tok_cap - 4u * pos; // (always, with the capacity the host allocates)
+    bool tok_ok = 4u * pos <= tok_cap && 4u * len + 8u <= tok_cap - 4u * pos; // (always, with the capacity the host allocates)
+    // tokens the run may hold: the segment's share is 4 per stream byte (+ the restart marker's), of which the alignment took up to 15. A token
+    // costs 3 bits of stream with the standard tables, but a file with optimised tables may spend 2 (a 1-bit AC code + a magnitude bit):
+    // a run that would leave its share raises the overflow flag -- the host decodes the frame through the planes -- and stores nothing more
+    const uint32_t room = 4u * pos + 4u * len + 8u - tbase;
     uint32_t* const OT = s_out + tid * GJ_WIN_OUT;
     uint16_t* const OT16 = reinterpret_cast<uint16_t*>(OT);
     uint32_t ntok = 0, blk_first = 0, blk_dc = 0, mx = 0;
@@ -475,6 +484,10 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
                 const uint32_t tok = (((uint32_t)v << 6) | s_zz[z + adv - 1u]) & 0xFFFFu;
                 OT16[ntok & 15u] = (uint16_t)tok;
                 ntok++;
+                if ((ntok & 15u) == 0 && tok_ok && ntok > room) {
+                    tok_ok = false;
+                    *overflow = 1u;
+                }
                 if ((ntok & 15u) == 0 && tok_ok) { // sixteen tokens: one 32-byte piece (16-byte aligned when the run starts on the segment's own boundary)
                     uint32_t* dst = reinterpret_cast<uint32_t*>(d_tok + tbase + ntok - 16u);
                     if ((tbase & 7u) == 0) {
@@ -532,6 +545,10 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
                 toff = tdc;
                 if (left == 0) {
                     active = false;
+                    if (tok_ok && ntok > room) {
+                        tok_ok = false;
+                        *overflow = 1u;
+                    }
                     if (tok_ok && (ntok & 15u) != 0) { // the last one to fifteen tokens: as a whole piece when the segment's part of the array has room for it
                         if ((tbase & 7u) == 0 && tbase + ((ntok + 15u) & ~15u) <= 4u * pos + 4u * len + 8u) {
                             uint4* dst = reinterpret_cast<uint4*>(d_tok + tbase + (ntok & ~15u));

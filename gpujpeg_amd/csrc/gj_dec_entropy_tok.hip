@@ -149,7 +149,7 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
             const uint32_t mag = (x ^ neg) >> ((32u - sz) & 31u);       // the compiler would turn it into compare + 2 selects, which
             const int v = (int)((mag ^ neg) - neg);                     // issue at half the rate of these)
             if ((int16_t)e < 0) { // a non-zero AC coefficient
-                const uint32_t pos = z + adv - 1u; // (zz[64..127] = 63: damaged streams only)
+                const uint32_t pos = z + adv - 1u; // (zz[64..127] = 0: damaged streams only, see there)
                 if (MODE == 1) {
                     mx = max(mx, sz);
                     *tp++ = (uint16_t)(((uint32_t)v << 6) | sm.zz[pos]);
@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     GJ_TRACE(0);
-    if (tid < 128) sm.zz[tid] = tid < 64 ? GJ_ZZ[tid] : 63;
+    if (tid < 128) sm.zz[tid] = tid < 64 ? GJ_ZZ[tid] : 0; // (behind a block's end, damaged streams only: position 0, which the IDCT overwrites with the DC term -- the
+                                                            //  coefficient is dropped, as the plane kernels and the reference's GPU decoder do, src/gpujpeg_huffman_gpu_decoder.cu:370)
     if (tid == 0) sm.U[0] = 0;
     const uint32_t* end = reinterpret_cast<const uint32_t*>((reinterpret_cast<uintptr_t>(jpeg) + jpeg_size + 3) & ~(uintptr_t)3);
 

@@ -232,8 +232,6 @@ __device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint16_t* stage, c
     if (in_plane) { // block of a segment that was decoded piece by piece: it is in the coefficient plane
 #pragma unroll
         for (int r = 0; r < 8; r++) *gj_slot_row(slot, lane, r) = plane_block[r];
-    } else {
-        *reinterpret_cast<uint16_t*>(slot + ((lane & 7) << 4)) = (uint16_t)dc;
     }
     const uint32_t end = start + cnt;
     const uint32_t swz = ((uint32_t)lane & 7u) << 3;
@@ -299,6 +297,9 @@ __device__ __forceinline__ void gj_tok_to_slot(uint8_t* slot, uint16_t* stage, c
             }
         }
     }
+    // the DC term last: a token of a damaged stream that ran past its block's end sits on position 0 (the entropy decoders' zig-zag
+    // tables say so) and disappears here, like in the plane kernels
+    if (!in_plane) *reinterpret_cast<uint16_t*>(slot + ((lane & 7) << 4)) = (uint16_t)dc;
     gj_wave_sync(); // (the stage is rewritten by the next component)
 }
 

@@ -51,6 +51,9 @@ struct gpujpeg_decoder {
     /* header cache: a stream that starts with the same bytes (SOI .. first SOS header) as the previous one has the same
      * tables and geometry, so the call goes straight to the kernels and is validated after the fact */
     uint8_t* hdr_cache; uint8_t* d_hdr_cache; size_t hdr_cache_len; bool hdr_cache_valid;
+    bool need_planes; /* a frame with the cached header raised the entropy decoders' overflow flag (a segment too long for the LDS stage, a coefficient
+                         too large for a token): the following frames with that header go through the kernels without those limits at once,
+                         instead of being decoded twice each */
     struct gj_reader_result hdr_cache_r;
     bool tab2_ok;
 };
@@ -485,7 +488,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         job.d_blkrec = d->d_blkrec;
     }
     job.tune = d->tune;
-    job.tune.dec_careful = careful;
+    job.tune.dec_careful = careful || d->need_planes;
     /* bytes per scan: what the entropy decoder's batch sizes are cut to (luminance segments are 2-3 x the chrominance ones) */
     /* the word the entropy decoders raise when they meet a segment they cannot stage: in the host's (pinned, device-visible) summary */
     d->h_summary->seq_overflow = 0;
@@ -546,6 +549,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
                                                                walk, a table whose longest segment the host did not foresee) */
         GJ_DEBUG(c->param.verbose, "a restart segment did not fit the entropy decoder's LDS stage: decoding again through the coefficient planes\n");
         free(host_copy);
+        d->need_planes = true; /* (and so for the frames that follow with this header) */
         return decoder_decode(d, image, image_size, output, true);
     }
     if (spec) { /* now the summary of this stream is on the host: was it what we assumed? */
@@ -556,8 +560,9 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         for (int i = 0; ok && i < g->comp_count; i++)
             if (chk.huff_map[i][0] != r.huff_map[i][0] || chk.huff_map[i][1] != r.huff_map[i][1]) ok = false;
         if (!ok) { /* different header or unusual scan structure: decode again the careful way */
-            const bool overflow_only = d->h_summary->seq_overflow != 0;
-            d->hdr_cache_valid = false;
+            const bool overflow_only = d->h_summary->seq_overflow != 0 && d->h_summary->header_differs == 0;
+            if (overflow_only) d->need_planes = true; /* (the header was the assumed one: it stays cached, the next frames launch on it with the other kernels) */
+            else d->hdr_cache_valid = false;
             free(host_copy);
             return decoder_decode(d, image, image_size, output, overflow_only);
         }
@@ -572,6 +577,9 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         if (!d->hdr_cache) d->hdr_cache = malloc(GJ_HDR_WINDOW);
         if (!d->d_hdr_cache) d->d_hdr_cache = gj_hip_malloc(GJ_HDR_WINDOW);
         if (d->hdr_cache && d->d_hdr_cache) {
+            /* another header than the cached one: what was learnt about the old one's frames does not apply (unless this very call is the
+             * second attempt that learnt it) */
+            if (!careful && !(d->hdr_cache_len == n && memcmp(d->hdr_cache, himage, n) == 0)) d->need_planes = false;
             memcpy(d->hdr_cache, himage, n);
             if (gj_hip_memcpy_h2d(d->d_hdr_cache, d->hdr_cache, n, c->stream) == 0 && gj_hip_stream_sync(c->stream) == 0) {
                 d->hdr_cache_len = n;

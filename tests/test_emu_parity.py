@@ -90,6 +90,16 @@ def test_emu_marker_scan_shapes(O, G, emu_lib, shape, monkeypatch):
     T.test_marker_scan_shapes(O, G, emu_lib, shape, monkeypatch)
 
 
+@pytest.mark.parametrize("w,h,ri", [(640, 64, 5), (320, 40, 1)])
+def test_emu_dense_two_bit_tokens_all_decoder_paths(O, G, emu_lib, w, h, ri, monkeypatch):
+    T.test_dense_two_bit_tokens_all_decoder_paths(O, G, emu_lib, w, h, ri, monkeypatch)
+
+
+@pytest.mark.parametrize("layout", ["rgb444", "uyvy422"])
+def test_emu_damaged_streams_token_mode_equals_plane_mode(O, G, emu_lib, layout, monkeypatch):
+    T.test_damaged_streams_token_mode_equals_plane_mode(O, G, emu_lib, layout, monkeypatch)
+
+
 def test_emu_reuse_padding_and_reconfiguration(O, G, emu_lib):
     T.test_width_padding(O, G, emu_lib)
     T.test_decoder_reuse_without_clearing(O, G, emu_lib)

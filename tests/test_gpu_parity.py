@@ -502,6 +502,42 @@ def test_token_mode_damaged_streams(O, G, gpu_lib, monkeypatch):
     dec.close()
 
 
+@pytest.mark.parametrize("layout", ["rgb444", "uyvy422"])
+def test_damaged_streams_token_mode_equals_plane_mode(O, G, gpu_lib, layout, monkeypatch):
+    """What a damaged stream decodes to must not depend on the path the frame's size chooses: a coefficient whose run carries it past
+    the end of its block is dropped by every entropy decoder -- in token mode it becomes a token on position 0, which the IDCT
+    overwrites with the DC term --, as the reference's GPU decoder does (src/gpujpeg_huffman_gpu_decoder.cu:370). Bytes inside the
+    entropy-coded data are replaced (never by 0xFF: the marker structure stays), token mode and plane mode decode the same samples."""
+    w, h = (640, 368) if layout == "rgb444" else (1288, 120)
+    if layout == "rgb444":
+        case, fmt = ("d", w, h, 1, 1, 90, -1, 0, None, 3), (1, 1)
+        raw = natural_image(w, h, 3, seed=5)
+    else:
+        case, fmt = ("d", w, h, 3, 3, 90, -1, 1, None, 3), (3, 3)
+        raw = O.noise(O.raw_size(w, h, 3), seed=9)
+    jpeg = O.encode(oracle_image(O, case), raw)
+    rng = np.random.default_rng(23)
+    decs = []
+    for env in ({"GJ_DEC_TOKENS": "1"}, {"GJ_DEC_TOKENS": "1", "GJ_DEC_SEQ": "1"}, {"GJ_DEC_NO_TOKENS": "1"}):
+        for k in ("GJ_DEC_TOKENS", "GJ_DEC_SEQ", "GJ_DEC_NO_TOKENS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = G.Decoder(gpu_lib)
+        d.set_output_format(*fmt)
+        decs.append(d)
+    for trial in range(12):
+        bad = jpeg.copy()
+        for i in rng.integers(800, bad.size - 4, size=1 + trial):
+            if bad[i] != 0xFF and bad[i - 1] != 0xFF:
+                bad[i] = rng.integers(0, 255)
+        outs = [d.decode(bad)[0] for d in decs]
+        assert np.array_equal(outs[0], outs[2]), (layout, trial, "token mode vs planes")
+        assert np.array_equal(outs[1], outs[2]), (layout, trial, "lane-per-segment token mode vs planes")
+    for d in decs:
+        d.close()
+
+
 TOKEN_422_CASES = [
     # name, w, h, quality, restart, noise?  (packed 4:2:2 in and out, interleaved scan: k_idct_tok_uyvy422)
     ("natural_auto", 1920, 136, 90, -1, False),
@@ -550,6 +586,57 @@ def test_token_mode_decoder_422(O, G, gpu_lib, tc, monkeypatch):
 
 
 
+
+
+def dense_two_bit_stream(w, h, ri):
+    """A baseline JPEG (4:2:2, interleaved, restart interval `ri` MCUs) as an encoder with OPTIMISED Huffman tables may write it: the AC
+    symbol (run 0, size 1) has a 1-bit code, so a coefficient costs 2 bits of stream -- the densest stream of non-zero coefficients the
+    format allows (every AC coefficient of every block is +-1, DC differences 0). Returns the file's bytes."""
+    def seg(marker, payload):
+        return bytes([0xFF, marker]) + (len(payload) + 2).to_bytes(2, "big") + payload
+    out = bytearray(b"\xff\xd8")
+    out += seg(0xDB, bytes([0]) + bytes([1] * 64))                                  # one quantisation table, all ones
+    out += seg(0xC0, bytes([8]) + h.to_bytes(2, "big") + w.to_bytes(2, "big") + bytes([3, 1, 0x21, 0, 2, 0x11, 0, 3, 0x11, 0]))
+    # DC table: symbol 0 -> '0' (1 bit), symbol 1 -> '10'; AC table: 0x01 -> '0' (1 bit), 0x00 (EOB) -> '10', 0xF0 -> '110'
+    out += seg(0xC4, bytes([0x00]) + bytes([1, 1] + [0] * 14) + bytes([0, 1]))
+    out += seg(0xC4, bytes([0x10]) + bytes([1, 1, 1] + [0] * 13) + bytes([0x01, 0x00, 0xF0]))
+    out += seg(0xDD, ri.to_bytes(2, "big"))
+    out += seg(0xDA, bytes([3, 1, 0x00, 2, 0x00, 3, 0x00, 0, 63, 0]))
+    mcus = ((w + 15) // 16) * ((h + 7) // 8)
+    rng = np.random.default_rng(w + h)
+    for m0 in range(0, mcus, ri):
+        bits = []
+        for _ in range(min(ri, mcus - m0) * 4):
+            bits.append("0")                                                          # DC difference 0
+            signs = rng.integers(0, 2, 63)
+            bits.append("".join("0" + ("1" if s else "0") for s in signs))            # 63 x (run 0, size 1) + sign bit: +1 / -1
+        b = "".join(bits)
+        b += "1" * (-len(b) % 8)
+        data = int(b, 2).to_bytes(len(b) // 8, "big")
+        out += data.replace(b"\xff", b"\xff\x00")
+        if m0 + ri < mcus:
+            out += bytes([0xFF, 0xD0 + (m0 // ri) % 8])
+    out += b"\xff\xd9"
+    return np.frombuffer(bytes(out), np.uint8).copy()
+
+
+@pytest.mark.parametrize("w,h,ri", [(640, 64, 5), (320, 40, 1), (1024, 72, 2)])
+def test_dense_two_bit_tokens_all_decoder_paths(O, G, gpu_lib, w, h, ri, monkeypatch):
+    """A foreign file with optimised Huffman tables: coefficients of 2 bits each (a token of the decoder's token mode is assumed to cost
+    3 with the standard tables; 4 tokens per stream byte is what its array provides). Every entropy decoder, token and plane mode, must
+    give the oracle's samples (src/gpujpeg_huffman_gpu_decoder.cu:287-495 decodes any baseline table)."""
+    jpeg = dense_two_bit_stream(w, h, ri)
+    want = O.decode(jpeg, 3, 3)[0]
+    for env in ({}, {"GJ_DEC_TOKENS": "1"}, {"GJ_DEC_TOKENS": "1", "GJ_DEC_SEQ": "1"}, {"GJ_DEC_NO_TOKENS": "1"}, {"GJ_DEC_SEQ": "1"}, {"GJ_DEC_ENTROPY": "serial"}):
+        for k in ("GJ_DEC_TOKENS", "GJ_DEC_SEQ", "GJ_DEC_NO_TOKENS", "GJ_DEC_ENTROPY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dec = G.Decoder(gpu_lib)
+        dec.set_output_format(3, 3)
+        for _ in range(2):
+            assert np.array_equal(dec.decode(jpeg)[0], want), (w, h, ri, env)
+        dec.close()
 
 
 @pytest.mark.parametrize("seed", range(160))

@@ -127,46 +127,71 @@ static int tst_load(const char* filename, uint8_t** image, size_t* size)
     return 0;
 }
 
-/* ------------------------------------------------------------------ PNM / PAM */
-static int pnm_token(FILE* f, char* buf, size_t n)
-{
-    int c;
-    do {
-        c = fgetc(f);
-        if (c == '#') while ((c = fgetc(f)) != '\n' && c != EOF) {}
-    } while (c != EOF && isspace(c));
-    size_t i = 0;
-    while (c != EOF && !isspace(c) && i + 1 < n) { buf[i++] = (char)c; c = fgetc(f); }
-    buf[i] = '\0';
-    return i > 0 ? 0 : -1;
-}
+/* ------------------------------------------------------------------ PNM / PAM
+ * What is accepted, and with which result, follows the reference's reader to the letter (src/utils/pam.c:46-78 PAM header, :88-140 PNM
+ * header, :168-232 pam_read; tests/test_file_formats_vs_ref.py feeds both libraries the same files):
+ *  - the magic is the first three bytes: "P7\n" exactly, or 'P', a type and ONE white-space byte; P1..P3 (plain) are refused, P4 is parsed
+ *    (and then refused for its single level);
+ *  - PNM: decimal numbers separated by white space, `#` starts a comment wherever a number is expected, and the byte behind the last number
+ *    must be a NEW LINE (a file with CR LF line ends is refused);
+ *  - PAM: lines of at most 126 bytes; "ENDHDR\n" ends the header and so does any line without a blank (a file without ENDHDR "parses", its
+ *    samples then come up short); lines that begin with `#` and unknown keys are skipped;
+ *  - width, height, depth > 0, 0 < maxval <= 65535, and this library (like the reference's delegate, image_delegate.c:186-211) takes 255
+ *    levels and 1, 3 or 4 channels only. */
+struct pnm_header { int width, height, depth, maxval; bool bitmap; };
 
-static int pnm_read_header(FILE* f, int* w, int* h, int* depth, int* maxval)
+static int pnm_read_header(FILE* f, struct pnm_header* hd)
 {
-    char tok[64];
-    if (pnm_token(f, tok, sizeof tok) != 0) return -1;
-    if (strcmp(tok, "P5") == 0 || strcmp(tok, "P6") == 0) {
-        *depth = tok[1] == '5' ? 1 : 3;
-        if (pnm_token(f, tok, sizeof tok) != 0) return -1;
-        *w = atoi(tok);
-        if (pnm_token(f, tok, sizeof tok) != 0) return -1;
-        *h = atoi(tok);
-        if (pnm_token(f, tok, sizeof tok) != 0) return -1;
-        *maxval = atoi(tok);
-        if (*w <= 0 || *h <= 0 || *maxval <= 0) return -1;
-        return 0; /* exactly one whitespace byte was consumed after maxval */
-    }
-    if (strcmp(tok, "P7") == 0) {
-        *w = *h = *depth = *maxval = 0;
-        char line[256]; /* (pnm_token took the line end after the magic with it) */
-        while (fgets(line, sizeof line, f)) {
-            if (strncmp(line, "ENDHDR", 6) == 0) return (*w > 0 && *h > 0 && *depth > 0) ? 0 : -1;
-            if (sscanf(line, "WIDTH %d", w) == 1 || sscanf(line, "HEIGHT %d", h) == 1 || sscanf(line, "DEPTH %d", depth) == 1 ||
-                sscanf(line, "MAXVAL %d", maxval) == 1)
-                continue;
+    memset(hd, 0, sizeof *hd);
+    char magic[4] = {0};
+    if (!fgets(magic, sizeof magic, f)) magic[0] = '\0';
+    if (strcmp(magic, "P7\n") == 0) {
+        char line[128];
+        while (fgets(line, sizeof line - 1, f)) {
+            if (strcmp(line, "ENDHDR\n") == 0) break;
+            if (line[0] == '#') continue;
+            char* blank = strchr(line, ' ');
+            if (!blank) break;
+            *blank = '\0';
+            const int v = atoi(blank + 1);
+            if (strcmp(line, "WIDTH") == 0) hd->width = v;
+            else if (strcmp(line, "HEIGHT") == 0) hd->height = v;
+            else if (strcmp(line, "DEPTH") == 0) hd->depth = v;
+            else if (strcmp(line, "MAXVAL") == 0) hd->maxval = v;
+            else if (strcmp(line, "TUPLTYPE") != 0) fprintf(stderr, "unrecognized key %s in PAM header\n", line);
         }
+    } else if (strlen(magic) == 3 && magic[0] == 'P' && isspace((unsigned char)magic[2])) {
+        switch (magic[1]) {
+        case '1': case '2': case '3': fprintf(stderr, "Plain (ASCII) PNM are not supported, input is P%c\n", magic[1]); return -1;
+        case '4': hd->depth = 1; hd->maxval = 1; hd->bitmap = true; break;
+        case '5': hd->depth = 1; break;
+        case '6': hd->depth = 3; break;
+        default: fprintf(stderr, "Wrong PNM type P%c\n", magic[1]); return -1;
+        }
+        int item = 0;
+        bool complete = false;
+        while (!complete && !feof(f) && !ferror(f)) {
+            int v = 0;
+            if (fscanf(f, "%d", &v) == 1) {
+                if (item == 0) hd->width = v;
+                else if (item == 1) hd->height = v;
+                else hd->maxval = v;
+                item++;
+                complete = item == (hd->bitmap ? 2 : 3);
+            } else if (getc(f) == '#') {
+                int ch;
+                while ((ch = getc(f)) != '\n' && ch != EOF) {}
+            } else {
+                break;
+            }
+        }
+        if (!complete) { fprintf(stderr, "Problem parsing PNM header, number of hdr items successfully read: %d\n", item); return -1; }
+        if (getc(f) != '\n') { fprintf(stderr, "PNM maximal value isn't immediately followed by <NL>\n"); return -1; }
+    } else {
+        return -1;
     }
-    return -1;
+    if (hd->width <= 0 || hd->height <= 0 || hd->depth <= 0 || hd->maxval <= 0 || hd->maxval > 65535) return -1;
+    return 0;
 }
 
 static enum gpujpeg_pixel_format depth_pixfmt(int depth)
@@ -185,14 +210,16 @@ static int pnm_probe(const char* filename, struct gpujpeg_image_parameters* pi, 
     }
     FILE* f = fopen(filename, "rb");
     if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
-    int w, h, depth, maxval;
-    const int rc = pnm_read_header(f, &w, &h, &depth, &maxval);
+    struct pnm_header hd;
+    const int rc = pnm_read_header(f, &hd);
     fclose(f);
-    if (rc != 0 || maxval != 255 || depth_pixfmt(depth) == GPUJPEG_PIXFMT_NONE) { GJ_ERROR("Unsupported PNM/PAM file %s (8-bit, 1/3/4 channels expected)\n", filename); return -1; }
-    pi->width = w;
-    pi->height = h;
-    pi->color_space = depth == 1 ? GPUJPEG_YCBCR_JPEG : GPUJPEG_RGB;
-    pi->pixel_format = depth_pixfmt(depth);
+    if (rc != 0) { GJ_ERROR("File '%s' doesn't seem to be valid PAM or PNM.\n", filename); return -1; }
+    if (hd.maxval != 255) { GJ_ERROR("PAM/PNM image %s reports %d levels but only 255 are currently supported!\n", filename, hd.maxval); return -1; }
+    if (depth_pixfmt(hd.depth) == GPUJPEG_PIXFMT_NONE) { GJ_ERROR("Unsupported PAM/PNM component count %d!\n", hd.depth); return -1; }
+    pi->width = hd.width;
+    pi->height = hd.height;
+    pi->color_space = hd.depth == 1 ? GPUJPEG_YCBCR_JPEG : GPUJPEG_RGB;
+    pi->pixel_format = depth_pixfmt(hd.depth);
     return 0;
 }
 
@@ -200,9 +227,13 @@ static int pnm_load(const char* filename, uint8_t** image, size_t* size)
 {
     FILE* f = fopen(filename, "rb");
     if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
-    int w, h, depth, maxval;
-    if (pnm_read_header(f, &w, &h, &depth, &maxval) != 0 || maxval != 255) { fclose(f); GJ_ERROR("Unsupported PNM/PAM file %s\n", filename); return -1; }
-    const size_t n = (size_t)w * h * depth;
+    struct pnm_header hd;
+    if (pnm_read_header(f, &hd) != 0 || hd.maxval != 255 || depth_pixfmt(hd.depth) == GPUJPEG_PIXFMT_NONE) { /* (the reference aborts, image_delegate.c:151) */
+        fclose(f);
+        GJ_ERROR("Unsupported PNM/PAM file %s\n", filename);
+        return -1;
+    }
+    const size_t n = (size_t)hd.width * hd.height * hd.depth;
     if (*size != 0 && *size != n) GJ_WARN("Image size mismatch: expected %zu, file has %zu bytes\n", *size, n);
     uint8_t* data = gj_hip_host_alloc(n);
     if (!data || fread(data, 1, n, f) != n) { fclose(f); gj_hip_host_free(data); GJ_ERROR("Failed to load image data [%zu bytes] from file %s!\n", n, filename); return -1; }
@@ -212,43 +243,72 @@ static int pnm_load(const char* filename, uint8_t** image, size_t* size)
     return 0;
 }
 
+/* src/utils/image_delegate.c:214-253 + src/utils/pam.c:234-294: grey, RGB and (PAM only) RGBA of 255 levels; anything but grey must be RGB */
 static int pnm_save(const char* filename, enum gpujpeg_image_file_format fmt, const uint8_t* image, const struct gpujpeg_image_parameters* pi)
 {
+    if (pi->pixel_format != GPUJPEG_U8 && pi->color_space != GPUJPEG_RGB) {
+        GJ_ERROR("Wrong color space %s for PAM!\n", gpujpeg_color_space_get_name(pi->color_space));
+        return -1;
+    }
     const int depth = pi->pixel_format == GPUJPEG_U8 ? 1 : pi->pixel_format == GPUJPEG_444_U8_P012 ? 3 : pi->pixel_format == GPUJPEG_4444_U8_P0123 ? 4 : 0;
-    if (depth == 0 || (depth == 4 && fmt != GPUJPEG_IMAGE_FILE_PAM)) { GJ_ERROR("Pixel format %s cannot be stored in this file type\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1; }
+    if (depth == 0) {
+        GJ_ERROR("Wrong pixel format %s for PAM/PNM! Only packed formats without subsampling are supported.\n", gpujpeg_pixel_format_get_name(pi->pixel_format));
+        return -1;
+    }
     FILE* f = fopen(filename, "wb");
     if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
-    if (fmt == GPUJPEG_IMAGE_FILE_PAM)
+    if (fmt == GPUJPEG_IMAGE_FILE_PAM) {
         fprintf(f, "P7\nWIDTH %d\nHEIGHT %d\nDEPTH %d\nMAXVAL 255\nTUPLTYPE %s\nENDHDR\n", pi->width, pi->height, depth,
                 depth == 1 ? "GRAYSCALE" : depth == 3 ? "RGB" : "RGB_ALPHA");
-    else
+    } else {
+        if (depth == 4) { /* (the reference creates the file first and leaves it empty, pam.c:246-251) */
+            GJ_ERROR("Only 1 or 3 channels supported for PNM!\n");
+            fclose(f);
+            return -1;
+        }
         fprintf(f, "P%d\n%d %d\n255\n", depth == 1 ? 5 : 6, pi->width, pi->height);
+    }
     const size_t line = (size_t)pi->width * depth;
     for (int y = 0; y < pi->height; y++) fwrite(image + (size_t)y * (line + pi->width_padding), 1, line, f);
     fclose(f);
     return 0;
 }
 
-/* ------------------------------------------------------------------ Y4M (8-bit planar) */
+/* ------------------------------------------------------------------ Y4M (8-bit planar)
+ * Reader after src/utils/y4m.c:42-75, 99-160: white-space separated tokens -- "YUV4MPEG2", then W<n>, H<n>, C<chroma>, X... until the token
+ * FRAME, which must be followed by a NEW LINE at once (frame parameters are refused). The chroma tag is required: "mono", "444alpha" (refused
+ * by the delegate, image_delegate.c:289-291) or a number with an optional p<depth> (420, 422, 444; "420jpeg" reads as 420; more than 8 bits are
+ * refused). The range is FULL unless XCOLORRANGE=LIMITED says otherwise. */
 static int y4m_read_header(FILE* f, int* w, int* h, enum gpujpeg_pixel_format* pf, bool* limited)
 {
-    char line[512];
-    if (!fgets(line, sizeof line, f) || strncmp(line, "YUV4MPEG2", 9) != 0) return -1;
-    *pf = GPUJPEG_420_U8_P0P1P2;
-    *limited = true;
-    for (char* t = strtok(line + 9, " \n"); t; t = strtok(NULL, " \n")) {
-        if (t[0] == 'W') *w = atoi(t + 1);
-        else if (t[0] == 'H') *h = atoi(t + 1);
-        else if (t[0] == 'C') {
-            if (strncmp(t + 1, "444", 3) == 0) *pf = GPUJPEG_444_U8_P0P1P2;
-            else if (strncmp(t + 1, "422", 3) == 0) *pf = GPUJPEG_422_U8_P0P1P2;
-            else if (strncmp(t + 1, "420", 3) == 0) *pf = GPUJPEG_420_U8_P0P1P2;
-            else if (strncmp(t + 1, "mono", 4) == 0) *pf = GPUJPEG_U8;
-            else return -1;
-            if (strstr(t, "p1") || strstr(t, "p9") == t + 4) return -1; /* high bit depth */
-        } else if (strncmp(t, "XCOLORRANGE=FULL", 16) == 0) *limited = false;
+    char item[129];
+    if (fscanf(f, "%128s", item) != 1 || strcmp(item, "YUV4MPEG2") != 0) return -1;
+    int subsampling = 0, depth = 0;
+    bool alpha = false;
+    *w = *h = 0;
+    *limited = false;
+    while (fscanf(f, " %128s", item) == 1 && strcmp(item, "FRAME") != 0) {
+        if (item[0] == 'W') *w = atoi(item + 1);
+        else if (item[0] == 'H') *h = atoi(item + 1);
+        else if (item[0] == 'C') {
+            depth = 8;
+            alpha = false;
+            if (strcmp(item + 1, "444alpha") == 0) alpha = true;
+            else if (strncmp(item + 1, "mono", 4) == 0) { subsampling = 400; sscanf(item + 1, "mono%d", &depth); }
+            else if (sscanf(item + 1, "%dp%d", &subsampling, &depth) == 0) return -1;
+        } else if (strcmp(item, "XCOLORRANGE=LIMITED") == 0) *limited = true;
     }
-    return (*w > 0 && *h > 0) ? 0 : -1;
+    if (getc(f) != '\n') return -1; /* behind FRAME */
+    if (alpha) { GJ_ERROR("[y4m] Planar YCbCr with alpha is not currently supported!\n"); return -1; }
+    switch (subsampling) {
+    case 400: *pf = GPUJPEG_U8; break;
+    case 420: *pf = GPUJPEG_420_U8_P0P1P2; break;
+    case 422: *pf = GPUJPEG_422_U8_P0P1P2; break;
+    case 444: *pf = GPUJPEG_444_U8_P0P1P2; break;
+    default: fprintf(stderr, "Unsupported subsampling '%d'\n", subsampling); return -1;
+    }
+    if (depth != 8) { GJ_ERROR("Currently only 8-bit Y4M pictures are supported but the file has %d bits!\n", depth); return -1; }
+    return 0;
 }
 
 static int y4m_probe(const char* filename, struct gpujpeg_image_parameters* pi, int file_exists)
@@ -261,9 +321,14 @@ static int y4m_probe(const char* filename, struct gpujpeg_image_parameters* pi, 
     FILE* f = fopen(filename, "rb");
     if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
     bool limited;
-    const int rc = y4m_read_header(f, &pi->width, &pi->height, &pi->pixel_format, &limited);
+    int w, h;
+    enum gpujpeg_pixel_format pf;
+    const int rc = y4m_read_header(f, &w, &h, &pf, &limited);
     fclose(f);
     if (rc != 0) { GJ_ERROR("Unsupported Y4M file %s\n", filename); return -1; }
+    pi->width = w;
+    pi->height = h;
+    pi->pixel_format = pf;
     pi->color_space = limited ? GPUJPEG_YCBCR_BT601 : GPUJPEG_YCBCR_BT601_256LVLS; /* src/utils/image_delegate.c:297 */
     return 0;
 }
@@ -274,8 +339,7 @@ static int y4m_load(const char* filename, uint8_t** image, size_t* size)
     if (!f) { GJ_ERROR("Failed open %s for reading: %s\n", filename, strerror(errno)); return -1; }
     struct gpujpeg_image_parameters pi = gpujpeg_default_image_parameters();
     bool limited;
-    char line[64];
-    if (y4m_read_header(f, &pi.width, &pi.height, &pi.pixel_format, &limited) != 0 || !fgets(line, sizeof line, f) || strncmp(line, "FRAME", 5) != 0) {
+    if (y4m_read_header(f, &pi.width, &pi.height, &pi.pixel_format, &limited) != 0 || pi.width <= 0 || pi.height <= 0) {
         fclose(f);
         GJ_ERROR("Unsupported Y4M file %s\n", filename);
         return -1;
@@ -289,19 +353,22 @@ static int y4m_load(const char* filename, uint8_t** image, size_t* size)
     return 0;
 }
 
+/* src/utils/image_delegate.c:308-338 + src/utils/y4m.c:162-209: planar YCbCr (any colour space but RGB; limited range unless it is the
+ * full-range BT.601 one), one frame */
 static int y4m_save(const char* filename, const uint8_t* image, size_t size, const struct gpujpeg_image_parameters* pi)
 {
+    if (pi->color_space == GPUJPEG_RGB) { GJ_ERROR("Y4M cannot use RGB colorspace!\n"); return -1; }
     const char* c;
     switch (pi->pixel_format) {
     case GPUJPEG_444_U8_P0P1P2: c = "444"; break;
     case GPUJPEG_422_U8_P0P1P2: c = "422"; break;
     case GPUJPEG_420_U8_P0P1P2: c = "420"; break;
     case GPUJPEG_U8: c = "mono"; break;
-    default: GJ_ERROR("Y4M needs a planar pixel format, not %s\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1;
+    default: GJ_ERROR("Wrong pixel format %s for Y4M! Only planar formats are supported.\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1;
     }
     FILE* f = fopen(filename, "wb");
     if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
-    fprintf(f, "YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C%s XCOLORRANGE=%s\nFRAME\n", pi->width, pi->height, c,
+    fprintf(f, "YUV4MPEG2 W%d H%d F25:1 Ip A0:0 C%s XCOLORRANGE=%s\nFRAME\n", pi->width, pi->height, c,
             pi->color_space == GPUJPEG_YCBCR_JPEG ? "FULL" : "LIMITED");
     fwrite(image, 1, size, f);
     fclose(f);
@@ -497,61 +564,110 @@ int gpujpeg_amd_read_raster_file(const char* filename, uint8_t* dst, size_t capa
 static void wr16(uint8_t* p, unsigned v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
 static void wr32(uint8_t* p, uint32_t v) { wr16(p, v & 0xFFFF); wr16(p + 2, v >> 16); }
 
+/* BMP and TGA as the reference writes them -- it hands both to stb_image_write (src/utils/image_delegate.c:476-515), and a drop-in CLI
+ * should leave the same files behind (tests/test_file_formats_vs_ref.py compares the bytes). Restated from that writer's behaviour
+ * (src/utils/stb_image_write.h:492-507, 532-612):
+ *   BMP  bottom-up, B G R; one and three channels as 24 bits with rows padded to four bytes behind a 14 + 40 byte header whose size-of-image
+ *        and resolution fields are zero; four channels as 32 bits with BI_BITFIELDS masks in a 108-byte V4 header;
+ *   TGA  run-length coded (types 10 / 11), bottom-up, origin bottom-left, B G R (A); a row is cut into packets of at most 128 pixels: a
+ *        run packet where a pixel repeats, otherwise a raw packet that is extended while pixel k differs from pixel k - 2 (sic) and
+ *        gives its last pixel back when it does not.
+ * The channel count is the pixel format's component count, as in the reference (a planar 4:4:4 image is written as if it were packed);
+ * formats whose buffer is smaller than width x height x components are refused (the reference reads past the buffer). */
+static void tga_pixel(FILE* f, const uint8_t* d, int c)
+{
+    if (c == 1) { fputc(d[0], f); return; }
+    fputc(d[2], f); fputc(d[1], f); fputc(d[0], f);
+    if (c == 4) fputc(d[3], f);
+}
+
 static int raster_save(const char* filename, enum gpujpeg_image_file_format fmt, const uint8_t* image, const struct gpujpeg_image_parameters* pi)
 {
-    const int c = pi->pixel_format == GPUJPEG_U8 ? 1 : pi->pixel_format == GPUJPEG_444_U8_P012 ? 3 : pi->pixel_format == GPUJPEG_4444_U8_P0123 ? 4 : 0;
-    if (c == 0) { GJ_ERROR("Pixel format %s cannot be stored in this file type\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1; }
     if (fmt == GPUJPEG_IMAGE_FILE_GIF) { /* src/utils/image_delegate.c:492-495 */
         GJ_ERROR("[stbi] Only gif decoder is present, the encoder is not supported!\n");
         return -1;
     }
+    const int c = gpujpeg_pixel_format_get_comp_count(pi->pixel_format);
+    const int w = pi->width, h = pi->height;
+    if (c != 1 && c != 3 && c != 4) { GJ_ERROR("Pixel format %s cannot be stored in this file type\n", gpujpeg_pixel_format_get_name(pi->pixel_format)); return -1; }
+    if (gpujpeg_image_calculate_size((struct gpujpeg_image_parameters*)pi) < (size_t)w * h * c) {
+        GJ_ERROR("Pixel format %s (subsampled) cannot be stored in this file type\n", gpujpeg_pixel_format_get_name(pi->pixel_format));
+        return -1;
+    }
+    const size_t spitch = (size_t)w * c + pi->width_padding;
     if (fmt == GPUJPEG_IMAGE_FILE_PNG) {
-        if (gj_png_save(filename, image, pi->width, pi->height, c, (size_t)pi->width * c + pi->width_padding) != 0) {
+        if (gj_png_save(filename, image, w, h, c, spitch) != 0) {
             GJ_ERROR("[stbi] Cannot write output file %s\n", filename);
             return -1;
         }
         return 0;
     }
     FILE* f = fopen(filename, "wb");
-    if (!f) { GJ_ERROR("Failed open %s for writing: %s\n", filename, strerror(errno)); return -1; }
-    const int w = pi->width, h = pi->height;
-    const size_t spitch = (size_t)w * c + pi->width_padding;
-    if (fmt == GPUJPEG_IMAGE_FILE_BMP) { /* 24 bit (grey replicated) or 32 bit, bottom-up, uncompressed */
-        const int oc = c == 4 ? 4 : 3;
-        const size_t pitch = (((size_t)w * oc * 8 + 31) / 32) * 4;
-        uint8_t hdr[54] = {'B', 'M'};
-        wr32(hdr + 2, (uint32_t)(54 + pitch * h)); wr32(hdr + 10, 54); wr32(hdr + 14, 40);
-        wr32(hdr + 18, (uint32_t)w); wr32(hdr + 22, (uint32_t)h); wr16(hdr + 26, 1); wr16(hdr + 28, (unsigned)oc * 8);
-        wr32(hdr + 34, (uint32_t)(pitch * h)); wr32(hdr + 38, 2835); wr32(hdr + 42, 2835);
-        fwrite(hdr, 1, 54, f);
-        uint8_t* row = calloc(1, pitch);
-        for (int y = h - 1; y >= 0 && row; y--) {
+    if (!f) { GJ_ERROR("[stbi] Cannot write output file %s: %s\n", filename, strerror(errno)); return -1; }
+    if (fmt == GPUJPEG_IMAGE_FILE_BMP) {
+        const int pad = c == 4 ? 0 : (-w * 3) & 3;
+        const uint32_t hdr_size = c == 4 ? 108u : 40u, data_size = c == 4 ? (uint32_t)w * h * 4u : (uint32_t)(w * 3 + pad) * (uint32_t)h;
+        uint8_t hdr[14 + 108] = {'B', 'M'};
+        wr32(hdr + 2, 14u + hdr_size + data_size);
+        wr32(hdr + 10, 14u + hdr_size);
+        wr32(hdr + 14, hdr_size);
+        wr32(hdr + 18, (uint32_t)w);
+        wr32(hdr + 22, (uint32_t)h);
+        wr16(hdr + 26, 1);
+        wr16(hdr + 28, c == 4 ? 32 : 24);
+        if (c == 4) { /* BI_BITFIELDS: red, green, blue, alpha masks */
+            wr32(hdr + 30, 3);
+            wr32(hdr + 54, 0x00FF0000u); wr32(hdr + 58, 0x0000FF00u); wr32(hdr + 62, 0x000000FFu); wr32(hdr + 66, 0xFF000000u);
+        }
+        fwrite(hdr, 1, 14 + hdr_size, f);
+        const uint8_t zero[4] = {0, 0, 0, 0};
+        for (int y = h - 1; y >= 0; y--) {
             const uint8_t* s = image + (size_t)y * spitch;
             for (int x = 0; x < w; x++) {
-                const uint8_t r = s[x * c], g = c == 1 ? r : s[x * c + 1], b = c == 1 ? r : s[x * c + 2];
-                row[x * oc] = b; row[x * oc + 1] = g; row[x * oc + 2] = r;
-                if (oc == 4) row[x * 4 + 3] = s[x * 4 + 3];
+                const uint8_t* d = s + (size_t)x * c;
+                if (c == 1) { fputc(d[0], f); fputc(d[0], f); fputc(d[0], f); }
+                else { fputc(d[2], f); fputc(d[1], f); fputc(d[0], f); if (c == 4) fputc(d[3], f); }
             }
-            fwrite(row, 1, pitch, f);
+            fwrite(zero, 1, (size_t)pad, f);
         }
-        free(row);
-    } else { /* TGA type 2 / 3, uncompressed, top-left origin */
+    } else {
         uint8_t hdr[18] = {0};
-        hdr[2] = c == 1 ? 3 : 2;
-        wr16(hdr + 12, (unsigned)w); wr16(hdr + 14, (unsigned)h);
+        hdr[2] = (uint8_t)((c == 1 ? 3 : 2) + 8);
+        wr16(hdr + 12, (unsigned)w);
+        wr16(hdr + 14, (unsigned)h);
         hdr[16] = (uint8_t)(c * 8);
-        hdr[17] = (uint8_t)(0x20 | (c == 4 ? 8 : 0));
+        hdr[17] = c == 4 ? 8 : 0;
         fwrite(hdr, 1, 18, f);
-        uint8_t* row = malloc((size_t)w * c);
-        for (int y = 0; y < h && row; y++) {
-            const uint8_t* s = image + (size_t)y * spitch;
-            for (int x = 0; x < w; x++) {
-                if (c == 1) row[x] = s[x];
-                else { row[x * c] = s[x * c + 2]; row[x * c + 1] = s[x * c + 1]; row[x * c + 2] = s[x * c]; if (c == 4) row[x * 4 + 3] = s[x * 4 + 3]; }
+        for (int y = h - 1; y >= 0; y--) {
+            const uint8_t* row = image + (size_t)y * spitch;
+            int len;
+            for (int i = 0; i < w; i += len) {
+                const uint8_t* begin = row + (size_t)i * c;
+                bool raw = true;
+                len = 1;
+                if (i < w - 1) {
+                    len = 2;
+                    raw = memcmp(begin, begin + c, (size_t)c) != 0;
+                    for (int k = i + 2; k < w && len < 128; k++) {
+                        const uint8_t* px = row + (size_t)k * c;
+                        if (raw) {
+                            if (memcmp(px - 2 * (size_t)c, px, (size_t)c) != 0) len++;
+                            else { len--; break; }
+                        } else {
+                            if (memcmp(begin, px, (size_t)c) == 0) len++;
+                            else break;
+                        }
+                    }
+                }
+                if (raw) {
+                    fputc(len - 1, f);
+                    for (int k = 0; k < len; k++) tga_pixel(f, begin + (size_t)k * c, c);
+                } else {
+                    fputc((uint8_t)(len - 129), f);
+                    tga_pixel(f, begin, c);
+                }
             }
-            fwrite(row, 1, (size_t)w * c, f);
         }
-        free(row);
     }
     fclose(f);
     return 0;

@@ -29,7 +29,7 @@ def asan_env():
 
 
 def _run(env, args, timeout=900):
-    r = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    r = subprocess.run([sys.executable] + args, capture_output=True, text=True, errors="replace", timeout=timeout, env=env, cwd=ROOT)
     tail = (r.stdout[-1500:] + "\n" + "\n".join(ln for ln in r.stderr.splitlines() if not ln.startswith("[GPUJPEG]"))[-3000:])
     assert r.returncode == 0, tail
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, tail

@@ -16,11 +16,16 @@ On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --
                     JPEG in + raw out for the decoder) / its average hipEvent duration in a SOLO timed region (one pipeline, the GPU
                     otherwise idle, events on the coder's own stream) against 8 TB/s; `by_kernel` has every kernel of the step,
                     `contended` the same kernel inside the headline region where four pipelines share the GPU; `traffic` = HBM bytes
-                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r3_traffic.json; dropped when the
+                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r4_traffic.json; dropped when the
                     device sources differ from the ones profiled)
   encode_only / decode_only   each direction alone, device resident ("w/o PCIe" in the reference's tables)
   full_api          host buffers in and out (pinned), i.e. what a drop-in caller of the reference API sees, PCIe included
-  workloads         HD / 4K / 8K / 16K RGB, 16K 4:2:2 interleaved q90 (BASELINE config 4), 256 x 4K batch (config 5)
+  workloads         HD / 4K / 8K / 16K RGB, 16K 4:2:2 interleaved q90 (BASELINE config 4), each with its own roofline; the 8K frame with the
+                    reference's own contents: `8k_noise` (7680x4320.random_12345.tst), `8k_gradient` (7680x4320.gradient.tst), `8k_camera`
+                    (its camera sample, tests/golden/make_camera_fixture.py); 256 x 4K batch (config 5) resident in HBM (`batch256_4k`) and
+                    from pinned host memory in and out (`batch256_4k_host`)
+The timed regions run with perf_stats = 0 (no per-kernel events); per-kernel durations come from their own short regions. The launch
+threads are bound to cores of the GPU's NUMA node (--no-pin leaves them to the scheduler).
   cpu_baseline      the reference's CPU path as it exists (its host C with the CPU Huffman coders) + the restated scalar stages for
                     what it only has as CUDA, one thread, on a bounded sample; `idct_cpu_s` = its own gpujpeg_idct_cpu on the same frame
   cpu_baseline_all_cores      the same with one frame per process on the host's cores (-O3 -march=native build)
@@ -54,7 +59,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 DTYPE_DETAIL = "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients"
 
 
-TRAFFIC_FILE = "r3_traffic.json"
+TRAFFIC_FILE = "r4_traffic.json"
 
 
 from gpujpeg_amd.source_hash import kernel_source_hash  # noqa: E402
@@ -62,7 +67,7 @@ from gpujpeg_amd.source_hash import kernel_source_hash  # noqa: E402
 
 def load_traffic(key="kernels", workload="8k"):
     """HBM bytes per launch (`kernels`) / vector instructions per launch (`valu_insts`) of a workload from the committed PMC passes
-    (profiles/r3_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
+    (profiles/r4_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
         if d.get("source_hash") != kernel_source_hash():
@@ -76,14 +81,14 @@ def load_traffic(key="kernels", workload="8k"):
 # cycles when it is a plain add / sub / and / or / xor / mov / not / ashr / fp32 mul-add-fma and for ~4.3 cycles otherwise (shifts, bit-field,
 # compare, select, convert, packed-fp32, three-operand integer: tools/ubench/valu_rate.hip on this GPU, profiles/r2_09_ubench.txt). The
 # issue floor of a kernel = SQ_INSTS_VALU per launch (PMC pass) x the cycles of its class mix (static mix of the kernel's code,
-# tools/isa_loops.py --mix -> profiles/r3_isa_mix.json) / 1024 SIMDs / 2.4 GHz; the floors with every instruction in the fast and in
+# tools/isa_loops.py --mix -> profiles/r4_isa_mix.json) / 1024 SIMDs / 2.4 GHz; the floors with every instruction in the fast and in
 # the slow class bracket it.
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def load_isa_mix():
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r3_isa_mix.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r4_isa_mix.json")))
         return d["cycles"], {k: v["whole"]["share4"] for k, v in d["kernels"].items()}
     except Exception:
         return {"valu2": 2.4, "valu4": 4.3}, {}
@@ -95,6 +100,8 @@ def synth_frame(lib, width, height, pattern, seed, device):
     noise / gradient: the reference's own `.tst` generators (src/utils/image_delegate.c:562-603: the 1664525 / 1013904223 LCG
               with seed `seed`, and rows of i * 255 / H) through gpujpeg_image_load_from_file, so the numbers can be reproduced
               with `gpujpegtool WxH.random_<seed>.tst`"""
+    if pattern == "camera":
+        return camera_frame(lib, width, height, device)
     if pattern in ("noise", "gradient"):
         name = f"{width}x{height}.{'random_%d' % seed if pattern == 'noise' else 'gradient'}.tst".encode()
         img, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
@@ -116,6 +123,25 @@ def synth_frame(lib, width, height, pattern, seed, device):
         nz = 3.0 * torch.randn((height, width), device=device, generator=g)
         chans.append((base + tex + nz).clamp(0, 255).to(torch.uint8))
     return torch.stack(chans, -1).contiguous()
+
+
+DATA_NOTE = {"natural": "synthetic photograph-like frame generated on the device (synth_frame)",
+             "noise": "the reference's {w}x{h}.random_12345.tst (src/utils/image_delegate.c:562-603)",
+             "gradient": "the reference's {w}x{h}.gradient.tst (src/utils/image_delegate.c:562-603)",
+             "camera": "the reference's camera sample colors/camera_bt709_422.yuv (HD), decoded to RGB once and tiled to {w}x{h}"}
+CAMERA_FIXTURE = os.path.join(ROOT, "tests", "golden", "camera_bt709_422_q95.jpg")
+
+
+def camera_frame(lib, width, height, device):
+    """camera: the reference's camera sample (colors/camera_bt709_422.yuv, one HD frame; committed as a q95 JPEG by
+    tests/golden/make_camera_fixture.py), decoded ONCE to RGB with the product's decoder and tiled to the size of the workload"""
+    jpeg = np.fromfile(CAMERA_FIXTURE, np.uint8)
+    d = G.Decoder(lib)
+    px, pi = d.decode(jpeg)
+    d.close()
+    tile = torch.from_numpy(px.reshape(pi.height, pi.width, 3).copy()).to(device)
+    reps = (-(-height // pi.height), -(-width // pi.width), 1)
+    return tile.repeat(*reps)[:height, :width].contiguous()
 
 
 def to_uyvy(frame):
@@ -149,6 +175,8 @@ class Spec:
             p.interleaved = 1
             lib.L.gpujpeg_parameters_chroma_subsampling(C.byref(p), G.SUBSAMPLING_422)
         self.p, self.pi = p, pi
+        self.p_quiet = type(p).from_buffer_copy(p)  # the timed regions run without the per-kernel events (perf_stats = 0)
+        self.p_quiet.perf_stats = 0
         self.pixels = self.width * self.height
         self.raw_bytes = self.pixels * (2 if self.is422 else 3)
 
@@ -158,15 +186,47 @@ class Spec:
         return f"{self.width}x{self.height} RGB 4:4:4 q{self.quality} non-interleaved, restart auto"
 
 
+_PIN = {"cpus": None}  # cores of this rank's launch threads (gpujpeg_amd.sharding.plan_affinity), None = leave the scheduler alone
+
+
+def plan_pinning(local_rank, local_world, threads, ndev):
+    """The launch threads of this rank go to cores of the NUMA node of its GPU, disjoint from the other ranks of the node."""
+    from gpujpeg_amd.sharding import gpu_local_cpus, plan_affinity
+    near = []
+    for r in range(local_world):
+        pr = torch.cuda.get_device_properties(r % ndev)
+        try:
+            near.append(gpu_local_cpus("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)))
+        except AttributeError:
+            near.append(None)
+    _PIN["cpus"] = plan_affinity(local_rank, local_world, threads, sorted(os.sched_getaffinity(0)), near)
+    return {"launch_thread_cpus": _PIN["cpus"], "gpu_numa_cpus_known": near[local_rank] is not None,
+            "note": "each launch thread (one per pipeline) is bound to one core of the NUMA node of its GPU; ranks of one node take disjoint cores"}
+
+
+def pin_worker(idx):
+    if _PIN["cpus"]:
+        from gpujpeg_amd.sharding import pin_current_thread
+        pin_current_thread(_PIN["cpus"][idx % len(_PIN["cpus"])])
+
+
 _STREAMS = {}
-_PREROLLED = set()
-PREROLL_FRAMES = 320  # per pipeline, see measure()
+
+
+def settle_interpreter():
+    """Round 3 saw every pipeline stall for 35-70 ms once, ~1000 frames into a process, and blamed the HIP runtime. It is this interpreter:
+    the ctypes calls of the launch threads allocate a dozen collector-tracked objects per frame, the ~14 000th allocation starts CPython's
+    first generation-2 collection, and with `import torch` alive that pass walks 170 000 objects holding the GIL (profiles/r4_07_halt_root_cause.txt:
+    33-45 ms, no HIP call in flight in any thread, gone with gc.freeze()). So: collect once, then move everything imported so far to the
+    permanent generation. The collector stays on; its passes now see only what the benchmark itself allocates."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
 
 
 def lane_stream(device, index):
-    """one HIP stream per pipeline index, made once per process and reused by every workload: each NEW stream pays the runtime's one-off
-    all-queue halt (see measure()) a few hundred frames in, which used to land inside the short timed regions of the later workloads
-    (HD 18 -> 33 Gpix/s, 4K 62 -> 89 with nothing else changed)"""
+    """one HIP stream per pipeline index, made once per process and reused by every workload (a caller of the library keeps its streams too)"""
     key = (str(device), index)
     if key not in _STREAMS:
         _STREAMS[key] = torch.cuda.Stream(device)
@@ -178,6 +238,7 @@ class Lanes:
 
     def __init__(self, lib, spec, device, streams, host_io=False, keep_coefs=False):
         self.lib, self.spec, self.device, self.host_io = lib, spec, device, host_io
+        self.p = spec.p
         self.lanes = []
         for si in range(max(1, streams)):
             ts = lane_stream(device, si)
@@ -205,9 +266,17 @@ class Lanes:
             inp = G.EncoderInput()
             inp.type, inp.image = G.ENCODER_INPUT_IMAGE, ln["frame"].data_ptr()
             out, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
-            assert self.lib.L.gpujpeg_encoder_encode(ln["enc"].h, C.byref(sp.p), C.byref(sp.pi), C.byref(inp), C.byref(out), C.byref(size)) == 0
+            assert self.lib.L.gpujpeg_encoder_encode(ln["enc"].h, C.byref(self.p), C.byref(sp.pi), C.byref(inp), C.byref(out), C.byref(size)) == 0
             return out, size.value
-        return ln["enc"].encode_noclone(sp.p, sp.pi, ln["frame"].data_ptr(), gpu=True)
+        return ln["enc"].encode_noclone(self.p, sp.pi, ln["frame"].data_ptr(), gpu=True)
+
+    def set_stats(self, on):
+        """perf_stats of every coder (the encoder reads it from the parameters of each call, the decoder from gpujpeg_decoder_init; neither
+        reconfigures for it, src/gpujpeg_common.c:632-637)"""
+        self.p = self.spec.p if on else self.spec.p_quiet
+        for ln in self.lanes:
+            ln["dec"].init(self.p, self.lib.default_image_parameters())
+        self.warm(1)
 
     def decode(self, ln, jp, js):
         o = G.DecoderOutput()
@@ -242,8 +311,11 @@ class Lanes:
         walls = [0.0, 0.0]
         kms = np.zeros(9)
 
+        stats = bool(self.p.perf_stats)
+
         def worker(idx):
             torch.cuda.set_device(local_rank)  # the HIP device is per host thread
+            pin_worker(idx)
             ln = self.lanes[idx]
             go.wait()
             jp, js = ln["last"]
@@ -258,6 +330,8 @@ class Lanes:
                 if idx == 0:
                     walls[0] += b - a
                     walls[1] += c - b
+                    if not stats:
+                        continue
                     if mode != "decode":
                         kms[:5] += np.array(ln["enc"].kernel_times())
                     if mode != "encode":
@@ -299,20 +373,19 @@ def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, step
     sync = lambda: torch.cuda.synchronize()
     L.warm(2)  # buffers allocated, tables uploaded, a stream for the decoders to start from
     solo = L.solo_kernel_ms() if want_solo else None
+    L.set_stats(False)  # nothing below records per-kernel events until the short contended-kernel region at the end
     # fix the batch: frames per pipeline and step so that `steps` steps last >= min_seconds
-    fresh = [k for k in ((str(device), i) for i in range(len(L.lanes))) if k not in _PREROLLED]
-    if fresh:
-        # once per HIP stream and process: about 4000 commands (200-250 frames) into a new stream the HIP runtime halts every queue of the
-        # device for ~60 ms, once (tools/exp_ramp.py: all four pipelines stall in the same frame, 8K and HD alike, and never again at that
-        # size). That is process start-up, like the first import; run past it before anything is timed.
-        L.run(mode, 1, PREROLL_FRAMES, sync, local_rank)
-        _PREROLLED.update(fresh)
-    t_probe, *_ = L.run(mode, 1, 8, sync, local_rank)  # (after the pre-roll: the first frames of a new stream are slower than the steady state)
+    L.run(mode, 1, 8, sync, local_rank)  # (the first frames of a new coder are slower than the steady state)
+    t_probe, *_ = L.run(mode, 1, 8, sync, local_rank)
     per_frame = max(t_probe / 8, 1e-6)
     reps = max(1, int(np.ceil(1.15 * min_seconds / (steps * per_frame)))) if min_seconds > 0 else 1
     if warmup > 0:  # W untimed steps of exactly the shape of the timed ones (same threads, same frames per step)
         L.run(mode, warmup, reps, sync, local_rank)
-    elapsed, enc_wall, dec_wall, kms = L.run(mode, steps, reps, barrier, local_rank)
+    elapsed, enc_wall, dec_wall, _ = L.run(mode, steps, reps, barrier, local_rank)
+    kms = np.zeros(9)
+    if want_solo:  # per-kernel durations with all pipelines running: their own short region, with the events on
+        L.set_stats(True)
+        *_, kms = L.run(mode, 1, max(8, reps // 2), sync, local_rank)
     jsize = int(L.lanes[0]["last"][1])
     S = len(L.lanes)
     L.close()
@@ -427,7 +500,11 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     from gpujpeg_amd.sharding import barrier_and_max, gather_counts, shard_frames
     mine = shard_frames(args.batch, rank, world)
     red = device if (world == 1 or dist.get_backend() == "nccl") else None  # where the reductions of the timing live (gloo: host)
+    host_io = getattr(args, "batch_io", "device") == "host"
     frames = [synth_frame(lib, width, height, args.pattern, 12345 + i, device) for i in mine]
+    if host_io:  # pinned host memory on both sides: the caller of the reference API (gpujpeg_image_load_from_file returns pinned memory too)
+        frames = [f.cpu().pin_memory() for f in frames]
+        torch.cuda.empty_cache()
     S = max(1, min(args.streams, len(frames)))
     p = lib.default_parameters()
     p.quality, p.restart_interval, p.verbose = args.quality, G.RESTART_AUTO, -1
@@ -437,16 +514,24 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     for si in range(S):
         ts = lane_stream(device, si)
         e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
-        assert e.set_option("enc_opt_out", "enc_out_val_device") == 0
-        lanes.append({"frames": frames[si::S], "out": torch.empty_like(frames[0]), "enc": e, "dec": d, "bytes": 0, "digest": []})
+        assert e.set_option("enc_opt_out", "enc_out_val_pinned" if host_io else "enc_out_val_device") == 0
+        lanes.append({"frames": frames[si::S], "out": torch.empty_like(frames[0]).pin_memory() if host_io else torch.empty_like(frames[0]),
+                      "enc": e, "dec": d, "bytes": 0, "digest": []})
     torch.cuda.synchronize()
 
     def one_pass(ln, digest=False):
         nbytes = 0
         for f in ln["frames"]:
-            jp, js = ln["enc"].encode_noclone(p, pi, f.data_ptr(), gpu=True)
+            if host_io:
+                inp = G.EncoderInput()
+                inp.type, inp.image = G.ENCODER_INPUT_IMAGE, f.data_ptr()
+                jp, size = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+                assert lib.L.gpujpeg_encoder_encode(ln["enc"].h, C.byref(p), C.byref(pi), C.byref(inp), C.byref(jp), C.byref(size)) == 0
+                js = size.value
+            else:
+                jp, js = ln["enc"].encode_noclone(p, pi, f.data_ptr(), gpu=True)
             o = G.DecoderOutput()
-            o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
+            o.type, o.data = G.DECODER_OUTPUT_CUSTOM_BUFFER if host_io else G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
             assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
             nbytes += js
         ln["bytes"] = nbytes
@@ -460,16 +545,14 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
 
     def worker(idx, passes, wait):
         torch.cuda.set_device(local_rank)
+        pin_worker(idx)
         if wait:
             go.wait()
         for _ in range(passes):
             one_pass(lanes[idx])
 
     elapsed = 0.0
-    fresh = [k for k in ((str(device), i) for i in range(S)) if k not in _PREROLLED]
-    preroll = int(np.ceil(PREROLL_FRAMES / max(1, len(lanes[0]["frames"])))) if fresh else 0  # see measure(): once per stream and process
-    _PREROLLED.update(fresh)
-    for passes, timed in ((preroll, False), (args.warmup, False), (args.steps, True)):
+    for passes, timed in ((args.warmup, False), (args.steps, True)):
         threads = [threading.Thread(target=worker, args=(i, passes, timed)) for i in range(S)]
         for t in threads:
             t.start()
@@ -501,10 +584,12 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
         "metric": f"frames/s encode+decode (batch of {args.batch} {args.workload} frames)", "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL,
-        "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) resident in HBM, sharded round-robin",
+        "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) "
+                + ("in pinned host memory, results to pinned host memory (PCIe both ways)" if host_io else "resident in HBM") + ", sharded round-robin",
         "config": {"workload": f"{args.batch} x {width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto, encode then decode of "
                                f"every frame per step", "frames_total": total, "frames_per_gpu": len(mine), "streams_per_gpu": S,
-                   "jpeg_bytes_total": jpeg_bytes, "parallelism": f"frame-sharded x{world}, no collective"},
+                   "jpeg_bytes_total": jpeg_bytes, "parallelism": f"frame-sharded x{world}, no collective", "io": "host" if host_io else "device",
+                   "cpu_affinity_rank0": getattr(args, "affinity", None)},
         "mpix_s": round(fps * width * height / 1e6, 2), "psnr_last_frame_db": round(10 * np.log10(255.0 ** 2 / max(mse, 1e-9)), 2)}
     if verified is not None:
         result["verified_bit_exact"] = verified
@@ -544,7 +629,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k", choices=sorted(WORKLOADS))
-    ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient"])
+    ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient", "camera"])
+    ap.add_argument("--batch-io", default="device", choices=["device", "host"],
+                    help="--batch: frames and results resident in HBM (default) or in pinned host memory on both sides (what a drop-in caller has)")
+    ap.add_argument("--no-pin", action="store_true", help="leave the launch threads to the scheduler (default: one core each, on the NUMA node of the GPU)")
     ap.add_argument("--quality", type=int, default=75)
     ap.add_argument("--batch", type=int, default=0,
                     help="BASELINE.json config 5: a fixed batch of this many distinct frames (seeds 12345 + i) sharded over the ranks "
@@ -591,7 +679,10 @@ def main():
 
     lib = G.Library(args.lib)  # raises if the HIP library has not been built: there is no fallback
     assert lib.L.gpujpeg_init_device(dev_index, 0) == 0
+    settle_interpreter()
     width, height = WORKLOADS[args.workload]
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    args.affinity = None if args.no_pin else plan_pinning(local_rank, local_world, max(1, args.streams), max(1, ndev))
     if args.batch:
         if args.workload.endswith("422"):
             raise SystemExit("--batch is defined for the RGB workloads")
@@ -662,19 +753,21 @@ def main():
             "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per pipeline",
             "config": {"workload": spec.describe() + (" (7680x4320 -> 36)" if args.workload == "8k" else "") + ", encode then decode of every frame",
                        "frames_per_step_per_gpu": S * reps, "frames_per_step_per_pipeline": reps, "streams_per_gpu": S, "timed_seconds": round(elapsed, 3),
-                       "untimed_before": f"{PREROLL_FRAMES} frames per pipeline once per process (HIP runtime's one-off ~60 ms all-queue halt ~4000 "
-                                         f"commands into a new stream), then {args.warmup} warm-up steps of the timed shape",
-                       "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective"},
+                       "untimed_before": f"16 frames per pipeline (sizing of the step), then {args.warmup} warm-up steps of the timed shape; the interpreter's "
+                                         "objects are frozen out of the garbage collector first (gc.freeze: round 3's 'stream halt' was a generation-2 collection)",
+                       "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective",
+                       "timed_with": "perf_stats = 0 (no per-kernel events in the timed region; `roofline.contended` comes from its own short region)",
+                       "cpu_affinity_rank0": args.affinity},
             # API calls of pipeline 0 alone (one call at a time per pipeline; the aggregate of all pipelines is `value`)
             "encode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["enc_wall"] / 1e6, 2) if args.mode != "decode" else None,
             "decode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["dec_wall"] / 1e6, 2) if args.mode != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"],
                          "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg), **issue(names[dom], solo[dom]),
-                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r3_traffic.json) x the cycles of the kernel's instruction class mix "
-                                      "(2.4 / 4.3 cycles per wave64 instruction, profiles/r3_isa_mix.json) / 1024 SIMDs / 2.4 GHz / duration -- the roofline that "
+                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r4_traffic.json) x the cycles of the kernel's instruction class mix "
+                                      "(2.4 / 4.3 cycles per wave64 instruction, profiles/r4_isa_mix.json) / 1024 SIMDs / 2.4 GHz / duration -- the roofline that "
                                       "actually bounds these kernels; the all-2-cycle and all-4-cycle floors bracket it",
                          "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
-                                   "coder's stream); profiles/r3_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
+                                   "coder's stream); profiles/r4_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
                          "by_kernel": by_kernel,
                          "by_direction": {"encode": dict(roof("all encoder kernels", enc_total)), "decode": dict(roof("all decoder kernels", dec_total))},
                          "contended": dict(roof(names[dom], cont[dom]), concurrent_pipelines=S,
@@ -732,11 +825,14 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
     if not args.no_workloads and args.workload == "8k" and args.mode == "both":
         table = {"8k": {"mpix_s": result["value"], "ms_per_frame": round(result["ms_per_step"] / result["config"]["frames_per_step_per_gpu"], 4),
                         "jpeg_bytes": result["config"]["jpeg_bytes"], "streams": result["config"]["streams_per_gpu"]}}
-        for name in ("hd", "4k", "16k", "16k422"):
-            sp = Spec(lib, name, args.pattern, args.quality, device, 12345)
+        # sizes with the headline's content, then the headline's size with the reference's own contents (`.tst` noise and
+        # gradient, src/utils/image_delegate.c:562-603, and its camera sample) -- each with the same roofline statement as the headline:
+        # algorithmic bytes (raw + JPEG) per launch against 8 TB/s for the dominant kernel and for each direction (durations: hipEvents
+        # with one pipeline, the GPU otherwise idle)
+        for key, name, pattern in (("hd", "hd", args.pattern), ("4k", "4k", args.pattern), ("16k", "16k", args.pattern), ("16k422", "16k422", args.pattern),
+                                   ("8k_noise", "8k", "noise"), ("8k_gradient", "8k", "gradient"), ("8k_camera", "8k", "camera")):
+            sp = Spec(lib, name, pattern, args.quality, device, 12345)
             m = measure(lib, sp, device, dev_index, barrier, mode="both", streams=args.streams, steps=5, warmup=2, min_seconds=0.3, want_solo=True)
-            # the same roofline statement as for the headline workload: algorithmic bytes (raw + JPEG) per launch against 8 TB/s, for the
-            # dominant kernel and for each direction (durations: hipEvents with one pipeline, the GPU otherwise idle)
             alg = sp.raw_bytes + m["jpeg_bytes"]
             nblk = ((sp.width + 7) // 8) * ((sp.height + 7) // 8) * (2 if sp.is422 else 3)
             tokm = nblk >= (900000 if sp.is422 else 300000) and m["jpeg_bytes"] <= (12 if sp.is422 else 8) * nblk and not os.environ.get("GJ_DEC_NO_TOKENS")
@@ -744,20 +840,26 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
             solo_ = m["solo_ms"]
             live_ = [i for i in range(9) if solo_[i] > 0.006]
             dom_ = max(live_, key=lambda i: solo_[i])
-            tr_ = load_traffic("kernels", name)
+            tr_ = load_traffic("kernels", key) if pattern == "natural" else {}
             fr = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None  # noqa: E731
-            table[name] = dict(brief(sp, m), workload=sp.describe(),
-                               solo_gpu_ms={"encode": round(float(solo_[:5].sum()), 4), "decode": round(float(solo_[5:].sum()), 4)},
-                               roofline={"bound": "hbm", "kernel": nm[dom_], "ms": round(float(solo_[dom_]), 4), "frac": fr(float(solo_[dom_])),
-                                         "algorithmic_bytes_per_launch": int(alg), "traffic": tr_.get(nm[dom_]),
-                                         "frac_encode_direction": fr(float(solo_[:5].sum())), "frac_decode_direction": fr(float(solo_[5:].sum())),
-                                         "by_kernel": {nm[i]: round(float(solo_[i]), 4) for i in live_}})
+            table[key] = dict(brief(sp, m), workload=sp.describe(), data=DATA_NOTE[pattern].format(w=sp.width, h=sp.height),
+                              solo_gpu_ms={"encode": round(float(solo_[:5].sum()), 4), "decode": round(float(solo_[5:].sum()), 4)},
+                              roofline={"bound": "hbm", "kernel": nm[dom_], "ms": round(float(solo_[dom_]), 4), "frac": fr(float(solo_[dom_])),
+                                        "achieved": round(alg / (float(solo_[dom_]) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "algorithmic_bytes_per_launch": int(alg), "traffic": tr_.get(nm[dom_]),
+                                        "frac_encode_direction": fr(float(solo_[:5].sum())), "frac_decode_direction": fr(float(solo_[5:].sum())),
+                                        "by_kernel": {nm[i]: round(float(solo_[i]), 4) for i in live_}})
             del sp
             torch.cuda.empty_cache()
         ba = argparse.Namespace(**vars(args))
         ba.batch, ba.workload, ba.steps, ba.warmup, ba.verify = 256, "4k", 2, 1, False
         b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS["4k"], emit=False)
         table["batch256_4k"] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"]}
+        torch.cuda.empty_cache()
+        ba.batch_io = "host"  # the same batch from pinned host memory in and out (6.4 GB each way per pass over PCIe)
+        b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS["4k"], emit=False)
+        table["batch256_4k_host"] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"],
+                                     "data": b["data"]}
         torch.cuda.empty_cache()
         result["workloads"] = table
     if not args.no_cpu_baseline:  # reported baselines, on the host cores of rank 0 at N = 1 only

@@ -31,3 +31,63 @@ def gather_counts(local_count, device=None):
     t = torch.tensor([local_count], dtype=torch.int64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+# ---------------------------------------------------------------- host threads next to their GPU
+# A rank drives its GPU from a handful of launch threads (one per pipeline). On a two-socket node the launch latency of a thread that
+# runs on the far socket is visibly higher and the pinned staging buffers land on the wrong memory, so each rank takes cores of the NUMA
+# node its GPU hangs off, disjoint from the other ranks of the node. (The reference leaves placement to the caller; its README times one
+# process per GPU, README.md:94-100.)
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (the kernel's list format) -> [0, 1, 2, 3, 8, 10, 11]"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(pci_bus_id, sysfs="/sys"):
+    """Cores of the NUMA node a PCI device is attached to (None when the platform does not say)."""
+    import os
+    base = os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower())
+    try:
+        cpus = parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except OSError:
+        return None
+    return cpus or None
+
+
+def plan_affinity(local_rank, local_world, threads, allowed, local_cpus_by_rank):
+    """Cores for the `threads` launch threads of rank `local_rank`: a slice of the cores next to its GPU that no other rank of the node
+    is given. `allowed` is what this process may run on at all; `local_cpus_by_rank[r]` the cores next to rank r's GPU (None = unknown).
+    Ranks whose GPUs share a NUMA node split its cores evenly. Returns a list of `threads` cores (repeating when there are fewer cores
+    than threads) or None when nothing can be said -- then nobody is pinned."""
+    allowed = sorted(set(allowed))
+    if not allowed or threads <= 0:
+        return None
+
+    def pool_of(r):
+        near = local_cpus_by_rank[r] if r < len(local_cpus_by_rank) else None
+        return [c for c in allowed if c in set(near)] if near else allowed
+
+    pool = pool_of(local_rank) or allowed
+    sharers = sorted({r for r in range(local_world) if (pool_of(r) or allowed) == pool} | {local_rank})
+    per = max(1, len(pool) // len(sharers))
+    k = sharers.index(local_rank)
+    share = pool[k * per:(k + 1) * per] or pool
+    # spread over the share (SMT siblings are usually numbered far apart, neighbours are distinct cores)
+    return [share[i % len(share)] for i in range(threads)]
+
+
+def pin_current_thread(cpu):
+    """Bind the CALLING thread (Linux: sched_setaffinity(0) is per thread). Returns False when the platform refuses."""
+    import os
+    try:
+        os.sched_setaffinity(0, {cpu})
+        return True
+    except (AttributeError, OSError):
+        return False

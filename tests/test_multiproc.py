@@ -62,3 +62,35 @@ def test_single_process_defaults():
     assert shard_frames(10, 3, 4) == [3, 7]
     assert barrier_and_max(0.25) == 0.25
     assert gather_counts(7) == 7
+
+
+def test_launch_thread_affinity_plan(tmp_path):
+    """gpujpeg_amd.sharding.plan_affinity: the launch threads of a rank get cores of the NUMA node of its GPU, the ranks of one node
+    disjoint cores; without platform information the allowed cores are split by rank; a thread can really be bound."""
+    import os
+    from gpujpeg_amd.sharding import gpu_local_cpus, parse_cpulist, pin_current_thread, plan_affinity
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(128))
+    near = [list(range(0, 64))] * 4 + [list(range(64, 128))] * 4
+    plans = [plan_affinity(r, 8, 5, allowed, near) for r in range(8)]
+    assert all(len(p) == 5 and len(set(p)) == 5 for p in plans)
+    assert all(set(plans[r]) <= set(near[r]) for r in range(8))
+    assert len(set().union(*map(set, plans))) == 40  # disjoint
+    # unknown topology: the allowed set split by rank; fewer cores than threads: cores repeat, ranks stay apart
+    a, b = plan_affinity(0, 2, 3, range(4), [None, None]), plan_affinity(1, 2, 3, range(4), [None, None])
+    assert set(a) == {0, 1} and set(b) == {2, 3} and len(a) == len(b) == 3
+    # near cores outside what the process may use fall back to the allowed set
+    assert set(plan_affinity(0, 1, 2, [5, 6], [[0, 1]])) <= {5, 6}
+    assert plan_affinity(0, 1, 0, [0], [None]) is None
+    # sysfs lookup (a fake tree) and a real bind of this thread, undone afterwards
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "local_cpulist").write_text("64-127\n")
+    assert gpu_local_cpus("0000:C1:00.0", sysfs=str(tmp_path)) == list(range(64, 128))
+    assert gpu_local_cpus("0000:00:00.0", sysfs=str(tmp_path)) is None
+    before = os.sched_getaffinity(0)
+    try:
+        one = sorted(before)[-1]
+        assert pin_current_thread(one) and os.sched_getaffinity(0) == {one}
+    finally:
+        os.sched_setaffinity(0, before)

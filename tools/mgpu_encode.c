@@ -5,7 +5,12 @@
  * another (PCIe, not xGMI, is the shared resource). Mirrors test/misc/mt_encode.c:12-45 of the reference (one encoder + stream
  * per thread) and extends it over devices.
  *
- *   mgpu_encode <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0]
+ *   mgpu_encode <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0] [pin=1]
+ *
+ * pin: every coder thread is bound to one core of the NUMA node its GPU hangs off (/sys/bus/pci/devices/<bdf>/local_cpulist), the
+ * devices of one node taking disjoint cores -- launch latency and the pinned staging traffic stay on the near socket. The frames are
+ * allocated before the threads exist, portable pinned memory, first touched by the main thread: on a two-socket node pass
+ * `numactl --interleave=all` for them.
  *
  * Thread t = (device d, coder c) takes frames t, t + T, t + 2T, ... (static round-robin like gpujpeg_amd/sharding.py). Host buffers
  * on both sides: this is the full-API figure (PCIe included), the one a drop-in caller sees. Prints one JSON line.
@@ -13,7 +18,9 @@
 #define _GNU_SOURCE
 #include <hip/hip_runtime_api.h>
 #include <libgpujpeg/gpujpeg.h>
+#include <ctype.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,6 +38,7 @@ struct shared {
 struct worker {
     struct shared* sh;
     int index, device;
+    int cpu; /* core this thread is bound to, -1 = not bound */
     pthread_t tid;
     int rc;
     long frames;
@@ -40,6 +48,59 @@ struct worker {
     int self_mismatch;       /* the same frame gave two different streams on this coder */
     double seconds;
 };
+
+/* cores next to a device: the kernel's list format ("0-31,64-95") of /sys/bus/pci/devices/<bdf>/local_cpulist */
+static int near_cpus(int device, int* cpus, int cap, char* key, size_t key_cap)
+{
+    char bdf[32] = {0}, path[128];
+    key[0] = '\0';
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return 0;
+    for (char* c = bdf; *c; c++) *c = (char)tolower((unsigned char)*c);
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    FILE* f = fopen(path, "r");
+    if (!f) return 0;
+    char line[1024] = {0};
+    if (!fgets(line, sizeof line, f)) line[0] = '\0';
+    fclose(f);
+    snprintf(key, key_cap, "%s", line);
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return 0;
+    int n = 0;
+    for (char* q = line; *q && n < cap;) {
+        char* end;
+        const long lo = strtol(q, &end, 10);
+        if (end == q) break;
+        long hi = lo;
+        if (*end == '-') hi = strtol(end + 1, &end, 10);
+        for (long c = lo; c <= hi && n < cap; c++)
+            if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET((int)c, &allowed)) cpus[n++] = (int)c;
+        q = *end == ',' ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    return n;
+}
+
+/* core for coder `slot` of `device`: the near cores are split evenly between the devices that share them */
+static int pick_cpu(int device, int ndev, int slot, int per_dev)
+{
+    enum { CAP = 1024 };
+    static int cpus[CAP];
+    char key[1024], other[1024];
+    const int n = near_cpus(device, cpus, CAP, key, sizeof key);
+    if (n == 0) return -1;
+    int rank_on_node = 0, on_node = 0, scratch[8];
+    for (int d = 0; d < ndev; d++) {
+        near_cpus(d, scratch, 8, other, sizeof other);
+        if (strcmp(other, key) == 0) {
+            if (d < device) rank_on_node++;
+            on_node++;
+        }
+    }
+    int per = n / (on_node > 0 ? on_node : 1);
+    if (per < 1) per = 1;
+    (void)per_dev;
+    return cpus[(rank_on_node * per + slot % per) % n];
+}
 
 static double now(void)
 {
@@ -68,6 +129,12 @@ static void* run(void* arg)
     struct worker* wk = arg;
     struct shared* sh = wk->sh;
     wk->rc = 1;
+    if (wk->cpu >= 0) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(wk->cpu, &one);
+        if (pthread_setaffinity_np(pthread_self(), sizeof one, &one) != 0) wk->cpu = -1;
+    }
     if (gpujpeg_init_device(wk->device, 0) != 0) return NULL; /* binds this thread to its device (src/gpujpeg_common.c:215) */
     hipStream_t stream;
     if (hipStreamCreate(&stream) != hipSuccess) return NULL;
@@ -125,7 +192,7 @@ static void* run(void* arg)
 int main(int argc, char** argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0]\n", argv[0]);
+        fprintf(stderr, "usage: %s <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0] [pin=1]\n", argv[0]);
         return 2;
     }
     struct shared sh;
@@ -138,6 +205,7 @@ int main(int argc, char** argv)
     const int devices = argc > 4 && atoi(argv[4]) > 0 ? atoi(argv[4]) : ndev;
     const int per_dev = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : 2;
     sh.decode = argc > 6 ? atoi(argv[6]) : 0;
+    const int pin = argc > 7 ? atoi(argv[7]) : 1;
     sh.threads = devices * per_dev;
     const size_t raw = (size_t)sh.width * sh.height * 3;
     for (int k = 0; k < DISTINCT; k++) {
@@ -146,10 +214,12 @@ int main(int argc, char** argv)
     }
     pthread_barrier_init(&sh.start, NULL, (unsigned)sh.threads + 1);
     struct worker* wk = calloc((size_t)sh.threads, sizeof *wk);
+    int coders_on[64] = {0};
     for (int t = 0; t < sh.threads; t++) {
         wk[t].sh = &sh;
         wk[t].index = t;
         wk[t].device = (t % devices) % ndev; /* (more requested devices than present: several threads share one, the 1-GPU proof) */
+        wk[t].cpu = pin ? pick_cpu(wk[t].device, ndev, coders_on[wk[t].device % 64]++, per_dev) : -1;
         pthread_create(&wk[t].tid, NULL, run, &wk[t]);
     }
     pthread_barrier_wait(&sh.start);
@@ -166,8 +236,9 @@ int main(int argc, char** argv)
     const double dt = now() - t0;
     /* equal frames must give equal streams on every coder and device: every distinct frame's digest is compared between all the
      * threads that coded it (and inside a thread between its repetitions); `compared` counts the cross-thread comparisons made */
-    int consistent = 1;
+    int consistent = 1, pinned = 0;
     long compared = 0;
+    for (int a = 0; a < sh.threads; a++) pinned += wk[a].cpu >= 0;
     for (int a = 0; a < sh.threads; a++) {
         if (wk[a].self_mismatch) consistent = 0;
         for (int b = a + 1; b < sh.threads; b++)
@@ -179,9 +250,9 @@ int main(int argc, char** argv)
     }
     printf("{\"tool\": \"mgpu_encode\", \"ok\": %s, \"frames\": %ld, \"width\": %d, \"height\": %d, \"devices\": %d, \"devices_present\": %d, "
            "\"coders_per_device\": %d, \"decode\": %d, \"seconds\": %.4f, \"frames_s\": %.2f, \"mpix_s\": %.1f, \"jpeg_bytes\": %zu, "
-           "\"streams_consistent\": %s, \"digest_comparisons\": %ld, \"io\": \"pinned host buffers in and out (PCIe included)\"}\n",
+           "\"streams_consistent\": %s, \"digest_comparisons\": %ld, \"threads_pinned\": %d, \"first_thread_cpu\": %d, \"io\": \"pinned host buffers in and out (PCIe included)\"}\n",
            rc == 0 && frames == sh.frames_total ? "true" : "false", frames, sh.width, sh.height, devices, ndev, per_dev, sh.decode, dt,
-           (double)frames / dt, (double)frames * sh.width * sh.height / dt / 1e6, bytes, consistent ? "true" : "false", compared);
+           (double)frames / dt, (double)frames * sh.width * sh.height / dt / 1e6, bytes, consistent ? "true" : "false", compared, pinned, wk[0].cpu);
     for (int k = 0; k < DISTINCT; k++) (void)hipHostFree(sh.frame[k]);
     free(wk);
     return rc == 0 && frames == sh.frames_total && consistent ? 0 : 1;

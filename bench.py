@@ -213,6 +213,43 @@ def pin_worker(idx):
 _STREAMS = {}
 
 
+class BenchLane(C.Structure):
+    """struct gj_bench_lane of tools/bench_loop.c"""
+    _fields_ = [("enc", C.c_void_p), ("dec", C.c_void_p), ("param", C.c_void_p), ("param_image", C.c_void_p), ("images", C.POINTER(C.c_void_p)),
+                ("image_count", C.c_int), ("images_on_device", C.c_int), ("out", C.c_void_p), ("out_on_device", C.c_int)]
+
+
+_CLOOP = {"lib": None, "tried": False}
+C_LOOP_OK = {"ok": True}  # (--lib / --python-loop: another build of the library is loaded, or the caller wants the interpreter's loop measured)
+
+
+def c_loop(enabled=True):
+    """tools/bench_loop.c: the frame loop of a launch thread in C, public API only (None: the Python loop is used)"""
+    if not enabled:
+        return None
+    if not _CLOOP["tried"]:
+        _CLOOP["tried"] = True
+        path = os.path.join(ROOT, "gpujpeg_amd", "lib", "libgj_benchloop.so")
+        if os.path.exists(path):
+            L = C.CDLL(path)
+            L.gj_bench_run.restype = C.c_int
+            L.gj_bench_run.argtypes = [C.POINTER(BenchLane), C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_size_t)]
+            _CLOOP["lib"] = L
+    return _CLOOP["lib"]
+
+
+def run_frames_c(loop, ln, p, pi, images, on_device, out_ptr, frames, mode, jp, js):
+    """`frames` frames of one pipeline through tools/bench_loop.c; returns (jpeg pointer, size, encoder seconds, decoder seconds, bytes)"""
+    arr = (C.c_void_p * len(images))(*images)
+    lane = BenchLane(ln["enc"].h, ln["dec"].h, C.addressof(p), C.addressof(pi), arr, len(images), int(on_device), out_ptr, int(on_device))
+    jpeg = C.cast(jp, C.POINTER(C.c_uint8))
+    size, secs, nbytes = C.c_size_t(int(js)), (C.c_double * 2)(), C.c_size_t(0)
+    rc = loop.gj_bench_run(C.byref(lane), frames, {"both": 0, "encode": 1, "decode": 2}[mode], C.byref(jpeg), C.byref(size), secs, C.byref(nbytes))
+    assert rc == 0, f"API call failed in the C frame loop ({rc})"
+    return jpeg, size.value, secs[0], secs[1], nbytes.value
+
+
 def settle_interpreter():
     """Round 3 saw every pipeline stall for 35-70 ms once, ~1000 frames into a process, and blamed the HIP runtime. It is this interpreter:
     the ctypes calls of the launch threads allocate a dozen collector-tracked objects per frame, the ~14 000th allocation starts CPython's
@@ -239,6 +276,7 @@ class Lanes:
     def __init__(self, lib, spec, device, streams, host_io=False, keep_coefs=False):
         self.lib, self.spec, self.device, self.host_io = lib, spec, device, host_io
         self.p = spec.p
+        self.c_loop = True
         self.lanes = []
         for si in range(max(1, streams)):
             ts = lane_stream(device, si)
@@ -312,6 +350,7 @@ class Lanes:
         kms = np.zeros(9)
 
         stats = bool(self.p.perf_stats)
+        loop = c_loop(self.c_loop)
 
         def worker(idx):
             torch.cuda.set_device(local_rank)  # the HIP device is per host thread
@@ -319,6 +358,13 @@ class Lanes:
             ln = self.lanes[idx]
             go.wait()
             jp, js = ln["last"]
+            if loop is not None and not stats:  # the whole region in one foreign call: nothing of the interpreter between two API calls
+                jp, js, te, td, _ = run_frames_c(loop, ln, self.p, self.spec.pi, [ln["frame"].data_ptr()], not self.host_io, ln["out"].data_ptr(),
+                                                 steps * reps, mode, jp, js)
+                if idx == 0:
+                    walls[0], walls[1] = te, td
+                ln["last"] = (jp, js)
+                return
             for _ in range(steps * reps):
                 a = time.perf_counter()
                 if mode != "decode":
@@ -370,10 +416,12 @@ def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, step
             want_solo=False):
     """Run one workload; returns a dict with throughput and timings."""
     L = Lanes(lib, spec, device, streams, host_io=host_io, keep_coefs=keep_coefs)
+    L.c_loop = C_LOOP_OK["ok"]
     sync = lambda: torch.cuda.synchronize()
     L.warm(2)  # buffers allocated, tables uploaded, a stream for the decoders to start from
     solo = L.solo_kernel_ms() if want_solo else None
-    L.set_stats(False)  # nothing below records per-kernel events until the short contended-kernel region at the end
+    if not os.environ.get("BENCH_TIMED_STATS"):  # (developer A/B: keep the per-kernel events in the timed regions as round 3 did)
+        L.set_stats(False)  # nothing below records per-kernel events until the short contended-kernel region at the end
     # fix the batch: frames per pipeline and step so that `steps` steps last >= min_seconds
     L.run(mode, 1, 8, sync, local_rank)  # (the first frames of a new coder are slower than the steady state)
     t_probe, *_ = L.run(mode, 1, 8, sync, local_rank)
@@ -519,7 +567,13 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
                       "enc": e, "dec": d, "bytes": 0, "digest": []})
     torch.cuda.synchronize()
 
+    loop = c_loop(C_LOOP_OK["ok"])
+
     def one_pass(ln, digest=False):
+        if loop is not None:  # the frames of this pipeline, in order, through tools/bench_loop.c
+            *_, ln["bytes"] = run_frames_c(loop, ln, p, pi, [f.data_ptr() for f in ln["frames"]], not host_io, ln["out"].data_ptr(),
+                                           len(ln["frames"]), "both", None, 0)
+            return
         nbytes = 0
         for f in ln["frames"]:
             if host_io:
@@ -632,6 +686,7 @@ def main():
     ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient", "camera"])
     ap.add_argument("--batch-io", default="device", choices=["device", "host"],
                     help="--batch: frames and results resident in HBM (default) or in pinned host memory on both sides (what a drop-in caller has)")
+    ap.add_argument("--python-loop", action="store_true", help="drive the API calls of the timed regions from Python instead of tools/bench_loop.c")
     ap.add_argument("--no-pin", action="store_true", help="leave the launch threads to the scheduler (default: one core each, on the NUMA node of the GPU)")
     ap.add_argument("--quality", type=int, default=75)
     ap.add_argument("--batch", type=int, default=0,
@@ -680,6 +735,7 @@ def main():
     lib = G.Library(args.lib)  # raises if the HIP library has not been built: there is no fallback
     assert lib.L.gpujpeg_init_device(dev_index, 0) == 0
     settle_interpreter()
+    C_LOOP_OK["ok"] = not (args.lib or args.python_loop)
     width, height = WORKLOADS[args.workload]
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     args.affinity = None if args.no_pin else plan_pinning(local_rank, local_world, max(1, args.streams), max(1, ndev))
@@ -756,7 +812,8 @@ def main():
                        "untimed_before": f"16 frames per pipeline (sizing of the step), then {args.warmup} warm-up steps of the timed shape; the interpreter's "
                                          "objects are frozen out of the garbage collector first (gc.freeze: round 3's 'stream halt' was a generation-2 collection)",
                        "jpeg_bytes": int(jsize), "parallelism": f"frame-sharded x{world}, no collective",
-                       "timed_with": "perf_stats = 0 (no per-kernel events in the timed region; `roofline.contended` comes from its own short region)",
+                       "timed_with": "perf_stats = 0 (no per-kernel events in the timed region; `roofline.contended` comes from its own short region); "
+                                     + ("frame loop of every launch thread in C (tools/bench_loop.c, public API only)" if c_loop(C_LOOP_OK["ok"]) else "frame loop in Python"),
                        "cpu_affinity_rank0": args.affinity},
             # API calls of pipeline 0 alone (one call at a time per pipeline; the aggregate of all pipelines is `value`)
             "encode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["enc_wall"] / 1e6, 2) if args.mode != "decode" else None,

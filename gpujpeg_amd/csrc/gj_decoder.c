@@ -282,7 +282,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     gj_geom* g = &c->geom;
 
     /* ---- 2. stream to HBM ---- */
-    if (stats) gj_hip_event_record(c->timers.copy_in[0], c->stream);
+    if (stats || !jpeg_on_device) gj_hip_event_record(c->timers.copy_in[0], c->stream); /* (without perf_stats too: see gj_internal.h, copy markers) */
     const uint8_t* d_jpeg;
     if (jpeg_on_device) {
         d_jpeg = image;
@@ -534,7 +534,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
             assert(output->data != NULL);
             dst = output->data;
         }
-        if (stats) gj_hip_event_record(c->timers.copy_out[0], c->stream);
+        gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
         if (gj_hip_memcpy_d2h(dst, d_raw, g->raw_size, c->stream) != 0) goto out;
         if (stats) gj_hip_event_record(c->timers.copy_out[1], c->stream);
     } else {

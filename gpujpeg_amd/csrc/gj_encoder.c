@@ -233,7 +233,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
         d_raw = input->image;
     } else if (input->type == GPUJPEG_ENCODER_INPUT_IMAGE) {
         if (gj_ensure_device_buffer((void**)&c->d_raw_own, &c->d_raw_cap, g->raw_size) != 0) return -1;
-        if (stats) gj_hip_event_record(c->timers.copy_in[0], c->stream);
+        gj_hip_event_record(c->timers.copy_in[0], c->stream); /* (also without perf_stats: see gj_internal.h, copy markers) */
         if (gj_hip_memcpy_h2d(c->d_raw_own, input->image, g->raw_size, c->stream) != 0) {
             GJ_ERROR("Encoder raw data copy failed: %s\n", gj_hip_last_error());
             return -1;
@@ -326,7 +326,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
         *image_compressed = e->d_jpeg;
     } else {
         if (ensure_out_buffer(e, e->d_jpeg_cap) != 0) return -1;
-        if (stats) gj_hip_event_record(c->timers.copy_out[0], c->stream);
+        gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
         if (gj_hip_memcpy_d2h(e->out_buf, e->d_jpeg, size, c->stream) != 0) return -1;
         if (stats) gj_hip_event_record(c->timers.copy_out[1], c->stream);
         if (gj_hip_stream_sync(c->stream) != 0) return -1;

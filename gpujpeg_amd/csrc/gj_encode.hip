@@ -24,7 +24,12 @@
 #ifdef GJ_TRACE_PHASES
 static __device__ unsigned long long* gj_trace_buf_e;
 extern "C" GJ_HIP_API int gj_hip_trace_set_encoder(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(gj_trace_buf_e), &p, sizeof p) == hipSuccess ? 0 : -1; }
-#define GJ_TRACE_E(slot) do { if (threadIdx.x == 0 && gj_trace_buf_e) gj_trace_buf_e[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// (gj_hip_trace_stop_encoder(n): every wave ends at stamp n -- the vector instructions of the phases in front of it are what SQ_INSTS_VALU then
+// counts, tools/encoder_valu_budget.py takes the differences; the streams of such a launch are garbage)
+static __device__ int gj_trace_stop_e = 1 << 30;
+extern "C" GJ_HIP_API int gj_hip_trace_stop_encoder(int n) { return hipMemcpyToSymbol(HIP_SYMBOL(gj_trace_stop_e), &n, sizeof n) == hipSuccess ? 0 : -1; }
+#define GJ_TRACE_E(slot) do { if (threadIdx.x == 0 && gj_trace_buf_e) gj_trace_buf_e[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+                              if ((slot) >= gj_trace_stop_e) __builtin_amdgcn_endpgm(); } while (0)
 #else
 #define GJ_TRACE_E(slot) ((void)0)
 #endif

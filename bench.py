@@ -70,6 +70,11 @@ def load_traffic(key="kernels", workload="8k"):
     (profiles/r4_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+        for w in d.get("workloads", {}).values():  # bench.py times the two marker kernels with one pair of events: one name for their sum
+            for table in ("kernels", "valu_insts"):
+                t = w.get(table, {})
+                if "dec:k_marker_scan" in t and "dec:k_marker_table" in t:
+                    t["dec:k_markers"] = t["dec:k_marker_scan"] + t["dec:k_marker_table"]
         if d.get("source_hash") != kernel_source_hash():
             return {}
         return d.get("workloads", {}).get(workload, {}).get(key, {})

@@ -206,6 +206,15 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     GJ_TRACE(0);
+    // v_perm_b32 selector of lane & 15 read as a set of kept bytes: they move to the top of the result, first byte in the most significant
+    // position, zeros (0x0C) below (the cooperative copy fetches the one it needs from lanes 0..15 with ds_bpermute_b32)
+    uint32_t sel_of_lane = 0x0C0C0C0Cu;
+    {
+        int at = 3;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (lane & (1 << k)) { sel_of_lane = (sel_of_lane & ~(0xFFu << (8 * at))) | ((uint32_t)k << (8 * at)); at--; }
+    }
     if (tid < 128) sm.zz[tid] = tid < 64 ? GJ_ZZ[tid] : 0; // (behind a block's end, damaged streams only: position 0, which the IDCT overwrites with the DC term -- the
                                                             //  coefficient is dropped, as the plane kernels and the reference's GPU decoder do, src/gpujpeg_huffman_gpu_decoder.cu:370)
     if (tid == 0) sm.U[0] = 0;
@@ -282,6 +291,11 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
         const unsigned long long mf = __ballot(lane + 1 > j0 && lane + 1 <= jstop && s_cap[lane + 1] - s_cap[j0] <= (uint32_t)CAP_U);
         const int j1 = max(j0 + 1, mf ? 64 - (int)__builtin_clzll(mf) : 0);
         const int ng = j1 - j0;
+        if (COOP) { // the cooperative copy ORs its bytes into the stage: zero what the group can use, and the 8 + 8 bytes the reader may look at behind it
+            const uint32_t n16 = min((s_cap[j1] - s_cap[j0] + 16u + 4u + 15u) >> 4, (uint32_t)(sizeof(sm.U) / 16));
+            uint4* const z = reinterpret_cast<uint4*>(sm.U);
+            for (uint32_t t = (uint32_t)tid; t < n16; t += 256u) z[t] = uint4{0u, 0u, 0u, 0u};
+        }
         __syncthreads();
         GJ_TRACE(1);
 
@@ -315,61 +329,88 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
                 win[i] = 0;
                 if ((uint32_t)i < C / 4 + 3u && off0 < total + 4u && src + i < end) win[i] = src[i];
             }
-            uint32_t prevb = off0 == 0 ? 0u : __builtin_amdgcn_alignbyte(win[1], win[0], lead) >> 24; // the byte in front of the share
-            uint64_t keep = 0; // bit b: byte b of the share goes to the stage
-            uint64_t mark = 0; // bit b: byte b starts a restart marker
-            uint32_t nkeep = 0, nmark = 0;
+            // Byte classes four at a time (SWAR on bit 7 of every byte): 0xFF, 0x00, second byte of a restart marker ((b & 0xF8) == 0xD0
+            // behind 0xFF). Dropped: stuffed zeros and both marker bytes. `keep` / `mark`: bit b = byte b of the share is kept / starts a marker.
+            // (Round 3 classified byte by byte -- ~20 instructions per byte -- and stored the kept bytes one ds_write_b8 each: 13 % of the kernel.)
+            constexpr int ND = GJ_TOK_CHUNK_MAX / 4;
+            uint64_t keep = 0, mark = 0;
+            {
+                const uint32_t K7 = 0x7F7F7F7Fu, K8 = 0x80808080u;
+                uint32_t eq_prev = 0, m2_prev = 0, st_prev = 0;
+                uint32_t ffc = 0; // 0xFF marks of the dword in front (only its last byte matters)
+                if (off0 != 0) {
+                    const uint32_t x = __builtin_amdgcn_alignbyte(win[1], win[0], lead);
+                    ffc = ((x & K7) + 0x01010101u) & x & K8;
+                }
 #pragma unroll
-            for (int i = 0; i < GJ_TOK_CHUNK_MAX / 4; i++) {
-                if ((uint32_t)(4 * i) < C) {
-                    const uint32_t w = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead);  // bytes 4i .. 4i + 3 of the share
-                    const uint32_t wn = __builtin_amdgcn_alignbyte(win[i + 3], win[i + 2], lead); // (its first byte follows the last one of w)
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t b = (w >> (8 * k)) & 0xFFu;
-                        const uint32_t nx = k < 3 ? (w >> (8 * k + 8)) & 0xFFu : wn & 0xFFu;
-                        const bool valid = off0 + (uint32_t)(4 * i + k) < total;
-                        const bool m1 = b == 0xFFu && (nx & 0xF8u) == 0xD0u;    // FF Dn: a restart marker starts here
-                        const bool m2 = prevb == 0xFFu && (b & 0xF8u) == 0xD0u; // its second byte
-                        const bool st = prevb == 0xFFu && b == 0u;              // stuffed zero
-                        if (valid && m1) { mark |= 1ull << (4 * i + k); nmark++; }
-                        if (valid && !m1 && !m2 && !st) { keep |= 1ull << (4 * i + k); nkeep++; }
-                        prevb = b;
+                for (int i = 0; i <= ND; i++) { // (one dword of look-ahead: a marker may start in the last byte of a dword)
+                    if ((uint32_t)(4 * i) <= C) {
+                        const uint32_t x = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead); // bytes 4i .. 4i + 3 of the share
+                        const uint32_t t = x & K7;
+                        const uint32_t eq = (t + 0x01010101u) & x & K8;
+                        const uint32_t zr = ~((t + K7) | x) & K8;
+                        const uint32_t y = (x ^ 0xD0D0D0D0u) & 0xF8F8F8F8u;
+                        const uint32_t rz = ~(((y & K7) + K7) | y) & K8;
+                        const uint32_t before = __builtin_amdgcn_alignbit(eq, ffc, 24); // bytes behind a 0xFF
+                        ffc = eq;
+                        const uint32_t m2 = before & rz, st = before & zr;
+                        if (i > 0) { // dword i - 1 is complete now
+                            const uint32_t m1 = eq_prev & __builtin_amdgcn_alignbit(m2, m2_prev, 8); // 0xFF whose next byte is the marker's second
+                            const uint32_t kp = K8 & ~(st_prev | m2_prev | m1);
+                            keep |= (uint64_t)((((kp >> 7) * 0x01020408u) >> 24) & 15u) << (4 * (i - 1));
+                            mark |= (uint64_t)((((m1 >> 7) * 0x01020408u) >> 24) & 15u) << (4 * (i - 1));
+                        }
+                        eq_prev = eq; m2_prev = m2; st_prev = st;
                     }
                 }
+                const uint32_t nvalid = off0 >= total ? 0u : min(total - off0, C);
+                const uint64_t valid = nvalid >= 64u ? ~0ull : (1ull << nvalid) - 1ull;
+                keep &= valid;
+                mark &= valid;
             }
+            const uint32_t nkeep = (uint32_t)__popcll(keep), nmark = (uint32_t)__popcll(mark);
             uint32_t tot;
             const uint32_t inc = gj_wg256_incl_scan(nkeep | (nmark << 16), s_tmp, &tot);
             uint32_t o = (inc & 0xFFFFu) - nkeep, m = (inc >> 16) - nmark; // kept bytes / markers in front of this lane's share
-            uint8_t* U8 = reinterpret_cast<uint8_t*>(s_stage);
             coop = (tot >> 16) == (uint32_t)(ng - 1); // (as many markers as the table says; the same for every lane)
             if (coop) {
+                // The kept bytes of a dword, compacted by v_perm_b32 (first byte on top: the stage holds big-endian dwords), are ORed into the zeroed
+                // stage at their byte position: kept bytes in front + 8 per marker in front (the 8 zero bytes behind every segment). A dword with a
+                // marker inside has a part in front of it and a part behind it, 8 bytes further on: both parts are placed by every lane, the second
+                // one empty as a rule -- no branch, and the selectors come out of lanes 0..15 of the wave (ds_bpermute_b32), which must be active.
 #pragma unroll
-                for (int i = 0; i < GJ_TOK_CHUNK_MAX / 4; i++) {
+                for (int i = 0; i < ND; i++) {
                     if ((uint32_t)(4 * i) < C) {
-                        const uint32_t w = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            if ((mark >> (4 * i + k)) & 1ull) { // segment j0 + m ends here: 8 zero bytes, the next one starts behind them
-                                for (uint32_t q = 0; q < 8; q++) U8[(o + 8u * m + q) ^ 3u] = 0;
-                                m++;
-                                s_ubyte[j0 + (int)m] = o + 8u * m;
-                            }
-                            if ((keep >> (4 * i + k)) & 1ull) {
-                                U8[(o + 8u * m) ^ 3u] = (uint8_t)(w >> (8 * k));
-                                o++;
-                            }
+                        const uint32_t x = __builtin_amdgcn_alignbyte(win[i + 2], win[i + 1], lead);
+                        const uint32_t nk = (uint32_t)(keep >> (4 * i)) & 15u, nm = (uint32_t)(mark >> (4 * i)) & 15u;
+                        const uint32_t below = nm ? ((nm & (0u - nm)) - 1u) : 15u; // the bytes in front of the (first) marker
+                        const uint32_t nA = nk & below, nB = nk & ~below;
+                        const uint32_t cA = (uint32_t)__popc(nA);
+                        const uint32_t compA = __builtin_amdgcn_perm(0u, x, (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nA << 2), (int)sel_of_lane));
+                        const uint32_t compB = __builtin_amdgcn_perm(0u, x, (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nB << 2), (int)sel_of_lane));
+                        const uint32_t pA = o + 8u * m, pB = pA + cA + 8u; // (a second marker in the same dword has no kept byte behind it in this dword)
+                        const uint32_t shA = 8u * (pA & 3u), shB = 8u * (pB & 3u);
+                        uint32_t* const dA = s_stage + (pA >> 2);
+                        uint32_t* const dB = s_stage + (pB >> 2);
+                        atomicOr(dA, compA >> shA);
+                        atomicOr(dA + 1, __builtin_amdgcn_alignbit(compA, 0u, shA));
+                        atomicOr(dB, compB >> shB);
+                        atomicOr(dB + 1, __builtin_amdgcn_alignbit(compB, 0u, shB));
+                        uint32_t mm = m;
+                        for (uint32_t q = nm; q; q &= q - 1u) { // the segments that start behind this dword's markers: 8 bytes behind the previous one's last byte
+                            mm++;
+                            s_ubyte[j0 + (int)mm] = o + (uint32_t)__popc(nk & ((q & (0u - q)) - 1u)) + 8u * mm;
                         }
+                        m = mm;
+                        o += (uint32_t)__popc(nk);
                     }
                 }
-                if (tid == 255) { // behind the last segment
-                    for (uint32_t q = 0; q < 12; q++) U8[(o + 8u * m + q) ^ 3u] = 0;
-                    s_ubyte[j1] = o + 8u * m + 8u;
-                }
+                if (tid == 255) s_ubyte[j1] = o + 8u * m + 8u; // behind the last segment (the stage is zero from there on)
                 if (tid == 0) s_ubyte[j0] = 0;
             }
         }
         __syncthreads();
+        if (tid == 0) GJ_STAT(coop ? 30 : 31, 1); // (groups copied cooperatively / segment by segment)
         if (coop) {
             if (tid >= j0 && tid < j1) s_ulen[tid] = s_ubyte[tid + 1] - s_ubyte[tid] - 8u;
         } else {

@@ -66,6 +66,10 @@ def test_emu_token_mode_longer_sub_sequences(O, G, emu_lib, monkeypatch):
     T.test_token_mode_longer_sub_sequences(O, G, emu_lib, monkeypatch)
 
 
+def test_emu_token_mode_tiny_segments(O, G, emu_lib, monkeypatch):
+    T.test_token_mode_tiny_segments(O, G, emu_lib, monkeypatch)
+
+
 def test_emu_token_mode_damaged_streams(O, G, emu_lib, monkeypatch):
     T.test_token_mode_damaged_streams(O, G, emu_lib, monkeypatch)
 

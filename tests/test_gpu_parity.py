@@ -477,6 +477,22 @@ def test_token_mode_longer_sub_sequences(O, G, gpu_lib, monkeypatch):
         dec.close()
 
 
+def test_token_mode_tiny_segments(O, G, gpu_lib, monkeypatch):
+    """The cooperative copy of k_huffman_decode_tok classifies the stream four bytes at a time and places what it keeps around the markers
+    of a dword: restart intervals of one and two blocks give segments of one to three bytes -- two markers in one dword, markers that
+    straddle dwords and lanes, 0xFF data bytes with their stuffing next to markers (noise)."""
+    monkeypatch.setenv("GJ_DEC_TOKENS", "1")
+    for w, h, q, ri, kind in ((256, 64, 75, 1, "flat"), (256, 64, 30, 1, "natural"), (264, 40, 75, 2, "natural"), (128, 64, 95, 1, "noise"), (200, 48, 100, 3, "noise")):
+        raw = np.full(w * h * 3, 200, np.uint8) if kind == "flat" else O.noise(w * h * 3, seed=ri + q) if kind == "noise" else natural_image(w, h, 3, seed=q)
+        jpeg = O.encode(oracle_image(O, ("tiny", w, h, 1, 1, q, ri, 0, None, 3)), raw)
+        want = O.decode(jpeg)[0]
+        for g in ("64", "7"):
+            monkeypatch.setenv("GJ_DEC_G", g)
+            dec = G.Decoder(gpu_lib)
+            assert np.array_equal(dec.decode(jpeg)[0], want), (w, h, q, ri, kind, g)
+            dec.close()
+
+
 def test_token_mode_damaged_streams(O, G, gpu_lib, monkeypatch):
     """Token mode on damaged input: flipped bytes and truncation must neither fault nor hang (records nobody wrote, token
     counts that no longer match)."""

@@ -63,7 +63,7 @@ def traffic(d, out, note):
     print(open(out).read())
 
 
-ENCODER_KERNELS = ("k_encode_", "k_fused_", "k_preprocess", "k_copy_planes_in", "k_dct", "k_huffman<", "k_huffman(", "k_scan_segments", "k_assemble", "k_segment_info")
+ENCODER_KERNELS = ("k_encode_", "k_fused_", "k_preprocess", "k_copy_planes_in", "k_dct", "k_huffman<", "k_huffman(", "k_scan_segments", "k_assemble", "k_gather", "k_segment_info")
 
 
 def traffic_json(d, out, note):

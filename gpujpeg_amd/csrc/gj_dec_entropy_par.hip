@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
 }
 
 
-GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const unsigned max_blocks, const unsigned gmax, const bool one_generation)
+GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const unsigned max_blocks, const unsigned gmax, const unsigned resident)
 {
     const gj_geom& g = job->g;
     // batches: as many segments as fill the LDS stage on average, at most max_blocks blocks, per scan where the bytes per scan are known
@@ -652,7 +652,7 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const u
             plan.batch0[1] = (job->seg_count + plan.g[0] - 1) / plan.g[0];
         }
         const int nb = plan.batch0[plan.n];
-        if (!one_generation || eg || nb <= GJ_PAR_RESIDENT || nb > GJ_PAR_RESIDENT * 5 / 4) break;
+        if (!resident || eg || nb <= (int)resident || nb > (int)resident * 5 / 4) break;
     }
     return plan;
 }
@@ -660,7 +660,7 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const u
 void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st)
 {
     const gj_geom& g = job->g;
-    const GjBatchPlan plan = gj_plan_batches(job, GJ_PAR_CAP_U, GJ_PAR_MAX_BLOCKS, GJ_PAR_GMAX, false);
+    const GjBatchPlan plan = gj_plan_batches(job, GJ_PAR_CAP_U, GJ_PAR_MAX_BLOCKS, GJ_PAR_GMAX, 0);
     const int es = job->tune.dec_sub; // tuning aid: bytes per sub-sequence
     const int sub = es ? es : (g.interleaved ? 32 : GJ_PAR_SUB); // interleaved scans synchronise later (the block inside the MCU
                                                                        // has to fall into step too): measured best with 32 B

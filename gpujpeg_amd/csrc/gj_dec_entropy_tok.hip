@@ -31,6 +31,10 @@
 // clamped to it all the same)
 #define GJ_TOK_MAX_SUBS (GJ_TOK_CAP_U / GJ_TOK_SUB + (GJ_TOK_SUB <= 17 ? GJ_TOK_GMAX / 2 : GJ_TOK_GMAX))
 #define GJ_TOK_WSTAGE 944                                       // tokens a wave can stage per flush at least (incl. up to 7 of alignment)
+// (Five workgroups per CU -- a 32 000-byte layout: stage 7.7 KB, 1728 blocks and 640..688 staged tokens per wave, 84 VGPRs -- was built and
+// measured in round 4, profiles/r4_10_tok_five_per_cu.txt: 16K, many generations, 293 against 298 us with 688 tokens and 315 us with 640; 8K 93 us
+// against 80 in one generation, 123 us when the batches tip into a second one; the kernel is not waiting for latency that a fifth workgroup hides.)
+#define GJ_TOK_WG_PER_CU 4
 #ifndef GJ_TOK_SYNC
 #define GJ_TOK_SYNC 48                                          // bits in front of a sub-sequence its lane decodes first to fall into step
 #endif
@@ -178,7 +182,7 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
 }
 
 template <bool COOP>
-__global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+__global__ __launch_bounds__(256, GJ_TOK_WG_PER_CU) void k_huffman_decode_tok(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
                                                                const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                                const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                                const uint32_t* __restrict__ seg_count_ptr, const GjBatchPlan plan,
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_tok(const gj_geom g, 
 void gj_launch_huffman_tok(const gj_dec_job* job, hipStream_t st)
 {
     const gj_geom& g = job->g;
-    const GjBatchPlan plan = gj_plan_batches(job, GJ_TOK_CAP_U, GJ_TOK_MAX_BLOCKS, GJ_TOK_GMAX, true);
+    const GjBatchPlan plan = gj_plan_batches(job, GJ_TOK_CAP_U, GJ_TOK_MAX_BLOCKS, GJ_TOK_GMAX, GJ_TOK_RESIDENT);
     auto kernel = job->tune.dec_tok_nocoop ? k_huffman_decode_tok<false> : k_huffman_decode_tok<true>;
     hipLaunchKernelGGL(kernel, dim3((unsigned)plan.batch0[plan.n]), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len, job->d_seg_index,
                        job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, (uint16_t*)job->d_tok, job->tok_cap, (uint2*)job->d_blkrec,

@@ -45,13 +45,14 @@ struct GjBatchPlan {
     int g[GJ_MAX_COMP];          // segments per batch
     int batch0[GJ_MAX_COMP + 1]; // first batch of range c; [n] = number of batches
 };
-// cap_u: bytes of the kernel's LDS stage, max_blocks / gmax: blocks / segments a batch may have; one_generation: prefer fuller batches when
-// that keeps the launch within the workgroups the GPU holds at once
-GjBatchPlan gj_plan_batches(const gj_dec_job* job, unsigned cap_u, unsigned max_blocks, unsigned gmax, bool one_generation);
+// cap_u: bytes of the kernel's LDS stage, max_blocks / gmax: blocks / segments a batch may have; resident (0: no preference): the workgroups
+// of the kernel the GPU holds at once -- fuller batches are preferred when they keep the launch within one such generation
+GjBatchPlan gj_plan_batches(const gj_dec_job* job, unsigned cap_u, unsigned max_blocks, unsigned gmax, unsigned resident);
 
 // k_huffman_decode_tok (shared with the launcher's choice of the kernel)
 #define GJ_TOK_CAP_U 10752     // bytes of unstuffed stream per group, incl. 8 B of zero padding per segment
 #define GJ_TOK_MAX_BLOCKS 2304 // blocks per batch
+#define GJ_TOK_RESIDENT 1024u  // workgroups the GPU holds at once (256 CUs x 4)
 #define GJ_TOK_GMAX 64         // segments per batch
 
 // ---- IDCT side

@@ -7,6 +7,7 @@
 #include <assert.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <strings.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -562,8 +563,18 @@ void gj_coder_process_stats(struct gj_coder* c, bool with_stats) /* common.c:217
     fprintf(stderr, "%s Image:        %10.4f ms\n", what, ms);
 }
 
+double gj_now_us(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
 void gj_coder_process_stats_overall(struct gj_coder* c) /* common.c:2238-2254 */
 {
+    if (c->ht_on && c->ht_calls > 0)
+        fprintf(stderr, "[gj host timing] %s, %ld calls: to the first launch %.1f us, launches %.1f us, waiting %.1f us, behind the wait %.1f us\n",
+                c->encoder ? "encoder" : "decoder", c->ht_calls, c->ht[0] / c->ht_calls, c->ht[1] / c->ht_calls, c->ht[2] / c->ht_calls, c->ht[3] / c->ht_calls);
     if (c->frames <= 1 || c->param.verbose <= GPUJPEG_LL_QUIET) return;
     fprintf(stderr, "\nAvg %s Duration: %10.4f ms\n", c->encoder ? "Encode" : "Decode", c->aggregate_duration / (double)c->frames);
     if (c->param.verbose >= GPUJPEG_LL_VERBOSE)

@@ -80,6 +80,7 @@ struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
     d->req_pixel_format = GPUJPEG_PIXFMT_AUTODETECT;
     d->req_color_space = GPUJPEG_CS_DEFAULT;
     gj_hip_tuning_from_env(&d->tune);
+    d->coder.ht_on = d->tune.host_timing != 0;
     d->use_fused = !d->tune.no_fused;
     gpujpeg_set_default_parameters(&d->coder.param);
     gpujpeg_image_set_default_parameters(&d->coder.param_image);
@@ -231,6 +232,7 @@ static void summary_take_maxlen(struct gpujpeg_decoder* d)
 static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t image_size, struct gpujpeg_decoder_output* output, bool careful)
 {
     struct gj_coder* c = &d->coder;
+    GJ_HT_START(c);
     const bool stats = c->param.perf_stats != 0 || c->param.verbose >= GPUJPEG_LL_STATUS;
     c->start_time = stats ? gpujpeg_get_time() : 0;
     memset(&c->stats, 0, sizeof c->stats);
@@ -315,6 +317,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         d->h_summary->rst_irregular = 0;
         d->h_summary->seq_overflow = 0;
         d->h_summary->header_differs = 0;
+        GJ_HT(c, 0);
         if (stats) gj_hip_event_record(c->timers.ev[4], c->stream); /* (the marker scan is GPU time of this call: events 4 and 5 bracket it) */
         if (frc == 0)
             frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
@@ -540,10 +543,12 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     } else {
         output->data = d_raw;
     }
+    GJ_HT(c, 1);
     if (gj_hip_stream_sync(c->stream) != 0) {
         GJ_ERROR("Decoder failed: %s\n", gj_hip_last_error());
         goto out;
     }
+    GJ_HT(c, 2);
 
     if (!spec && d->h_summary->seq_overflow && !careful) { /* (a kernel forced on a stream with segments it cannot stage; or, after a host
                                                                walk, a table whose longest segment the host did not foresee) */
@@ -614,6 +619,8 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
                 gpujpeg_pixel_format_get_name(output->param_image.pixel_format), gpujpeg_color_space_get_name(output->param_image.color_space));
     output->metadata = &d->metadata;
     rc = 0;
+    GJ_HT(c, 3);
+    c->ht_calls++;
 out:
     free(host_copy);
     return rc;

@@ -66,6 +66,7 @@ struct gpujpeg_encoder* gpujpeg_encoder_create(cudaStream_t stream)
     e->coder.stream = (gj_stream_t)stream;
     e->table_quality = -1;
     gj_hip_tuning_from_env(&e->tune);
+    e->coder.ht_on = e->tune.host_timing != 0;
     e->use_fused = !e->tune.no_fused;
     gpujpeg_set_default_parameters(&e->coder.param);
     gpujpeg_image_set_default_parameters(&e->coder.param_image);
@@ -206,6 +207,7 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     assert(param->restart_interval >= RESTART_AUTO);
     assert(param->interleaved == 0 || param->interleaved == 1);
     struct gj_coder* c = &e->coder;
+    GJ_HT_START(c);
     const bool img_changed = !c->configured || !gj_image_parameters_equal(&c->param_image, pi);
     struct gpujpeg_parameters p = adjust_params(c, param, pi, img_changed);
     p.perf_stats = param->perf_stats || param->verbose >= GPUJPEG_LL_STATUS;
@@ -306,17 +308,20 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.segment_info = p.segment_info;
     job.use_fused = e->use_fused && !e->flipped;
     job.keep_coefs = e->keep_coefs;
+    GJ_HT(c, 0);
     if (gj_hip_encode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Encoder kernels failed: %s\n", gj_hip_last_error());
         c->configured = false; /* (the next call sets the device-side state up again) */
         return -1;
     }
+    GJ_HT(c, 1);
     /* size first, then the bytes (:550-563) */
     if (gj_hip_stream_sync(c->stream) != 0) { /* (the two result words are in host memory once the kernels have run) */
         GJ_ERROR("Encoder failed: %s\n", gj_hip_last_error());
         c->configured = false;
         return -1;
     }
+    GJ_HT(c, 2);
     const size_t size = e->h_result[0];
     if (e->h_result[1]) {
         GJ_ERROR("Compressed stream (%zu B) does not fit the output buffer (%zu B)!\n", size, e->d_jpeg_cap);
@@ -351,6 +356,8 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
         fprintf(stderr, "Compressed Size:%15zu bytes %dx%d %s %s%s\n", size, pi->width, pi->height,
                 gpujpeg_color_space_get_name(p.color_space_internal), gpujpeg_subsampling_get_name(p.comp_count, p.sampling_factor), il);
     }
+    GJ_HT(c, 3);
+    c->ht_calls++;
     return 0;
 }
 

@@ -81,7 +81,15 @@ struct gj_coder {
     double first_frame_duration, aggregate_duration;
     long frames;
     bool encoder;
+    /* GJ_HOST_TIMING=1 (developer switch): where the host's time of a call goes -- [0] entry -> first launch, [1] the launches, [2] waiting for the
+     * stream, [3] behind the wait; printed when the coder is destroyed */
+    bool ht_on;
+    double ht[4], ht_mark;
+    long ht_calls;
 };
+#define GJ_HT_START(c) do { if ((c)->ht_on) (c)->ht_mark = gj_now_us(); } while (0)
+#define GJ_HT(c, i) do { if ((c)->ht_on) { const double t_ = gj_now_us(); (c)->ht[i] += t_ - (c)->ht_mark; (c)->ht_mark = t_; } } while (0)
+double gj_now_us(void);
 
 void gj_coder_process_stats(struct gj_coder* c, bool with_stats);
 void gj_coder_process_stats_overall(struct gj_coder* c);

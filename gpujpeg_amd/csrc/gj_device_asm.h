@@ -18,6 +18,15 @@ template <int OFF, int WIDTH> __device__ __forceinline__ uint32_t gj_bfe_u32(uin
 }
 
 // per-half minimum of two packed u16 pairs (the compiler scalarises the vector form, hence the instruction itself)
+// v_ffbh_i32: the number of leading bits that equal the sign bit (31 for 1 and for -2; -1 when all 32 are alike). For t = v - (v < 0)
+// of a non-zero v, 32 minus it is the JPEG magnitude category of v -- one instruction where |v| and a count of leading zeros take three
+__device__ __forceinline__ int gj_ffbh_i32(int v)
+{
+    int r;
+    asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t gj_pk_min_u16(uint32_t a, uint32_t b)
 {
     uint32_t r;

@@ -739,10 +739,13 @@ __device__ __forceinline__ void gj_put(GjWalk& w, const uint32_t cw, const int n
 template <bool NONZERO>
 __device__ __forceinline__ void gj_value_bits2(const int v, int& nbits, uint32_t& bits)
 {
-    const int s = v >> 31, t = v + s;                           // t = v - 1 for negative v
-    const uint32_t a = (uint32_t)(t ^ s) | (NONZERO ? 0u : 1u); // |v| = t ^ s (the 1 keeps clz defined for v == 0)
-    nbits = 32 - __builtin_clz(a);
-    if (!NONZERO) nbits = v ? nbits : 0;
+    const int s = v >> 31, t = v + s; // t = v - 1 for negative v
+    if (NONZERO) {
+        nbits = 32 - gj_ffbh_i32(t); // (t is neither 0 nor -1 for a non-zero v: the first bit that differs from the sign is the top bit of |v|)
+    } else {
+        const uint32_t a = (uint32_t)(t ^ s) | 1u; // |v| = t ^ s (the 1 keeps clz defined for v == 0)
+        nbits = v ? 32 - __builtin_clz(a) : 0;
+    }
     bits = __builtin_amdgcn_ubfe((uint32_t)t, 0, (uint32_t)nbits);
 }
 

@@ -8,6 +8,12 @@
 
 template <int OFF, int WIDTH> __device__ __forceinline__ uint32_t gj_bfe_u32(uint32_t v) { return (v >> OFF) & ((1u << WIDTH) - 1u); }
 
+__device__ __forceinline__ int gj_ffbh_i32(int v)
+{
+    const uint32_t x = (uint32_t)(v ^ (v >> 31)); // leading sign bits become leading zeros
+    return x ? __builtin_clz(x) : -1;
+}
+
 __device__ __forceinline__ uint32_t gj_pk_min_u16(uint32_t a, uint32_t b)
 {
     const uint32_t lo = (a & 0xFFFFu) < (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);

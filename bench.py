@@ -25,7 +25,7 @@ On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --
                     (its camera sample, tests/golden/make_camera_fixture.py); 256 x 4K batch (config 5) resident in HBM (`batch256_4k`) and
                     from pinned host memory in and out (`batch256_4k_host`)
 The timed regions run with perf_stats = 0 (no per-kernel events); per-kernel durations come from their own short regions. The launch
-threads are bound to cores of the GPU's NUMA node (--no-pin leaves them to the scheduler).
+threads are bound to idle cores of the GPU's NUMA node when several ranks share the node (--pin on / off forces or forbids it).
   cpu_baseline      the reference's CPU path as it exists (its host C with the CPU Huffman coders) + the restated scalar stages for
                     what it only has as CUDA, one thread, on a bounded sample; `idct_cpu_s` = its own gpujpeg_idct_cpu on the same frame
   cpu_baseline_all_cores      the same with one frame per process on the host's cores (-O3 -march=native build)
@@ -196,7 +196,7 @@ _PIN = {"cpus": None}  # cores of this rank's launch threads (gpujpeg_amd.shardi
 
 def plan_pinning(local_rank, local_world, threads, ndev):
     """The launch threads of this rank go to cores of the NUMA node of its GPU, disjoint from the other ranks of the node."""
-    from gpujpeg_amd.sharding import gpu_local_cpus, plan_affinity
+    from gpujpeg_amd.sharding import busy_cpus, gpu_local_cpus, plan_affinity
     near = []
     for r in range(local_world):
         pr = torch.cuda.get_device_properties(r % ndev)
@@ -204,9 +204,9 @@ def plan_pinning(local_rank, local_world, threads, ndev):
             near.append(gpu_local_cpus("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)))
         except AttributeError:
             near.append(None)
-    _PIN["cpus"] = plan_affinity(local_rank, local_world, threads, sorted(os.sched_getaffinity(0)), near)
+    _PIN["cpus"] = plan_affinity(local_rank, local_world, threads, sorted(os.sched_getaffinity(0)), near, avoid=busy_cpus())
     return {"launch_thread_cpus": _PIN["cpus"], "gpu_numa_cpus_known": near[local_rank] is not None,
-            "note": "each launch thread (one per pipeline) is bound to one core of the NUMA node of its GPU; ranks of one node take disjoint cores"}
+            "note": "each launch thread (one per pipeline) is bound to one idle core of the NUMA node of its GPU; ranks of one node take disjoint cores"}
 
 
 def pin_worker(idx):
@@ -692,7 +692,10 @@ def main():
     ap.add_argument("--batch-io", default="device", choices=["device", "host"],
                     help="--batch: frames and results resident in HBM (default) or in pinned host memory on both sides (what a drop-in caller has)")
     ap.add_argument("--python-loop", action="store_true", help="drive the API calls of the timed regions from Python instead of tools/bench_loop.c")
-    ap.add_argument("--no-pin", action="store_true", help="leave the launch threads to the scheduler (default: one core each, on the NUMA node of the GPU)")
+    ap.add_argument("--pin", default="auto", choices=["auto", "on", "off"],
+                    help="bind the launch threads to idle cores of the GPU's NUMA node: `auto` (default) does it when several ranks share the node -- "
+                         "that is when placement matters -- and leaves a single rank to the scheduler, which steers clear of cores other tenants keep busy")
+    ap.add_argument("--no-pin", action="store_true", help="same as --pin off")
     ap.add_argument("--quality", type=int, default=75)
     ap.add_argument("--batch", type=int, default=0,
                     help="BASELINE.json config 5: a fixed batch of this many distinct frames (seeds 12345 + i) sharded over the ranks "
@@ -743,7 +746,8 @@ def main():
     C_LOOP_OK["ok"] = not (args.lib or args.python_loop)
     width, height = WORKLOADS[args.workload]
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    args.affinity = None if args.no_pin else plan_pinning(local_rank, local_world, max(1, args.streams), max(1, ndev))
+    pin = "off" if args.no_pin else args.pin
+    args.affinity = plan_pinning(local_rank, local_world, max(1, args.streams), max(1, ndev)) if pin == "on" or (pin == "auto" and local_world > 1) else None
     if args.batch:
         if args.workload.endswith("422"):
             raise SystemExit("--batch is defined for the RGB workloads")

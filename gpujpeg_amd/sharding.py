@@ -61,11 +61,40 @@ def gpu_local_cpus(pci_bus_id, sysfs="/sys"):
     return cpus or None
 
 
-def plan_affinity(local_rank, local_world, threads, allowed, local_cpus_by_rank):
+def busy_cpus(interval=0.05, threshold=0.2, stat="/proc/stat"):
+    """Cores that other work keeps busy right now (share of non-idle time over `interval` seconds above `threshold`): a launch thread bound to
+    one of them queues behind a stranger. Empty when the platform does not say."""
+    import time
+
+    def snap():
+        out = {}
+        try:
+            for ln in open(stat):
+                if ln.startswith("cpu") and ln[3:4].isdigit():
+                    f = ln.split()
+                    v = [int(x) for x in f[1:9]]
+                    out[int(f[0][3:])] = (sum(v), v[3] + v[4])  # total, idle + iowait
+        except OSError:
+            pass
+        return out
+
+    a = snap()
+    time.sleep(interval)
+    b = snap()
+    busy = set()
+    for c, (tot, idle) in b.items():
+        if c in a and tot > a[c][0]:
+            if 1.0 - (idle - a[c][1]) / (tot - a[c][0]) > threshold:
+                busy.add(c)
+    return busy
+
+
+def plan_affinity(local_rank, local_world, threads, allowed, local_cpus_by_rank, avoid=()):
     """Cores for the `threads` launch threads of rank `local_rank`: a slice of the cores next to its GPU that no other rank of the node
     is given. `allowed` is what this process may run on at all; `local_cpus_by_rank[r]` the cores next to rank r's GPU (None = unknown).
     Ranks whose GPUs share a NUMA node split its cores evenly. Returns a list of `threads` cores (repeating when there are fewer cores
-    than threads) or None when nothing can be said -- then nobody is pinned."""
+    than threads) or None when nothing can be said -- then nobody is pinned. Cores in `avoid` (busy_cpus()) are used only when the
+    share has no others."""
     allowed = sorted(set(allowed))
     if not allowed or threads <= 0:
         return None
@@ -79,6 +108,9 @@ def plan_affinity(local_rank, local_world, threads, allowed, local_cpus_by_rank)
     per = max(1, len(pool) // len(sharers))
     k = sharers.index(local_rank)
     share = pool[k * per:(k + 1) * per] or pool
+    idle = [c for c in share if c not in set(avoid)]
+    if len(idle) >= min(threads, len(share)) or (idle and len(idle) * 2 >= len(share)):
+        share = idle
     # spread over the share (SMT siblings are usually numbered far apart, neighbours are distinct cores)
     return [share[i % len(share)] for i in range(threads)]
 

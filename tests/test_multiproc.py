@@ -68,7 +68,7 @@ def test_launch_thread_affinity_plan(tmp_path):
     """gpujpeg_amd.sharding.plan_affinity: the launch threads of a rank get cores of the NUMA node of its GPU, the ranks of one node
     disjoint cores; without platform information the allowed cores are split by rank; a thread can really be bound."""
     import os
-    from gpujpeg_amd.sharding import gpu_local_cpus, parse_cpulist, pin_current_thread, plan_affinity
+    from gpujpeg_amd.sharding import busy_cpus, gpu_local_cpus, parse_cpulist, pin_current_thread, plan_affinity
     assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     allowed = list(range(128))
     near = [list(range(0, 64))] * 4 + [list(range(64, 128))] * 4
@@ -82,6 +82,14 @@ def test_launch_thread_affinity_plan(tmp_path):
     # near cores outside what the process may use fall back to the allowed set
     assert set(plan_affinity(0, 1, 2, [5, 6], [[0, 1]])) <= {5, 6}
     assert plan_affinity(0, 1, 0, [0], [None]) is None
+    # cores that strangers keep busy are left out while the share has enough others
+    assert plan_affinity(0, 2, 3, range(16), [list(range(8))] * 2, avoid={0, 1}) == [2, 3, 2]
+    assert set(plan_affinity(0, 1, 4, range(16), [list(range(8))], avoid={0, 1, 2})) == {3, 4, 5, 6}
+    assert plan_affinity(0, 1, 4, range(16), [list(range(4))], avoid={0, 1, 2, 3}) == [0, 1, 2, 3]  # all busy: no better choice
+    stat = tmp_path / "stat"  # (identical snapshots: nothing is busy; the parser takes per-core lines only)
+    stat.write_text("cpu  10 0 10 100 0 0 0 0 0 0\ncpu0 5 0 5 50 0 0 0 0 0 0\ncpu1 5 0 5 50 0 0 0 0 0 0\nintr 1\n")
+    assert busy_cpus(0.0, stat=str(stat)) == set()
+    assert isinstance(busy_cpus(0.01), set)
     # sysfs lookup (a fake tree) and a real bind of this thread, undone afterwards
     dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
     dev.mkdir(parents=True)

@@ -1,5 +1,9 @@
 #!/bin/bash
+# what the round ends with: every -m gpu test, the profile set of every BASELINE configuration, the driver's bench command
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+( time timeout 1500 python -m pytest tests -m gpu -q -n 4 2>&1 | tail -4 ) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4_gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+tools/profile_all.sh 2>&1 | grep -v amdgpu.ids | grep -E "^==|^k_|merged" 
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4_11_bench.json 2> gpurun_out/r4_11_bench.err
 python - <<'PY'
 import json

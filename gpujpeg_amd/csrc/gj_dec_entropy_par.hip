@@ -654,6 +654,46 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const u
         const int nb = plan.batch0[plan.n];
         if (!resident || eg || nb <= (int)resident || nb > (int)resident * 5 / 4) break;
     }
+    // One generation of workgroups ends with its slowest batch, and batches of equal BYTES are not equally slow: a workgroup's time grows with
+    // its bytes and with its blocks (8K, round-4 phase trace: 27 luminance segments = 7.8 KB and 972 blocks take 59 us, 64 chrominance segments =
+    // 7.0 KB and 2 304 blocks 71 us; ~5.5 us per KB + ~12 us per 1000 blocks). When the frame fits one generation, cut the scans so that the
+    // estimated times are equal: segments per batch ~ 1 / (cost of a segment of that scan), as small as the resident workgroups allow. What it
+    // buys is a full generation for sparse content, where batches of equal bytes are few and long (8K camera frame: 695 batches, 68.9 us; cut
+    // this way 1014 batches, 57.5 us). A plan that already fills nine tenths of the generation is left alone: for the natural 8K frame the
+    // cut by time gave 74.9 against 74.1 us (a CU's four workgroups share its throughput: moving work between them does not change when the
+    // last one ends). OFF by default (GJ_DEC_BALANCE=1): it is a latency optimisation for a lone decode -- with four pipelines sharing the GPU the same
+    // camera frame runs at 230 instead of 241 Gpix/s, because more, smaller batches are more work in total and nothing is idle to begin with.
+    if (resident && per_scan && !eg && job->tune.dec_balance && plan.batch0[plan.n] <= (int)resident * 9 / 10) {
+        double w[GJ_MAX_COMP], work = 0.0, worst_now = 0.0;
+        for (int c = 0; c < g.comp_count; c++) {
+            const double avg = (double)job->scan_bytes[c] / (double)max(1, plan.count[c]) + 12.0;
+            w[c] = avg * 5.5e-3 + (double)g.seg_blocks * 12.1e-3; // us per segment
+            work += w[c] * plan.count[c];
+            worst_now = max(worst_now, w[c] * plan.g[c]);
+        }
+        // (a batch also costs ~15 us whatever it holds -- table, tables, stage, barriers: below ~25 us per batch more, smaller batches lose, which is
+        // what the 768-batch rule above encodes for HD and 4K: 4K natural 42.8 against 41.5 us, 4K camera 48.7 against 46.5 us when cut this way)
+        for (int step = 0; step < 40 && work / (double)resident >= 25.0; step++) {
+            const double T = work / (double)resident * (1.0 + 0.01 * step); // time of every batch
+            GjBatchPlan q = plan;
+            bool ok = true;
+            double worst = 0.0;
+            for (int c = 0; c < g.comp_count && ok; c++) {
+                const unsigned avg = (unsigned)(job->scan_bytes[c] / (uint64_t)max(1, plan.count[c])) + 12u;
+                const int cap_g = (int)min(min(gmax, max_blocks / (unsigned)max(1, g.seg_blocks)), (cap_u * 27u / 32u) / avg);
+                const int G = min((int)(T / w[c]), cap_g);
+                ok = G >= 1;
+                if (!ok) break;
+                q.g[c] = G;
+                q.batch0[c + 1] = q.batch0[c] + (q.count[c] + G - 1) / G;
+                worst = max(worst, w[c] * G);
+            }
+            if (ok && q.batch0[q.n] <= (int)resident) {
+                if (worst < worst_now * 0.97) plan = q;
+                break;
+            }
+        }
+    }
     return plan;
 }
 

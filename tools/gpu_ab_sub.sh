@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; R=$PWD
+for l in libgpujpeg.so libgpujpeg_sub17.so libgpujpeg_sub18.so libgpujpeg_sub20.so; do for w in 8k 4k; do
+rm -rf /tmp/kt; cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --lean --streams 1 --workload $w --lib $R/gpujpeg_amd/lib/$l > /tmp/kt.log 2>&1; cd $R
+echo "$l $w: $(python - <<'PY'
+import csv,glob
+for f in glob.glob('/tmp/kt/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'k_huffman_decode_tok' in r['Name']: print('tok avg us', round(float(r['AverageNs'])/1e3,2), 'calls', r['Calls'])
+PY
+)"; done; done

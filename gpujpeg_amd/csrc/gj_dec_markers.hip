@@ -394,14 +394,18 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     gj_scan_shape(size - begin, &iters, &rounds);
     if (tune->scan_shape > 0) { // (developer switch: a given shape)
         const uint32_t it = (uint32_t)tune->scan_shape / 100u, rd = (uint32_t)tune->scan_shape % 100u;
-        if ((it == 1 || it == 2 || it == 4 || it == 8 || it == 16) && rd >= 1 && rd <= 4 && (size - begin + 16 + 4096ull * it * rd - 1) / (4096ull * it * rd) <= maxlen_capacity) {
+        // (only while the scratch -- records and lists for gj_hip_find_segments_max_chunks() workgroups -- and the host's array hold that many
+        // workgroups: a forced shape of small parts on a long stream used to write behind the scratch, found under AddressSanitizer in round 4)
+        const uint64_t forced = (size - begin + 16 + 4096ull * it * rd - 1) / (4096ull * it * rd);
+        if ((it == 1 || it == 2 || it == 4 || it == 8 || it == 16) && rd >= 1 && rd <= 4 && forced <= maxlen_capacity &&
+            forced < gj_hip_find_segments_max_chunks(begin, size)) {
             iters = it;
             rounds = rd;
         }
     }
     const uint64_t lead = (reinterpret_cast<uintptr_t>(d_jpeg) + begin) & 15u, part = 4096ull * iters * rounds;
     const uint32_t wgs = (uint32_t)((size - begin + lead + part - 1) / part);
-    if (wgs > maxlen_capacity) return -1;
+    if (wgs > maxlen_capacity || wgs >= gj_hip_find_segments_max_chunks(begin, size)) return -1;
     *maxlen_part_count = wgs;
     uint32_t* recs = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15); // [wgs] records, then [wgs] lists
     uint32_t* lists = recs + (size_t)gj_hip_find_segments_max_chunks(begin, size) * GJ_SCAN_REC_WORDS;

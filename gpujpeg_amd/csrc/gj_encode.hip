@@ -991,6 +991,7 @@ struct GjTail {
     uint32_t segs[GJ_MAX_COMP];        // segments of the scan
     uint32_t block_first[GJ_MAX_COMP]; // coding-order index of the scan's first block (addresses d_temp)
     uint32_t spt, seg_blocks;          // segments per tile, blocks per full segment
+    uint64_t temp_blocks;              // blocks d_temp has room for (the last segment of a scan may be shorter than seg_blocks: its tile's area ends early)
     uint32_t main_hdr;
     uint32_t* d_result;
     uint32_t* h_result;
@@ -1029,8 +1030,12 @@ __global__ __launch_bounds__(256) void k_gather(const GjTail T)
     const uint32_t t = (have ? p : 0u) - gj_pick4(T.scan_first, scan), seg0 = t * T.spt, scan_segs = gj_pick4(T.segs, scan);
     const uint32_t nseg = have ? min(T.spt, scan_segs - seg0) : 0u;
     const uint32_t s0 = gj_pick4(T.seg_first, scan) + seg0;
-    const uint32_t* const src = reinterpret_cast<const uint32_t*>(T.temp + ((uint64_t)gj_pick4(T.block_first, scan) + (uint64_t)seg0 * T.seg_blocks) * GJ_TEMP_BYTES_PER_BLOCK);
-    const uint32_t src_dw = nseg * T.seg_blocks * (GJ_TEMP_BYTES_PER_BLOCK / 4u); // (dwords of the tile's area: nothing is read behind them)
+    const uint64_t src_block = (uint64_t)gj_pick4(T.block_first, scan) + (uint64_t)seg0 * T.seg_blocks;
+    const uint32_t* const src = reinterpret_cast<const uint32_t*>(T.temp + src_block * GJ_TEMP_BYTES_PER_BLOCK);
+    // dwords of the tile's area: nothing is read behind them, nor behind the buffer (the area of a scan's last tile ends with its last,
+    // shorter segment; found by the execution model under AddressSanitizer in round 4: the preload below read up to 35 blocks further)
+    const uint64_t room = T.temp_blocks > src_block ? T.temp_blocks - src_block : 0u;
+    const uint32_t src_dw = (uint32_t)min((uint64_t)nseg * T.seg_blocks, room) * (GJ_TEMP_BYTES_PER_BLOCK / 4u);
     // ---- one trip: group totals, the sizes of the tiles of the group in front of the workgroup's first one and of the workgroup's
     // own, the segments' counts, the first rounds of the stream
     const uint32_t ga = p0 >> 5;
@@ -1743,6 +1748,7 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     T.piece = job->d_tail + 2 * ngcap;
     T.npieces = pieces;
     T.temp = job->d_temp;
+    T.temp_blocks = (uint64_t)g.block_count;
     T.seg_bytes = job->d_seg_bytes;
     T.seg_ff = job->d_seg_ff;
     T.jpeg = job->d_jpeg;

@@ -30,7 +30,7 @@ def emu_lib(G):
         fcntl.flock(lock, fcntl.LOCK_EX)
         r = subprocess.run(["make", "-s", "-j8", "-C", EMU_DIR], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
-    lib = G.Library(EMU_LIB)
+    lib = G.Library(os.environ.get("GJ_EMU_LIB") or EMU_LIB)  # (GJ_EMU_LIB: another build of the execution model, e.g. the ASan one with its runtime preloaded)
     assert lib.L.gpujpeg_init_device(0, 0) == 0
     return lib
 

@@ -279,10 +279,14 @@ def test_width_padding(O, G, gpu_lib):
     p, pi = api_params(gpu_lib, G, case)
     pi.width_padding = pad
     img = O.make_image(w, h, restart_interval=5, width_padding=pad)
+    # the API counts the padding in PIXELS when it sizes the caller's buffer ((width + width_padding) * height * bpp,
+    # src/gpujpeg_common.c:1188) and in BYTES when it walks the rows: the buffer a caller hands over has to be the larger of the two
+    buf = np.zeros(gpu_lib.L.gpujpeg_image_calculate_size(C.byref(pi)), np.uint8)
+    buf[: raw.size] = raw
     for fused in (True, False):
         enc = G.Encoder(gpu_lib)
         enc.set_fused(fused)
-        assert np.array_equal(enc.encode(p, pi, raw), O.encode(img, raw))
+        assert np.array_equal(enc.encode(p, pi, buf), O.encode(img, raw))
 
 
 # ---- entropy decoder variants: sub-sequence parallel kernel (default), lane-per-segment kernel, and the hand-over of

@@ -1,6 +1,11 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_refhip.py -q -x -n 4 -k "encode or tiles or bit_exact or refhip or stress" 2>&1 | tail -2
-for w in 8k 4k hd; do python tools/solo_kernels.py gpujpeg_amd/lib/libgpujpeg.so $w 2>/dev/null | tail -1; done
-timeout 300 python bench.py --lean 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['metric'], d['value'])"
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; R=$PWD
+for l in libgpujpeg_ahead0.so libgpujpeg_ahead1.so libgpujpeg.so; do for w in 8k 4k; do
+rm -rf /tmp/kt; cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --lean --streams 1 --workload $w --lib $R/gpujpeg_amd/lib/$l > /tmp/kt.log 2>&1; cd $R
+echo "$l $w: $(python - <<'PY'
+import csv,glob
+for f in glob.glob('/tmp/kt/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'k_gather' in r['Name']: print(r['Name'][:16], round(float(r['AverageNs'])/1e3,2), end='; ')
+PY
+)"; done; done

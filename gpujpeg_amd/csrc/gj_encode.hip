@@ -1222,8 +1222,13 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     __syncthreads(); // tables are in LDS
     GJ_TRACE_E(1); // pixels loaded and converted
 
+    // A small frame has fewer tiles than the GPU has places for workgroups (HD: 135 for 1024): launched with gridDim.y == 3 every workgroup codes
+    // ONE component of its tile -- the pixels are loaded and converted three times, by CUs that would otherwise idle, and a tile's components
+    // run side by side instead of one after the other.
+    const bool one_component = gridDim.y == 3;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
+        if (one_component && c != (int)blockIdx.y) continue;
         const gj_comp_geom& kc = g.comp[c];
         // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
 #pragma unroll
@@ -1854,7 +1859,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         T = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, (unsigned)spt);
-        hipLaunchKernelGGL(whole, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
+        // (a component per workgroup while three times the tiles still fit the places the GPU has: GJ_ENC_SPLIT=<tiles> moves the limit, 0 = never)
+        const unsigned split_up_to = job->tune.enc_split >= 0 ? (unsigned)job->tune.enc_split : 341u;
+        hipLaunchKernelGGL(whole, dim3(wgs, wgs <= split_up_to ? 3 : 1), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
                            job->d_seg_bytes, job->d_seg_ff, T);
     } else {
     tiles = false;

@@ -85,8 +85,8 @@ def test_emu_packed_422_whole_frame_encoder(O, G, emu_lib, w, h, restart):
 
 
 @pytest.mark.parametrize("tc", T.TAIL_CASES, ids=[c[0] for c in T.TAIL_CASES])
-def test_emu_encoder_tiles_and_gather(O, G, emu_lib, tc):
-    T.test_encoder_tiles_and_gather(O, G, emu_lib, tc)
+def test_emu_encoder_tiles_and_gather(O, G, emu_lib, tc, monkeypatch):
+    T.test_encoder_tiles_and_gather(O, G, emu_lib, tc, monkeypatch)
 
 
 @pytest.mark.parametrize("shape", [101, 103, 204, 401, 802, 1601, 1604])

@@ -381,7 +381,7 @@ TAIL_CASES = [
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tc", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
-def test_encoder_tiles_and_gather(O, G, gpu_lib, tc):
+def test_encoder_tiles_and_gather(O, G, gpu_lib, tc, monkeypatch):
     """k_encode_* leave the unstuffed stream of every tile and its size in the file; k_gather (one wave per tile stream) places, stuffs
     and marks them: the file's bytes must be the oracle's (replaces src/gpujpeg_huffman_gpu_encoder.cu:417-613 and the host stitching of
     src/gpujpeg_encoder.c:567-629), with and without the APP13 index, three times in a row on the same coder (the group totals
@@ -390,13 +390,19 @@ def test_encoder_tiles_and_gather(O, G, gpu_lib, tc):
     case = (name, w, h, pf, cs, q, restart, il, sub, 3)
     comps = {0: 1, 1: 3}.get(pf)
     raw = natural_image(w, h, comps, seed=w) if comps and not noisy else O.noise(O.raw_size(w, h, pf), seed=w * 7 + h)
-    enc = G.Encoder(gpu_lib)  # (reads the switch)
-    for seg_info in (0, 1, 0):
-        want = O.encode(oracle_image(O, case, segment_info=seg_info), raw)
-        p, pi = api_params(gpu_lib, G, case, segment_info=seg_info)
-        got = enc.encode(p, pi, raw)
-        assert got.size == want.size and np.array_equal(got, want), (name, seg_info, got.size, want.size)
-    enc.close()
+    # (k_encode_rgb444 codes a small frame one component per workgroup, a large one all three in one: GJ_ENC_SPLIT moves the limit -- both ways here)
+    for split in (None, "0", "100000"):
+        if split is None:
+            monkeypatch.delenv("GJ_ENC_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("GJ_ENC_SPLIT", split)
+        enc = G.Encoder(gpu_lib)  # (reads the switch)
+        for seg_info in (0, 1, 0):
+            want = O.encode(oracle_image(O, case, segment_info=seg_info), raw)
+            p, pi = api_params(gpu_lib, G, case, segment_info=seg_info)
+            got = enc.encode(p, pi, raw)
+            assert got.size == want.size and np.array_equal(got, want), (name, seg_info, split, got.size, want.size)
+        enc.close()
 
 
 @pytest.mark.gpu

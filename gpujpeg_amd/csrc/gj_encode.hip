@@ -1184,7 +1184,7 @@ __device__ __forceinline__ void gj_load_coder_lut(uint32_t* s_lut, const uint32_
 // stream in d_temp, byte and 0xFF counts per segment, the stream's size in the file) is what k_gather turns into the file.
 // Used for non-interleaved 4:4:4 with restart intervals of 4 .. 256 blocks.
 // ================================================================================================
-template <int CS_FROM, int CS_TO>
+template <int CS_FROM, int CS_TO, bool ONE_COMPONENT = false>
 __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const uint8_t* __restrict__ raw, const float* __restrict__ q_luma,
                                                           const float* __restrict__ q_chroma, const uint32_t* __restrict__ lut,
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
@@ -1222,13 +1222,13 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     __syncthreads(); // tables are in LDS
     GJ_TRACE_E(1); // pixels loaded and converted
 
-    // A small frame has fewer tiles than the GPU has places for workgroups (HD: 135 for 1024): launched with gridDim.y == 3 every workgroup codes
+    // A small frame has fewer tiles than the GPU has places for workgroups (HD: 135 for 1024): ONE_COMPONENT, launched with gridDim.y == 3, codes
     // ONE component of its tile -- the pixels are loaded and converted three times, by CUs that would otherwise idle, and a tile's components
     // run side by side instead of one after the other.
-    const bool one_component = gridDim.y == 3;
+    // (a template parameter: the check costs the three-component instantiation of the 8K frame 0.7 us when it is made at run time)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        if (one_component && c != (int)blockIdx.y) continue;
+        if (ONE_COMPONENT && c != (int)blockIdx.y) continue;
         const gj_comp_geom& kc = g.comp[c];
         // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
 #pragma unroll
@@ -1781,17 +1781,17 @@ static gj_fused_kernel_t gj_fused_kernel(const gj_geom& g)
 }
 
 // fully fused kernel for this configuration, or nullptr
-static gj_encode_kernel_t gj_encode_kernel(const gj_geom& g)
+static gj_encode_kernel_t gj_encode_kernel(const gj_geom& g, const bool one_component = false)
 {
     if (g.pixel_format != GJ_PF_444_P012 || g.comp_count != 3 || g.interleaved || g.restart_interval <= 0 || g.seg_blocks > 256 || g.seg_blocks < 256 / GJ_ENC_MAX_SPT) return nullptr;
     for (int c = 0; c < 3; c++)
         if (g.comp[c].samp_h != 1 || g.comp[c].samp_v != 1) return nullptr;
     const int from = g.color_space, to = g.color_space_internal;
-    if (from == to || from == GJ_CS_NONE || to == GJ_CS_NONE) return k_encode_rgb444<GJ_CS_NONE, GJ_CS_NONE>;
-    if (from == GJ_CS_RGB && to == GJ_CS_BT601_256) return k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601_256>;
-    if (from == GJ_CS_RGB && to == GJ_CS_BT601) return k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601>;
-    if (from == GJ_CS_RGB && to == GJ_CS_BT709) return k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT709>;
-    if (from == GJ_CS_BT601_256 && to == GJ_CS_RGB) return k_encode_rgb444<GJ_CS_BT601_256, GJ_CS_RGB>;
+    if (from == to || from == GJ_CS_NONE || to == GJ_CS_NONE) return one_component ? k_encode_rgb444<GJ_CS_NONE, GJ_CS_NONE, true> : k_encode_rgb444<GJ_CS_NONE, GJ_CS_NONE>;
+    if (from == GJ_CS_RGB && to == GJ_CS_BT601_256) return one_component ? k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601_256, true> : k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601_256>;
+    if (from == GJ_CS_RGB && to == GJ_CS_BT601) return one_component ? k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601, true> : k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT601>;
+    if (from == GJ_CS_RGB && to == GJ_CS_BT709) return one_component ? k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT709, true> : k_encode_rgb444<GJ_CS_RGB, GJ_CS_BT709>;
+    if (from == GJ_CS_BT601_256 && to == GJ_CS_RGB) return one_component ? k_encode_rgb444<GJ_CS_BT601_256, GJ_CS_RGB, true> : k_encode_rgb444<GJ_CS_BT601_256, GJ_CS_RGB>;
     return nullptr;
 }
 
@@ -1861,7 +1861,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         T = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, (unsigned)spt);
         // (a component per workgroup while three times the tiles still fit the places the GPU has: GJ_ENC_SPLIT=<tiles> moves the limit, 0 = never)
         const unsigned split_up_to = job->tune.enc_split >= 0 ? (unsigned)job->tune.enc_split : 341u;
-        hipLaunchKernelGGL(whole, dim3(wgs, wgs <= split_up_to ? 3 : 1), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
+        const bool split = wgs <= split_up_to;
+        if (split) whole = gj_encode_kernel(g, true);
+        hipLaunchKernelGGL(whole, dim3(wgs, split ? 3 : 1), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
                            job->d_seg_bytes, job->d_seg_ff, T);
     } else {
     tiles = false;

@@ -1,5 +1,12 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -n 4 -k "token or tok or damaged or decoder or dense or baseline or full" 2>&1 | tail -2
-for p in natural camera gradient; do timeout 300 python bench.py --lean --pattern $p 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$p', d['value'], [ (k['kernel'],k['ms']) for k in d['roofline']['by_kernel']])"; done
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; R=$PWD
+for tk in "" 1; do
+rm -rf /tmp/kt; cd /tmp; GJ_DEC_TOKENS=$tk timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --lean --streams 1 --workload hd > /tmp/kt.log 2>&1; cd $R
+echo "GJ_DEC_TOKENS=$tk hd: $(python - <<'PY'
+import csv,glob
+for f in glob.glob('/tmp/kt/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r['Name'].startswith(('k_','void k_')): print(r['Name'].replace('void ','')[:22], round(float(r['AverageNs'])/1e3,2), end='; ')
+PY
+)"; GJ_DEC_TOKENS=$tk timeout 300 python bench.py --lean --workload hd 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('   throughput', d['value'])"; done

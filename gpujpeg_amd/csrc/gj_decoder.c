@@ -11,6 +11,7 @@
 #include <strings.h>
 
 #include "gj_internal.h"
+#include "gpujpeg_amd_ext.h"
 
 struct gpujpeg_decoder {
     struct gj_coder coder;
@@ -704,7 +705,6 @@ void gpujpeg_decoder_print_options(void)
 }
 
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
-#include "gpujpeg_amd_ext.h"
 
 size_t gpujpeg_amd_decoder_read_coefficients(struct gpujpeg_decoder* d, int16_t* dst, size_t capacity)
 {

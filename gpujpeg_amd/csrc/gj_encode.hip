@@ -995,6 +995,9 @@ struct GjTail {
     uint32_t main_hdr;
     uint32_t* d_result;
     uint32_t* h_result;
+    // frame batch (gj_enc_job::batch: blockIdx.z = frame): what lies between the buffers of two frames; all zero for a single frame
+    uint64_t f_raw, f_temp, f_jpeg; // bytes
+    uint32_t f_seg, f_tail;         // words of seg_bytes / seg_ff, of the tile list and of the group totals
 };
 
 __device__ __forceinline__ uint32_t gj_pick4(const uint32_t (&a)[GJ_MAX_COMP], const uint32_t s)
@@ -1007,16 +1010,24 @@ __device__ __forceinline__ uint32_t gj_tail_scan_of(const GjTail& T, const uint3
     return (p >= T.scan_first[1] ? 1u : 0u) + (p >= T.scan_first[2] ? 1u : 0u) + (p >= T.scan_first[3] ? 1u : 0u);
 }
 // an encoder workgroup's entry for tile stream p
-__device__ __forceinline__ void gj_piece_put(const GjTail& T, const uint32_t p, const uint32_t size)
+__device__ __forceinline__ void gj_piece_put(const GjTail& T, const uint32_t p, const uint32_t size, const size_t frame_words = 0)
 {
-    T.piece[p] = size;
-    (void)__hip_atomic_fetch_add(&T.group[p >> 5], size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T.piece[frame_words + p] = size;
+    (void)__hip_atomic_fetch_add(&T.group[frame_words + (p >> 5)], size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #define GJ_GATHER_PRELOAD 8 // rounds of 64 dwords whose loads are issued before anything is known about the tile stream
 #define GJ_GATHER_MARK_DW 2048 // dwords of a tile stream whose segment starts are marked in LDS at a time
-__global__ __launch_bounds__(256) void k_gather(const GjTail T)
+__global__ __launch_bounds__(256) void k_gather(const GjTail T0)
 {
+    GjTail T = T0;
+    { // frame blockIdx.z of a batch: its own tile list, group totals, tile streams, segment counts, stream buffer and result words
+        const size_t fz = blockIdx.z;
+        T.piece += fz * T0.f_tail; T.group += fz * T0.f_tail; T.group_other += fz * T0.f_tail;
+        T.temp += fz * T0.f_temp; T.seg_bytes += fz * T0.f_seg; T.seg_ff += fz * T0.f_seg;
+        T.jpeg += fz * T0.f_jpeg; T.d_result += fz * 2;
+        if (T.h_result) T.h_result += fz * 2;
+    }
     __shared__ uint32_t s_tmp[4];
     __shared__ __attribute__((aligned(16))) uint8_t s_mark[4][GJ_GATHER_MARK_DW];
     const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
@@ -1202,6 +1213,12 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     GJ_TRACE_E(0);
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
+    // frame blockIdx.z of a batch (gj_enc_job::batch; strides zero for a single frame)
+    const size_t fz = blockIdx.z;
+    raw += fz * T.f_raw;
+    temp += fz * T.f_temp;
+    seg_bytes += fz * T.f_seg;
+    seg_ff += fz * T.f_seg;
 
     const gj_comp_geom& k0 = g.comp[0];
     const int B = g.seg_blocks;
@@ -1239,7 +1256,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
                                            temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
         // file order: the luminance scan's tiles, then the two chrominance scans'
-        if (i == 0) gj_piece_put(T, (uint32_t)c * gridDim.x + blockIdx.x, size);
+        if (i == 0) gj_piece_put(T, (uint32_t)c * gridDim.x + blockIdx.x, size, fz * T.f_tail);
     }
 }
 
@@ -1762,6 +1779,12 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     T.main_hdr = job->main_hdr_size;
     T.d_result = job->d_result;
     T.h_result = job->h_result;
+    const bool batch = job->batch.count > 1;
+    T.f_raw = batch ? job->batch.raw : 0;
+    T.f_temp = batch ? job->batch.temp : 0;
+    T.f_jpeg = batch ? job->batch.jpeg : 0;
+    T.f_seg = batch ? job->batch.seg : 0;
+    T.f_tail = batch ? job->batch.tail : 0;
     return T;
 }
 
@@ -1807,11 +1830,20 @@ static int gj_blocks_kernel_mode(const gj_geom& g)
     return 0;
 }
 
+// a batch of frames takes the fully fused 4:4:4 kernel and nothing else (no options that touch other buffers)
+extern "C" int gj_hip_encode_batchable(const gj_enc_job* job)
+{
+    return job->use_fused && !job->keep_coefs && !job->channel_remap && !job->flipped && !job->segment_info && gj_encode_kernel(job->g) != nullptr &&
+           !(job->tune.enc_by_blocks > 0);
+}
+
 extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS])
 {
     hipStream_t st = (hipStream_t)stream;
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
+    const unsigned frames = job->batch.count > 1 ? job->batch.count : 1u;
+    if (frames > 1 && (!gj_hip_encode_batchable(job) || frames > 65535u)) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
     if (job->channel_remap) { // the reference permutes the channels of the raw image in place first (src/gpujpeg_preprocessor.cu:570-575)
         const unsigned n = (unsigned)g.width * (unsigned)g.height;
@@ -1861,9 +1893,9 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         T = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, (unsigned)spt);
         // (a component per workgroup while three times the tiles still fit the places the GPU has: GJ_ENC_SPLIT=<tiles> moves the limit, 0 = never)
         const unsigned split_up_to = job->tune.enc_split >= 0 ? (unsigned)job->tune.enc_split : 341u;
-        const bool split = wgs <= split_up_to;
+        const bool split = wgs * frames <= split_up_to;
         if (split) whole = gj_encode_kernel(g, true);
-        hipLaunchKernelGGL(whole, dim3(wgs, split ? 3 : 1), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
+        hipLaunchKernelGGL(whole, dim3(wgs, split ? 3 : 1, frames), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
                            job->d_seg_bytes, job->d_seg_ff, T);
     } else {
     tiles = false;
@@ -1897,7 +1929,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     }
     if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
     if (tiles) // the tile streams -> the file: one wave each
-        hipLaunchKernelGGL(k_gather, dim3((T.npieces + 3) / 4), dim3(256), 0, st, T);
+        hipLaunchKernelGGL(k_gather, dim3((T.npieces + 3) / 4, 1, frames), dim3(256), 0, st, T);
     const bool seg_info = job->segment_info && g.restart_interval > 0;
     // (behind k_gather the segment offsets are needed for the APP13 index only)
     const unsigned scan_wgs = ((unsigned)g.segment_count + 1023) / 1024;

@@ -10,6 +10,7 @@
 #include <strings.h>
 
 #include "gj_internal.h"
+#include "gpujpeg_amd_ext.h"
 
 enum { GJ_OUT_PAGEABLE = 0, GJ_OUT_PINNED = 1, GJ_OUT_DEVICE = 2 };
 #define GJ_MAIN_HEADER_CAP 4096 /* staging of the main header (the writer never stores behind it and reports the size it would need) */
@@ -46,6 +47,16 @@ struct gpujpeg_encoder {
     int use_fused;
     gj_tuning tune; /* developer switches, read from the environment when the encoder is created */
     int keep_coefs; /* gpujpeg_amd_encoder_keep_coefficients */
+    /* frame batches (gpujpeg_amd_encoder_encode_batch): work buffers of one chunk of frames, the streams and result words of all frames */
+    uint8_t* b_temp; size_t b_temp_cap;
+    uint32_t* b_seg; size_t b_seg_cap;
+    uint32_t* b_tail; size_t b_tail_cap;
+    uint8_t* b_jpeg; size_t b_jpeg_cap;
+    uint32_t* b_result; size_t b_result_cap;
+    uint32_t* bh_result; size_t bh_result_cap; /* pinned */
+    uint8_t* b_raw; size_t b_raw_cap;          /* frames handed over in host memory */
+    uint8_t* b_hdr_sent; size_t b_hdr_len; const uint8_t* b_hdr_to; size_t b_hdr_slot; int b_hdr_frames; /* the header bytes at the start of b_jpeg's slots */
+    uint8_t* b_out; size_t b_out_cap; bool b_out_pinned; /* streams handed back in host memory */
 };
 
 /* ------------------------------------------------------------------ input helpers (gpujpeg_encoder.h:77-110) */
@@ -99,6 +110,9 @@ int gpujpeg_encoder_destroy(struct gpujpeg_encoder* e)
     gj_hip_free(e->d_temp); gj_hip_free(e->d_tail); gj_hip_free(e->d_scan_partial); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
     gj_hip_free(e->coder.d_raw_own); gj_hip_free(e->coder.d_planes); gj_hip_free(e->coder.d_coefs);
     gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header); free(e->hdr_sent);
+    gj_hip_free(e->b_temp); gj_hip_free(e->b_seg); gj_hip_free(e->b_tail); gj_hip_free(e->b_jpeg); gj_hip_free(e->b_result); gj_hip_free(e->b_raw);
+    gj_hip_host_free(e->bh_result); free(e->b_hdr_sent);
+    if (e->b_out_pinned) gj_hip_host_free(e->b_out); else free(e->b_out);
     gj_exif_tags_destroy(e->exif_tags);
     if (e->out_buf_pinned) gj_hip_host_free(e->out_buf); else free(e->out_buf);
     free(e->scan_hdrs.bytes);
@@ -368,6 +382,197 @@ int gpujpeg_encoder_get_stats(struct gpujpeg_encoder* e, struct gpujpeg_duration
     return 0;
 }
 
+
+/* ------------------------------------------------------------------ frame batches (MI355X extension, include/gpujpeg_amd_ext.h) */
+/* Frames of one geometry coded by ONE pair of launches per chunk (k_encode_rgb444 + k_gather with blockIdx.z = frame): an HD frame has 135
+ * tiles for the 1024 workgroup places of the device and six dependent launches per encode + decode, so frame-at-a-time calls leave the GPU
+ * mostly idle however many coders run side by side; a batch fills it. Same bytes as gpujpeg_encoder_encode frame by frame (which is what
+ * happens for configurations outside the fully fused 4:4:4 kernel). */
+#define GJ_BATCH_CHUNK_MAX 64
+#define GJ_BATCH_TEMP_BYTES ((size_t)6 << 30) /* tile areas of one chunk (address space: only the streams' bytes are touched) */
+
+int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi,
+                                     const uint8_t* frames, size_t frame_stride, int count, uint8_t** images_compressed, size_t* images_compressed_size)
+{
+    if (!e || !param || !pi || !frames || count < 1 || !images_compressed || !images_compressed_size) return -1;
+    struct gj_coder* c = &e->coder;
+    const bool img_changed = !c->configured || !gj_image_parameters_equal(&c->param_image, pi);
+    struct gpujpeg_parameters p = adjust_params(c, param, pi, img_changed);
+    p.perf_stats = 0;
+    if (e->table_quality != param->quality) {
+        for (int t = 0; t < 2; t++) {
+            float fwd[64];
+            gj_quant_table_raw(t, param->quality, e->qraw[t]);
+            gj_quant_table_forward(e->qraw[t], fwd);
+            if (gj_hip_memcpy_h2d(e->d_fwd_q[t], fwd, sizeof fwd, c->stream) != 0) return -1;
+        }
+        if (gj_hip_stream_sync(c->stream) != 0) return -1;
+        e->table_quality = param->quality;
+    }
+    if (encoder_configure(e, &p, pi) != 0) return -1;
+    const gj_geom* g = &c->geom;
+    if (frame_stride < g->raw_size) {
+        GJ_ERROR("Frame stride %zu is smaller than a frame (%zu B)!\n", frame_stride, (size_t)g->raw_size);
+        return -1;
+    }
+    const bool frames_on_device = gj_hip_is_device_ptr(frames) != 0;
+    /* the streams of ALL frames stay valid until the next call: a slot per frame, sized like the single-frame buffer */
+    const size_t slot = (e->d_jpeg_cap + 255) & ~(size_t)255;
+    if (gj_ensure_device_buffer((void**)&e->b_jpeg, &e->b_jpeg_cap, slot * (size_t)count) != 0) return -1;
+    if (gj_ensure_device_buffer((void**)&e->b_result, &e->b_result_cap, (size_t)count * 2 * sizeof(uint32_t)) != 0) return -1;
+    if ((size_t)count * 2 * sizeof(uint32_t) > e->bh_result_cap) {
+        gj_hip_host_free(e->bh_result);
+        e->bh_result_cap = (size_t)count * 2 * sizeof(uint32_t) * 2;
+        e->bh_result = gj_hip_host_alloc(e->bh_result_cap);
+        if (!e->bh_result) { e->bh_result_cap = 0; return -1; }
+    }
+
+    gj_enc_job job;
+    memset(&job, 0, sizeof job);
+    job.g = *g;
+    job.flipped = e->flipped;
+    job.channel_remap = e->channel_remap;
+    job.d_planes = c->d_planes;
+    job.d_coefs = c->d_coefs;
+    job.d_fwd_q[0] = e->d_fwd_q[0];
+    job.d_fwd_q[1] = e->d_fwd_q[1];
+    job.d_huff_lut = e->d_huff_lut;
+    job.tune = e->tune;
+    job.d_scan_hdr = e->d_scan_hdr;
+    memcpy(job.scan_hdr_offset, e->scan_hdrs.offset, sizeof job.scan_hdr_offset);
+    memcpy(job.scan_info_payload, e->scan_hdrs.info_payload, sizeof job.scan_info_payload);
+    job.segment_info = p.segment_info;
+    job.use_fused = e->use_fused && !e->flipped;
+    job.keep_coefs = e->keep_coefs;
+
+    if (!gj_hip_encode_batchable(&job)) {
+        /* another configuration than the fully fused kernel's: frame by frame, every stream copied to its slot */
+        for (int f = 0; f < count; f++) {
+            struct gpujpeg_encoder_input in;
+            if (frames_on_device) gpujpeg_encoder_input_set_gpu_image(&in, (uint8_t*)(uintptr_t)(frames + (size_t)f * frame_stride));
+            else gpujpeg_encoder_input_set_image(&in, (uint8_t*)(uintptr_t)(frames + (size_t)f * frame_stride));
+            const int loc = e->out_location;
+            e->out_location = GJ_OUT_DEVICE;
+            uint8_t* one = NULL;
+            size_t n = 0;
+            const int rc = gpujpeg_encoder_encode(e, param, pi, &in, &one, &n);
+            e->out_location = loc;
+            if (rc != 0 || n > slot) return -1;
+            if (gj_hip_memcpy_d2d(e->b_jpeg + (size_t)f * slot, one, n, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) return -1;
+            e->bh_result[2 * f] = (uint32_t)n;
+            e->bh_result[2 * f + 1] = 0;
+        }
+        e->b_hdr_to = NULL; /* (the slots' headers were overwritten by whole streams) */
+    } else {
+        /* main header: the same bytes at the start of every slot, uploaded when they change (as gpujpeg_encoder_encode does for its one buffer) */
+        const size_t hdr = gj_write_main_header(e->h_header, GJ_MAIN_HEADER_CAP, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata, e->exif_tags);
+        if (hdr > GJ_MAIN_HEADER_CAP) {
+            GJ_ERROR("The main header (%zu B: Exif tags, metadata) does not fit its %d B staging buffer.\n", hdr, GJ_MAIN_HEADER_CAP);
+            return -1;
+        }
+        if (!e->b_hdr_sent) e->b_hdr_sent = malloc(GJ_MAIN_HEADER_CAP);
+        if (!e->b_hdr_sent) return -1;
+        if (e->b_hdr_to != e->b_jpeg || e->b_hdr_slot != slot || e->b_hdr_frames < count || e->b_hdr_len != hdr || memcmp(e->b_hdr_sent, e->h_header, hdr) != 0) {
+            for (int f = 0; f < count; f++)
+                if (gj_hip_memcpy_h2d(e->b_jpeg + (size_t)f * slot, e->h_header, hdr, c->stream) != 0) return -1;
+            if (gj_hip_stream_sync(c->stream) != 0) return -1;
+            memcpy(e->b_hdr_sent, e->h_header, hdr);
+            e->b_hdr_len = hdr;
+            e->b_hdr_to = e->b_jpeg;
+            e->b_hdr_slot = slot;
+            e->b_hdr_frames = count;
+        }
+        /* chunks: as many frames per launch as their tile areas may take */
+        const size_t temp_frame = (((size_t)g->block_count * GJ_TEMP_BYTES_PER_BLOCK + 256) + 255) & ~(size_t)255;
+        const size_t seg_frame = ((size_t)g->segment_count * 2 + 16 + 3) & ~(size_t)3;          /* words: bytes | ff */
+        const size_t tail_frame = ((size_t)GJ_TAIL_WORDS(g->segment_count) + 3) & ~(size_t)3; /* words */
+        int chunk = (int)(GJ_BATCH_TEMP_BYTES / temp_frame);
+        if (chunk > GJ_BATCH_CHUNK_MAX) chunk = GJ_BATCH_CHUNK_MAX;
+        if (chunk > count) chunk = count;
+        if (chunk < 1) chunk = 1;
+        if (gj_ensure_device_buffer((void**)&e->b_temp, &e->b_temp_cap, temp_frame * (size_t)chunk) != 0) return -1;
+        if (gj_ensure_device_buffer((void**)&e->b_seg, &e->b_seg_cap, seg_frame * (size_t)chunk * sizeof(uint32_t)) != 0) return -1;
+        if (gj_ensure_device_buffer((void**)&e->b_tail, &e->b_tail_cap, tail_frame * (size_t)chunk * sizeof(uint32_t)) != 0) return -1;
+        const uint8_t* d_frames = frames;
+        size_t d_stride = frame_stride;
+        if (!frames_on_device) {
+            if (gj_ensure_device_buffer((void**)&e->b_raw, &e->b_raw_cap, (size_t)g->raw_size * (size_t)count) != 0) return -1;
+            gj_hip_event_record(c->timers.copy_in[0], c->stream); /* (copy marker, see gj_internal.h) */
+            for (int f = 0; f < count; f++)
+                if (gj_hip_memcpy_h2d(e->b_raw + (size_t)f * g->raw_size, frames + (size_t)f * frame_stride, g->raw_size, c->stream) != 0) return -1;
+            d_frames = e->b_raw;
+            d_stride = g->raw_size;
+        }
+        job.main_hdr_size = (uint32_t)hdr;
+        job.jpeg_capacity = e->d_jpeg_cap;
+        job.d_temp = e->b_temp;
+        job.d_seg_bytes = e->b_seg;
+        job.d_seg_ff = e->b_seg + g->segment_count;
+        job.d_seg_out = NULL;
+        job.d_scan_partial = e->d_scan_partial;
+        job.d_tail = e->b_tail;
+        job.tail_set = 0;
+        job.batch.raw = d_stride;
+        job.batch.jpeg = slot;
+        job.batch.temp = temp_frame;
+        job.batch.seg = (uint32_t)seg_frame;
+        job.batch.tail = (uint32_t)tail_frame;
+        for (int f0 = 0; f0 < count; f0 += chunk) {
+            const int n = count - f0 < chunk ? count - f0 : chunk;
+            /* (the group totals a launch adds to: zero for every frame of the chunk, whatever the chunks before it looked like) */
+            if (gj_hip_memset(e->b_tail, 0, tail_frame * (size_t)n * sizeof(uint32_t), c->stream) != 0) return -1;
+            job.d_raw = d_frames + (size_t)f0 * d_stride;
+            job.d_jpeg = e->b_jpeg + (size_t)f0 * slot;
+            job.d_result = e->b_result + 2 * (size_t)f0;
+            job.h_result = e->bh_result + 2 * (size_t)f0;
+            job.batch.count = (uint32_t)n;
+            if (++e->epoch == 0) e->epoch = 1;
+            job.epoch = e->epoch;
+            if (gj_hip_encode(&job, c->stream, NULL) != 0) {
+                GJ_ERROR("Encoder kernels failed: %s\n", gj_hip_last_error());
+                c->configured = false;
+                return -1;
+            }
+        }
+        if (gj_hip_stream_sync(c->stream) != 0) {
+            GJ_ERROR("Encoder failed: %s\n", gj_hip_last_error());
+            c->configured = false;
+            return -1;
+        }
+    }
+    size_t total = 0;
+    for (int f = 0; f < count; f++) {
+        if (e->bh_result[2 * f + 1]) {
+            GJ_ERROR("Compressed stream (%u B) of frame %d does not fit the output buffer (%zu B)!\n", e->bh_result[2 * f], f, e->d_jpeg_cap);
+            return -1;
+        }
+        images_compressed_size[f] = e->bh_result[2 * f];
+        total += (e->bh_result[2 * f] + 15u) & ~(size_t)15;
+    }
+    if (e->out_location == GJ_OUT_DEVICE) {
+        for (int f = 0; f < count; f++) images_compressed[f] = e->b_jpeg + (size_t)f * slot;
+    } else {
+        const bool want_pinned = e->out_location == GJ_OUT_PINNED;
+        if (total > e->b_out_cap || want_pinned != e->b_out_pinned) {
+            if (e->b_out_pinned) gj_hip_host_free(e->b_out); else free(e->b_out);
+            e->b_out = want_pinned ? gj_hip_host_alloc(total + total / 4) : malloc(total + total / 4);
+            e->b_out_pinned = want_pinned;
+            e->b_out_cap = e->b_out ? total + total / 4 : 0;
+            if (!e->b_out) return -1;
+        }
+        gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
+        size_t at = 0;
+        for (int f = 0; f < count; f++) {
+            if (gj_hip_memcpy_d2h(e->b_out + at, e->b_jpeg + (size_t)f * slot, images_compressed_size[f], c->stream) != 0) return -1;
+            images_compressed[f] = e->b_out + at;
+            at += (images_compressed_size[f] + 15u) & ~(size_t)15;
+        }
+        if (gj_hip_stream_sync(c->stream) != 0) return -1;
+    }
+    c->frames += count;
+    return 0;
+}
+
 /* ------------------------------------------------------------------ memory planning (src/gpujpeg_encoder.c:165-288) */
 size_t gpujpeg_encoder_max_memory(struct gpujpeg_parameters* param, struct gpujpeg_image_parameters* pi, enum gpujpeg_encoder_input_type type, int max_pixels)
 {
@@ -502,7 +707,6 @@ void gpujpeg_encoder_print_options(void)
 }
 
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
-#include "gpujpeg_amd_ext.h"
 
 size_t gpujpeg_amd_encoder_read_coefficients(struct gpujpeg_encoder* e, int16_t* dst, size_t capacity)
 {

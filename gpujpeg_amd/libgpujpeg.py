@@ -137,6 +137,11 @@ class Library:
             for n in ("gpujpeg_amd_encoder_set_fused", "gpujpeg_amd_decoder_set_fused", "gpujpeg_amd_decoder_keep_coefficients", "gpujpeg_amd_encoder_keep_coefficients"):
                 getattr(L, n).restype = None
                 getattr(L, n).argtypes = [vp, C.c_int]
+        if hasattr(L, "gpujpeg_amd_encoder_encode_batch"):  # frame batches (include/gpujpeg_amd_ext.h)
+            L.gpujpeg_amd_encoder_encode_batch.argtypes = [vp, C.POINTER(Parameters), C.POINTER(ImageParameters), vp, C.c_size_t, C.c_int,
+                                                           C.POINTER(vp), C.POINTER(C.c_size_t)]
+        if hasattr(L, "gpujpeg_amd_decoder_decode_batch"):
+            L.gpujpeg_amd_decoder_decode_batch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t, C.POINTER(ImageParameters)]
 
     # ---- parameter helpers ----
     def default_parameters(self):
@@ -183,6 +188,29 @@ class Encoder:
         if rc != 0:
             raise RuntimeError(f"gpujpeg_encoder_encode failed ({rc})")
         return out, size.value
+
+    def encode_batch_noclone(self, param, param_image, frames, count, stride=None, gpu=False):
+        """gpujpeg_amd_encoder_encode_batch: `count` frames of one geometry behind one set of launches. frames: numpy uint8 array holding
+        the frames back to back (host), or an integer device pointer when gpu=True; stride: bytes between two frames (default: a frame).
+        Returns ([pointer], [size]) of the streams -- device pointers with enc_opt_out=device, host pointers otherwise."""
+        if gpu:
+            base = int(frames)
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            self._keep = frames
+            base = frames.ctypes.data
+        if stride is None:
+            stride = self.lib.image_size(param_image)
+        ptrs, sizes = (C.c_void_p * count)(), (C.c_size_t * count)()
+        rc = self.lib.L.gpujpeg_amd_encoder_encode_batch(self.h, C.byref(param), C.byref(param_image), base, stride, count, ptrs, sizes)
+        if rc != 0:
+            raise RuntimeError(f"gpujpeg_amd_encoder_encode_batch failed ({rc})")
+        return [int(p or 0) for p in ptrs], [int(n) for n in sizes]
+
+    def encode_batch(self, param, param_image, frames, count, stride=None):
+        """host frames in, list of numpy uint8 copies of the streams out (encoder output in host memory, the default)"""
+        ptrs, sizes = self.encode_batch_noclone(param, param_image, frames, count, stride)
+        return [np.frombuffer((C.c_uint8 * n).from_address(p), np.uint8).copy() for p, n in zip(ptrs, sizes)]
 
     def stats(self):
         s = DurationStats()

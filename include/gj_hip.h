@@ -132,6 +132,24 @@ typedef struct gj_tuning {
 } gj_tuning;
 GJ_HIP_API void gj_hip_tuning_from_env(gj_tuning* t);
 
+/* Frame batch (MI355X extension, gpujpeg_amd_{encoder_encode,decoder_decode}_batch): `count` frames of ONE geometry, tables and header behind
+ * one set of launches (blockIdx.z = frame) -- an HD frame has 135 encoder tiles for the 1024 workgroup places of the device, a batch fills
+ * them. Frame f's buffers lie f x stride behind the job's pointers. count <= 1: a single frame, the strides are ignored. */
+typedef struct gj_batch {
+    uint32_t count;
+    uint64_t raw;            /* bytes between the frames' pixels (d_raw) */
+    uint64_t jpeg;           /* bytes between the frames' streams (d_jpeg) */
+    uint64_t temp;           /* encoder: bytes between the frames' tile areas (d_temp) */
+    uint64_t coefs;          /* decoder: int16 elements between the frames' coefficient planes */
+    uint64_t tok;            /* decoder: tokens between the frames' token arrays */
+    uint64_t rec;            /* decoder: block records between the frames' record arrays */
+    uint32_t seg;            /* words between the frames' per-segment arrays (encoder: seg_bytes, seg_ff; decoder: each of seg_pos, seg_len, seg_index) */
+    uint32_t tail;           /* encoder: words between the frames' d_tail */
+    uint32_t scratch;        /* decoder: words between the frames' marker-scan scratch */
+    uint32_t maxlen;         /* decoder: words between the frames' longest-segment words in pinned host memory */
+    const uint32_t* d_sizes; /* decoder: [count] bytes of every frame's stream, in device memory */
+} gj_batch;
+
 typedef struct gj_enc_job {
     gj_geom g;
     const uint8_t* d_raw;          /* input pixels in HBM */
@@ -162,7 +180,10 @@ typedef struct gj_enc_job {
     int keep_coefs;                /* 1: the caller wants the coefficient planes in d_coefs (tests): do not use the fully fused kernel */
     int flipped;                   /* enc_opt_flipped: flip the component planes vertically after the colour stage (generic path) */
     uint32_t channel_remap;        /* enc_opt_channel_remap: packed mapping, 0 = none; applied to d_raw IN PLACE before anything else */
+    gj_batch batch;                /* count > 1: a batch of frames (fully fused 4:4:4 kernel only; d_result / h_result hold two words per frame) */
 } gj_enc_job;
+/* 1 when gj_hip_encode takes a batch (gj_enc_job::batch.count > 1) of this job's configuration */
+GJ_HIP_API int gj_hip_encode_batchable(const gj_enc_job* job);
 
 /* events (may be NULL): 0 start, 1 after preprocess, 2 after DCT/quant, 3 after k_huffman, 4 after k_scan_segments,
  * 5 after k_assemble (+ segment info) */
@@ -207,7 +228,11 @@ typedef struct gj_dec_job {
     uint32_t tok_cap;              /* >= 4 x jpeg_size (tokens) */
     void* d_blkrec;                /* [g.block_count] uint2 per block in coding order: first token, count << 16 | (uint16) DC term;
                                       count 0xFFFF = the block is in d_coefs (segment decoded piece by piece) */
+    gj_batch batch;                /* count > 1: a batch of frames with the same header (speculative launches only: d_seg_count and d_overflow
+                                      point to frame 0's words inside arrays of gj_scan_summary) */
 } gj_dec_job;
+/* 1 when gj_hip_decode takes a batch (gj_dec_job::batch.count > 1) of this job's configuration */
+GJ_HIP_API int gj_hip_decode_batchable(const gj_dec_job* job);
 
 /* 1 when a frame of this geometry (requested output included) and stream size is decoded in token mode: a token-fed IDCT kernel
  * exists for it and the measured size / density rule (or the GJ_DEC_TOKENS / GJ_DEC_NO_TOKENS override) says so. The host asks

@@ -70,6 +70,25 @@ GPUJPEG_API int gpujpeg_amd_host_huffman_table_check(const uint8_t bits[17], con
 GPUJPEG_API int gpujpeg_amd_encoder_get_kernel_times(struct gpujpeg_encoder* encoder, float ms[8]);
 GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* decoder, float ms[8]);
 
+/* ---- frame batches: many frames of ONE geometry behind one set of kernel launches --------------------------------------------------
+ * The libgpujpeg API codes a frame per call. An HD frame is 135 workgroups of the encoder kernel on a device with 1024 places for them,
+ * and a call is 2 (encode) or 4 (decode) dependent launches: frame-at-a-time calls cannot fill an MI355X with small frames however many
+ * coders run side by side. These two calls take `count` frames that share parameters (encoder) or the header (decoder) and launch every
+ * kernel once per chunk of frames (the frame is a grid dimension). Results are identical, byte for byte, to the frame-at-a-time calls;
+ * configurations or streams the batched kernels do not cover are coded frame by frame inside the call.
+ *
+ * gpujpeg_amd_encoder_encode_batch: frame f lies at frames + f * frame_stride (device memory = GPU_IMAGE semantics, or host memory: copied);
+ *   images_compressed[f] / images_compressed_size[f] receive every frame's stream -- in device memory with enc_opt_out=device, else in
+ *   pinned / pageable host memory -- owned by the encoder and valid until its next call.
+ * gpujpeg_amd_decoder_decode_batch: stream f lies at streams + f * stream_stride and has sizes[f] bytes (device or host memory); frame f's
+ *   pixels go to output + f * output_stride (device memory) in the format set with gpujpeg_decoder_set_output_format. All streams must
+ *   decode to the same image parameters; returns 0 when every frame was decoded. */
+GPUJPEG_API int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* encoder, const struct gpujpeg_parameters* param,
+                                                 const struct gpujpeg_image_parameters* param_image, const uint8_t* frames, size_t frame_stride,
+                                                 int count, uint8_t** images_compressed, size_t* images_compressed_size);
+GPUJPEG_API int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* decoder, const uint8_t* streams, size_t stream_stride, const size_t* sizes,
+                                                 int count, uint8_t* output, size_t output_stride, struct gpujpeg_image_parameters* param_image);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,7 +120,7 @@ __device__ __forceinline__ uint32_t gj_decode_sub(const uint32_t* __restrict__ U
 }
 
 template <bool INTERLEAVED, int SUB_BYTES>
-__global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+__global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, const uint8_t* __restrict__ jpeg, uint64_t jpeg_size,
                                                             const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const GjBatchPlan plan,
@@ -131,6 +131,14 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     // hold only for short sub-sequences; nsub is clamped below all the same, so that a fault in this arithmetic cannot become a write
     // behind the per-sub-sequence arrays)
     constexpr int MAX_SUBS = GJ_PAR_CAP_U / SUB_BYTES + GJ_PAR_GMAX;
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch: its stream, its table, its summary word, its coefficient planes
+        const size_t z = blockIdx.z;
+        jpeg += z * g.fb.jpeg;
+        jpeg_size = g.fb.sizes[z];
+        seg_pos += z * g.fb.seg; seg_len += z * g.fb.seg; seg_index += z * g.fb.seg;
+        if (seg_count_ptr) seg_count_ptr += z * (sizeof(gj_scan_summary) / 4);
+        coefs += z * g.fb.coefs;
+    }
     static_assert(MAX_SUBS <= GJ_PAR_MAX_BLOCKS, "the work list lives in the DC array");
     constexpr uint32_t SUB_BITS = SUB_BYTES * 8;
     __shared__ uint32_t s_U[GJ_PAR_CAP_U / 4 + 4];
@@ -626,7 +634,8 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const u
     auto batch_size = [&](uint64_t bytes, int segs, unsigned fill /* 32nds of the stage */) {
         const unsigned avg = (unsigned)(bytes / (uint64_t)max(1, segs)) + 12u;
         int G = eg ? eg : (int)((cap_u * fill / 32u) / avg); // (a batch that outgrows the stage is decoded in two groups)
-        if (!eg) G = min(G, max(1, job->seg_count / 768)); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
+        const long all_segs = (long)job->seg_count * (job->batch.count > 1 ? (long)job->batch.count : 1L); // (a batch of frames: the segments of all of them)
+        if (!eg) G = min(G, (int)max(1L, all_segs / 768)); // small frames: rather more, shorter batches than idle CUs (measured: HD, 4K)
         return max(1, min(G, (int)min(gmax, max_blocks / (unsigned)max(1, g.seg_blocks))));
     };
     GjBatchPlan plan = {};
@@ -711,6 +720,6 @@ void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st)
                                 : (sub == 256 ? k_huffman_decode_par<false, 256> : sub == 128 ? k_huffman_decode_par<false, 128>
                                    : sub == 64 ? k_huffman_decode_par<false, 64> : sub == 32 ? k_huffman_decode_par<false, 32>
                                    : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
-    hipLaunchKernelGGL(kernel, dim3(batches), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
+    hipLaunchKernelGGL(kernel, dim3(batches, 1, job->batch.count > 1 ? job->batch.count : 1u), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
                        job->d_seg_index, job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1);
 }

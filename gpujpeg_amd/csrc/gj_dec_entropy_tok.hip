@@ -182,7 +182,7 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
 }
 
 template <bool COOP>
-__global__ __launch_bounds__(256, GJ_TOK_WG_PER_CU) void k_huffman_decode_tok(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+__global__ __launch_bounds__(256, GJ_TOK_WG_PER_CU) void k_huffman_decode_tok(const gj_geom g, const uint8_t* __restrict__ jpeg, uint64_t jpeg_size,
                                                                const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                                const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                                const uint32_t* __restrict__ seg_count_ptr, const GjBatchPlan plan,
@@ -191,6 +191,15 @@ __global__ __launch_bounds__(256, GJ_TOK_WG_PER_CU) void k_huffman_decode_tok(co
                                                                uint32_t* __restrict__ overflow)
 {
     constexpr int CAP_U = GJ_TOK_CAP_U, MAX_BLOCKS = GJ_TOK_MAX_BLOCKS, GMAX = GJ_TOK_GMAX, MAX_SUBS = GJ_TOK_MAX_SUBS;
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch: its stream, its table, its summary words, its tokens and records
+        const size_t z = blockIdx.z;
+        jpeg += z * g.fb.jpeg;
+        jpeg_size = g.fb.sizes[z];
+        seg_pos += z * g.fb.seg; seg_len += z * g.fb.seg; seg_index += z * g.fb.seg;
+        if (seg_count_ptr) seg_count_ptr += z * (sizeof(gj_scan_summary) / 4);
+        overflow += z * (sizeof(gj_scan_summary) / 4);
+        coefs += z * g.fb.coefs; d_tok += z * g.fb.tok; d_rec += z * g.fb.rec;
+    }
     __shared__ GjTokLds sm;
     constexpr int POOL = sizeof(sm.pool) / 2; // 16-bit units
     uint32_t* const s_stage = sm.U + 1;      // where the unstuffed bytes go: bit position 32 of the reader
@@ -658,9 +667,11 @@ __global__ __launch_bounds__(256, GJ_TOK_WG_PER_CU) void k_huffman_decode_tok(co
 void gj_launch_huffman_tok(const gj_dec_job* job, hipStream_t st)
 {
     const gj_geom& g = job->g;
-    const GjBatchPlan plan = gj_plan_batches(job, GJ_TOK_CAP_U, GJ_TOK_MAX_BLOCKS, GJ_TOK_GMAX, GJ_TOK_RESIDENT);
+    const unsigned frames = job->batch.count > 1 ? job->batch.count : 1u;
+    // (a batch of frames fills the device with frames: the fullest batches, no preference for one generation of workgroups)
+    const GjBatchPlan plan = gj_plan_batches(job, GJ_TOK_CAP_U, GJ_TOK_MAX_BLOCKS, GJ_TOK_GMAX, frames > 1 ? 0u : GJ_TOK_RESIDENT);
     auto kernel = job->tune.dec_tok_nocoop ? k_huffman_decode_tok<false> : k_huffman_decode_tok<true>;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)plan.batch0[plan.n]), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len, job->d_seg_index,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)plan.batch0[plan.n], 1, frames), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len, job->d_seg_index,
                        job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, (uint16_t*)job->d_tok, job->tok_cap, (uint2*)job->d_blkrec,
                        job->d_overflow);
 }

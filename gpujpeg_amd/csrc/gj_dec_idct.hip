@@ -114,6 +114,10 @@ template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256, 3) void k_idct_fused_rgb444(const gj_geom g, int16_t* __restrict__ coefs,
                                                               const float* __restrict__ qtab, uint8_t* __restrict__ raw, const int zero)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch
+        coefs += (size_t)blockIdx.z * g.fb.coefs;
+        raw += (size_t)blockIdx.z * g.fb.raw;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * GJ_TILE_PITCH];
     __shared__ __attribute__((aligned(8))) float s_q[3][64]; // dequantisation tables: read as VGPR pairs for v_pk_mul_f32
     if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
@@ -308,6 +312,11 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
                                                             const uint16_t* __restrict__ d_tok, const uint32_t tok_cap,
                                                             const float* __restrict__ qtab, uint8_t* __restrict__ raw)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch
+        const size_t z = blockIdx.z;
+        coefs += z * g.fb.coefs; d_rec += z * g.fb.rec; d_tok += z * g.fb.tok;
+        raw += z * g.fb.raw;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
     __shared__ __attribute__((aligned(16))) uint16_t s_stage[4][GJ_TOK_STAGE];
     // dequantisation tables: [0] for blocks rebuilt from tokens (AC entries / 64: the slot holds 64 x the value, see gj_slot_put; the DC term is
@@ -658,14 +667,17 @@ gj_idct_tok_t gj_idct_tok_for(const gj_geom& g)
     return nullptr;
 }
 
+bool gj_idct_takes_batches(const gj_geom& g) { return !g.interleaved && gj_idct_fused_kernel(g) != nullptr && gj_idct_tok_kernel(g) != nullptr; }
+
 void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_tok, gj_event_t* ev)
 {
     const gj_geom& g = job->g;
     const bool uyvy = job->use_fused && gj_is_uyvy422(g);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
+    const unsigned frames = job->batch.count > 1 ? job->batch.count : 1u; // (batches: the two rgb444 kernels only, gj_hip_decode_batchable)
     if (idct_tok) {
         const unsigned nb = g.interleaved ? (unsigned)g.block_count : (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block (position)
-        hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, (const uint16_t*)job->d_tok, job->tok_cap,
+        hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, (const uint16_t*)job->d_tok, job->tok_cap,
                            job->d_qtabf, job->d_raw);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else if (uyvy) {
@@ -674,7 +686,7 @@ void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_to
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else if (fused) {
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
-        hipLaunchKernelGGL(fused, dim3((nb + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
+        hipLaunchKernelGGL(fused, dim3((nb + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else {
         hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf,

@@ -39,12 +39,26 @@ extern "C" GJ_HIP_API int gj_hip_trace_set_markers(void* p) { return hipMemcpyTo
 //   than two other markers   [4 + 4 q ..] other marker q: position, code, the 16 bits behind the code (segment length), restart markers of
 //   the workgroup behind it
 
+// the frames of a batch (blockIdx.z = frame): sizes == nullptr for a single stream
+struct GjScanBatch {
+    const uint32_t* sizes;         // [frames] bytes of every stream
+    uint64_t jpeg;                 // bytes between two streams
+    uint32_t seg, scratch, maxlen; // words between the frames' tables, scratch areas (records, then lists) and longest-segment words
+};
+
 // ITERS pieces of 4 KB per round (16 bytes per lane and piece), `rounds` rounds per workgroup
 template <int ITERS>
-__global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size, const uint32_t rounds,
+__global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__ jpeg, const uint64_t begin, uint64_t size, const uint32_t rounds,
                                                      uint32_t* __restrict__ recs, uint32_t* __restrict__ lists, gj_scan_summary* __restrict__ hsum /* host memory */,
-                                                     const uint8_t* __restrict__ hdr_ref, const uint32_t hdr_n)
+                                                     const uint8_t* __restrict__ hdr_ref, const uint32_t hdr_n, const GjScanBatch B)
 {
+    if (B.sizes != nullptr) {
+        const size_t z = blockIdx.z;
+        jpeg += z * B.jpeg;
+        size = B.sizes[z];
+        recs += z * B.scratch; lists += z * B.scratch;
+        hsum += z;
+    }
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_blk[ITERS * 4 < 4 ? 4 : ITERS * 4]; // restart markers of (piece, wave), then their exclusive prefix sums
     __shared__ uint32_t s_own_other, s_own_q[2], s_own_after[2];
@@ -184,12 +198,21 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
     GJ_TRACE_M(2);
 }
 
-__global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, const uint64_t size, const uint32_t part_bytes,
+__global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t begin, uint64_t size, const uint32_t part_bytes,
                                                       const uint32_t* __restrict__ recs, const uint32_t* __restrict__ lists, uint32_t* __restrict__ wg_maxlen /* host memory */,
                                                       gj_scan_summary* __restrict__ sum, gj_scan_summary* __restrict__ hsum /* host memory: what the host reads */,
                                                       uint32_t* __restrict__ seg_pos, uint32_t* __restrict__ seg_len, uint32_t* __restrict__ seg_index,
-                                                      const uint32_t max_segments)
+                                                      const uint32_t max_segments, const GjScanBatch B)
 {
+    if (B.sizes != nullptr) {
+        const size_t z = blockIdx.z;
+        jpeg += z * B.jpeg;
+        size = B.sizes[z];
+        recs += z * B.scratch; lists += z * B.scratch;
+        wg_maxlen += z * B.maxlen;
+        sum += z; hsum += z;
+        seg_pos += z * B.seg; seg_len += z * B.seg; seg_index += z * B.seg;
+    }
     __shared__ uint32_t s_mpos[GJ_SCAN_LIST];              // the workgroup's restart markers in order: offset in its part | code & 7 << 24
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_opos[GJ_SCAN_MAX_OTHER], s_ocode[GJ_SCAN_MAX_OTHER], s_olen[GJ_SCAN_MAX_OTHER], s_orank[GJ_SCAN_MAX_OTHER]; // other markers so far
@@ -388,7 +411,28 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
                                     uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
                                     const gj_tuning* tune)
 {
+    return gj_hip_find_segments_batch(g, d_jpeg, begin, size, d_seg_pos, d_seg_len, d_seg_index, max_segments, d_scratch, d_summary, d_hdr_ref, hdr_n, h_summary,
+                                      h_maxlen_parts, maxlen_capacity, maxlen_part_count, stream, tune, nullptr);
+}
+
+extern "C" int gj_hip_find_segments_batch(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                          uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                          gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
+                                          uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
+                                          const gj_tuning* tune, const gj_batch* batch)
+{
     hipStream_t st = (hipStream_t)stream;
+    GjScanBatch B = {nullptr, 0, 0, 0, 0};
+    unsigned frames = 1;
+    if (batch && batch->d_sizes != nullptr) { // (also a batch of one frame: its size comes from d_sizes like the others')
+        if ((batch->jpeg & 15u) != 0 || batch->count > 65535u || batch->count < 1u) return -1;
+        B.sizes = batch->d_sizes;
+        B.jpeg = batch->jpeg;
+        B.seg = batch->seg;
+        B.scratch = batch->scratch;
+        B.maxlen = batch->maxlen;
+        frames = batch->count;
+    }
     if (size <= begin || size > 0xFFFFFFF0ull) return -1;
     uint32_t iters, rounds;
     gj_scan_shape(size - begin, &iters, &rounds);
@@ -410,10 +454,10 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
     uint32_t* recs = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(d_scratch) + 15) & ~(uintptr_t)15); // [wgs] records, then [wgs] lists
     uint32_t* lists = recs + (size_t)gj_hip_find_segments_max_chunks(begin, size) * GJ_SCAN_REC_WORDS;
     auto kern = iters == 1 ? k_marker_scan<1> : iters == 2 ? k_marker_scan<2> : iters == 4 ? k_marker_scan<4> : iters == 8 ? k_marker_scan<8> : k_marker_scan<16>;
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, st, d_jpeg, begin, size, rounds, recs, lists, h_summary, d_hdr_ref, hdr_n);
+    hipLaunchKernelGGL(kern, dim3(wgs, 1, frames), dim3(256), 0, st, d_jpeg, begin, size, rounds, recs, lists, h_summary, d_hdr_ref, hdr_n, B);
     gj_debug_stage(tune->debug_sync != 0, st, "k_marker_scan");
-    hipLaunchKernelGGL(k_marker_table, dim3(wgs), dim3(256), 0, st, *g, d_jpeg, begin, size, (uint32_t)part, recs, lists, h_maxlen_parts, d_summary, h_summary, d_seg_pos,
-                       d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP);
+    hipLaunchKernelGGL(k_marker_table, dim3(wgs, 1, frames), dim3(256), 0, st, *g, d_jpeg, begin, size, (uint32_t)part, recs, lists, h_maxlen_parts, d_summary, h_summary, d_seg_pos,
+                       d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP, B);
     gj_debug_stage(tune->debug_sync != 0, st, "k_marker_table");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

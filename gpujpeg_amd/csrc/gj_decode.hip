@@ -20,11 +20,22 @@ extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, 
     return g->block_count >= (g->interleaved ? 900000 : 300000) && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
 }
 
+// A batch of frames (gj_dec_job::batch) takes the sub-sequence entropy decoders (tokens or planes) and the fused 4:4:4 IDCT kernels -- the path of
+// every RGB frame from HD to 16K -- as a speculative launch on one header, nothing else.
+extern "C" int gj_hip_decode_batchable(const gj_dec_job* job)
+{
+    const gj_geom& g = job->g;
+    return !g.interleaved && job->use_fused && job->d_huff_tab2 != nullptr && job->d_overflow != nullptr && job->d_seg_count != nullptr && job->seg_count > 0 &&
+           !job->flipped && !job->channel_remap && !job->clear_coefs && !job->tune.dec_serial && !job->tune.dec_careful && job->tune.dec_seq != 1 &&
+           g.restart_interval > 0 && gj_idct_takes_batches(g);
+}
+
 extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4])
 {
     hipStream_t st = (hipStream_t)stream;
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
+    if ((job->batch.count > 1 || g.fb.sizes != nullptr) && (!gj_hip_decode_batchable(job) || g.fb.sizes == nullptr || job->batch.count > 65535u)) return -1;
     if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
     bool par = job->d_huff_tab2 != nullptr && job->seg_count > 0;
     if (job->tune.dec_serial) par = false; // the lane-per-segment kernel (A/B measurements, tests)

@@ -57,6 +57,20 @@ struct gpujpeg_decoder {
                          instead of being decoded twice each */
     struct gj_reader_result hdr_cache_r;
     bool tab2_ok;
+    /* frame batches (gpujpeg_amd_decoder_decode_batch): per-frame words for ALL frames of a call, work buffers for one chunk of frames */
+    gj_scan_summary* b_dsum; size_t b_dsum_cap;    /* device: segment counts */
+    gj_scan_summary* bh_sum; size_t bh_sum_cap;    /* pinned: what the host validates */
+    uint32_t* bh_maxlen; size_t bh_maxlen_cap;     /* pinned: longest segments per scanning workgroup */
+    uint32_t* b_sizes; size_t b_sizes_cap;         /* device: stream sizes */
+    uint32_t* bh_sizes; size_t bh_sizes_cap;       /* pinned staging of the same */
+    uint32_t* b_seg; size_t b_seg_cap;
+    uint32_t* b_scratch; size_t b_scratch_cap;
+    int16_t* b_coefs; size_t b_coefs_cap;
+    uint16_t* b_tok; size_t b_tok_cap;
+    void* b_rec; size_t b_rec_cap;
+    uint8_t* b_jpeg; size_t b_jpeg_cap;            /* streams handed over in host memory */
+    uint8_t* b_raw; size_t b_raw_cap;              /* pixels wanted in host memory */
+    int b_last_batched, b_last_single;             /* frames of the last batch call that the batched launches decoded / that went the ordinary way */
 };
 
 #define GJ_HDR_WINDOW 65536
@@ -133,6 +147,9 @@ int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
     free(d->hdr_cache); gj_hip_free(d->d_hdr_cache);
     gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_host_free(d->h_maxlen); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
     free(d->segs.pos); free(d->segs.len); free(d->segs.index);
+    gj_hip_free(d->b_dsum); gj_hip_free(d->b_sizes); gj_hip_free(d->b_seg); gj_hip_free(d->b_scratch); gj_hip_free(d->b_coefs); gj_hip_free(d->b_tok);
+    gj_hip_free(d->b_rec); gj_hip_free(d->b_jpeg); gj_hip_free(d->b_raw);
+    gj_hip_host_free(d->bh_sum); gj_hip_host_free(d->bh_maxlen); gj_hip_host_free(d->bh_sizes);
     free(d);
     return 0;
 }
@@ -639,6 +656,253 @@ int gpujpeg_decoder_get_stats(struct gpujpeg_decoder* d, struct gpujpeg_duration
     return 0;
 }
 
+
+/* ------------------------------------------------------------------ frame batches (MI355X extension, include/gpujpeg_amd_ext.h) */
+/* Streams with ONE header (a sequence from one encoder) decoded by one set of launches per chunk of frames -- marker scan, marker table, entropy
+ * decoder, IDCT, each with blockIdx.z = frame. It is the speculative path of decoder_decode (kernels launched on the cached header, the device
+ * compares every stream's header with it, the host validates every frame's summary afterwards) for many frames at once; a frame whose
+ * summary does not pass -- another header, an unusual scan structure, a segment the fast kernels cannot stage -- is decoded again by
+ * gpujpeg_decoder_decode's own path, and so is everything the batched kernels do not cover. */
+#define GJ_DEC_BATCH_CHUNK_MAX 64
+#define GJ_DEC_BATCH_BYTES ((size_t)8 << 30) /* work buffers of one chunk */
+
+static int pinned_ensure(void** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    gj_hip_host_free(*p);
+    *p = gj_hip_host_alloc(need + need / 2);
+    *cap = *p ? need + need / 2 : 0;
+    return *p ? 0 : -1;
+}
+
+static int batch_decode_one(struct gpujpeg_decoder* d, const uint8_t* stream, size_t size, uint8_t* d_out)
+{
+    struct gpujpeg_decoder_output o;
+    gpujpeg_decoder_output_set_custom_cuda(&o, d_out);
+    return decoder_decode(d, (uint8_t*)(uintptr_t)stream, size, &o, false);
+}
+
+int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* streams, size_t stream_stride, const size_t* sizes, int count,
+                                     uint8_t* output, size_t output_stride, struct gpujpeg_image_parameters* param_image)
+{
+    if (!d || !streams || !sizes || count < 1 || !output) return -1;
+    struct gj_coder* c = &d->coder;
+    const bool streams_on_device = gj_hip_is_device_ptr(streams) != 0, out_on_device = gj_hip_is_device_ptr(output) != 0;
+    int rc = -1;
+    uint8_t* frame_done = calloc((size_t)count, 1);
+    if (!frame_done) return -1;
+    /* where the pixels go on the device: the caller's buffer, or a staging area that is copied out at the end */
+    uint8_t* d_out = output;
+    size_t d_out_stride = output_stride;
+    int first = 0;
+    /* the header cache is what a batch launches on: the first frame goes the ordinary way when there is none (or when it has to) */
+    const uint8_t* s0 = streams;
+    if (!out_on_device || !d->hdr_cache_valid) {
+        /* (the output size is known once a frame has been parsed: decode frame 0 into the decoder's own buffer first) */
+        struct gpujpeg_decoder_output o;
+        gpujpeg_decoder_output_set_cuda_buffer(&o);
+        if (decoder_decode(d, (uint8_t*)(uintptr_t)s0, sizes[0], &o, false) != 0) goto out;
+        const size_t raw = c->geom.raw_size;
+        if (!out_on_device) {
+            if (gj_ensure_device_buffer((void**)&d->b_raw, &d->b_raw_cap, raw * (size_t)count) != 0) goto out;
+            d_out = d->b_raw;
+            d_out_stride = raw;
+        }
+        if (output_stride < raw) {
+            GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, raw);
+            goto out;
+        }
+        if (gj_hip_memcpy_d2d(d_out, o.data, raw, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) goto out;
+        frame_done[0] = 1;
+        first = 1;
+    }
+    const gj_geom* g = &c->geom;
+    bool batched = d->hdr_cache_valid && !d->need_planes && !d->host_scan && !d->tune.dec_no_spec && !d->keep_coefs && c->configured &&
+                   (streams_on_device ? (stream_stride & 15u) == 0 : true) && d->tab2_ok;
+    if (batched && output_stride < g->raw_size) {
+        GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, (size_t)g->raw_size);
+        goto out;
+    }
+    size_t max_size = 0;
+    for (int f = first; f < count; f++) {
+        if (sizes[f] > max_size) max_size = sizes[f];
+        if (sizes[f] <= d->hdr_cache_len + 2 || sizes[f] > 0x1FFFFFF0u) batched = false;
+    }
+    gj_dec_job job;
+    memset(&job, 0, sizeof job);
+    if (batched && first < count) {
+        struct gj_reader_result r = d->hdr_cache_r;
+        if (decoder_configure(d, &r.param, &r.param_image) != 0) goto out;
+        for (int i = 0; i < c->geom.comp_count; i++) {
+            c->geom.comp[i].q_table = r.quant_map[i];
+            c->geom.comp[i].dc_table = r.huff_map[i][0];
+            c->geom.comp[i].ac_table = r.huff_map[i][1];
+        }
+        job.g = *g;
+        job.seg_count = g->segment_count;
+        job.d_huff_tab = d->d_huff_tab;
+        job.d_qtab = d->d_qtab;
+        job.d_qtabf = (const float*)(const void*)(d->d_huff_tab + GJ_TABS_QF_OFFSET);
+        job.d_huff_tab2 = d->d_qtab + 4 * 64;
+        job.d_planes = c->d_planes;
+        job.use_fused = d->use_fused && !d->flipped;
+        job.flipped = d->flipped;
+        job.channel_remap = d->channel_remap;
+        job.tune = d->tune;
+        job.tune.dec_careful = 0;
+        job.max_seg_len = d->last_max_seg_len;
+        memcpy(job.scan_bytes, d->last_scan_bytes, sizeof job.scan_bytes);
+        job.jpeg_size = max_size;
+        /* (the two pointers only have to be non-null for the question; they are set per chunk below) */
+        job.d_seg_count = &d->d_summary->segment_count;
+        job.d_overflow = &d->h_summary->seq_overflow;
+        if (!gj_hip_decode_batchable(&job)) batched = false;
+    }
+    if (batched && first < count) {
+        const int n_all = count - first;
+        const size_t begin = d->hdr_cache_r.scan_begin[0];
+        /* streams in host memory: one staging area, slots on 16-byte addresses */
+        const uint8_t* d_streams = streams + (size_t)first * stream_stride;
+        size_t d_stride = stream_stride;
+        if (!streams_on_device) {
+            d_stride = (max_size + 64 + 15) & ~(size_t)15;
+            if (gj_ensure_device_buffer((void**)&d->b_jpeg, &d->b_jpeg_cap, d_stride * (size_t)n_all) != 0) goto out;
+            gj_hip_event_record(c->timers.copy_in[0], c->stream); /* (copy marker, see gj_internal.h) */
+            for (int f = first; f < count; f++)
+                if (gj_hip_memcpy_h2d(d->b_jpeg + (size_t)(f - first) * d_stride, streams + (size_t)f * stream_stride, sizes[f], c->stream) != 0) goto out;
+            d_streams = d->b_jpeg;
+        }
+        /* per-frame words of all frames */
+        const size_t max_chunks = gj_hip_find_segments_max_chunks(begin, max_size);
+        if (gj_ensure_device_buffer((void**)&d->b_sizes, &d->b_sizes_cap, (size_t)n_all * sizeof(uint32_t)) != 0) goto out;
+        if (pinned_ensure((void**)&d->bh_sizes, &d->bh_sizes_cap, (size_t)n_all * sizeof(uint32_t)) != 0) goto out;
+        if (pinned_ensure((void**)&d->bh_sum, &d->bh_sum_cap, (size_t)n_all * sizeof(gj_scan_summary)) != 0) goto out;
+        if (pinned_ensure((void**)&d->bh_maxlen, &d->bh_maxlen_cap, (size_t)n_all * max_chunks * sizeof(uint32_t)) != 0) goto out;
+        {
+            const size_t had = d->b_dsum_cap;
+            if (gj_ensure_device_buffer((void**)&d->b_dsum, &d->b_dsum_cap, (size_t)n_all * sizeof(gj_scan_summary)) != 0) goto out;
+            if (d->b_dsum_cap != had && gj_hip_memset(d->b_dsum, 0, d->b_dsum_cap, c->stream) != 0) goto out;
+        }
+        memset(d->bh_sum, 0, (size_t)n_all * sizeof(gj_scan_summary));
+        for (int i = 0; i < n_all; i++) d->bh_sizes[i] = (uint32_t)sizes[first + i];
+        if (gj_hip_memcpy_h2d(d->b_sizes, d->bh_sizes, (size_t)n_all * sizeof(uint32_t), c->stream) != 0) goto out;
+        /* work buffers of a chunk */
+        const size_t S = (size_t)g->segment_count + GJ_MAX_COMP;
+        const size_t seg_frame = (3 * S + 8 + 3) & ~(size_t)3;                                                                   /* words */
+        const size_t scratch_frame = (gj_hip_find_segments_scratch_words(begin, max_size, (uint32_t)g->segment_count) + 3) & ~(size_t)3; /* words */
+        const size_t coefs_frame = ((size_t)g->data_size + 63) & ~(size_t)63;                                                   /* int16 */
+        const bool tokens = gj_hip_decode_wants_tokens(g, max_size, &d->tune) != 0;
+        const size_t tok_frame = tokens ? (max_size * 4 + 64 + 63) & ~(size_t)63 : 0;                                            /* tokens */
+        const size_t rec_frame = tokens ? ((size_t)g->block_count + 8 + 7) & ~(size_t)7 : 0;                                    /* records */
+        const size_t frame_bytes = seg_frame * 4 + scratch_frame * 4 + coefs_frame * 2 + tok_frame * 2 + rec_frame * 8;
+        int chunk = (int)(GJ_DEC_BATCH_BYTES / frame_bytes);
+        if (chunk > GJ_DEC_BATCH_CHUNK_MAX) chunk = GJ_DEC_BATCH_CHUNK_MAX;
+        if (chunk > n_all) chunk = n_all;
+        if (chunk < 1) chunk = 1;
+        if (gj_ensure_device_buffer((void**)&d->b_seg, &d->b_seg_cap, seg_frame * 4 * (size_t)chunk) != 0) goto out;
+        if (gj_ensure_device_buffer((void**)&d->b_scratch, &d->b_scratch_cap, scratch_frame * 4 * (size_t)chunk + 64) != 0) goto out;
+        if (gj_ensure_device_buffer((void**)&d->b_coefs, &d->b_coefs_cap, coefs_frame * 2 * (size_t)chunk) != 0) goto out;
+        if (tokens) {
+            if (gj_ensure_device_buffer((void**)&d->b_tok, &d->b_tok_cap, tok_frame * 2 * (size_t)chunk) != 0) goto out;
+            const size_t had = d->b_rec_cap;
+            if (gj_ensure_device_buffer((void**)&d->b_rec, &d->b_rec_cap, rec_frame * 8 * (size_t)chunk) != 0) goto out;
+            if (d->b_rec_cap != had && gj_hip_memset(d->b_rec, 0, d->b_rec_cap, c->stream) != 0) goto out;
+        }
+        job.d_seg_pos = d->b_seg;
+        job.d_seg_len = d->b_seg + S;
+        job.d_seg_index = d->b_seg + 2 * S;
+        job.d_coefs = d->b_coefs;
+        job.tokens = tokens ? 1 : 0;
+        job.d_tok = tokens ? d->b_tok : NULL;
+        job.tok_cap = tokens ? (uint32_t)(max_size * 4) : 0;
+        job.d_blkrec = tokens ? d->b_rec : NULL;
+        for (int a = 0; a < n_all; a += chunk) {
+            const int n = n_all - a < chunk ? n_all - a : chunk;
+            gj_batch B;
+            memset(&B, 0, sizeof B);
+            B.count = (uint32_t)n;
+            B.jpeg = d_stride;
+            B.raw = d_out_stride;
+            B.coefs = coefs_frame;
+            B.tok = tok_frame;
+            B.rec = rec_frame;
+            B.seg = (uint32_t)seg_frame;
+            B.scratch = (uint32_t)scratch_frame;
+            B.maxlen = (uint32_t)max_chunks;
+            B.d_sizes = d->b_sizes + a;
+            job.batch = B;
+            job.g.fb.sizes = B.d_sizes;
+            job.g.fb.jpeg = B.jpeg;
+            job.g.fb.raw = B.raw;
+            job.g.fb.coefs = B.coefs;
+            job.g.fb.tok = B.tok;
+            job.g.fb.rec = B.rec;
+            job.g.fb.seg = B.seg;
+            job.d_jpeg = d_streams + (size_t)a * d_stride;
+            job.d_raw = d_out + (size_t)(first + a) * d_out_stride;
+            job.d_seg_count = &d->b_dsum[a].segment_count;
+            job.d_overflow = &d->bh_sum[a].seq_overflow;
+            uint32_t parts = 0;
+            if (gj_hip_find_segments_batch(g, job.d_jpeg, begin, max_size, d->b_seg, d->b_seg + S, d->b_seg + 2 * S, (uint32_t)g->segment_count, d->b_scratch,
+                                           d->b_dsum + a, d->d_hdr_cache, (uint32_t)d->hdr_cache_len, d->bh_sum + a, d->bh_maxlen + (size_t)a * max_chunks,
+                                           (uint32_t)max_chunks, &parts, c->stream, &d->tune, &B) != 0 ||
+                gj_hip_decode(&job, c->stream, NULL) != 0) {
+                GJ_ERROR("Decoder kernels failed: %s\n", gj_hip_last_error());
+                goto out;
+            }
+            d->maxlen_parts = parts;
+        }
+        if (gj_hip_stream_sync(c->stream) != 0) {
+            GJ_ERROR("Decoder failed: %s\n", gj_hip_last_error());
+            goto out;
+        }
+        /* every frame's summary: was the stream what the launch assumed? (the checks of decoder_decode's speculative path) */
+        for (int i = 0; i < n_all; i++) {
+            gj_scan_summary* su = d->bh_sum + i;
+            uint32_t m = 0;
+            for (uint32_t k = 0; k < d->maxlen_parts; k++)
+                if (d->bh_maxlen[(size_t)i * max_chunks + k] > m) m = d->bh_maxlen[(size_t)i * max_chunks + k];
+            su->max_seg_len = m;
+            struct gj_reader_result chk = d->hdr_cache_r;
+            bool ok = su->header_differs == 0 && su->seq_overflow == 0 && accept_device_scan(su, &chk, g) == 0 && (int)su->segment_count == g->segment_count;
+            for (int k = 0; ok && k < g->comp_count; k++)
+                if (chk.huff_map[k][0] != d->hdr_cache_r.huff_map[k][0] || chk.huff_map[k][1] != d->hdr_cache_r.huff_map[k][1]) ok = false;
+            if (ok) {
+                frame_done[first + i] = 1;
+                for (int sc = 0; sc < GJ_MAX_COMP; sc++) d->last_scan_bytes[sc] = sc < (int)su->scan_count ? su->scan_end[sc] - su->scan_start[sc] : 0;
+                d->last_max_seg_len = su->max_seg_len;
+            }
+        }
+    }
+    /* whatever is left: the ordinary call, frame by frame */
+    d->b_last_batched = 0;
+    for (int f = first; f < count; f++) d->b_last_batched += frame_done[f] ? 1 : 0;
+    d->b_last_single = count - d->b_last_batched;
+    for (int f = 0; f < count; f++) {
+        if (frame_done[f]) continue;
+        if (batch_decode_one(d, streams + (size_t)f * stream_stride, sizes[f], d_out + (size_t)f * d_out_stride) != 0) goto out;
+        if (c->geom.raw_size > d_out_stride) {
+            GJ_ERROR("Frame %d decodes to %zu B, more than the output stride!\n", f, (size_t)c->geom.raw_size);
+            goto out;
+        }
+    }
+    if (!out_on_device) {
+        gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
+        for (int f = 0; f < count; f++)
+            if (gj_hip_memcpy_d2h(output + (size_t)f * output_stride, d_out + (size_t)f * d_out_stride, c->geom.raw_size, c->stream) != 0) goto out;
+        if (gj_hip_stream_sync(c->stream) != 0) goto out;
+    }
+    if (param_image) {
+        *param_image = c->param_image;
+        if (param_image->color_space == GPUJPEG_NONE) param_image->color_space = c->param.color_space_internal;
+    }
+    c->frames += count;
+    rc = 0;
+out:
+    free(frame_done);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ image info (src/gpujpeg_reader.c:1739-1872) */
 int gpujpeg_decoder_get_image_info2(uint8_t* image, size_t image_size, struct gpujpeg_image_info* info, int verbose, unsigned flags)
 {
@@ -705,6 +969,14 @@ void gpujpeg_decoder_print_options(void)
 }
 
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
+
+int gpujpeg_amd_decoder_last_batch(struct gpujpeg_decoder* d, int* batched, int* single)
+{
+    if (!d) return -1;
+    if (batched) *batched = d->b_last_batched;
+    if (single) *single = d->b_last_single;
+    return 0;
+}
 
 size_t gpujpeg_amd_decoder_read_coefficients(struct gpujpeg_decoder* d, int16_t* dst, size_t capacity)
 {

@@ -57,6 +57,7 @@ struct gpujpeg_encoder {
     uint8_t* b_raw; size_t b_raw_cap;          /* frames handed over in host memory */
     uint8_t* b_hdr_sent; size_t b_hdr_len; const uint8_t* b_hdr_to; size_t b_hdr_slot; int b_hdr_frames; /* the header bytes at the start of b_jpeg's slots */
     uint8_t* b_out; size_t b_out_cap; bool b_out_pinned; /* streams handed back in host memory */
+    int b_last_batched, b_last_single; /* frames of the last batch call coded by batched launches / frame by frame */
 };
 
 /* ------------------------------------------------------------------ input helpers (gpujpeg_encoder.h:77-110) */
@@ -463,7 +464,11 @@ int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpu
             e->bh_result[2 * f + 1] = 0;
         }
         e->b_hdr_to = NULL; /* (the slots' headers were overwritten by whole streams) */
+        e->b_last_batched = 0;
+        e->b_last_single = count;
     } else {
+        e->b_last_batched = count;
+        e->b_last_single = 0;
         /* main header: the same bytes at the start of every slot, uploaded when they change (as gpujpeg_encoder_encode does for its one buffer) */
         const size_t hdr = gj_write_main_header(e->h_header, GJ_MAIN_HEADER_CAP, g, &p, e->header_type, (const uint8_t(*)[64])e->qraw, &e->metadata, e->exif_tags);
         if (hdr > GJ_MAIN_HEADER_CAP) {
@@ -707,6 +712,14 @@ void gpujpeg_encoder_print_options(void)
 }
 
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
+
+int gpujpeg_amd_encoder_last_batch(struct gpujpeg_encoder* e, int* batched, int* single)
+{
+    if (!e) return -1;
+    if (batched) *batched = e->b_last_batched;
+    if (single) *single = e->b_last_single;
+    return 0;
+}
 
 size_t gpujpeg_amd_encoder_read_coefficients(struct gpujpeg_encoder* e, int16_t* dst, size_t capacity)
 {

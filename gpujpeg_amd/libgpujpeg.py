@@ -140,6 +140,9 @@ class Library:
         if hasattr(L, "gpujpeg_amd_encoder_encode_batch"):  # frame batches (include/gpujpeg_amd_ext.h)
             L.gpujpeg_amd_encoder_encode_batch.argtypes = [vp, C.POINTER(Parameters), C.POINTER(ImageParameters), vp, C.c_size_t, C.c_int,
                                                            C.POINTER(vp), C.POINTER(C.c_size_t)]
+        for n in ("gpujpeg_amd_encoder_last_batch", "gpujpeg_amd_decoder_last_batch"):
+            if hasattr(L, n):
+                getattr(L, n).argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         if hasattr(L, "gpujpeg_amd_decoder_decode_batch"):
             L.gpujpeg_amd_decoder_decode_batch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t, C.POINTER(ImageParameters)]
 
@@ -206,6 +209,12 @@ class Encoder:
         if rc != 0:
             raise RuntimeError(f"gpujpeg_amd_encoder_encode_batch failed ({rc})")
         return [int(p or 0) for p in ptrs], [int(n) for n in sizes]
+
+    def last_batch(self):
+        """(frames coded by the batched launches, frames coded one by one) of the last encode_batch call"""
+        a, b = C.c_int(0), C.c_int(0)
+        self.lib.L.gpujpeg_amd_encoder_last_batch(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def encode_batch(self, param, param_image, frames, count, stride=None):
         """host frames in, list of numpy uint8 copies of the streams out (encoder output in host memory, the default)"""
@@ -279,6 +288,47 @@ class Decoder:
             return None, out.param_image
         buf = (C.c_uint8 * out.data_size).from_address(out.data)
         return np.frombuffer(buf, np.uint8).copy(), out.param_image
+
+    def last_batch(self):
+        """(frames decoded by the batched launches, frames decoded one by one) of the last decode_batch call"""
+        a, b = C.c_int(0), C.c_int(0)
+        self.lib.L.gpujpeg_amd_decoder_last_batch(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def decode_batch(self, streams, device_out=None, out_stride=None, device_in=None, in_stride=None, sizes=None):
+        """gpujpeg_amd_decoder_decode_batch: streams with one header behind one set of launches. streams: list of numpy uint8 arrays (host;
+        packed into one buffer here), or device_in = integer device pointer of stream 0 with in_stride and sizes. Pixels go to device_out
+        (integer device pointer, frames out_stride apart) or come back as a list of numpy arrays. Returns (pixels or None, ImageParameters)."""
+        if device_in is None:
+            sizes = [int(x.size) for x in streams]
+            in_stride = (max(sizes) + 64 + 15) & ~15
+            buf = np.zeros(in_stride * len(sizes), np.uint8)
+            for i, x in enumerate(streams):
+                buf[i * in_stride:i * in_stride + x.size] = x
+            self._keep = buf
+            base = buf.ctypes.data
+        else:
+            base = int(device_in)
+        n = len(sizes)
+        csz = (C.c_size_t * n)(*sizes)
+        pi = ImageParameters()
+        if device_out is not None:
+            rc = self.lib.L.gpujpeg_amd_decoder_decode_batch(self.h, base, in_stride, csz, n, int(device_out), out_stride, C.byref(pi))
+            if rc != 0:
+                raise RuntimeError(f"gpujpeg_amd_decoder_decode_batch failed ({rc})")
+            return None, pi
+        # host output: the frame size is not known before the first stream has been parsed -- ask the library
+        pi0, p0 = ImageParameters(), Parameters()
+        first = np.ascontiguousarray(streams[0] if device_in is None else np.zeros(0, np.uint8))
+        if self.lib.L.gpujpeg_decoder_get_image_info(first.ctypes.data_as(C.c_void_p), first.size, C.byref(pi0), C.byref(p0), None) != 0:
+            raise RuntimeError("gpujpeg_decoder_get_image_info failed")
+        bound = max(int(pi0.width) * int(pi0.height) * 4 + 4096, 1)  # (the library checks the real frame size against the stride)
+        out = np.empty(bound * n, np.uint8)
+        rc = self.lib.L.gpujpeg_amd_decoder_decode_batch(self.h, base, in_stride, csz, n, out.ctypes.data, bound, C.byref(pi))
+        if rc != 0:
+            raise RuntimeError(f"gpujpeg_amd_decoder_decode_batch failed ({rc})")
+        raw = self.lib.image_size(pi)
+        return [out[i * bound:i * bound + raw].copy() for i in range(n)], pi
 
     def stats(self):
         s = DurationStats()

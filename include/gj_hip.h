@@ -82,6 +82,16 @@ typedef struct gj_comp_geom {
     uint64_t data_offset;      /* offset in samples of the plane / coefficient plane */
 } gj_comp_geom;
 
+/* Decoder kernels of a frame batch (gj_dec_job::batch, blockIdx.z = frame): what lies between the buffers of two frames. It travels with
+ * the geometry because every decoder kernel takes the geometry by value; sizes == NULL (everything zero) for a single frame. */
+typedef struct gj_frame_strides {
+    const uint32_t* sizes;    /* [frames] bytes of every frame's stream, device memory */
+    uint64_t jpeg, raw;       /* bytes */
+    uint64_t coefs, tok, rec; /* int16 coefficients, tokens, block records */
+    uint32_t seg;             /* words between the frames' seg_pos (and seg_len, seg_index) */
+    uint32_t reserved;
+} gj_frame_strides;
+
 typedef struct gj_geom {
     int width, height, width_padding;
     int pixel_format, color_space, color_space_internal;
@@ -103,6 +113,7 @@ typedef struct gj_geom {
     uint8_t mcu_bx[GJ_MAX_MCU_BLOCKS];   /* block x inside the MCU */
     uint8_t mcu_by[GJ_MAX_MCU_BLOCKS];
     uint8_t mcu_prev[GJ_MAX_MCU_BLOCKS]; /* distance (in scan order) to the previous block of the same component */
+    gj_frame_strides fb;       /* decoder kernels of a frame batch; all zero for a single frame */
 } gj_geom;
 
 /* ------------------------------------------------------------------ encoder */
@@ -291,6 +302,14 @@ GJ_HIP_API int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
                                     gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
                                     uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
                                     const gj_tuning* tune);
+/* The same for the frames of a batch (batch->count streams with the same header: begin, and d_hdr_ref compared with every one of them): `size` is
+ * the LONGEST stream, batch->d_sizes the streams' sizes, batch->jpeg / seg / scratch / maxlen the strides of d_jpeg, the three tables, d_scratch
+ * and h_maxlen_parts; d_summary and h_summary are arrays of batch->count summaries. batch->jpeg must be a multiple of 16. */
+GJ_HIP_API int gj_hip_find_segments_batch(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                          uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                          gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
+                                          uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
+                                          const gj_tuning* tune, const gj_batch* batch);
 /* workgroups the marker scan cuts [begin, size) into at most (capacity of h_maxlen_parts) */
 GJ_HIP_API size_t gj_hip_find_segments_max_chunks(uint64_t begin, uint64_t size);
 

@@ -86,6 +86,9 @@ GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* dec
 GPUJPEG_API int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* encoder, const struct gpujpeg_parameters* param,
                                                  const struct gpujpeg_image_parameters* param_image, const uint8_t* frames, size_t frame_stride,
                                                  int count, uint8_t** images_compressed, size_t* images_compressed_size);
+/* how the frames of the last batch call were coded: by the batched launches / frame by frame inside the call (tests, benchmarks) */
+GPUJPEG_API int gpujpeg_amd_encoder_last_batch(struct gpujpeg_encoder* encoder, int* batched, int* single);
+GPUJPEG_API int gpujpeg_amd_decoder_last_batch(struct gpujpeg_decoder* decoder, int* batched, int* single);
 GPUJPEG_API int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* decoder, const uint8_t* streams, size_t stream_stride, const size_t* sizes,
                                                  int count, uint8_t* output, size_t output_stride, struct gpujpeg_image_parameters* param_image);
 

@@ -163,3 +163,12 @@ def test_emu_marker_between_scans_like_the_reference(O, G, emu_lib, _ref_lib):
     rc, ok = rc_of(emu_lib)
     rc_ref, _ = rc_of(_ref_lib)
     assert ok and rc == rc_ref and rc != 0, (rc, rc_ref)
+
+
+@pytest.mark.parametrize("bc", T.BATCH_CASES, ids=[c[0] for c in T.BATCH_CASES])
+def test_emu_frame_batches(O, G, emu_lib, bc, monkeypatch):
+    T.test_frame_batches(O, G, emu_lib, bc, monkeypatch)
+
+
+def test_emu_frame_batch_with_strangers(O, G, emu_lib):
+    T.test_frame_batch_with_strangers(O, G, emu_lib)

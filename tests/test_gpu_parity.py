@@ -724,3 +724,75 @@ def test_random_streams_all_decoder_paths(O, G, gpu_lib, seed, monkeypatch):
         px, _ = dec.decode(jpeg)
         assert np.array_equal(px, want), (case, env)
         dec.close()
+
+
+# ---- frame batches (include/gpujpeg_amd_ext.h: gpujpeg_amd_encoder_encode_batch / gpujpeg_amd_decoder_decode_batch)
+# name, w, h, pixel format, quality, restart, interleaved, subsampling, frames, GJ_DEC_TOKENS, batched launches expected (encoder, decoder)
+BATCH_CASES = [
+    ("planes_640x480", 640, 480, 1, 75, -1, 0, None, 5, None, True, True),
+    ("tokens_640x480", 640, 480, 1, 75, -1, 0, None, 5, "1", True, True),
+    ("odd_size_q90", 331, 277, 1, 90, 7, 0, None, 3, None, True, True),
+    ("two_chunks_of_small_frames", 64, 64, 1, 50, 4, 0, None, 70, None, True, False),  # (a 2 KB stream has its three scans inside one scanning workgroup: host walk)
+    ("interleaved_rgb", 320, 240, 1, 75, -1, 1, None, 3, None, False, False),          # other kernels: frame by frame inside the call
+    ("planar_420", 320, 240, 5, 75, -1, 0, None, 3, None, False, False),
+]
+
+
+@pytest.mark.parametrize("bc", BATCH_CASES, ids=[c[0] for c in BATCH_CASES])
+def test_frame_batches(O, G, gpu_lib, bc, monkeypatch):
+    """N frames of one geometry behind one set of launches (blockIdx.z = frame): every stream equals the oracle's, every decoded frame the
+    oracle's decoding of it -- i.e. the batch calls give what frame-at-a-time calls give --, also when the coder objects are reused with
+    fewer and more frames, when single calls follow, and for configurations the batched kernels do not cover (coded frame by frame
+    inside the call). last_batch() says which way the frames went."""
+    name, w, h, pf, q, ri, il, ss, n, tok, enc_batched, dec_batched = bc
+    case = (name, w, h, pf, 1 if pf == 1 else 3, q, ri, il, ss, 3)
+    img = oracle_image(O, case)
+    p, pi = api_params(gpu_lib, G, case)
+    size = gpu_lib.image_size(pi)
+    if pf == 1:
+        frames = np.stack([natural_image(w, h, 3, seed=10 + f) for f in range(n)])
+    else:
+        frames = np.stack([O.noise(size, seed=20 + f) // 2 + 60 for f in range(n)]).astype(np.uint8)
+    want = [O.encode(img, frames[f]) for f in range(n)]
+    want_px = [O.decode(s)[0] for s in want]
+    if tok:
+        monkeypatch.setenv("GJ_DEC_TOKENS", tok)
+    enc, dec = G.Encoder(gpu_lib), G.Decoder(gpu_lib)
+    for count in (n, 2, n):
+        got = enc.encode_batch(p, pi, frames[:count].reshape(-1), count)
+        assert enc.last_batch() == ((count, 0) if enc_batched else (0, count))
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), "stream of a batched frame differs from the oracle"
+        px, info = dec.decode_batch(got)
+        assert (info.width, info.height) == (w, h)
+        assert all(np.array_equal(a, b) for a, b in zip(px, want_px)), "pixels of a batched frame differ from the oracle"
+        # (host memory in and out: the first frame goes the ordinary way, it is the one that is parsed)
+        assert dec.last_batch() == ((count - 1, 1) if dec_batched else (0, count))
+    assert np.array_equal(enc.encode(p, pi, frames[1]), want[1])
+    assert np.array_equal(dec.decode(want[1])[0], want_px[1])
+    enc.close()
+    dec.close()
+
+
+def test_frame_batch_with_strangers(O, G, gpu_lib):
+    """A batch is launched on ONE header. A stream with another header (other quality), a stream with a damaged restart marker and a truncated
+    stream in the middle of it are found by the per-frame validation and decoded the ordinary way; every frame still equals the oracle's."""
+    w, h, n = 640, 480, 6
+    case = ("b", w, h, 1, 1, 75, -1, 0, None, 3)
+    frames = [natural_image(w, h, 3, seed=40 + f) for f in range(n)]
+    streams = [O.encode(oracle_image(O, case), f) for f in frames]
+    streams[2] = O.encode(oracle_image(O, ("c", w, h, 1, 1, 50, -1, 0, None, 3)), frames[2])  # other tables, same size
+    bad = streams[4].copy()
+    pos = [i for i in range(len(bad) - 1) if bad[i] == 0xFF and 0xD0 <= bad[i + 1] <= 0xD7]
+    bad[pos[len(pos) // 2] + 1] = 0xD0 + ((int(bad[pos[len(pos) // 2] + 1]) - 0xD0 + 3) & 7)  # a restart marker with the wrong number
+    streams[4] = bad
+    want = [O.decode(s)[0] for s in streams]
+    dec = G.Decoder(gpu_lib)
+    px, _ = dec.decode_batch(streams)
+    batched, single = dec.last_batch()
+    assert batched == 3 and single == 3, (batched, single)  # frames 1, 3, 5 | 0 (parsed), 2, 4
+    for f in (0, 1, 2, 3, 5):
+        assert np.array_equal(px[f], want[f]), f
+    ref = G.Decoder(gpu_lib)
+    assert np.array_equal(px[4], ref.decode(streams[4])[0])  # (damaged: whatever the ordinary call makes of it)
+    dec.close()
+    ref.close()

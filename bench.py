@@ -558,7 +558,10 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     if host_io:  # pinned host memory on both sides: the caller of the reference API (gpujpeg_image_load_from_file returns pinned memory too)
         frames = [f.cpu().pin_memory() for f in frames]
         torch.cuda.empty_cache()
-    S = max(1, min(args.streams, len(frames)))
+    # --batch-api batch: the frames of a pipeline go through gpujpeg_amd_encoder_encode_batch / gpujpeg_amd_decoder_decode_batch (every kernel
+    # launched once per chunk of frames, the frame is a grid dimension) instead of one libgpujpeg call per frame
+    batch_api = getattr(args, "batch_api", "frame") == "batch" and not host_io
+    S = max(1, min(getattr(args, "batch_streams", 0) or args.streams, len(frames))) if batch_api else max(1, min(args.streams, len(frames)))
     p = lib.default_parameters()
     p.quality, p.restart_interval, p.verbose = args.quality, G.RESTART_AUTO, -1
     pi = lib.default_image_parameters()
@@ -568,13 +571,31 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
         ts = lane_stream(device, si)
         e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
         assert e.set_option("enc_opt_out", "enc_out_val_pinned" if host_io else "enc_out_val_device") == 0
-        lanes.append({"frames": frames[si::S], "out": torch.empty_like(frames[0]).pin_memory() if host_io else torch.empty_like(frames[0]),
-                      "enc": e, "dec": d, "bytes": 0, "digest": []})
+        ln = {"frames": frames[si::S], "out": torch.empty_like(frames[0]).pin_memory() if host_io else torch.empty_like(frames[0]),
+              "enc": e, "dec": d, "bytes": 0, "digest": [], "batched": None}
+        if batch_api:  # the pipeline's frames back to back, and room for as many decoded frames
+            ln["stack"] = torch.stack(ln["frames"]).contiguous()
+            ln["frames"] = [ln["stack"][k] for k in range(ln["stack"].shape[0])]
+            ln["out_stack"] = torch.empty_like(ln["stack"])
+            ln["out"] = ln["out_stack"][-1]
+        lanes.append(ln)
+    if batch_api:
+        del frames
+        torch.cuda.empty_cache()
     torch.cuda.synchronize()
 
     loop = c_loop(C_LOOP_OK["ok"])
 
     def one_pass(ln, digest=False):
+        if batch_api:
+            n = len(ln["frames"])
+            raw = ln["stack"][0].numel()
+            ptrs, sizes = ln["enc"].encode_batch_noclone(p, pi, ln["stack"].data_ptr(), n, stride=raw, gpu=True)
+            stride = ptrs[1] - ptrs[0] if n > 1 else (sizes[0] + 64 + 15) & ~15
+            ln["dec"].decode_batch(None, device_out=ln["out_stack"].data_ptr(), out_stride=raw, device_in=ptrs[0], in_stride=stride, sizes=sizes)
+            ln["bytes"] = sum(sizes)
+            ln["batched"] = (ln["enc"].last_batch(), ln["dec"].last_batch())
+            return
         if loop is not None:  # the frames of this pipeline, in order, through tools/bench_loop.c
             *_, ln["bytes"] = run_frames_c(loop, ln, p, pi, [f.data_ptr() for f in ln["frames"]], not host_io, ln["out"].data_ptr(),
                                            len(ln["frames"]), "both", None, 0)
@@ -648,6 +669,9 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
         "config": {"workload": f"{args.batch} x {width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto, encode then decode of "
                                f"every frame per step", "frames_total": total, "frames_per_gpu": len(mine), "streams_per_gpu": S,
                    "jpeg_bytes_total": jpeg_bytes, "parallelism": f"frame-sharded x{world}, no collective", "io": "host" if host_io else "device",
+                   "api": ("gpujpeg_amd_encoder_encode_batch + gpujpeg_amd_decoder_decode_batch: one set of launches per chunk of frames; (frames coded by "
+                           f"batched launches, one by one) encoder / decoder of pipeline 0's last pass: {lanes[0]['batched']}") if batch_api
+                          else "gpujpeg_encoder_encode + gpujpeg_decoder_decode per frame",
                    "cpu_affinity_rank0": getattr(args, "affinity", None)},
         "mpix_s": round(fps * width * height / 1e6, 2), "psnr_last_frame_db": round(10 * np.log10(255.0 ** 2 / max(mse, 1e-9)), 2)}
     if verified is not None:
@@ -667,7 +691,24 @@ def verify_batch(lib, lanes, p, pi, width, height, quality, mine, S):
     import oracle as O
     ok = True
     img = O.make_image(width, height, quality=quality)
+    hip = C.cdll.LoadLibrary("libamdhip64.so")
     for si, ln in enumerate(lanes):
+        if "stack" in ln:  # the batch calls: every stream and every decoded frame of one more pass
+            n, raw = len(ln["frames"]), ln["stack"][0].numel()
+            ptrs, sizes = ln["enc"].encode_batch_noclone(p, pi, ln["stack"].data_ptr(), n, stride=raw, gpu=True)
+            streams = []
+            for ptr, js in zip(ptrs, sizes):
+                jt = np.empty(js, np.uint8)
+                hip.hipMemcpy(C.c_void_p(jt.ctypes.data), C.c_void_p(ptr), C.c_size_t(js), 2)
+                streams.append(jt)
+            ln["out_stack"].zero_()
+            ln["dec"].decode_batch(None, device_out=ln["out_stack"].data_ptr(), out_stride=raw, device_in=ptrs[0],
+                                   in_stride=ptrs[1] - ptrs[0] if n > 1 else (sizes[0] + 79) & ~15, sizes=sizes)
+            torch.cuda.synchronize()
+            for k in range(n):
+                want = O.encode(img, ln["stack"][k].cpu().numpy().reshape(-1))
+                ok = ok and bool(np.array_equal(streams[k], want)) and bool(np.array_equal(ln["out_stack"][k].cpu().numpy().reshape(-1), O.decode(want)[0]))
+            continue
         for f in ln["frames"]:
             host = f.cpu().numpy().reshape(-1)
             want = O.encode(img, host)
@@ -691,6 +732,10 @@ def main():
     ap.add_argument("--pattern", default="natural", choices=["natural", "noise", "gradient", "camera"])
     ap.add_argument("--batch-io", default="device", choices=["device", "host"],
                     help="--batch: frames and results resident in HBM (default) or in pinned host memory on both sides (what a drop-in caller has)")
+    ap.add_argument("--batch-api", default="frame", choices=["frame", "batch"],
+                    help="--batch: `frame` = one libgpujpeg call per frame and direction (the reference's API), `batch` = the frames of a pipeline through "
+                         "gpujpeg_amd_encoder_encode_batch / gpujpeg_amd_decoder_decode_batch (MI355X extension: the frame is a grid dimension of every kernel)")
+    ap.add_argument("--batch-streams", type=int, default=2, help="pipelines per GPU with --batch-api batch (a batch call fills the device by itself: two hide each other's host gaps)")
     ap.add_argument("--python-loop", action="store_true", help="drive the API calls of the timed regions from Python instead of tools/bench_loop.c")
     ap.add_argument("--pin", default="auto", choices=["auto", "on", "off"],
                     help="bind the launch threads to idle cores of the GPU's NUMA node: `auto` (default) does it when several ranks share the node -- "
@@ -922,6 +967,13 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
         b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS["4k"], emit=False)
         table["batch256_4k"] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"]}
         torch.cuda.empty_cache()
+        # the same batch, and one of 256 HD frames, through the batch calls (every kernel once per chunk of frames) and, for HD, frame by frame
+        for key, wl, api in (("batch256_4k_batched", "4k", "batch"), ("batch256_hd", "hd", "frame"), ("batch256_hd_batched", "hd", "batch")):
+            ba.workload, ba.batch_api = wl, api
+            b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS[wl], emit=False)
+            table[key] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"], "api": b["config"]["api"]}
+            torch.cuda.empty_cache()
+        ba.workload, ba.batch_api = "4k", "frame"
         ba.batch_io = "host"  # the same batch from pinned host memory in and out (6.4 GB each way per pass over PCIe)
         b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS["4k"], emit=False)
         table["batch256_4k_host"] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"],

@@ -623,13 +623,17 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
 
     go = threading.Event()
 
+    pass_ms = [[] for _ in range(S)]
+
     def worker(idx, passes, wait):
         torch.cuda.set_device(local_rank)
         pin_worker(idx)
         if wait:
             go.wait()
         for _ in range(passes):
+            t_ = time.perf_counter()
             one_pass(lanes[idx])
+            pass_ms[idx].append(round((time.perf_counter() - t_) * 1e3, 2))
 
     elapsed = 0.0
     for passes, timed in ((args.warmup, False), (args.steps, True)):
@@ -672,7 +676,9 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
                    "api": ("gpujpeg_amd_encoder_encode_batch + gpujpeg_amd_decoder_decode_batch: one set of launches per chunk of frames; (frames coded by "
                            f"batched launches, one by one) encoder / decoder of pipeline 0's last pass: {lanes[0]['batched']}") if batch_api
                           else "gpujpeg_encoder_encode + gpujpeg_decoder_decode per frame",
-                   "cpu_affinity_rank0": getattr(args, "affinity", None)},
+                   "cpu_affinity_rank0": getattr(args, "affinity", None),
+                   "pass_ms_per_pipeline": [pm[-args.steps:] for pm in pass_ms],
+                   "hbm_free_gb_at_end": round(torch.cuda.mem_get_info(device)[0] / 2**30, 1), "hbm_total_gb": round(torch.cuda.mem_get_info(device)[1] / 2**30, 1)},
         "mpix_s": round(fps * width * height / 1e6, 2), "psnr_last_frame_db": round(10 * np.log10(255.0 ** 2 / max(mse, 1e-9)), 2)}
     if verified is not None:
         result["verified_bit_exact"] = verified

@@ -17,7 +17,9 @@ extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, 
     // (interleaved scans -- packed 4:2:2, BASELINE config 4 at q90: 10.4 B per block -- go through the lane-per-segment kernel, whose plane mode
     // pays for the zero fill and the scattered stores of 128-byte blocks: tokens win up to denser streams there)
     // (round 3, k_huffman_decode_tok: a 4K RGB frame -- 389 K blocks -- gains 9 % enc+dec and 7 % decode-only, an HD frame loses 4 %)
-    return g->block_count >= (g->interleaved ? 900000 : 300000) && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
+    // (a batch of frames, gj_frame_strides: the blocks of all its frames fill the GPU, so HD frames take token mode too)
+    const uint64_t blocks_in_flight = (uint64_t)g->block_count * (g->fb.frames > 1 ? g->fb.frames : 1u);
+    return blocks_in_flight >= (g->interleaved ? 900000u : 300000u) && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
 }
 
 // A batch of frames (gj_dec_job::batch) takes the sub-sequence entropy decoders (tokens or planes) and the fused 4:4:4 IDCT kernels -- the path of

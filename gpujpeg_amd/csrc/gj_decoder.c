@@ -791,7 +791,8 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
         const size_t seg_frame = (3 * S + 8 + 3) & ~(size_t)3;                                                                   /* words */
         const size_t scratch_frame = (gj_hip_find_segments_scratch_words(begin, max_size, (uint32_t)g->segment_count) + 3) & ~(size_t)3; /* words */
         const size_t coefs_frame = ((size_t)g->data_size + 63) & ~(size_t)63;                                                   /* int16 */
-        const bool tokens = gj_hip_decode_wants_tokens(g, max_size, &d->tune) != 0;
+        job.g.fb.frames = (uint32_t)(n_all < GJ_DEC_BATCH_CHUNK_MAX ? n_all : GJ_DEC_BATCH_CHUNK_MAX); /* (what the token / plane choice looks at) */
+        const bool tokens = gj_hip_decode_wants_tokens(&job.g, max_size, &d->tune) != 0;
         const size_t tok_frame = tokens ? (max_size * 4 + 64 + 63) & ~(size_t)63 : 0;                                            /* tokens */
         const size_t rec_frame = tokens ? ((size_t)g->block_count + 8 + 7) & ~(size_t)7 : 0;                                    /* records */
         const size_t frame_bytes = seg_frame * 4 + scratch_frame * 4 + coefs_frame * 2 + tok_frame * 2 + rec_frame * 8;

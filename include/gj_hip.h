@@ -89,7 +89,7 @@ typedef struct gj_frame_strides {
     uint64_t jpeg, raw;       /* bytes */
     uint64_t coefs, tok, rec; /* int16 coefficients, tokens, block records */
     uint32_t seg;             /* words between the frames' seg_pos (and seg_len, seg_index) */
-    uint32_t reserved;
+    uint32_t frames;          /* frames of the launch (what fills the device is the batch, not the frame: gj_hip_decode_wants_tokens) */
 } gj_frame_strides;
 
 typedef struct gj_geom {

@@ -43,6 +43,17 @@ def test_two_ranks_shard_a_batch_bit_exact(gpu_lib):
     assert d["scaling"] == "strong" and d["value"] > 0 and d["psnr_last_frame_db"] > 30
 
 
+def test_two_ranks_shard_a_batch_through_the_batch_calls(gpu_lib):
+    """the same shards through gpujpeg_amd_encoder_encode_batch / gpujpeg_amd_decoder_decode_batch (every kernel once per chunk of frames): every
+    stream and every decoded frame of both ranks against the oracle, and the line says that the batched launches did the work"""
+    d = _torchrun(2, ["--gpus", "2", "--batch", "16", "--workload", "hd", "--steps", "2", "--warmup", "1", "--verify", "--batch-api", "batch",
+                      "--batch-streams", "1"])
+    assert d["n_gpus"] == 2 and d["config"]["frames_total"] == 16 and d["config"]["frames_per_gpu"] == 8
+    assert d["verified_bit_exact"] is True
+    assert "((8, 0), (8, 0))" in d["config"]["api"], d["config"]["api"]
+    assert d["value"] > 0 and d["psnr_last_frame_db"] > 30
+
+
 def test_two_ranks_headline_line(gpu_lib):
     """the weak-scaling headline path at N = 2: one JSON line, whole-job throughput over both ranks, per-rank frames of their own seed"""
     d = _torchrun(2, ["--gpus", "2", "--workload", "hd", "--steps", "3", "--warmup", "1", "--min-seconds", "0.1", "--lean", "--verify"])

@@ -643,8 +643,10 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, const unsigned cap_u, const u
     for (int c = 0; per_scan && c < g.comp_count; c++) per_scan = job->scan_bytes[c] != 0 && g.comp[c].segment_count > 0;
     // 23/32 of the stage on average is the measured optimum; when that gives a little more than one generation of resident
     // workgroups, fuller batches (up to 27/32) that fit into one are better than a second generation of a few
-    const unsigned fill0 = job->tune.dec_fill >= 8 && job->tune.dec_fill <= 31 ? (unsigned)job->tune.dec_fill : 23u;
-    for (unsigned fill = fill0; fill <= (job->tune.dec_fill ? fill0 : 27u); fill += 2) {
+    // (a batch of frames is dozens of generations of workgroups: measured best at 26/32 -- 256 x 4K 21 030 frames/s against 20 860 at 23 and 20 700 at
+    // 29, 256 x HD 70 020 against 69 230 and 68 100; profiles/r4_15_frame_batches.txt)
+    const unsigned fill0 = job->tune.dec_fill >= 8 && job->tune.dec_fill <= 31 ? (unsigned)job->tune.dec_fill : (job->batch.count > 1 ? 26u : 23u);
+    for (unsigned fill = fill0; fill <= (job->tune.dec_fill || job->batch.count > 1 ? fill0 : 27u); fill += 2) {
         if (per_scan) {
             plan.n = g.comp_count;
             int first = 0;

@@ -545,15 +545,18 @@ int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpu
             return -1;
         }
     }
-    size_t total = 0;
+    size_t longest = 0;
     for (int f = 0; f < count; f++) {
         if (e->bh_result[2 * f + 1]) {
             GJ_ERROR("Compressed stream (%u B) of frame %d does not fit the output buffer (%zu B)!\n", e->bh_result[2 * f], f, e->d_jpeg_cap);
             return -1;
         }
         images_compressed_size[f] = e->bh_result[2 * f];
-        total += (e->bh_result[2 * f] + 15u) & ~(size_t)15;
+        if (e->bh_result[2 * f] > longest) longest = e->bh_result[2 * f];
     }
+    /* (host copies too lie a constant number of bytes apart -- images_compressed[1] - images_compressed[0], a multiple of 16 --, so that the
+     * pointers can go straight into gpujpeg_amd_decoder_decode_batch) */
+    const size_t host_stride = (longest + 64 + 15) & ~(size_t)15, total = host_stride * (size_t)count;
     if (e->out_location == GJ_OUT_DEVICE) {
         for (int f = 0; f < count; f++) images_compressed[f] = e->b_jpeg + (size_t)f * slot;
     } else {
@@ -566,11 +569,9 @@ int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpu
             if (!e->b_out) return -1;
         }
         gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
-        size_t at = 0;
         for (int f = 0; f < count; f++) {
-            if (gj_hip_memcpy_d2h(e->b_out + at, e->b_jpeg + (size_t)f * slot, images_compressed_size[f], c->stream) != 0) return -1;
-            images_compressed[f] = e->b_out + at;
-            at += (images_compressed_size[f] + 15u) & ~(size_t)15;
+            if (gj_hip_memcpy_d2h(e->b_out + (size_t)f * host_stride, e->b_jpeg + (size_t)f * slot, images_compressed_size[f], c->stream) != 0) return -1;
+            images_compressed[f] = e->b_out + (size_t)f * host_stride;
         }
         if (gj_hip_stream_sync(c->stream) != 0) return -1;
     }

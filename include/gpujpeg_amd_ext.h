@@ -79,7 +79,9 @@ GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* dec
  *
  * gpujpeg_amd_encoder_encode_batch: frame f lies at frames + f * frame_stride (device memory = GPU_IMAGE semantics, or host memory: copied);
  *   images_compressed[f] / images_compressed_size[f] receive every frame's stream -- in device memory with enc_opt_out=device, else in
- *   pinned / pageable host memory -- owned by the encoder and valid until its next call.
+ *   pinned / pageable host memory -- owned by the encoder and valid until its next call. The streams lie a constant number of bytes apart
+ *   (images_compressed[1] - images_compressed[0], a multiple of 16), so the pointers can go straight into gpujpeg_amd_decoder_decode_batch.
+ *   perf_stats / get_stats are not kept for batch calls.
  * gpujpeg_amd_decoder_decode_batch: stream f lies at streams + f * stream_stride and has sizes[f] bytes (device or host memory); frame f's
  *   pixels go to output + f * output_stride (device memory) in the format set with gpujpeg_decoder_set_output_format. All streams must
  *   decode to the same image parameters; returns 0 when every frame was decoded. */

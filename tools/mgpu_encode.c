@@ -5,7 +5,11 @@
  * another (PCIe, not xGMI, is the shared resource). Mirrors test/misc/mt_encode.c:12-45 of the reference (one encoder + stream
  * per thread) and extends it over devices.
  *
- *   mgpu_encode <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0] [pin=1]
+ *   mgpu_encode <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0] [pin=1] [batch=0]
+ *
+ * batch: B > 0 = every coder hands B frames at a time to gpujpeg_amd_encoder_encode_batch (and the B streams to
+ * gpujpeg_amd_decoder_decode_batch): one set of kernel launches per B frames instead of per frame (include/gpujpeg_amd_ext.h; B <= 16
+ * here, the distinct frames lie back to back in one pinned allocation). 0 = one libgpujpeg call per frame, the reference's API.
  *
  * pin: every coder thread is bound to one core of the NUMA node its GPU hangs off (/sys/bus/pci/devices/<bdf>/local_cpulist), the
  * devices of one node taking disjoint cores -- launch latency and the pinned staging traffic stay on the near socket. The frames are
@@ -18,6 +22,7 @@
 #define _GNU_SOURCE
 #include <hip/hip_runtime_api.h>
 #include <libgpujpeg/gpujpeg.h>
+#include <gpujpeg_amd_ext.h>
 #include <ctype.h>
 #include <pthread.h>
 #include <sched.h>
@@ -27,10 +32,10 @@
 #include <string.h>
 #include <time.h>
 
-#define DISTINCT 8 /* distinct synthetic frames, reused round-robin */
+#define DISTINCT 16 /* distinct synthetic frames, reused round-robin (one pinned allocation, back to back) */
 
 struct shared {
-    int frames_total, width, height, threads, decode;
+    int frames_total, width, height, threads, decode, batch;
     uint8_t* frame[DISTINCT]; /* pinned */
     pthread_barrier_t start;
 };
@@ -159,9 +164,36 @@ static void* run(void* arg)
     uint8_t* jpeg = NULL;
     size_t size = 0;
     if (gpujpeg_encoder_encode(enc, &param, &pi, &in, &jpeg, &size) != 0) return NULL;
+    uint8_t* outs = NULL; /* batch mode: room for the decoded frames of one batch */
+    if (sh->batch > 0 && sh->decode && hipHostMalloc((void**)&outs, raw * (size_t)sh->batch, hipHostMallocDefault) != hipSuccess) return NULL;
     pthread_barrier_wait(&sh->start);
     const double t0 = now();
     int it = 0;
+    if (sh->batch > 0) { /* this thread's share of the frames, B at a time: frames 0 .. B - 1 of the distinct set */
+        long mine = 0;
+        for (int f = wk->index; f < sh->frames_total; f += sh->threads) mine++;
+        while (mine > 0) {
+            const int n = mine < sh->batch ? (int)mine : sh->batch;
+            uint8_t* js[DISTINCT];
+            size_t sz[DISTINCT];
+            if (gpujpeg_amd_encoder_encode_batch(enc, &param, &pi, sh->frame[0], raw, n, js, sz) != 0) return NULL;
+            for (int k = 0; k < n; k++) {
+                uint64_t dg = 1469598103934665603ull;
+                for (size_t i = 0; i < sz[k]; i += 97) dg = (dg ^ js[k][i]) * 1099511628211ull;
+                dg = (dg ^ (uint64_t)sz[k]) * 1099511628211ull;
+                if (wk->fseen[k] && wk->fdig[k] != dg) wk->self_mismatch = 1;
+                wk->fdig[k] = dg;
+                wk->fseen[k] = 1;
+                wk->jpeg_bytes += sz[k];
+            }
+            if (sh->decode) {
+                struct gpujpeg_image_parameters opi;
+                if (gpujpeg_amd_decoder_decode_batch(dec, js[0], n > 1 ? (size_t)(js[1] - js[0]) : ((sz[0] + 79) & ~(size_t)15), sz, n, outs, raw, &opi) != 0) return NULL;
+            }
+            wk->frames += n;
+            mine -= n;
+        }
+    } else
     for (int f = wk->index; f < sh->frames_total; f += sh->threads, it++) {
         const int k = (wk->index + 3 * it) % DISTINCT; /* (3 is coprime to DISTINCT: every thread walks through all the distinct frames) */
         gpujpeg_encoder_input_set_image(&in, sh->frame[k]);
@@ -184,6 +216,7 @@ static void* run(void* arg)
     gpujpeg_encoder_destroy(enc);
     if (dec) gpujpeg_decoder_destroy(dec);
     if (out) (void)hipHostFree(out);
+    if (outs) (void)hipHostFree(outs);
     (void)hipStreamDestroy(stream);
     wk->rc = 0;
     return NULL;
@@ -192,7 +225,7 @@ static void* run(void* arg)
 int main(int argc, char** argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0] [pin=1]\n", argv[0]);
+        fprintf(stderr, "usage: %s <frames_total> <width> <height> [devices=all] [coders_per_device=2] [decode=0] [pin=1] [batch=0]\n", argv[0]);
         return 2;
     }
     struct shared sh;
@@ -206,10 +239,14 @@ int main(int argc, char** argv)
     const int per_dev = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : 2;
     sh.decode = argc > 6 ? atoi(argv[6]) : 0;
     const int pin = argc > 7 ? atoi(argv[7]) : 1;
+    sh.batch = argc > 8 ? atoi(argv[8]) : 0;
+    if (sh.batch < 0 || sh.batch > DISTINCT) { fprintf(stderr, "batch must be 0 .. %d\n", DISTINCT); return 2; }
     sh.threads = devices * per_dev;
     const size_t raw = (size_t)sh.width * sh.height * 3;
+    uint8_t* all_frames = NULL;
+    if (hipHostMalloc((void**)&all_frames, raw * DISTINCT, hipHostMallocPortable) != hipSuccess) { fprintf(stderr, "pinned allocation failed\n"); return 1; }
     for (int k = 0; k < DISTINCT; k++) {
-        if (hipHostMalloc((void**)&sh.frame[k], raw, hipHostMallocPortable) != hipSuccess) { fprintf(stderr, "pinned allocation failed\n"); return 1; }
+        sh.frame[k] = all_frames + (size_t)k * raw;
         fill_frame(sh.frame[k], sh.width, sh.height, (unsigned)k);
     }
     pthread_barrier_init(&sh.start, NULL, (unsigned)sh.threads + 1);
@@ -249,11 +286,11 @@ int main(int argc, char** argv)
                 }
     }
     printf("{\"tool\": \"mgpu_encode\", \"ok\": %s, \"frames\": %ld, \"width\": %d, \"height\": %d, \"devices\": %d, \"devices_present\": %d, "
-           "\"coders_per_device\": %d, \"decode\": %d, \"seconds\": %.4f, \"frames_s\": %.2f, \"mpix_s\": %.1f, \"jpeg_bytes\": %zu, "
+           "\"coders_per_device\": %d, \"decode\": %d, \"batch\": %d, \"seconds\": %.4f, \"frames_s\": %.2f, \"mpix_s\": %.1f, \"jpeg_bytes\": %zu, "
            "\"streams_consistent\": %s, \"digest_comparisons\": %ld, \"threads_pinned\": %d, \"first_thread_cpu\": %d, \"io\": \"pinned host buffers in and out (PCIe included)\"}\n",
-           rc == 0 && frames == sh.frames_total ? "true" : "false", frames, sh.width, sh.height, devices, ndev, per_dev, sh.decode, dt,
+           rc == 0 && frames == sh.frames_total ? "true" : "false", frames, sh.width, sh.height, devices, ndev, per_dev, sh.decode, sh.batch, dt,
            (double)frames / dt, (double)frames * sh.width * sh.height / dt / 1e6, bytes, consistent ? "true" : "false", compared, pinned, wk[0].cpu);
-    for (int k = 0; k < DISTINCT; k++) (void)hipHostFree(sh.frame[k]);
+    (void)hipHostFree(all_frames);
     free(wk);
     return rc == 0 && frames == sh.frames_total && consistent ? 0 : 1;
 }

@@ -74,6 +74,16 @@ def test_mgpu_encode_threads_and_pinned_staging(gpu_lib):
     assert d["digest_comparisons"] >= 8  # (the consistency check really compared streams of equal frames between coders)
 
 
+def test_mgpu_encode_batch_calls(gpu_lib):
+    """the same tool with every coder handing 8 frames at a time to the batch calls (C caller of include/gpujpeg_amd_ext.h, pinned host memory in
+    and out): equal frames still give equal streams on every coder"""
+    exe = os.path.join(ROOT, "gpujpeg_amd", "lib", "mgpu_encode")
+    r = subprocess.run([exe, "64", "1920", "1080", "2", "2", "1", "1", "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["ok"] and d["frames"] == 64 and d["batch"] == 8 and d["streams_consistent"] and d["digest_comparisons"] >= 8
+
+
 def test_bench_self_launches_its_ranks(gpu_lib):
     """`python bench.py --gpus 2` as ONE process (the driver's command shape, no torchrun in front): bench.py becomes the launcher, two
     ranks run, and the line says so."""

@@ -796,3 +796,37 @@ def test_frame_batch_with_strangers(O, G, gpu_lib):
     assert np.array_equal(px[4], ref.decode(streams[4])[0])  # (damaged: whatever the ordinary call makes of it)
     dec.close()
     ref.close()
+
+
+def test_frame_batch_argument_errors(O, G, gpu_lib):
+    """the batch calls refuse what they cannot do (return -1, nothing written behind a caller's buffer): no frames, a stride smaller than a
+    frame, an output stride smaller than a decoded frame, a stream that is no JPEG -- and work again afterwards"""
+    w, h, n = 320, 240, 3
+    case = ("e", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    frames = np.stack([natural_image(w, h, 3, seed=70 + f) for f in range(n)])
+    raw = w * h * 3
+    enc, dec = G.Encoder(gpu_lib), G.Decoder(gpu_lib)
+    ptrs, sizes = (C.c_void_p * n)(), (C.c_size_t * n)()
+    L = gpu_lib.L
+    assert L.gpujpeg_amd_encoder_encode_batch(enc.h, C.byref(p), C.byref(pi), frames.ctypes.data, raw, 0, ptrs, sizes) == -1
+    assert L.gpujpeg_amd_encoder_encode_batch(enc.h, C.byref(p), C.byref(pi), frames.ctypes.data, raw - 1, n, ptrs, sizes) == -1
+    streams = enc.encode_batch(p, pi, frames.reshape(-1), n)
+    want = [O.decode(s)[0] for s in streams]
+    stride = (max(s.size for s in streams) + 79) & ~15
+    buf = np.zeros(stride * n, np.uint8)
+    for i, s in enumerate(streams):
+        buf[i * stride:i * stride + s.size] = s
+    csz = (C.c_size_t * n)(*[s.size for s in streams])
+    out = np.full(raw * n + 64, 0xAB, np.uint8)
+    opi = G.ImageParameters()
+    assert L.gpujpeg_amd_decoder_decode_batch(dec.h, buf.ctypes.data, stride, csz, 0, out.ctypes.data, raw, C.byref(opi)) == -1
+    assert L.gpujpeg_amd_decoder_decode_batch(dec.h, buf.ctypes.data, stride, csz, n, out.ctypes.data, raw - 16, C.byref(opi)) == -1
+    junk = buf.copy()
+    junk[stride:stride + 64] = 0x55  # the second stream is no JPEG any more
+    assert L.gpujpeg_amd_decoder_decode_batch(dec.h, junk.ctypes.data, stride, csz, n, out.ctypes.data, raw, C.byref(opi)) == -1
+    assert np.all(out[raw * n:] == 0xAB)
+    assert L.gpujpeg_amd_decoder_decode_batch(dec.h, buf.ctypes.data, stride, csz, n, out.ctypes.data, raw, C.byref(opi)) == 0
+    assert all(np.array_equal(out[i * raw:(i + 1) * raw], want[i]) for i in range(n)) and np.all(out[raw * n:] == 0xAB)
+    enc.close()
+    dec.close()

@@ -30,7 +30,7 @@ def child(name, mode):
     import oracle as O
     from conftest import natural_image, oracle_image
     from gpujpeg_amd import libgpujpeg as G
-    if mode == "tokens":
+    if mode in ("tokens", "batchtok"):
         os.environ["GJ_DEC_TOKENS"] = "1"
     if mode == "seq":  # the lane-per-segment entropy decoder over an LDS stage (plane mode)
         os.environ["GJ_DEC_NO_TOKENS"] = "1"
@@ -94,6 +94,17 @@ def child(name, mode):
             app13 = np.concatenate([np.array([0xFF, 0xED, (3 + body.size) >> 8, (3 + body.size) & 255, 0], np.uint8), body])
             bad = np.concatenate([bad[:sos], app13, bad[sos:]])
         print(f"trial {t} kind {kind}", flush=True)
+        if mode.startswith("batch"):
+            # the damaged stream between two good ones in ONE batch call (gpujpeg_amd_decoder_decode_batch: every kernel launched once for the three):
+            # the call fails as a whole or decodes, and a decoded good frame is exactly what it is alone -- nothing leaks between the frames of a batch
+            try:
+                px, _ = dec.decode_batch([jpeg, bad, jpeg])
+                assert np.array_equal(px[0], want) and np.array_equal(px[2], want), f"a good frame of the batch differs after trial {t}"
+                outcomes["decoded"] += 1
+            except RuntimeError:
+                outcomes["error"] += 1
+            assert np.array_equal(dec.decode(jpeg)[0], want), f"decoder damaged after trial {t}"
+            continue
         try:
             dec.decode(bad)
             outcomes["decoded"] += 1
@@ -110,7 +121,7 @@ if __name__ == "__main__":
     bad = 0
     only = [a for a in sys.argv[1:] if a in CONFIGS]
     for name in (only or CONFIGS):
-        for mode in ("default", "tokens", "seq", "seqtok"):
+        for mode in ("default", "tokens", "seq", "seqtok") + (("batch", "batchtok") if name == "rgb_auto" else ()):
             try:
                 r = subprocess.run([sys.executable, __file__, name, mode], capture_output=True, text=True, timeout=300)
                 lines = r.stdout.strip().splitlines()

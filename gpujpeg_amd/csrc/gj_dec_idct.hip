@@ -11,6 +11,10 @@
 __global__ __launch_bounds__(256) void k_idct(const gj_geom g, int16_t* __restrict__ coefs, const float* __restrict__ qtab,
                                               uint8_t* __restrict__ planes, const int zero)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch (the planes of a frame take as many bytes as its coefficients take elements)
+        coefs += (size_t)blockIdx.z * g.fb.coefs;
+        planes += (size_t)blockIdx.z * g.fb.coefs;
+    }
     const unsigned gb = blockIdx.x * 256u + threadIdx.x;
     if (gb >= (unsigned)g.block_count) return;
     int c = 0;
@@ -480,6 +484,10 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_uyvy422(const gj_geom g, co
 __global__ __launch_bounds__(256, 2) void k_idct_fused_uyvy422(const gj_geom g, int16_t* __restrict__ coefs, const float* __restrict__ qtab,
                                                                uint8_t* __restrict__ raw, const int zero)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch
+        coefs += (size_t)blockIdx.z * g.fb.coefs;
+        raw += (size_t)blockIdx.z * g.fb.raw;
+    }
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
     if (threadIdx.x < 192) s_q[threadIdx.x >> 6][threadIdx.x & 63] = qtab[g.comp[threadIdx.x >> 6].q_table * 64 + (threadIdx.x & 63)];
     __syncthreads();
@@ -545,6 +553,10 @@ __global__ __launch_bounds__(256, 2) void k_idct_fused_uyvy422(const gj_geom g, 
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_postprocess(const gj_geom g, const uint8_t* __restrict__ planes, uint8_t* __restrict__ raw)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch
+        planes += (size_t)blockIdx.z * g.fb.coefs;
+        raw += (size_t)blockIdx.z * g.fb.raw;
+    }
     const unsigned W = (unsigned)g.raw_width, H = (unsigned)g.height;
     const unsigned pos = blockIdx.x * 256u + threadIdx.x;
     if (pos >= W * H) return;
@@ -600,6 +612,10 @@ __global__ __launch_bounds__(256) void k_postprocess(const gj_geom g, const uint
 // planar output whose layout equals the component layout (src/gpujpeg_postprocessor.cu:404-434)
 __global__ __launch_bounds__(256) void k_copy_planes_out(const gj_geom g, const uint8_t* __restrict__ planes, uint8_t* __restrict__ raw)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch
+        planes += (size_t)blockIdx.z * g.fb.coefs;
+        raw += (size_t)blockIdx.z * g.fb.raw;
+    }
     size_t dst_off = 0;
     for (int c = 0; c < g.comp_count; c++) {
         const gj_comp_geom& k = g.comp[c];
@@ -667,14 +683,18 @@ gj_idct_tok_t gj_idct_tok_for(const gj_geom& g)
     return nullptr;
 }
 
-bool gj_idct_takes_batches(const gj_geom& g) { return !g.interleaved && gj_idct_fused_kernel(g) != nullptr && gj_idct_tok_kernel(g) != nullptr; }
+// does the IDCT side of this configuration go through the component planes (generic kernels)? A batch needs a set per frame then.
+extern "C" int gj_hip_decode_uses_planes(const gj_geom* g, int use_fused)
+{
+    return !(use_fused && (gj_is_uyvy422(*g) || gj_idct_fused_kernel(*g) != nullptr));
+}
 
 void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_tok, gj_event_t* ev)
 {
     const gj_geom& g = job->g;
     const bool uyvy = job->use_fused && gj_is_uyvy422(g);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
-    const unsigned frames = job->batch.count > 1 ? job->batch.count : 1u; // (batches: the two rgb444 kernels only, gj_hip_decode_batchable)
+    const unsigned frames = job->batch.count > 1 ? job->batch.count : 1u; // (batches: every kernel below but the token-fed 4:2:2 one, the flip and the remap)
     if (idct_tok) {
         const unsigned nb = g.interleaved ? (unsigned)g.block_count : (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block (position)
         hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, (const uint16_t*)job->d_tok, job->tok_cap,
@@ -682,22 +702,22 @@ void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_to
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else if (uyvy) {
         const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);
-        hipLaunchKernelGGL(k_idct_fused_uyvy422, dim3((nm + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
+        hipLaunchKernelGGL(k_idct_fused_uyvy422, dim3((nm + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else if (fused) {
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
         hipLaunchKernelGGL(fused, dim3((nb + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
     } else {
-        hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf,
+        hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf,
                            job->d_planes, job->zero_coefs);
         if (job->flipped) hipLaunchKernelGGL(k_flip_planes, dim3(1024), dim3(256), 0, st, g, job->d_planes); // src/gpujpeg_postprocessor.cu:447
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         if (g.no_transform) {
-            hipLaunchKernelGGL(k_copy_planes_out, dim3(2048), dim3(256), 0, st, g, job->d_planes, job->d_raw);
+            hipLaunchKernelGGL(k_copy_planes_out, dim3(2048, 1, frames), dim3(256), 0, st, g, job->d_planes, job->d_raw);
         } else {
             const unsigned n = (unsigned)g.raw_width * (unsigned)g.height;
-            hipLaunchKernelGGL(k_postprocess, dim3((n + 255) / 256), dim3(256), 0, st, g, job->d_planes, job->d_raw);
+            hipLaunchKernelGGL(k_postprocess, dim3((n + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_planes, job->d_raw);
         }
     }
     gj_debug_stage(job->tune.debug_sync != 0, st, "idct / postprocess");

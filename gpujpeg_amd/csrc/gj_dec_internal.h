@@ -59,6 +59,5 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, unsigned cap_u, unsigned max_
 typedef void (*gj_idct_tok_t)(const gj_geom, const int16_t*, const uint2*, const uint16_t*, uint32_t, const float*, uint8_t*);
 gj_idct_tok_t gj_idct_tok_for(const gj_geom& g); // the token-fed IDCT kernel for this configuration, or nullptr
 bool gj_is_uyvy422(const gj_geom& g);
-bool gj_idct_takes_batches(const gj_geom& g); // the configuration's IDCT kernels (from planes and from tokens) are the rgb444 ones, which know blockIdx.z = frame
 // dequantisation + IDCT + postprocessing of the frame; ev (may be null): events 2 and 3 of gj_hip_decode
 void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_tok, gj_event_t* ev);

@@ -11,6 +11,7 @@
 extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, const gj_tuning* tune)
 {
     if (tune->dec_tokens == 0 || gj_idct_tok_for(*g) == nullptr) return 0;
+    if (g->fb.frames > 0 && g->interleaved) return 0; // (a batch: the token mode of interleaved scans belongs to the lane-per-segment kernel, which takes single frames)
     if (g->seg_blocks > GJ_TOK_MAX_BLOCKS || g->restart_interval == 0) return 0; // (k_huffman_decode_tok takes whole segments into its LDS stage)
     if (tune->dec_sub) return 0; // (the tuning aid sweeps the plane-mode kernels)
     if (tune->dec_tokens == 1) return 1;
@@ -22,14 +23,15 @@ extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, 
     return blocks_in_flight >= (g->interleaved ? 900000u : 300000u) && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
 }
 
-// A batch of frames (gj_dec_job::batch) takes the sub-sequence entropy decoders (tokens or planes) and the fused 4:4:4 IDCT kernels -- the path of
-// every RGB frame from HD to 16K -- as a speculative launch on one header, nothing else.
+// A batch of frames (gj_dec_job::batch) is a speculative launch on one header through the sub-sequence entropy decoders -- tokens for non-interleaved
+// 4:4:4, coefficient planes for everything else (the lane-per-segment kernels and the token-fed 4:2:2 IDCT do not know the frame dimension) -- and any
+// of the IDCT-side kernels; no option that touches other buffers.
 extern "C" int gj_hip_decode_batchable(const gj_dec_job* job)
 {
     const gj_geom& g = job->g;
-    return !g.interleaved && job->use_fused && job->d_huff_tab2 != nullptr && job->d_overflow != nullptr && job->d_seg_count != nullptr && job->seg_count > 0 &&
+    return job->d_huff_tab2 != nullptr && job->d_overflow != nullptr && job->d_seg_count != nullptr && job->seg_count > 0 &&
            !job->flipped && !job->channel_remap && !job->clear_coefs && !job->tune.dec_serial && !job->tune.dec_careful && job->tune.dec_seq != 1 &&
-           g.restart_interval > 0 && gj_idct_takes_batches(g);
+           g.restart_interval > 0;
 }
 
 extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event_t ev[4])
@@ -44,7 +46,8 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const bool fast_ok = par && !job->tune.dec_careful && job->d_overflow != nullptr; // kernels that take whole segments into LDS are allowed
     // interleaved scans with many short segments: one lane per segment (k_huffman_decode_seq); the host vouches for the longest segment
     // (this stream's, or the previous frame's on the speculative path, where `d_overflow` is checked afterwards)
-    const bool seq = fast_ok && job->tune.dec_seq != 2 &&
+    const bool batch = g.fb.sizes != nullptr;
+    const bool seq = !batch && fast_ok && job->tune.dec_seq != 2 &&
                      (job->tune.dec_seq == 1 || (g.interleaved && job->max_seg_len != 0 && job->max_seg_len <= 1024u && job->seg_count >= 16384));
     // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
     // record per block instead of through the coefficient planes: k_huffman_decode_tok for non-interleaved scans (every segment has to

@@ -66,6 +66,7 @@ struct gpujpeg_decoder {
     uint32_t* b_seg; size_t b_seg_cap;
     uint32_t* b_scratch; size_t b_scratch_cap;
     int16_t* b_coefs; size_t b_coefs_cap;
+    uint8_t* b_planes; size_t b_planes_cap;        /* component planes per frame (configurations whose IDCT side is the generic kernels) */
     uint16_t* b_tok; size_t b_tok_cap;
     void* b_rec; size_t b_rec_cap;
     uint8_t* b_jpeg; size_t b_jpeg_cap;            /* streams handed over in host memory */
@@ -147,7 +148,7 @@ int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
     free(d->hdr_cache); gj_hip_free(d->d_hdr_cache);
     gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_host_free(d->h_maxlen); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
     free(d->segs.pos); free(d->segs.len); free(d->segs.index);
-    gj_hip_free(d->b_dsum); gj_hip_free(d->b_sizes); gj_hip_free(d->b_seg); gj_hip_free(d->b_scratch); gj_hip_free(d->b_coefs); gj_hip_free(d->b_tok);
+    gj_hip_free(d->b_dsum); gj_hip_free(d->b_sizes); gj_hip_free(d->b_seg); gj_hip_free(d->b_scratch); gj_hip_free(d->b_coefs); gj_hip_free(d->b_planes); gj_hip_free(d->b_tok);
     gj_hip_free(d->b_rec); gj_hip_free(d->b_jpeg); gj_hip_free(d->b_raw);
     gj_hip_host_free(d->bh_sum); gj_hip_host_free(d->bh_maxlen); gj_hip_host_free(d->bh_sizes);
     free(d);
@@ -795,7 +796,8 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
         const bool tokens = gj_hip_decode_wants_tokens(&job.g, max_size, &d->tune) != 0;
         const size_t tok_frame = tokens ? (max_size * 4 + 64 + 63) & ~(size_t)63 : 0;                                            /* tokens */
         const size_t rec_frame = tokens ? ((size_t)g->block_count + 8 + 7) & ~(size_t)7 : 0;                                    /* records */
-        const size_t frame_bytes = seg_frame * 4 + scratch_frame * 4 + coefs_frame * 2 + tok_frame * 2 + rec_frame * 8;
+        const bool planes = gj_hip_decode_uses_planes(g, job.use_fused) != 0;
+        const size_t frame_bytes = seg_frame * 4 + scratch_frame * 4 + coefs_frame * 2 + tok_frame * 2 + rec_frame * 8 + (planes ? coefs_frame : 0);
         int chunk = (int)(GJ_DEC_BATCH_BYTES / frame_bytes);
         if (chunk > GJ_DEC_BATCH_CHUNK_MAX) chunk = GJ_DEC_BATCH_CHUNK_MAX;
         if (chunk > n_all) chunk = n_all;
@@ -803,6 +805,8 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
         if (gj_ensure_device_buffer((void**)&d->b_seg, &d->b_seg_cap, seg_frame * 4 * (size_t)chunk) != 0) goto out;
         if (gj_ensure_device_buffer((void**)&d->b_scratch, &d->b_scratch_cap, scratch_frame * 4 * (size_t)chunk + 64) != 0) goto out;
         if (gj_ensure_device_buffer((void**)&d->b_coefs, &d->b_coefs_cap, coefs_frame * 2 * (size_t)chunk) != 0) goto out;
+        if (planes && gj_ensure_device_buffer((void**)&d->b_planes, &d->b_planes_cap, coefs_frame * (size_t)chunk) != 0) goto out;
+        if (planes) job.d_planes = d->b_planes;
         if (tokens) {
             if (gj_ensure_device_buffer((void**)&d->b_tok, &d->b_tok_cap, tok_frame * 2 * (size_t)chunk) != 0) goto out;
             const size_t had = d->b_rec_cap;

@@ -1284,6 +1284,11 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
     const int i = threadIdx.x;
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
+    // frame blockIdx.z of a batch (gj_enc_job::batch; strides zero for a single frame)
+    raw += (size_t)blockIdx.z * T.f_raw;
+    temp += (size_t)blockIdx.z * T.f_temp;
+    seg_bytes += (size_t)blockIdx.z * T.f_seg;
+    seg_ff += (size_t)blockIdx.z * T.f_seg;
 
     const gj_comp_geom& kc = g.comp[1];
     const int ri = g.restart_interval;
@@ -1365,7 +1370,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
                                            p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0,
                                            temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)seg0);
-        if (i == 0) gj_piece_put(T, blockIdx.x, size);
+        if (i == 0) gj_piece_put(T, blockIdx.x, size, (size_t)blockIdx.z * T.f_tail);
     }
 }
 
@@ -1411,6 +1416,11 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
     const int i = threadIdx.x;
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 128) s_q[i >> 6][i & 63] = (i < 64 ? q_luma : q_chroma)[i & 63];
+    // frame blockIdx.z of a batch (gj_enc_job::batch; strides zero for a single frame)
+    raw += (size_t)blockIdx.z * T.f_raw;
+    temp += (size_t)blockIdx.z * T.f_temp;
+    seg_bytes += (size_t)blockIdx.z * T.f_seg;
+    seg_ff += (size_t)blockIdx.z * T.f_seg;
 
     const int B = g.seg_blocks;
     const int spt = 256 / B;       // segments per workgroup
@@ -1561,7 +1571,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0,
                                            temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(scan_first + seg0));
         // (workgroups are numbered in file order: the tiles of scan 0, of scan 1, ...)
-        if (i == 0) gj_piece_put(T, blockIdx.x, size);
+        if (i == 0) gj_piece_put(T, blockIdx.x, size, (size_t)blockIdx.z * T.f_tail);
     }
 }
 
@@ -1830,11 +1840,35 @@ static int gj_blocks_kernel_mode(const gj_geom& g)
     return 0;
 }
 
-// a batch of frames takes the fully fused 4:4:4 kernel and nothing else (no options that touch other buffers)
+// packed 4:2:2 without colour transform in the layout k_fused_uyvy422 / k_encode_uyvy422 take
+static bool gj_is_uyvy_layout(const gj_enc_job* job)
+{
+    const gj_geom& g = job->g;
+    return job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 && g.no_transform == 0 &&
+           (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
+           g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
+           g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
+           g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
+}
+// which kernel leaves the tile streams k_gather takes: 1 = k_encode_uyvy422, 2 = k_encode_blocks, 3 = k_encode_rgb444, 0 = none (coefficient planes + k_huffman)
+static int gj_tile_kernel(const gj_enc_job* job)
+{
+    const gj_geom& g = job->g;
+    const bool segs_ok = g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT;
+    gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
+    if (whole && job->tune.enc_by_blocks > 0 && gj_blocks_kernel_mode(g) == 0) whole = nullptr; // (k_encode_blocks instead)
+    if (gj_is_uyvy_layout(job) && !job->keep_coefs && g.interleaved && segs_ok && g.blocks_per_mcu == 4 && g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y &&
+        g.comp[1].type == g.comp[2].type && !job->tune.enc_no_whole422)
+        return 1;
+    if (!whole && job->use_fused && !job->keep_coefs && segs_ok && gj_blocks_kernel_mode(g) >= 0) return 2;
+    return whole ? 3 : 0;
+}
+
+// a batch of frames takes the kernels that go from pixels to tile streams (k_encode_rgb444, k_encode_uyvy422, k_encode_blocks: every layout with restart
+// segments of 4 .. 256 blocks) and k_gather, and no option that touches other buffers
 extern "C" int gj_hip_encode_batchable(const gj_enc_job* job)
 {
-    return job->use_fused && !job->keep_coefs && !job->channel_remap && !job->flipped && !job->segment_info && gj_encode_kernel(job->g) != nullptr &&
-           !(job->tune.enc_by_blocks > 0);
+    return job->use_fused && !job->keep_coefs && !job->channel_remap && !job->flipped && !job->segment_info && gj_tile_kernel(job) != 0;
 }
 
 extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS])
@@ -1852,25 +1886,19 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
     bool tiles = true; // k_encode_*: tile streams for k_gather
     GjTail T;
     T.npieces = 0;
-    gj_encode_kernel_t whole = (job->use_fused && !job->keep_coefs) ? gj_encode_kernel(g) : nullptr;
-    if (whole && job->tune.enc_by_blocks > 0 && gj_blocks_kernel_mode(g) == 0) whole = nullptr; // (k_encode_blocks below)
+    const int tile_kernel = gj_tile_kernel(job);
+    gj_encode_kernel_t whole = tile_kernel == 3 ? gj_encode_kernel(g) : nullptr;
     gj_fused_kernel_t fused = job->use_fused ? gj_fused_kernel(g) : nullptr;
-    const bool uyvy = job->use_fused && g.pixel_format == GJ_PF_422_P1020 && g.comp_count == 3 && g.no_transform == 0 &&
-                      (g.color_space == g.color_space_internal || g.color_space == GJ_CS_NONE || g.color_space_internal == GJ_CS_NONE) &&
-                      g.comp[0].samp_h == 2 && g.comp[0].samp_v == 1 && g.comp[1].samp_h == 1 && g.comp[1].samp_v == 1 && g.comp[2].samp_h == 1 &&
-                      g.comp[2].samp_v == 1 && g.comp[0].blocks_x == 2 * g.comp[1].blocks_x && g.comp[0].blocks_y == g.comp[1].blocks_y &&
-                      g.comp[2].blocks_x == g.comp[1].blocks_x && g.comp[2].blocks_y == g.comp[1].blocks_y;
-    if (uyvy && !job->keep_coefs && g.interleaved && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT && g.blocks_per_mcu == 4 &&
-        g.mcu_count == g.comp[1].blocks_x * g.comp[1].blocks_y && g.comp[1].type == g.comp[2].type && !job->tune.enc_no_whole422) {
+    const bool uyvy = gj_is_uyvy_layout(job);
+    if (tile_kernel == 1) {
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
         const int spt = 256 / g.seg_blocks;
         const unsigned wgs = ((unsigned)g.segment_count + spt - 1) / spt;
         T = gj_make_tail(job, wgs, {0u, ~0u, ~0u, ~0u}, (unsigned)spt);
-        hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
+        hipLaunchKernelGGL(k_encode_uyvy422, dim3(wgs, 1, frames), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut,
                            job->d_temp, job->d_seg_bytes, job->d_seg_ff, T);
-    } else if (!whole && job->use_fused && !job->keep_coefs && g.restart_interval > 0 && g.seg_blocks <= 256 && g.seg_blocks >= 256 / GJ_ENC_MAX_SPT &&
-               gj_blocks_kernel_mode(g) >= 0) {
+    } else if (tile_kernel == 2) {
         // every other layout with short restart segments: one lane per block in coding order (k_encode_blocks)
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
         if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
@@ -1883,7 +1911,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
                 wgs += ((unsigned)g.comp[c].segment_count + spt - 1) / spt;
             }
         T = gj_make_tail(job, wgs, scan_first, (unsigned)spt);
-        hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
+        hipLaunchKernelGGL(gj_blocks_kernel_mode(g) ? k_encode_blocks<true> : k_encode_blocks<false>, dim3(wgs, 1, frames), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0],
                            job->d_fwd_q[1], job->d_huff_lut, job->d_temp, job->d_seg_bytes, job->d_seg_ff, T);
     } else if (whole) { // pixels -> segment streams in one kernel, no coefficient planes
         if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);

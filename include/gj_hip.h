@@ -246,6 +246,9 @@ typedef struct gj_dec_job {
 } gj_dec_job;
 /* 1 when gj_hip_decode takes a batch (gj_dec_job::batch.count > 1) of this job's configuration */
 GJ_HIP_API int gj_hip_decode_batchable(const gj_dec_job* job);
+/* 1 when the IDCT side of this configuration goes through the component planes (gj_dec_job::d_planes; a batch needs a set per frame,
+ * gj_frame_strides::coefs bytes apart) */
+GJ_HIP_API int gj_hip_decode_uses_planes(const gj_geom* g, int use_fused);
 
 /* 1 when a frame of this geometry (requested output included) and stream size is decoded in token mode: a token-fed IDCT kernel
  * exists for it and the measured size / density rule (or the GJ_DEC_TOKENS / GJ_DEC_NO_TOKENS override) says so. The host asks

@@ -733,8 +733,14 @@ BATCH_CASES = [
     ("tokens_640x480", 640, 480, 1, 75, -1, 0, None, 5, "1", True, True),
     ("odd_size_q90", 331, 277, 1, 90, 7, 0, None, 3, None, True, True),
     ("two_chunks_of_small_frames", 64, 64, 1, 50, 4, 0, None, 70, None, True, False),  # (a 2 KB stream has its three scans inside one scanning workgroup: host walk)
-    ("interleaved_rgb", 320, 240, 1, 75, -1, 1, None, 3, None, False, False),          # other kernels: frame by frame inside the call
-    ("planar_420", 320, 240, 5, 75, -1, 0, None, 3, None, False, False),
+    # every layout that goes from pixels to tile streams (k_encode_blocks, k_encode_uyvy422) and back through the sub-sequence decoder's planes and any
+    # of the IDCT-side kernels (k_idct_fused_uyvy422; k_idct + k_postprocess / k_copy_planes_out)
+    ("interleaved_rgb", 320, 240, 1, 75, -1, 1, None, 3, None, True, True),
+    ("planar_420", 320, 240, 5, 75, -1, 0, None, 3, None, True, True),
+    ("uyvy_422_interleaved", 322, 150, 3, 90, -1, 1, None, 4, None, True, True),
+    ("rgb_to_420_interleaved", 320, 240, 1, 75, 3, 1, [(2, 2), (1, 1), (1, 1)], 3, None, True, True),
+    ("gray", 333, 211, 0, 75, -1, 0, None, 3, None, True, True),
+    ("restart_0", 160, 120, 1, 75, 0, 0, None, 2, None, False, False),                  # one segment per scan: coefficient planes + k_huffman, frame by frame
 ]
 
 

@@ -75,7 +75,8 @@ GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* dec
  * and a call is 2 (encode) or 4 (decode) dependent launches: frame-at-a-time calls cannot fill an MI355X with small frames however many
  * coders run side by side. These two calls take `count` frames that share parameters (encoder) or the header (decoder) and launch every
  * kernel once per chunk of frames (the frame is a grid dimension). Results are identical, byte for byte, to the frame-at-a-time calls;
- * configurations or streams the batched kernels do not cover are coded frame by frame inside the call.
+ * configurations (restart interval 0, flip, channel remap, APP13 index) or streams (another header, damaged markers) the batched kernels do
+ * not cover are coded frame by frame inside the call.
  *
  * gpujpeg_amd_encoder_encode_batch: frame f lies at frames + f * frame_stride (device memory = GPU_IMAGE semantics, or host memory: copied);
  *   images_compressed[f] / images_compressed_size[f] receive every frame's stream -- in device memory with enc_opt_out=device, else in

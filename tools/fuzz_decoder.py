@@ -121,7 +121,8 @@ if __name__ == "__main__":
     bad = 0
     only = [a for a in sys.argv[1:] if a in CONFIGS]
     for name in (only or CONFIGS):
-        for mode in ("default", "tokens", "seq", "seqtok") + (("batch", "batchtok") if name == "rgb_auto" else ()):
+        # (the batch calls cover every layout: plane mode everywhere, token mode for the non-interleaved 4:4:4 configuration)
+        for mode in ("default", "tokens", "seq", "seqtok", "batch") + (("batchtok",) if name == "rgb_auto" else ()):
             try:
                 r = subprocess.run([sys.executable, __file__, name, mode], capture_output=True, text=True, timeout=300)
                 lines = r.stdout.strip().splitlines()

@@ -554,7 +554,11 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     mine = shard_frames(args.batch, rank, world)
     red = device if (world == 1 or dist.get_backend() == "nccl") else None  # where the reductions of the timing live (gloo: host)
     host_io = getattr(args, "batch_io", "device") == "host"
+    is422 = args.workload.endswith("422")  # packed YCbCr 4:2:2 (UYVY), interleaved scan, q90 when the quality was left at 75 (like Spec)
+    quality = 90 if (is422 and args.quality == 75) else args.quality
     frames = [synth_frame(lib, width, height, args.pattern, 12345 + i, device) for i in mine]
+    if is422:
+        frames = [to_uyvy(f) for f in frames]
     if host_io:  # pinned host memory on both sides: the caller of the reference API (gpujpeg_image_load_from_file returns pinned memory too)
         frames = [f.cpu().pin_memory() for f in frames]
         torch.cuda.empty_cache()
@@ -563,13 +567,19 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     batch_api = getattr(args, "batch_api", "frame") == "batch" and not host_io
     S = max(1, min(getattr(args, "batch_streams", 0) or args.streams, len(frames))) if batch_api else max(1, min(args.streams, len(frames)))
     p = lib.default_parameters()
-    p.quality, p.restart_interval, p.verbose = args.quality, G.RESTART_AUTO, -1
+    p.quality, p.restart_interval, p.verbose = quality, G.RESTART_AUTO, -1
     pi = lib.default_image_parameters()
     pi.width, pi.height = width, height
+    if is422:
+        pi.pixel_format, pi.color_space = G.P1020_422, G.YCBCR_JPEG
+        p.interleaved = 1
+        lib.L.gpujpeg_parameters_chroma_subsampling(C.byref(p), G.SUBSAMPLING_422)
     lanes = []
     for si in range(S):
         ts = lane_stream(device, si)
         e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
+        if is422:
+            d.set_output_format(G.YCBCR_JPEG, G.P1020_422)
         assert e.set_option("enc_opt_out", "enc_out_val_pinned" if host_io else "enc_out_val_device") == 0
         ln = {"frames": frames[si::S], "out": torch.empty_like(frames[0]).pin_memory() if host_io else torch.empty_like(frames[0]),
               "enc": e, "dec": d, "bytes": 0, "digest": [], "batched": None}
@@ -654,7 +664,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     mse = float(((lanes[0]["out"].float() - last) ** 2).mean().item())
     verified = None
     if args.verify:  # every frame of this rank's shard against the CPU oracle: encoder bytes (sha256) and decoded samples
-        verified = verify_batch(lib, lanes, p, pi, width, height, args.quality, mine, S)
+        verified = verify_batch(lib, lanes, p, pi, width, height, quality, mine, S, is422)
     elapsed = barrier_and_max(elapsed, red)
     total = gather_counts(len(mine), red)
     jpeg_bytes = gather_counts(sum(ln["bytes"] for ln in lanes), red)
@@ -670,7 +680,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL,
         "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) "
                 + ("in pinned host memory, results to pinned host memory (PCIe both ways)" if host_io else "resident in HBM") + ", sharded round-robin",
-        "config": {"workload": f"{args.batch} x {width}x{height} RGB 4:4:4 q{args.quality} non-interleaved, restart auto, encode then decode of "
+        "config": {"workload": f"{args.batch} x {width}x{height} " + (f"YCbCr 4:2:2 (UYVY) q{quality} interleaved" if is422 else f"RGB 4:4:4 q{quality} non-interleaved") + ", restart auto, encode then decode of "
                                f"every frame per step", "frames_total": total, "frames_per_gpu": len(mine), "streams_per_gpu": S,
                    "jpeg_bytes_total": jpeg_bytes, "parallelism": f"frame-sharded x{world}, no collective", "io": "host" if host_io else "device",
                    "api": ("gpujpeg_amd_encoder_encode_batch + gpujpeg_amd_decoder_decode_batch: one set of launches per chunk of frames; (frames coded by "
@@ -691,12 +701,13 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     return result
 
 
-def verify_batch(lib, lanes, p, pi, width, height, quality, mine, S):
+def verify_batch(lib, lanes, p, pi, width, height, quality, mine, S, is422=False):
     """oracle check of a rank's shard (tests / --verify only; the oracle is the checker, never the thing measured)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     ok = True
-    img = O.make_image(width, height, quality=quality)
+    img = O.make_image(width, height, pixel_format=3, color_space=3, quality=quality, interleaved=1) if is422 else O.make_image(width, height, quality=quality)
+    odec = (lambda j: O.decode(j, 3, 3)[0]) if is422 else (lambda j: O.decode(j)[0])
     hip = C.cdll.LoadLibrary("libamdhip64.so")
     for si, ln in enumerate(lanes):
         if "stack" in ln:  # the batch calls: every stream and every decoded frame of one more pass
@@ -713,7 +724,7 @@ def verify_batch(lib, lanes, p, pi, width, height, quality, mine, S):
             torch.cuda.synchronize()
             for k in range(n):
                 want = O.encode(img, ln["stack"][k].cpu().numpy().reshape(-1))
-                ok = ok and bool(np.array_equal(streams[k], want)) and bool(np.array_equal(ln["out_stack"][k].cpu().numpy().reshape(-1), O.decode(want)[0]))
+                ok = ok and bool(np.array_equal(streams[k], want)) and bool(np.array_equal(ln["out_stack"][k].cpu().numpy().reshape(-1), odec(want)))
             continue
         for f in ln["frames"]:
             host = f.cpu().numpy().reshape(-1)
@@ -725,7 +736,7 @@ def verify_batch(lib, lanes, p, pi, width, height, quality, mine, S):
             o.type, o.data = G.DECODER_OUTPUT_CUSTOM_CUDA_BUFFER, ln["out"].data_ptr()
             assert lib.L.gpujpeg_decoder_decode(ln["dec"].h, C.cast(jp, C.c_void_p), js, C.byref(o)) == 0
             torch.cuda.synchronize()
-            ok = ok and bool(np.array_equal(jt.cpu().numpy(), want)) and bool(np.array_equal(ln["out"].cpu().numpy().reshape(-1), O.decode(want)[0]))
+            ok = ok and bool(np.array_equal(jt.cpu().numpy(), want)) and bool(np.array_equal(ln["out"].cpu().numpy().reshape(-1), odec(want)))
     return ok
 
 
@@ -800,8 +811,6 @@ def main():
     pin = "off" if args.no_pin else args.pin
     args.affinity = plan_pinning(local_rank, local_world, max(1, args.streams), max(1, ndev)) if pin == "on" or (pin == "auto" and local_world > 1) else None
     if args.batch:
-        if args.workload.endswith("422"):
-            raise SystemExit("--batch is defined for the RGB workloads")
         return run_batch(args, lib, device, dev_index, rank, world, width, height)
 
     def barrier():

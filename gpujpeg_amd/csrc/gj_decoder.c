@@ -720,10 +720,6 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
     const gj_geom* g = &c->geom;
     bool batched = d->hdr_cache_valid && !d->need_planes && !d->host_scan && !d->tune.dec_no_spec && !d->keep_coefs && c->configured &&
                    (streams_on_device ? (stream_stride & 15u) == 0 : true) && d->tab2_ok;
-    if (batched && output_stride < g->raw_size) {
-        GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, (size_t)g->raw_size);
-        goto out;
-    }
     size_t max_size = 0;
     for (int f = first; f < count; f++) {
         if (sizes[f] > max_size) max_size = sizes[f];
@@ -733,7 +729,11 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
     memset(&job, 0, sizeof job);
     if (batched && first < count) {
         struct gj_reader_result r = d->hdr_cache_r;
-        if (decoder_configure(d, &r.param, &r.param_image) != 0) goto out;
+        if (decoder_configure(d, &r.param, &r.param_image) != 0) goto out; /* (the geometry of the cached header, whatever the coder was last set up for) */
+        if (output_stride < g->raw_size) {
+            GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, (size_t)g->raw_size);
+            goto out;
+        }
         for (int i = 0; i < c->geom.comp_count; i++) {
             c->geom.comp[i].q_table = r.quant_map[i];
             c->geom.comp[i].dc_table = r.huff_map[i][0];

@@ -176,3 +176,7 @@ def test_emu_frame_batch_with_strangers(O, G, emu_lib):
 
 def test_emu_frame_batch_argument_errors(O, G, emu_lib):
     T.test_frame_batch_argument_errors(O, G, emu_lib)
+
+
+def test_emu_frame_batch_device_resident(O, G, emu_lib):
+    T.test_frame_batch_device_resident(O, G, emu_lib)

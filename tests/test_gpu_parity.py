@@ -836,3 +836,55 @@ def test_frame_batch_argument_errors(O, G, gpu_lib):
     assert all(np.array_equal(out[i * raw:(i + 1) * raw], want[i]) for i in range(n)) and np.all(out[raw * n:] == 0xAB)
     enc.close()
     dec.close()
+
+
+def test_frame_batch_device_resident(O, G, gpu_lib):
+    """frames, streams and decoded frames in device memory (what bench.py does): once the decoder knows the header EVERY frame goes through the batched
+    launches -- none is parsed on the host --, and streams that are not 16 bytes apart in device memory are still decoded (frame by frame)"""
+    L = gpu_lib.L
+    L.gj_hip_malloc.restype = C.c_void_p
+    L.gj_hip_malloc.argtypes = [C.c_size_t]
+    L.gj_hip_free.argtypes = [C.c_void_p]
+    for f in (L.gj_hip_memcpy_h2d, L.gj_hip_memcpy_d2h, L.gj_hip_memcpy_d2d):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gj_hip_stream_sync.argtypes = [C.c_void_p]
+    w, h, n = 640, 480, 4
+    case = ("d", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    raw = w * h * 3
+    frames = np.stack([natural_image(w, h, 3, seed=80 + f) for f in range(n)])
+    want = [O.encode(oracle_image(O, case), frames[f]) for f in range(n)]
+    want_px = [O.decode(s)[0] for s in want]
+    d_frames, d_out = L.gj_hip_malloc(raw * n), L.gj_hip_malloc(raw * n)
+    assert d_frames and d_out
+    assert L.gj_hip_memcpy_h2d(d_frames, frames.ctypes.data, raw * n, None) == 0 and L.gj_hip_stream_sync(None) == 0
+    enc, dec = G.Encoder(gpu_lib), G.Decoder(gpu_lib)
+    assert enc.set_option("enc_opt_out", "enc_out_val_device") == 0
+    ptrs, sizes = enc.encode_batch_noclone(p, pi, d_frames, n, stride=raw, gpu=True)
+    assert enc.last_batch() == (n, 0) and sizes == [s.size for s in want]
+    got = np.empty(max(sizes), np.uint8)
+    for f in range(n):
+        assert L.gj_hip_memcpy_d2h(got.ctypes.data, ptrs[f], sizes[f], None) == 0 and L.gj_hip_stream_sync(None) == 0
+        assert np.array_equal(got[:sizes[f]], want[f])
+    stride = ptrs[1] - ptrs[0]
+    assert stride % 16 == 0
+    px = np.empty(raw * n, np.uint8)
+    for rnd in range(2):  # the first call parses frame 0 the ordinary way (no header cache yet), the second launches all four at once
+        dec.decode_batch(None, device_out=d_out, out_stride=raw, device_in=ptrs[0], in_stride=stride, sizes=sizes)
+        assert dec.last_batch() == ((n - 1, 1) if rnd == 0 else (n, 0))
+        assert L.gj_hip_memcpy_d2h(px.ctypes.data, d_out, raw * n, None) == 0 and L.gj_hip_stream_sync(None) == 0
+        assert all(np.array_equal(px[f * raw:(f + 1) * raw], want_px[f]) for f in range(n))
+    # the same streams packed 8 bytes off the 16-byte grid: no batched launch (the marker scan reads whole 16-byte pieces per frame), same pixels
+    odd = (max(sizes) + 64 + 15) // 16 * 16 + 8
+    d_odd = L.gj_hip_malloc(odd * n + 64)
+    for f in range(n):
+        assert L.gj_hip_memcpy_d2d(d_odd + f * odd, ptrs[f], sizes[f], None) == 0
+    assert L.gj_hip_stream_sync(None) == 0
+    dec.decode_batch(None, device_out=d_out, out_stride=raw, device_in=d_odd, in_stride=odd, sizes=sizes)
+    assert dec.last_batch() == (0, n)
+    assert L.gj_hip_memcpy_d2h(px.ctypes.data, d_out, raw * n, None) == 0 and L.gj_hip_stream_sync(None) == 0
+    assert all(np.array_equal(px[f * raw:(f + 1) * raw], want_px[f]) for f in range(n))
+    enc.close()
+    dec.close()
+    for q in (d_frames, d_out, d_odd):
+        L.gj_hip_free(q)

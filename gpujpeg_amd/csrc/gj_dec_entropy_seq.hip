@@ -286,13 +286,22 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
 #define GJ_WIN_AHEAD 128 // complete-dword bits the ring must hold in front of the bit position before a symbol is decoded
 
 template <bool INTERLEAVED>
-__global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size,
+__global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, const uint8_t* __restrict__ jpeg, uint64_t jpeg_size,
                                                                const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
                                                                const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                                const uint32_t* __restrict__ seg_count_ptr, const uint16_t* __restrict__ tabs,
                                                                uint32_t* __restrict__ overflow, uint16_t* __restrict__ d_tok, const uint32_t tok_cap,
                                                                uint2* __restrict__ d_rec)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch: its stream, its table, its summary words, its tokens and records
+        const size_t z = blockIdx.z;
+        jpeg += z * g.fb.jpeg;
+        jpeg_size = g.fb.sizes[z];
+        seg_pos += z * g.fb.seg; seg_len += z * g.fb.seg; seg_index += z * g.fb.seg;
+        if (seg_count_ptr) seg_count_ptr += z * (sizeof(gj_scan_summary) / 4);
+        overflow += z * (sizeof(gj_scan_summary) / 4);
+        d_tok += z * g.fb.tok; d_rec += z * g.fb.rec;
+    }
     __shared__ uint32_t s_ring[256 * GJ_WIN_STRIDE];
     __shared__ uint32_t s_out[256 * GJ_WIN_OUT];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[4 * GJ_DEC2_WORDS];
@@ -571,9 +580,9 @@ void gj_launch_huffman_seq(const gj_dec_job* job, hipStream_t st, const bool tok
 #ifndef GJ_SEQ_NO_RING
     if (tokens) { // (token mode: the ring kernel; -DGJ_SEQ_NO_RING builds the A/B variant with the staged one)
         auto kernel = g.interleaved ? k_huffman_decode_win<true> : k_huffman_decode_win<false>;
-        hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + 255u) / 256u), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                           job->d_seg_index, job->seg_count, job->d_seg_count, job->d_huff_tab2, job->d_overflow, (uint16_t*)job->d_tok, job->tok_cap,
-                           (uint2*)job->d_blkrec);
+        hipLaunchKernelGGL(kernel, dim3(((unsigned)job->seg_count + 255u) / 256u, 1, job->batch.count > 1 ? job->batch.count : 1u), dim3(256), 0, st, g, job->d_jpeg,
+                           job->jpeg_size, job->d_seg_pos, job->d_seg_len, job->d_seg_index, job->seg_count, job->d_seg_count, job->d_huff_tab2, job->d_overflow,
+                           (uint16_t*)job->d_tok, job->tok_cap, (uint2*)job->d_blkrec);
         return;
     }
 #endif

@@ -396,6 +396,11 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_uyvy422(const gj_geom g, co
                                                              const uint16_t* __restrict__ d_tok, const uint32_t tok_cap,
                                                              const float* __restrict__ qtab, uint8_t* __restrict__ raw)
 {
+    if (g.fb.sizes != nullptr) { // frame blockIdx.z of a batch
+        const size_t z = blockIdx.z;
+        coefs += z * g.fb.coefs; d_rec += z * g.fb.rec; d_tok += z * g.fb.tok;
+        raw += z * g.fb.raw;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t s_blk[256 * 128];
     __shared__ __attribute__((aligned(16))) uint16_t s_stage[4][GJ_TOK_STAGE];
     // dequantisation tables: [0] for blocks rebuilt from tokens (AC entries / 64, see gj_slot_put), [1] for blocks from the coefficient planes
@@ -694,7 +699,7 @@ void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_to
     const gj_geom& g = job->g;
     const bool uyvy = job->use_fused && gj_is_uyvy422(g);
     gj_idct_fused_t fused = job->use_fused ? gj_idct_fused_kernel(g) : nullptr;
-    const unsigned frames = job->batch.count > 1 ? job->batch.count : 1u; // (batches: every kernel below but the token-fed 4:2:2 one, the flip and the remap)
+    const unsigned frames = job->batch.count > 1 ? job->batch.count : 1u; // (batches: every kernel below but the flip and the remap)
     if (idct_tok) {
         const unsigned nb = g.interleaved ? (unsigned)g.block_count : (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block (position)
         hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, (const uint16_t*)job->d_tok, job->tok_cap,

@@ -11,7 +11,6 @@
 extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, const gj_tuning* tune)
 {
     if (tune->dec_tokens == 0 || gj_idct_tok_for(*g) == nullptr) return 0;
-    if (g->fb.frames > 0 && g->interleaved) return 0; // (a batch: the token mode of interleaved scans belongs to the lane-per-segment kernel, which takes single frames)
     if (g->seg_blocks > GJ_TOK_MAX_BLOCKS || g->restart_interval == 0) return 0; // (k_huffman_decode_tok takes whole segments into its LDS stage)
     if (tune->dec_sub) return 0; // (the tuning aid sweeps the plane-mode kernels)
     if (tune->dec_tokens == 1) return 1;
@@ -46,9 +45,11 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const bool fast_ok = par && !job->tune.dec_careful && job->d_overflow != nullptr; // kernels that take whole segments into LDS are allowed
     // interleaved scans with many short segments: one lane per segment (k_huffman_decode_seq); the host vouches for the longest segment
     // (this stream's, or the previous frame's on the speculative path, where `d_overflow` is checked afterwards)
+    // (a batch of frames: its segments are in flight together; only the token mode of the lane-per-segment decoder -- the ring kernel -- knows the frame dimension)
     const bool batch = g.fb.sizes != nullptr;
-    const bool seq = !batch && fast_ok && job->tune.dec_seq != 2 &&
-                     (job->tune.dec_seq == 1 || (g.interleaved && job->max_seg_len != 0 && job->max_seg_len <= 1024u && job->seg_count >= 16384));
+    const uint64_t segs_in_flight = (uint64_t)job->seg_count * (batch && g.fb.frames > 1 ? g.fb.frames : 1u);
+    bool seq = fast_ok && job->tune.dec_seq != 2 &&
+               (job->tune.dec_seq == 1 || (g.interleaved && job->max_seg_len != 0 && job->max_seg_len <= 1024u && segs_in_flight >= 16384u));
     // token mode: the entropy decoder hands the non-zero coefficients to the fused IDCT as a dense token array plus one
     // record per block instead of through the coefficient planes: k_huffman_decode_tok for non-interleaved scans (every segment has to
     // fit its LDS stage), the lane-per-segment kernel for interleaved ones
@@ -57,6 +58,7 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const bool tok_seq = tok_wanted && seq;
     gj_idct_tok_t idct_tok = (tok_sub || tok_seq) ? gj_idct_tok_for(g) : nullptr;
     const bool tokens = idct_tok != nullptr;
+    if (batch && !tokens) seq = false; // (planes: the sub-sequence decoder)
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
     // decodes itself; clear_coefs asks for a full clear first (segments missing from the table, lane-per-segment kernel).
     if (tokens) {

@@ -676,11 +676,21 @@ static int pinned_ensure(void** p, size_t* cap, size_t need)
     return *p ? 0 : -1;
 }
 
-static int batch_decode_one(struct gpujpeg_decoder* d, const uint8_t* stream, size_t size, uint8_t* d_out)
+/* one frame of a batch the ordinary way: into the decoder's own buffer first -- a stream that is not what the caller promised (other dimensions) must
+ * not be written over the neighbours' slots --, then into its slot; *frame_raw = the size every frame of the batch decodes to (0: not known yet) */
+static int batch_decode_one(struct gpujpeg_decoder* d, const uint8_t* stream, size_t size, uint8_t* d_out, size_t out_stride, size_t* frame_raw)
 {
     struct gpujpeg_decoder_output o;
-    gpujpeg_decoder_output_set_custom_cuda(&o, d_out);
-    return decoder_decode(d, (uint8_t*)(uintptr_t)stream, size, &o, false);
+    gpujpeg_decoder_output_set_cuda_buffer(&o);
+    if (decoder_decode(d, (uint8_t*)(uintptr_t)stream, size, &o, false) != 0) return -1;
+    const size_t raw = d->coder.geom.raw_size;
+    if (*frame_raw == 0) *frame_raw = raw;
+    if (raw != *frame_raw || raw > out_stride) {
+        GJ_ERROR("A frame of the batch decodes to %zu B, the others to %zu B (output stride %zu)!\n", raw, *frame_raw, out_stride);
+        return -1;
+    }
+    if (gj_hip_memcpy_d2d(d_out, o.data, raw, d->coder.stream) != 0 || gj_hip_stream_sync(d->coder.stream) != 0) return -1;
+    return 0;
 }
 
 int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* streams, size_t stream_stride, const size_t* sizes, int count,
@@ -698,20 +708,22 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
     int first = 0;
     /* the header cache is what a batch launches on: the first frame goes the ordinary way when there is none (or when it has to) */
     const uint8_t* s0 = streams;
+    size_t frame_raw = 0; /* what every frame decodes to */
     if (!out_on_device || !d->hdr_cache_valid) {
         /* (the output size is known once a frame has been parsed: decode frame 0 into the decoder's own buffer first) */
         struct gpujpeg_decoder_output o;
         gpujpeg_decoder_output_set_cuda_buffer(&o);
         if (decoder_decode(d, (uint8_t*)(uintptr_t)s0, sizes[0], &o, false) != 0) goto out;
         const size_t raw = c->geom.raw_size;
+        frame_raw = raw;
+        if (output_stride < raw) {
+            GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, raw);
+            goto out;
+        }
         if (!out_on_device) {
             if (gj_ensure_device_buffer((void**)&d->b_raw, &d->b_raw_cap, raw * (size_t)count) != 0) goto out;
             d_out = d->b_raw;
             d_out_stride = raw;
-        }
-        if (output_stride < raw) {
-            GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, raw);
-            goto out;
         }
         if (gj_hip_memcpy_d2d(d_out, o.data, raw, c->stream) != 0 || gj_hip_stream_sync(c->stream) != 0) goto out;
         frame_done[0] = 1;
@@ -730,10 +742,11 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
     if (batched && first < count) {
         struct gj_reader_result r = d->hdr_cache_r;
         if (decoder_configure(d, &r.param, &r.param_image) != 0) goto out; /* (the geometry of the cached header, whatever the coder was last set up for) */
-        if (output_stride < g->raw_size) {
+        if (output_stride < g->raw_size || (frame_raw != 0 && frame_raw != g->raw_size)) {
             GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, (size_t)g->raw_size);
             goto out;
         }
+        frame_raw = g->raw_size;
         for (int i = 0; i < c->geom.comp_count; i++) {
             c->geom.comp[i].q_table = r.quant_map[i];
             c->geom.comp[i].dc_table = r.huff_map[i][0];
@@ -885,16 +898,12 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
     d->b_last_single = count - d->b_last_batched;
     for (int f = 0; f < count; f++) {
         if (frame_done[f]) continue;
-        if (batch_decode_one(d, streams + (size_t)f * stream_stride, sizes[f], d_out + (size_t)f * d_out_stride) != 0) goto out;
-        if (c->geom.raw_size > d_out_stride) {
-            GJ_ERROR("Frame %d decodes to %zu B, more than the output stride!\n", f, (size_t)c->geom.raw_size);
-            goto out;
-        }
+        if (batch_decode_one(d, streams + (size_t)f * stream_stride, sizes[f], d_out + (size_t)f * d_out_stride, d_out_stride, &frame_raw) != 0) goto out;
     }
     if (!out_on_device) {
         gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
         for (int f = 0; f < count; f++)
-            if (gj_hip_memcpy_d2h(output + (size_t)f * output_stride, d_out + (size_t)f * d_out_stride, c->geom.raw_size, c->stream) != 0) goto out;
+            if (gj_hip_memcpy_d2h(output + (size_t)f * output_stride, d_out + (size_t)f * d_out_stride, frame_raw, c->stream) != 0) goto out;
         if (gj_hip_stream_sync(c->stream) != 0) goto out;
     }
     if (param_image) {

@@ -805,6 +805,13 @@ def test_frame_batch_with_strangers(O, G, gpu_lib):
         assert np.array_equal(px[f], want[f]), f
     ref = G.Decoder(gpu_lib)
     assert np.array_equal(px[4], ref.decode(streams[4])[0])  # (damaged: whatever the ordinary call makes of it)
+    # a frame of other dimensions is not what the caller promised: the call fails, nothing is written over a neighbour's slot or behind the buffer
+    small = O.encode(oracle_image(O, ("s", 320, 240, 1, 1, 75, -1, 0, None, 3)), natural_image(320, 240, 3, seed=9))
+    big = O.encode(oracle_image(O, ("g", 800, 600, 1, 1, 75, -1, 0, None, 3)), natural_image(800, 600, 3, seed=9))
+    for other in (small, big):
+        with pytest.raises(RuntimeError):
+            dec.decode_batch([streams[0], streams[1], other, streams[3]])
+    assert np.array_equal(dec.decode(streams[1])[0], want[1])
     dec.close()
     ref.close()
 

@@ -33,7 +33,8 @@ extern "C" GJ_HIP_API int gj_hip_trace_set_markers(void* p) { return hipMemcpyTo
 #define GJ_TRACE_M(slot) ((void)0)
 #endif
 #define GJ_SCAN_LIST 2048    // restart markers a workgroup may hold (beyond that the host walks the stream)
-#define GJ_SCAN_WGS 256      // workgroups (= records every workgroup reads) up to 64 MB of stream; larger streams take more of them
+#define GJ_SCAN_WGS 256      // workgroups (= records every workgroup reads in one pass) up to 16 MB of stream
+#define GJ_SCAN_WGS_MAX 1024 // ... of one round of 16 pieces each up to 64 MB (k_marker_table reads their records in passes of 256); rounds beyond
 #define GJ_SCAN_REC_WORDS 16 // 32-bit words of a record:
 //   [0] restart markers   [1] position of the last one   [2] other markers (0 .. 2)   [3] 1 = more restart markers than the list holds / more
 //   than two other markers   [4 + 4 q ..] other marker q: position, code, the 16 bits behind the code (segment length), restart markers of
@@ -394,13 +395,19 @@ __global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uin
     GJ_TRACE_M(7);
 }
 
-// 4 KB pieces per workgroup and round for a stream of this size (1 .. 16), and rounds (1 .. 4): 256 workgroups up to 64 MB
+// 4 KB pieces per workgroup and round for a stream of this size (1 .. 16), and rounds (1 .. 4): 256 workgroups up to 16 MB; beyond that MORE
+// workgroups of one round each (up to 1024 at 64 MB) rather than rounds -- a round is a dependent trip to memory plus a workgroup prefix sum, and 256
+// workgroups are one per CU: config 4's 43 MB took 3 rounds on 225 workgroups, 110 us (round 4, first session), against 672 workgroups of one round
 static void gj_scan_shape(uint64_t bytes, uint32_t* iters, uint32_t* rounds)
 {
     const uint64_t per_wg = (bytes + 16 + GJ_SCAN_WGS - 1) / GJ_SCAN_WGS;
     uint32_t it = 1, rd = 1;
     while (it < 16 && 4096ull * it < per_wg) it *= 2;
-    while (rd < 4 && 4096ull * it * rd < per_wg) rd++;
+    if (4096ull * it < per_wg) { // (more than 16 MB)
+        const uint64_t wgs1 = (bytes + 16 + 65535) / 65536;
+        rd = (uint32_t)((wgs1 + GJ_SCAN_WGS_MAX - 1) / GJ_SCAN_WGS_MAX);
+        if (rd > 4) rd = 4;
+    }
     *iters = it;
     *rounds = rd;
 }
@@ -473,6 +480,10 @@ extern "C" size_t gj_hip_find_segments_scratch_words(uint64_t begin, uint64_t si
 extern "C" size_t gj_hip_find_segments_max_chunks(uint64_t begin, uint64_t size)
 {
     const uint64_t bytes = size - begin + 16;
-    const uint64_t wgs = (bytes + 4096ull * 64 - 1) / (4096ull * 64); // (at 4 rounds of 16 pieces per workgroup)
-    return (size_t)(wgs > GJ_SCAN_WGS ? wgs : GJ_SCAN_WGS) + 1;
+    uint32_t it, rd;
+    gj_scan_shape(size - begin, &it, &rd); // (the shape gj_hip_find_segments will choose)
+    const uint64_t wgs = (bytes + 4096ull * it * rd - 1) / (4096ull * it * rd);
+    // (at least 512: a forced shape -- GJ_SCAN_SHAPE, tests -- may cut a small stream into more parts than its size would, which is how the
+    // passes of k_marker_table over more than 256 records are exercised without a 16 MB stream)
+    return (size_t)(wgs > 2 * GJ_SCAN_WGS ? wgs : 2 * GJ_SCAN_WGS) + 1;
 }

@@ -23,7 +23,9 @@ On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --
   workloads         HD / 4K / 8K / 16K RGB, 16K 4:2:2 interleaved q90 (BASELINE config 4), each with its own roofline; the 8K frame with the
                     reference's own contents: `8k_noise` (7680x4320.random_12345.tst), `8k_gradient` (7680x4320.gradient.tst), `8k_camera`
                     (its camera sample, tests/golden/make_camera_fixture.py); 256 x 4K batch (config 5) resident in HBM (`batch256_4k`) and
-                    from pinned host memory in and out (`batch256_4k_host`)
+                    from pinned host memory in and out (`batch256_4k_host`); the same batch, 256 HD frames and 256 HD packed 4:2:2 frames through the
+                    batch calls of include/gpujpeg_amd_ext.h -- every kernel launched once per chunk of 64 frames -- (`batch256_4k_batched`,
+                    `batch256_hd_batched`, `batch256_hd422_batched`) next to 256 HD frames one call per frame (`batch256_hd`)
 The timed regions run with perf_stats = 0 (no per-kernel events); per-kernel durations come from their own short regions. The launch
 threads are bound to idle cores of the GPU's NUMA node when several ranks share the node (--pin on / off forces or forbids it).
   cpu_baseline      the reference's CPU path as it exists (its host C with the CPU Huffman coders) + the restated scalar stages for
@@ -983,7 +985,8 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
         table["batch256_4k"] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"]}
         torch.cuda.empty_cache()
         # the same batch, and one of 256 HD frames, through the batch calls (every kernel once per chunk of frames) and, for HD, frame by frame
-        for key, wl, api in (("batch256_4k_batched", "4k", "batch"), ("batch256_hd", "hd", "frame"), ("batch256_hd_batched", "hd", "batch")):
+        for key, wl, api in (("batch256_4k_batched", "4k", "batch"), ("batch256_hd", "hd", "frame"), ("batch256_hd_batched", "hd", "batch"),
+                             ("batch256_hd422_batched", "hd422", "batch")):
             ba.workload, ba.batch_api = wl, api
             b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS[wl], emit=False)
             table[key] = {"frames_s": b["value"], "mpix_s": b["mpix_s"], "ms_per_step": b["ms_per_step"], "workload": b["config"]["workload"], "api": b["config"]["api"]}

@@ -22,7 +22,10 @@ CLANG_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so
 def asan_env():
     if not os.path.exists(CLANG_RT) or shutil.which("make") is None:
         pytest.skip("needs ROCm's clang with its AddressSanitizer runtime")
-    r = subprocess.run(["make", "-s", "-j8", "-C", EMU_DIR, "SAN=1", "OPT=-O1", f"OUT={ASAN_DIR}"], capture_output=True, text=True)
+    import fcntl
+    with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:  # (pytest-xdist: one worker builds, the others wait -- a relink under a running test removes its library)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        r = subprocess.run(["make", "-s", "-j8", "-C", EMU_DIR, "SAN=1", "OPT=-O1", f"OUT={ASAN_DIR}"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
     return dict(os.environ, LD_PRELOAD=CLANG_RT, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0:abort_on_error=1",
                 UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", GJ_FUZZ_LIB=ASAN_LIB, FUZZ_TRIALS="18")

@@ -24,7 +24,7 @@ On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --
                     reference's own contents: `8k_noise` (7680x4320.random_12345.tst), `8k_gradient` (7680x4320.gradient.tst), `8k_camera`
                     (its camera sample, tests/golden/make_camera_fixture.py); 256 x 4K batch (config 5) resident in HBM (`batch256_4k`) and
                     from pinned host memory in and out (`batch256_4k_host`); the same batch, 256 HD frames and 256 HD packed 4:2:2 frames through the
-                    batch calls of include/gpujpeg_amd_ext.h -- every kernel launched once per chunk of 64 frames -- (`batch256_4k_batched`,
+                    batch calls of include/gpujpeg_amd_ext.h -- every kernel launched once per chunk of frames -- (`batch256_4k_batched`,
                     `batch256_hd_batched`, `batch256_hd422_batched`) next to 256 HD frames one call per frame (`batch256_hd`)
 The timed regions run with perf_stats = 0 (no per-kernel events); per-kernel durations come from their own short regions. The launch
 threads are bound to idle cores of the GPU's NUMA node when several ranks share the node (--pin on / off forces or forbids it).

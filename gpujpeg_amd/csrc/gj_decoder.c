@@ -72,6 +72,7 @@ struct gpujpeg_decoder {
     uint8_t* b_jpeg; size_t b_jpeg_cap;            /* streams handed over in host memory */
     uint8_t* b_raw; size_t b_raw_cap;              /* pixels wanted in host memory */
     int b_last_batched, b_last_single;             /* frames of the last batch call that the batched launches decoded / that went the ordinary way */
+    int b_chunk;                                   /* gpujpeg_amd_decoder_set_batch_chunk: frames per launch at most, 0 = the default */
 };
 
 #define GJ_HDR_WINDOW 65536
@@ -664,7 +665,7 @@ int gpujpeg_decoder_get_stats(struct gpujpeg_decoder* d, struct gpujpeg_duration
  * compares every stream's header with it, the host validates every frame's summary afterwards) for many frames at once; a frame whose
  * summary does not pass -- another header, an unusual scan structure, a segment the fast kernels cannot stage -- is decoded again by
  * gpujpeg_decoder_decode's own path, and so is everything the batched kernels do not cover. */
-#define GJ_DEC_BATCH_CHUNK_MAX 64
+#define GJ_DEC_BATCH_CHUNK_MAX 256
 #define GJ_DEC_BATCH_BYTES ((size_t)8 << 30) /* work buffers of one chunk */
 
 static int pinned_ensure(void** p, size_t* cap, size_t need)
@@ -805,14 +806,15 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
         const size_t seg_frame = (3 * S + 8 + 3) & ~(size_t)3;                                                                   /* words */
         const size_t scratch_frame = (gj_hip_find_segments_scratch_words(begin, max_size, (uint32_t)g->segment_count) + 3) & ~(size_t)3; /* words */
         const size_t coefs_frame = ((size_t)g->data_size + 63) & ~(size_t)63;                                                   /* int16 */
-        job.g.fb.frames = (uint32_t)(n_all < GJ_DEC_BATCH_CHUNK_MAX ? n_all : GJ_DEC_BATCH_CHUNK_MAX); /* (what the token / plane choice looks at) */
+        const int chunk_cap = d->b_chunk > 0 && d->b_chunk < GJ_DEC_BATCH_CHUNK_MAX ? d->b_chunk : GJ_DEC_BATCH_CHUNK_MAX;
+        job.g.fb.frames = (uint32_t)(n_all < chunk_cap ? n_all : chunk_cap); /* (what the token / plane choice looks at) */
         const bool tokens = gj_hip_decode_wants_tokens(&job.g, max_size, &d->tune) != 0;
         const size_t tok_frame = tokens ? (max_size * 4 + 64 + 63) & ~(size_t)63 : 0;                                            /* tokens */
         const size_t rec_frame = tokens ? ((size_t)g->block_count + 8 + 7) & ~(size_t)7 : 0;                                    /* records */
         const bool planes = gj_hip_decode_uses_planes(g, job.use_fused) != 0;
         const size_t frame_bytes = seg_frame * 4 + scratch_frame * 4 + coefs_frame * 2 + tok_frame * 2 + rec_frame * 8 + (planes ? coefs_frame : 0);
         int chunk = (int)(GJ_DEC_BATCH_BYTES / frame_bytes);
-        if (chunk > GJ_DEC_BATCH_CHUNK_MAX) chunk = GJ_DEC_BATCH_CHUNK_MAX;
+        if (chunk > chunk_cap) chunk = chunk_cap;
         if (chunk > n_all) chunk = n_all;
         if (chunk < 1) chunk = 1;
         if (gj_ensure_device_buffer((void**)&d->b_seg, &d->b_seg_cap, seg_frame * 4 * (size_t)chunk) != 0) goto out;
@@ -983,6 +985,8 @@ void gpujpeg_decoder_print_options(void)
 }
 
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
+
+void gpujpeg_amd_decoder_set_batch_chunk(struct gpujpeg_decoder* d, int frames) { if (d) d->b_chunk = frames > 0 ? frames : 0; }
 
 int gpujpeg_amd_decoder_last_batch(struct gpujpeg_decoder* d, int* batched, int* single)
 {

@@ -140,6 +140,10 @@ class Library:
         if hasattr(L, "gpujpeg_amd_encoder_encode_batch"):  # frame batches (include/gpujpeg_amd_ext.h)
             L.gpujpeg_amd_encoder_encode_batch.argtypes = [vp, C.POINTER(Parameters), C.POINTER(ImageParameters), vp, C.c_size_t, C.c_int,
                                                            C.POINTER(vp), C.POINTER(C.c_size_t)]
+        for n in ("gpujpeg_amd_encoder_set_batch_chunk", "gpujpeg_amd_decoder_set_batch_chunk"):
+            if hasattr(L, n):
+                getattr(L, n).restype = None
+                getattr(L, n).argtypes = [vp, C.c_int]
         for n in ("gpujpeg_amd_encoder_last_batch", "gpujpeg_amd_decoder_last_batch"):
             if hasattr(L, n):
                 getattr(L, n).argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -209,6 +213,9 @@ class Encoder:
         if rc != 0:
             raise RuntimeError(f"gpujpeg_amd_encoder_encode_batch failed ({rc})")
         return [int(p or 0) for p in ptrs], [int(n) for n in sizes]
+
+    def set_batch_chunk(self, frames):
+        self.lib.L.gpujpeg_amd_encoder_set_batch_chunk(self.h, int(frames))
 
     def last_batch(self):
         """(frames coded by the batched launches, frames coded one by one) of the last encode_batch call"""
@@ -288,6 +295,9 @@ class Decoder:
             return None, out.param_image
         buf = (C.c_uint8 * out.data_size).from_address(out.data)
         return np.frombuffer(buf, np.uint8).copy(), out.param_image
+
+    def set_batch_chunk(self, frames):
+        self.lib.L.gpujpeg_amd_decoder_set_batch_chunk(self.h, int(frames))
 
     def last_batch(self):
         """(frames decoded by the batched launches, frames decoded one by one) of the last decode_batch call"""

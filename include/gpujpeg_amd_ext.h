@@ -89,6 +89,10 @@ GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* dec
 GPUJPEG_API int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* encoder, const struct gpujpeg_parameters* param,
                                                  const struct gpujpeg_image_parameters* param_image, const uint8_t* frames, size_t frame_stride,
                                                  int count, uint8_t** images_compressed, size_t* images_compressed_size);
+/* frames per set of launches at most (0 = the default: up to 256, fewer for large frames whose work buffers would exceed 6 / 8 GB); tests use it to cut
+ * small batches into several chunks */
+GPUJPEG_API void gpujpeg_amd_encoder_set_batch_chunk(struct gpujpeg_encoder* encoder, int frames);
+GPUJPEG_API void gpujpeg_amd_decoder_set_batch_chunk(struct gpujpeg_decoder* decoder, int frames);
 /* how the frames of the last batch call were coded: by the batched launches / frame by frame inside the call (tests, benchmarks) */
 GPUJPEG_API int gpujpeg_amd_encoder_last_batch(struct gpujpeg_encoder* encoder, int* batched, int* single);
 GPUJPEG_API int gpujpeg_amd_decoder_last_batch(struct gpujpeg_decoder* decoder, int* batched, int* single);

@@ -769,6 +769,13 @@ def test_frame_batches(O, G, gpu_lib, bc, monkeypatch):
     enc, dec = G.Encoder(gpu_lib), G.Decoder(gpu_lib)
     if native:
         dec.set_output_format(3, 3)
+    if name in ("planes_640x480", "tokens_640x480", "planar_420"):  # several chunks per call: 2 + 2 + 1 frames
+        enc.set_batch_chunk(2)
+        dec.set_batch_chunk(2)
+    if name == "two_chunks_of_small_frames":
+        enc.set_batch_chunk(32)
+    if name == "uyvy_422_tokens_ring":  # 64 + 1 frames (the ring kernel wants 16 384 segments in flight: 64 frames of 256)
+        dec.set_batch_chunk(64)
     for count in (n, 2, n):
         got = enc.encode_batch(p, pi, frames[:count].reshape(-1), count)
         assert enc.last_batch() == ((count, 0) if enc_batched else (0, count))

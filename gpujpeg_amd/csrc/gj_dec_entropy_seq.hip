@@ -280,6 +280,18 @@ __global__ __launch_bounds__(256, 4) void k_huffman_decode_seq(const gj_geom g, 
 //   * symbols as in k_huffman_decode_seq<il, true>; sixteen tokens and four block records are collected in LDS and leave as aligned
 //     32-byte pieces (see "Output" below).
 // ================================================================================================
+// a 16-byte store that does not stay in the L2: the ring kernel's tokens and records are written once and read by the NEXT kernel, while the lines of
+// the stream every lane comes back to sixteen bytes later should stay (measured: FETCH_SIZE of the kernel at config 4, profiles/r4_20_*)
+typedef uint32_t gj_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gj_store16_stream(void* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+#ifdef GJ_NO_NT_STORES // (A/B build: make variant NAME=nont DEFS=-DGJ_NO_NT_STORES)
+    *reinterpret_cast<gj_u32x4*>(dst) = gj_u32x4{a, b, c, d};
+#else
+    __builtin_nontemporal_store(gj_u32x4{a, b, c, d}, reinterpret_cast<gj_u32x4*>(dst));
+#endif
+}
+
 #define GJ_WIN_DW 20     // dwords of a lane's ring
 #define GJ_WIN_STRIDE 21 // dwords between the rings of neighbouring lanes: the ring + the mirror of its slot 0 (odd: the lanes of a half wave hit different banks)
 #define GJ_WIN_OUT 17    // dwords of a lane's output stage: 16 tokens, 4 block records (+ 1: odd again)
@@ -500,8 +512,8 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
                 if ((ntok & 15u) == 0 && tok_ok) { // sixteen tokens: one 32-byte piece (16-byte aligned when the run starts on the segment's own boundary)
                     uint32_t* dst = reinterpret_cast<uint32_t*>(d_tok + tbase + ntok - 16u);
                     if ((tbase & 7u) == 0) {
-                        reinterpret_cast<uint4*>(dst)[0] = make_uint4(OT[0], OT[1], OT[2], OT[3]);
-                        reinterpret_cast<uint4*>(dst)[1] = make_uint4(OT[4], OT[5], OT[6], OT[7]);
+                        gj_store16_stream(dst, OT[0], OT[1], OT[2], OT[3]);
+                        gj_store16_stream(dst + 4, OT[4], OT[5], OT[6], OT[7]);
                     } else {
                         for (int q = 0; q < 4; q++) reinterpret_cast<uint2*>(dst)[q] = make_uint2(OT[2 * q], OT[2 * q + 1]);
                     }
@@ -532,9 +544,9 @@ __global__ __launch_bounds__(256, 3) void k_huffman_decode_win(const gj_geom g, 
                     nrec++;
                     if (slot == 3u || left == 0) { // the group of four records ends (or the segment does): whole if all four are this lane's
                         if (nrec == 4u) {
-                            uint4* dst = reinterpret_cast<uint4*>(d_rec + (rec & ~3u));
-                            dst[0] = make_uint4(OT[8], OT[9], OT[10], OT[11]);
-                            dst[1] = make_uint4(OT[12], OT[13], OT[14], OT[15]);
+                            uint32_t* dst = reinterpret_cast<uint32_t*>(d_rec + (rec & ~3u));
+                            gj_store16_stream(dst, OT[8], OT[9], OT[10], OT[11]);
+                            gj_store16_stream(dst + 4, OT[12], OT[13], OT[14], OT[15]);
                         } else {
                             for (uint32_t q = slot + 1u - nrec; q <= slot; q++) d_rec[(rec & ~3u) + q] = make_uint2(OT[8u + 2u * q], OT[9u + 2u * q]);
                         }

@@ -54,6 +54,18 @@ def test_two_ranks_shard_a_batch_through_the_batch_calls(gpu_lib):
     assert d["value"] > 0 and d["psnr_last_frame_db"] > 30
 
 
+@pytest.mark.parametrize("workload,frames", [("4k", 10), ("hd422", 20)])
+def test_batch_calls_at_full_size_bit_exact(gpu_lib, workload, frames):
+    """BASELINE config 5's frames (4K RGB) and HD packed 4:2:2 frames through the batch calls with everything resident in HBM, one process:
+    every stream and every decoded frame against the oracle (bench.py --verify), all of them coded by the batched launches"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(frames), "--workload", workload, "--batch-api", "batch",
+                        "--batch-streams", "1", "--steps", "1", "--warmup", "1", "--verify"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["verified_bit_exact"] is True and d["config"]["frames_total"] == frames
+    assert f"(({frames}, 0), ({frames}, 0))" in d["config"]["api"], d["config"]["api"]
+
+
 def test_two_ranks_headline_line(gpu_lib):
     """the weak-scaling headline path at N = 2: one JSON line, whole-job throughput over both ranks, per-rank frames of their own seed"""
     d = _torchrun(2, ["--gpus", "2", "--workload", "hd", "--steps", "3", "--warmup", "1", "--min-seconds", "0.1", "--lean", "--verify"])

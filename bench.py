@@ -567,6 +567,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
     # --batch-api batch: the frames of a pipeline go through gpujpeg_amd_encoder_encode_batch / gpujpeg_amd_decoder_decode_batch (every kernel
     # launched once per chunk of frames, the frame is a grid dimension) instead of one libgpujpeg call per frame
     batch_api = getattr(args, "batch_api", "frame") == "batch" and not host_io
+    direction = getattr(args, "mode", "both") if batch_api else "both"  # (one direction alone: the batch calls only)
     S = max(1, min(getattr(args, "batch_streams", 0) or args.streams, len(frames))) if batch_api else max(1, min(args.streams, len(frames)))
     p = lib.default_parameters()
     p.quality, p.restart_interval, p.verbose = quality, G.RESTART_AUTO, -1
@@ -602,9 +603,14 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
         if batch_api:
             n = len(ln["frames"])
             raw = ln["stack"][0].numel()
-            ptrs, sizes = ln["enc"].encode_batch_noclone(p, pi, ln["stack"].data_ptr(), n, stride=raw, gpu=True)
-            stride = ptrs[1] - ptrs[0] if n > 1 else (sizes[0] + 64 + 15) & ~15
-            ln["dec"].decode_batch(None, device_out=ln["out_stack"].data_ptr(), out_stride=raw, device_in=ptrs[0], in_stride=stride, sizes=sizes)
+            # --mode encode / decode: one direction per pass (decode: the streams of the warm-up's encode stay in the encoder's buffer)
+            if direction != "decode" or "streams" not in ln:
+                ptrs, sizes = ln["enc"].encode_batch_noclone(p, pi, ln["stack"].data_ptr(), n, stride=raw, gpu=True)
+                ln["streams"] = (ptrs, sizes)
+            ptrs, sizes = ln["streams"]
+            if direction != "encode":
+                stride = ptrs[1] - ptrs[0] if n > 1 else (sizes[0] + 64 + 15) & ~15
+                ln["dec"].decode_batch(None, device_out=ln["out_stack"].data_ptr(), out_stride=raw, device_in=ptrs[0], in_stride=stride, sizes=sizes)
             ln["bytes"] = sum(sizes)
             ln["batched"] = (ln["enc"].last_batch(), ln["dec"].last_batch())
             return
@@ -677,7 +683,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
         ln["dec"].close()
     fps = total * args.steps / elapsed
     result = {
-        "metric": f"frames/s encode+decode (batch of {args.batch} {args.workload} frames)", "value": round(fps, 2), "unit": "frames/s",
+        "metric": f"frames/s {'encode+decode' if direction == 'both' else direction + ' only'} (batch of {args.batch} {args.workload} frames)", "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL,
         "data": f"synthetic ({args.pattern}), {args.batch} distinct {width}x{height} frames (seed 12345 + i) "

@@ -71,6 +71,8 @@ struct gpujpeg_decoder {
     void* b_rec; size_t b_rec_cap;
     uint8_t* b_jpeg; size_t b_jpeg_cap;            /* streams handed over in host memory */
     uint8_t* b_raw; size_t b_raw_cap;              /* pixels wanted in host memory */
+    uint8_t* b_gather; size_t b_gather_cap;        /* streams given as separate buffers (decode_batch_ptrs), gathered 16-byte aligned */
+    uint8_t* b_scatter; size_t b_scatter_cap;      /* ... and the frames decoded back to back before they go to separate buffers */
     int b_last_batched, b_last_single;             /* frames of the last batch call that the batched launches decoded / that went the ordinary way */
     int b_chunk;                                   /* gpujpeg_amd_decoder_set_batch_chunk: frames per launch at most, 0 = the default */
 };
@@ -150,7 +152,7 @@ int gpujpeg_decoder_destroy(struct gpujpeg_decoder* d)
     gj_hip_host_free(d->h_hdr); gj_hip_host_free(d->h_summary); gj_hip_host_free(d->h_maxlen); gj_hip_free(d->d_summary); gj_hip_free(d->d_scan_scratch);
     free(d->segs.pos); free(d->segs.len); free(d->segs.index);
     gj_hip_free(d->b_dsum); gj_hip_free(d->b_sizes); gj_hip_free(d->b_seg); gj_hip_free(d->b_scratch); gj_hip_free(d->b_coefs); gj_hip_free(d->b_planes); gj_hip_free(d->b_tok);
-    gj_hip_free(d->b_rec); gj_hip_free(d->b_jpeg); gj_hip_free(d->b_raw);
+    gj_hip_free(d->b_rec); gj_hip_free(d->b_jpeg); gj_hip_free(d->b_raw); gj_hip_free(d->b_gather); gj_hip_free(d->b_scatter);
     gj_hip_host_free(d->bh_sum); gj_hip_host_free(d->bh_maxlen); gj_hip_host_free(d->bh_sizes);
     free(d);
     return 0;
@@ -917,6 +919,41 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
 out:
     free(frame_done);
     return rc;
+}
+
+/* The same for streams and destinations that are separate buffers (device or host memory). The streams are gathered 16 bytes aligned in a staging
+ * buffer (they are small), the frames are decoded back to back and copied to their destinations; `frame_bytes` = room in every destination. */
+int gpujpeg_amd_decoder_decode_batch_ptrs(struct gpujpeg_decoder* d, const uint8_t* const* streams, const size_t* sizes, int count, uint8_t* const* outputs,
+                                          size_t frame_bytes, struct gpujpeg_image_parameters* param_image)
+{
+    if (!d || !streams || !sizes || !outputs || count < 1) return -1;
+    size_t longest = 0;
+    for (int f = 0; f < count; f++) {
+        if (!streams[f] || !outputs[f]) return -1;
+        if (sizes[f] > longest) longest = sizes[f];
+    }
+    const size_t in_stride = (longest + 64 + 15) & ~(size_t)15;
+    struct gj_coder* c = &d->coder;
+    if (gj_ensure_device_buffer((void**)&d->b_gather, &d->b_gather_cap, in_stride * (size_t)count) != 0) return -1;
+    for (int f = 0; f < count; f++) {
+        const int rc = gj_hip_is_device_ptr(streams[f]) ? gj_hip_memcpy_d2d(d->b_gather + (size_t)f * in_stride, streams[f], sizes[f], c->stream)
+                                                        : gj_hip_memcpy_h2d(d->b_gather + (size_t)f * in_stride, streams[f], sizes[f], c->stream);
+        if (rc != 0) return -1;
+    }
+    if (gj_hip_stream_sync(c->stream) != 0) return -1; /* (host sources may change once the call has returned; the first frame may be parsed from the staged copy) */
+    if (frame_bytes == 0) return -1;
+    if (gj_ensure_device_buffer((void**)&d->b_scatter, &d->b_scatter_cap, frame_bytes * (size_t)count) != 0) return -1;
+    struct gpujpeg_image_parameters pi;
+    if (gpujpeg_amd_decoder_decode_batch(d, d->b_gather, in_stride, sizes, count, d->b_scatter, frame_bytes, &pi) != 0) return -1;
+    const size_t raw = c->geom.raw_size;
+    for (int f = 0; f < count; f++) {
+        const int rc = gj_hip_is_device_ptr(outputs[f]) ? gj_hip_memcpy_d2d(outputs[f], d->b_scatter + (size_t)f * frame_bytes, raw, c->stream)
+                                                        : gj_hip_memcpy_d2h(outputs[f], d->b_scatter + (size_t)f * frame_bytes, raw, c->stream);
+        if (rc != 0) return -1;
+    }
+    if (gj_hip_stream_sync(c->stream) != 0) return -1;
+    if (param_image) *param_image = pi;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ image info (src/gpujpeg_reader.c:1739-1872) */

@@ -57,6 +57,7 @@ struct gpujpeg_encoder {
     uint8_t* b_raw; size_t b_raw_cap;          /* frames handed over in host memory */
     uint8_t* b_hdr_sent; size_t b_hdr_len; const uint8_t* b_hdr_to; size_t b_hdr_slot; int b_hdr_frames; /* the header bytes at the start of b_jpeg's slots */
     uint8_t* b_out; size_t b_out_cap; bool b_out_pinned; /* streams handed back in host memory */
+    uint8_t* b_gather; size_t b_gather_cap;              /* frames given as separate buffers (encode_batch_ptrs), gathered back to back */
     int b_last_batched, b_last_single; /* frames of the last batch call coded by batched launches / frame by frame */
     int b_chunk;                       /* gpujpeg_amd_encoder_set_batch_chunk: frames per launch at most, 0 = the default */
 };
@@ -112,6 +113,7 @@ int gpujpeg_encoder_destroy(struct gpujpeg_encoder* e)
     gj_hip_free(e->d_temp); gj_hip_free(e->d_tail); gj_hip_free(e->d_scan_partial); gj_hip_free(e->d_seg); gj_hip_free(e->d_jpeg); gj_hip_free(e->d_scan_hdr);
     gj_hip_free(e->coder.d_raw_own); gj_hip_free(e->coder.d_planes); gj_hip_free(e->coder.d_coefs);
     gj_hip_host_free(e->h_result); gj_hip_host_free(e->h_header); free(e->hdr_sent);
+    gj_hip_free(e->b_gather);
     gj_hip_free(e->b_temp); gj_hip_free(e->b_seg); gj_hip_free(e->b_tail); gj_hip_free(e->b_jpeg); gj_hip_free(e->b_result); gj_hip_free(e->b_raw);
     gj_hip_host_free(e->bh_result); free(e->b_hdr_sent);
     if (e->b_out_pinned) gj_hip_host_free(e->b_out); else free(e->b_out);
@@ -580,6 +582,36 @@ int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpu
     }
     c->frames += count;
     return 0;
+}
+
+/* The same for frames that are separate buffers (device or host memory, mixed if need be). Buffers that happen to lie a constant distance apart
+ * are coded where they are; otherwise they are gathered back to back in a staging buffer first (one device copy per frame in front of the kernels:
+ * ~4 us each, i.e. a third of the time an HD frame takes in a batch and a tenth of a 4K frame's). */
+int gpujpeg_amd_encoder_encode_batch_ptrs(struct gpujpeg_encoder* e, const struct gpujpeg_parameters* param, const struct gpujpeg_image_parameters* pi,
+                                          const uint8_t* const* frames, int count, uint8_t** images_compressed, size_t* images_compressed_size)
+{
+    if (!e || !param || !pi || !frames || count < 1) return -1;
+    for (int f = 0; f < count; f++)
+        if (!frames[f]) return -1;
+    const size_t raw = gpujpeg_image_calculate_size((struct gpujpeg_image_parameters*)(uintptr_t)pi);
+    if (raw == 0) return -1;
+    /* a constant stride between buffers of one kind: nothing to gather */
+    bool strided = true;
+    const int dev0 = gj_hip_is_device_ptr(frames[0]);
+    const ptrdiff_t step = count > 1 ? frames[1] - frames[0] : (ptrdiff_t)raw;
+    for (int f = 1; f < count && strided; f++)
+        strided = frames[f] - frames[f - 1] == step && gj_hip_is_device_ptr(frames[f]) == dev0;
+    if (strided && step >= (ptrdiff_t)raw)
+        return gpujpeg_amd_encoder_encode_batch(e, param, pi, frames[0], (size_t)step, count, images_compressed, images_compressed_size);
+    if (gj_ensure_device_buffer((void**)&e->b_gather, &e->b_gather_cap, raw * (size_t)count) != 0) return -1;
+    for (int f = 0; f < count; f++) {
+        const int rc = gj_hip_is_device_ptr(frames[f]) ? gj_hip_memcpy_d2d(e->b_gather + (size_t)f * raw, frames[f], raw, e->coder.stream)
+                                                       : gj_hip_memcpy_h2d(e->b_gather + (size_t)f * raw, frames[f], raw, e->coder.stream);
+        if (rc != 0) return -1;
+    }
+    /* (the copies and the kernels are on the coder's stream: ordered. Host sources must stay untouched until the call returns, which it does after
+     * a synchronisation) */
+    return gpujpeg_amd_encoder_encode_batch(e, param, pi, e->b_gather, raw, count, images_compressed, images_compressed_size);
 }
 
 /* ------------------------------------------------------------------ memory planning (src/gpujpeg_encoder.c:165-288) */

@@ -147,6 +147,11 @@ class Library:
         for n in ("gpujpeg_amd_encoder_last_batch", "gpujpeg_amd_decoder_last_batch"):
             if hasattr(L, n):
                 getattr(L, n).argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if hasattr(L, "gpujpeg_amd_encoder_encode_batch_ptrs"):
+            L.gpujpeg_amd_encoder_encode_batch_ptrs.argtypes = [vp, C.POINTER(Parameters), C.POINTER(ImageParameters), C.POINTER(vp), C.c_int,
+                                                                C.POINTER(vp), C.POINTER(C.c_size_t)]
+            L.gpujpeg_amd_decoder_decode_batch_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.POINTER(vp), C.c_size_t,
+                                                                C.POINTER(ImageParameters)]
         if hasattr(L, "gpujpeg_amd_decoder_decode_batch"):
             L.gpujpeg_amd_decoder_decode_batch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t, C.POINTER(ImageParameters)]
 
@@ -222,6 +227,19 @@ class Encoder:
         a, b = C.c_int(0), C.c_int(0)
         self.lib.L.gpujpeg_amd_encoder_last_batch(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def encode_batch_ptrs(self, param, param_image, frames):
+        """gpujpeg_amd_encoder_encode_batch_ptrs: frames = list of numpy uint8 arrays (host) and / or integer device pointers, one buffer per frame.
+        Returns the streams as numpy copies (encoder output in host memory, the default)."""
+        n = len(frames)
+        keep = [np.ascontiguousarray(f, np.uint8) if not isinstance(f, int) else f for f in frames]
+        self._keep = keep
+        fp = (C.c_void_p * n)(*[f if isinstance(f, int) else f.ctypes.data for f in keep])
+        ptrs, sizes = (C.c_void_p * n)(), (C.c_size_t * n)()
+        rc = self.lib.L.gpujpeg_amd_encoder_encode_batch_ptrs(self.h, C.byref(param), C.byref(param_image), fp, n, ptrs, sizes)
+        if rc != 0:
+            raise RuntimeError(f"gpujpeg_amd_encoder_encode_batch_ptrs failed ({rc})")
+        return [np.frombuffer((C.c_uint8 * int(s)).from_address(int(p)), np.uint8).copy() for p, s in zip(ptrs, sizes)]
 
     def encode_batch(self, param, param_image, frames, count, stride=None):
         """host frames in, list of numpy uint8 copies of the streams out (encoder output in host memory, the default)"""
@@ -304,6 +322,21 @@ class Decoder:
         a, b = C.c_int(0), C.c_int(0)
         self.lib.L.gpujpeg_amd_decoder_last_batch(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def decode_batch_ptrs(self, streams, frame_bytes):
+        """gpujpeg_amd_decoder_decode_batch_ptrs: one buffer per stream and per decoded frame (host memory here). Returns (list of pixel arrays, ImageParameters)."""
+        n = len(streams)
+        keep = [np.ascontiguousarray(s, np.uint8) for s in streams]
+        outs = [np.empty(frame_bytes, np.uint8) for _ in range(n)]
+        sp = (C.c_void_p * n)(*[s.ctypes.data for s in keep])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        csz = (C.c_size_t * n)(*[s.size for s in keep])
+        pi = ImageParameters()
+        rc = self.lib.L.gpujpeg_amd_decoder_decode_batch_ptrs(self.h, sp, csz, n, op, frame_bytes, C.byref(pi))
+        if rc != 0:
+            raise RuntimeError(f"gpujpeg_amd_decoder_decode_batch_ptrs failed ({rc})")
+        raw = self.lib.image_size(pi)
+        return [o[:raw] for o in outs], pi
 
     def decode_batch(self, streams, device_out=None, out_stride=None, device_in=None, in_stride=None, sizes=None):
         """gpujpeg_amd_decoder_decode_batch: streams with one header behind one set of launches. streams: list of numpy uint8 arrays (host;

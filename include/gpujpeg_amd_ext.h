@@ -89,6 +89,14 @@ GPUJPEG_API int gpujpeg_amd_decoder_get_kernel_times(struct gpujpeg_decoder* dec
 GPUJPEG_API int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* encoder, const struct gpujpeg_parameters* param,
                                                  const struct gpujpeg_image_parameters* param_image, const uint8_t* frames, size_t frame_stride,
                                                  int count, uint8_t** images_compressed, size_t* images_compressed_size);
+/* The same for frames / streams / destinations that are separate buffers (device or host memory, mixed if need be): buffers that lie a constant
+ * distance apart are coded where they are, others are gathered into (scattered from) a staging buffer with one copy per frame on the coder's
+ * stream. frame_bytes: room in every destination (>= the decoded frame). */
+GPUJPEG_API int gpujpeg_amd_encoder_encode_batch_ptrs(struct gpujpeg_encoder* encoder, const struct gpujpeg_parameters* param,
+                                                      const struct gpujpeg_image_parameters* param_image, const uint8_t* const* frames, int count,
+                                                      uint8_t** images_compressed, size_t* images_compressed_size);
+GPUJPEG_API int gpujpeg_amd_decoder_decode_batch_ptrs(struct gpujpeg_decoder* decoder, const uint8_t* const* streams, const size_t* sizes, int count,
+                                                      uint8_t* const* outputs, size_t frame_bytes, struct gpujpeg_image_parameters* param_image);
 /* frames per set of launches at most (0 = the default: up to 256, fewer for large frames whose work buffers would exceed 6 / 8 GB); tests use it to cut
  * small batches into several chunks */
 GPUJPEG_API void gpujpeg_amd_encoder_set_batch_chunk(struct gpujpeg_encoder* encoder, int frames);

@@ -180,3 +180,7 @@ def test_emu_frame_batch_argument_errors(O, G, emu_lib):
 
 def test_emu_frame_batch_device_resident(O, G, emu_lib):
     T.test_frame_batch_device_resident(O, G, emu_lib)
+
+
+def test_emu_frame_batch_separate_buffers(O, G, emu_lib):
+    T.test_frame_batch_separate_buffers(O, G, emu_lib)

@@ -907,3 +907,27 @@ def test_frame_batch_device_resident(O, G, gpu_lib):
     dec.close()
     for q in (d_frames, d_out, d_odd):
         L.gj_hip_free(q)
+
+
+def test_frame_batch_separate_buffers(O, G, gpu_lib):
+    """the batch calls for frames, streams and destinations that are separate buffers (gpujpeg_amd_*_batch_ptrs): gathered into / scattered from a
+    staging buffer, or coded in place when the buffers happen to lie a constant distance apart; results as always the oracle's"""
+    w, h, n = 640, 480, 5
+    case = ("p", w, h, 1, 1, 75, -1, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    raw = w * h * 3
+    frames = [natural_image(w, h, 3, seed=90 + f) for f in range(n)]
+    want = [O.encode(oracle_image(O, case), f) for f in frames]
+    want_px = [O.decode(s)[0] for s in want]
+    enc, dec = G.Encoder(gpu_lib), G.Decoder(gpu_lib)
+    got = enc.encode_batch_ptrs(p, pi, frames)  # five separate numpy buffers
+    assert enc.last_batch() == (n, 0) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    block = np.concatenate(frames)  # ... and five views a frame apart: coded where they lie
+    got = enc.encode_batch_ptrs(p, pi, [block[f * raw:(f + 1) * raw] for f in range(n)])
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    for rnd in range(2):
+        px, info = dec.decode_batch_ptrs(got, raw + 256)
+        assert (info.width, info.height) == (w, h) and all(np.array_equal(a, b) for a, b in zip(px, want_px))
+    assert dec.last_batch()[0] >= n - 1
+    enc.close()
+    dec.close()

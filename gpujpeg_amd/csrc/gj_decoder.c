@@ -932,19 +932,40 @@ int gpujpeg_amd_decoder_decode_batch_ptrs(struct gpujpeg_decoder* d, const uint8
         if (!streams[f] || !outputs[f]) return -1;
         if (sizes[f] > longest) longest = sizes[f];
     }
-    const size_t in_stride = (longest + 64 + 15) & ~(size_t)15;
     struct gj_coder* c = &d->coder;
-    if (gj_ensure_device_buffer((void**)&d->b_gather, &d->b_gather_cap, in_stride * (size_t)count) != 0) return -1;
-    for (int f = 0; f < count; f++) {
-        const int rc = gj_hip_is_device_ptr(streams[f]) ? gj_hip_memcpy_d2d(d->b_gather + (size_t)f * in_stride, streams[f], sizes[f], c->stream)
-                                                        : gj_hip_memcpy_h2d(d->b_gather + (size_t)f * in_stride, streams[f], sizes[f], c->stream);
-        if (rc != 0) return -1;
-    }
-    if (gj_hip_stream_sync(c->stream) != 0) return -1; /* (host sources may change once the call has returned; the first frame may be parsed from the staged copy) */
     if (frame_bytes == 0) return -1;
-    if (gj_ensure_device_buffer((void**)&d->b_scatter, &d->b_scatter_cap, frame_bytes * (size_t)count) != 0) return -1;
+    /* buffers of one kind a constant distance apart (streams: a multiple of 16 bytes in device memory): used where they are */
+    bool in_strided = true, out_strided = true;
+    const ptrdiff_t in_step = count > 1 ? streams[1] - streams[0] : (ptrdiff_t)((longest + 64 + 15) & ~(size_t)15);
+    const ptrdiff_t out_step = count > 1 ? outputs[1] - outputs[0] : (ptrdiff_t)frame_bytes;
+    const int in_dev = gj_hip_is_device_ptr(streams[0]), out_dev = gj_hip_is_device_ptr(outputs[0]);
+    for (int f = 1; f < count; f++) {
+        in_strided = in_strided && streams[f] - streams[f - 1] == in_step && gj_hip_is_device_ptr(streams[f]) == in_dev;
+        out_strided = out_strided && outputs[f] - outputs[f - 1] == out_step && gj_hip_is_device_ptr(outputs[f]) == out_dev;
+    }
+    in_strided = in_strided && in_step > 0 && (size_t)in_step >= longest && (!in_dev || (in_step & 15) == 0);
+    out_strided = out_strided && out_step >= (ptrdiff_t)frame_bytes;
+    const uint8_t* src = streams[0];
+    size_t in_stride = (size_t)in_step;
+    if (!in_strided) {
+        in_stride = (longest + 64 + 15) & ~(size_t)15;
+        if (gj_ensure_device_buffer((void**)&d->b_gather, &d->b_gather_cap, in_stride * (size_t)count) != 0) return -1;
+        for (int f = 0; f < count; f++) {
+            const int rc = gj_hip_is_device_ptr(streams[f]) ? gj_hip_memcpy_d2d(d->b_gather + (size_t)f * in_stride, streams[f], sizes[f], c->stream)
+                                                            : gj_hip_memcpy_h2d(d->b_gather + (size_t)f * in_stride, streams[f], sizes[f], c->stream);
+            if (rc != 0) return -1;
+        }
+        if (gj_hip_stream_sync(c->stream) != 0) return -1; /* (the first frame may be parsed on the host from the staged copy) */
+        src = d->b_gather;
+    }
     struct gpujpeg_image_parameters pi;
-    if (gpujpeg_amd_decoder_decode_batch(d, d->b_gather, in_stride, sizes, count, d->b_scatter, frame_bytes, &pi) != 0) return -1;
+    if (out_strided) { /* (device or host memory: decode_batch takes both) */
+        if (gpujpeg_amd_decoder_decode_batch(d, src, in_stride, sizes, count, outputs[0], (size_t)out_step, &pi) != 0) return -1;
+        if (param_image) *param_image = pi;
+        return 0;
+    }
+    if (gj_ensure_device_buffer((void**)&d->b_scatter, &d->b_scatter_cap, frame_bytes * (size_t)count) != 0) return -1;
+    if (gpujpeg_amd_decoder_decode_batch(d, src, in_stride, sizes, count, d->b_scatter, frame_bytes, &pi) != 0) return -1;
     const size_t raw = c->geom.raw_size;
     for (int f = 0; f < count; f++) {
         const int rc = gj_hip_is_device_ptr(outputs[f]) ? gj_hip_memcpy_d2d(outputs[f], d->b_scatter + (size_t)f * frame_bytes, raw, c->stream)

@@ -929,5 +929,16 @@ def test_frame_batch_separate_buffers(O, G, gpu_lib):
         px, info = dec.decode_batch_ptrs(got, raw + 256)
         assert (info.width, info.height) == (w, h) and all(np.array_equal(a, b) for a, b in zip(px, want_px))
     assert dec.last_batch()[0] >= n - 1
+    # streams and destinations a constant distance apart (one block each): used where they are
+    stride = (max(s.size for s in got) + 79) & ~15
+    sblock, oblock = np.zeros(stride * n, np.uint8), np.zeros((raw + 64) * n, np.uint8)
+    for f, s_ in enumerate(got):
+        sblock[f * stride:f * stride + s_.size] = s_
+    L = gpu_lib.L
+    sp = (C.c_void_p * n)(*[sblock.ctypes.data + f * stride for f in range(n)])
+    op = (C.c_void_p * n)(*[oblock.ctypes.data + f * (raw + 64) for f in range(n)])
+    csz = (C.c_size_t * n)(*[s_.size for s_ in got])
+    assert L.gpujpeg_amd_decoder_decode_batch_ptrs(dec.h, sp, csz, n, op, raw, None) == 0
+    assert all(np.array_equal(oblock[f * (raw + 64):f * (raw + 64) + raw], want_px[f]) for f in range(n))
     enc.close()
     dec.close()

@@ -712,7 +712,9 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
     /* the header cache is what a batch launches on: the first frame goes the ordinary way when there is none (or when it has to) */
     const uint8_t* s0 = streams;
     size_t frame_raw = 0; /* what every frame decodes to */
-    if (!out_on_device || !d->hdr_cache_valid) {
+    bool force_first = false; /* the cached header turned out to be another sequence's: frame 0 the ordinary way (which replaces the cache), then the batch */
+again:
+    if (first == 0 && (!out_on_device || !d->hdr_cache_valid || force_first)) {
         /* (the output size is known once a frame has been parsed: decode frame 0 into the decoder's own buffer first) */
         struct gpujpeg_decoder_output o;
         gpujpeg_decoder_output_set_cuda_buffer(&o);
@@ -746,9 +748,18 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
         struct gj_reader_result r = d->hdr_cache_r;
         if (decoder_configure(d, &r.param, &r.param_image) != 0) goto out; /* (the geometry of the cached header, whatever the coder was last set up for) */
         if (output_stride < g->raw_size || (frame_raw != 0 && frame_raw != g->raw_size)) {
-            GJ_ERROR("Output stride %zu is smaller than a decoded frame (%zu B)!\n", output_stride, (size_t)g->raw_size);
-            goto out;
+            /* the cached header is an OLDER sequence's (a larger image than the caller's slots, ADVICE r4: this used to fail the call): these
+             * streams are strangers to it. Frame 0 goes the ordinary way, which replaces the cache, and the batch is planned again */
+            if (first == 0 && !force_first) {
+                force_first = true;
+                frame_raw = 0;
+                goto again;
+            }
+            batched = false;
         }
+    }
+    if (batched && first < count) {
+        struct gj_reader_result r = d->hdr_cache_r;
         frame_raw = g->raw_size;
         for (int i = 0; i < c->geom.comp_count; i++) {
             c->geom.comp[i].q_table = r.quant_map[i];
@@ -896,6 +907,16 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
             }
         }
     }
+    if (batched && first == 0 && !force_first) {
+        /* not one frame passed: the cached header (an older sequence's, of dimensions the slots happen to hold) is not these streams' */
+        int accepted = 0;
+        for (int f = 0; f < count; f++) accepted += frame_done[f];
+        if (accepted == 0) {
+            force_first = true;
+            frame_raw = 0;
+            goto again;
+        }
+    }
     /* whatever is left: the ordinary call, frame by frame */
     d->b_last_batched = 0;
     for (int f = first; f < count; f++) d->b_last_batched += frame_done[f] ? 1 : 0;
@@ -914,8 +935,7 @@ int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* d, const uint8_t* s
         *param_image = c->param_image;
         if (param_image->color_space == GPUJPEG_NONE) param_image->color_space = c->param.color_space_internal;
     }
-    c->frames += count;
-    rc = 0;
+    rc = 0; /* (c->frames counts the frames TIMED with perf_stats, src/gpujpeg_common.c:2238-2254: a batch adds none) */
 out:
     free(frame_done);
     return rc;
@@ -936,13 +956,16 @@ int gpujpeg_amd_decoder_decode_batch_ptrs(struct gpujpeg_decoder* d, const uint8
     if (frame_bytes == 0) return -1;
     /* buffers of one kind a constant distance apart (streams: a multiple of 16 bytes in device memory): used where they are */
     bool in_strided = true, out_strided = true;
-    const ptrdiff_t in_step = count > 1 ? streams[1] - streams[0] : (ptrdiff_t)((longest + 64 + 15) & ~(size_t)15);
-    const ptrdiff_t out_step = count > 1 ? outputs[1] - outputs[0] : (ptrdiff_t)frame_bytes;
+    /* (addresses compared as integers: the buffers may be unrelated allocations, whose pointers C does not let us subtract) */
+#define GJ_ADDR_STEP(a, b) ((ptrdiff_t)((uintptr_t)(a) - (uintptr_t)(b)))
+    const ptrdiff_t in_step = count > 1 ? GJ_ADDR_STEP(streams[1], streams[0]) : (ptrdiff_t)((longest + 64 + 15) & ~(size_t)15);
+    const ptrdiff_t out_step = count > 1 ? GJ_ADDR_STEP(outputs[1], outputs[0]) : (ptrdiff_t)frame_bytes;
     const int in_dev = gj_hip_is_device_ptr(streams[0]), out_dev = gj_hip_is_device_ptr(outputs[0]);
     for (int f = 1; f < count; f++) {
-        in_strided = in_strided && streams[f] - streams[f - 1] == in_step && gj_hip_is_device_ptr(streams[f]) == in_dev;
-        out_strided = out_strided && outputs[f] - outputs[f - 1] == out_step && gj_hip_is_device_ptr(outputs[f]) == out_dev;
+        in_strided = in_strided && GJ_ADDR_STEP(streams[f], streams[f - 1]) == in_step && gj_hip_is_device_ptr(streams[f]) == in_dev;
+        out_strided = out_strided && GJ_ADDR_STEP(outputs[f], outputs[f - 1]) == out_step && gj_hip_is_device_ptr(outputs[f]) == out_dev;
     }
+#undef GJ_ADDR_STEP
     in_strided = in_strided && in_step > 0 && (size_t)in_step >= longest && (!in_dev || (in_step & 15) == 0);
     out_strided = out_strided && out_step >= (ptrdiff_t)frame_bytes;
     const uint8_t* src = streams[0];

@@ -1871,6 +1871,8 @@ extern "C" int gj_hip_encode_batchable(const gj_enc_job* job)
     return job->use_fused && !job->keep_coefs && !job->channel_remap && !job->flipped && !job->segment_info && gj_tile_kernel(job) != 0;
 }
 
+extern "C" int gj_hip_encode_tiles(const gj_enc_job* job) { return gj_tile_kernel(job) != 0; }
+
 extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event_t ev[GJ_ENC_EVENTS])
 {
     hipStream_t st = (hipStream_t)stream;

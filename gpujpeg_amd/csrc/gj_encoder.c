@@ -315,7 +315,6 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.d_scan_partial = e->d_scan_partial;
     job.d_tail = e->d_tail;
     job.tail_set = e->tail_set;
-    e->tail_set ^= 1;
     if (++e->epoch == 0) e->epoch = 1;
     job.epoch = e->epoch;
     job.tune = e->tune;
@@ -326,6 +325,10 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     job.segment_info = p.segment_info;
     job.use_fused = e->use_fused && !e->flipped;
     job.keep_coefs = e->keep_coefs;
+    /* the sets of group totals alternate only between calls that end in k_gather, which clears the idle one: a call that takes the
+     * coefficient planes (flip, kept coefficients, fused path off) leaves both as they are (it used to flip, and the next
+     * tile-path call added its sizes to an older frame's totals) */
+    if (gj_hip_encode_tiles(&job)) e->tail_set ^= 1;
     GJ_HT(c, 0);
     if (gj_hip_encode(&job, c->stream, stats ? c->timers.ev : NULL) != 0) {
         GJ_ERROR("Encoder kernels failed: %s\n", gj_hip_last_error());
@@ -580,8 +583,7 @@ int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpu
         }
         if (gj_hip_stream_sync(c->stream) != 0) return -1;
     }
-    c->frames += count;
-    return 0;
+    return 0; /* (c->frames counts the frames timed with perf_stats: a batch adds none, see gj_coder_process_stats_overall) */
 }
 
 /* The same for frames that are separate buffers (device or host memory, mixed if need be). Buffers that happen to lie a constant distance apart
@@ -598,9 +600,10 @@ int gpujpeg_amd_encoder_encode_batch_ptrs(struct gpujpeg_encoder* e, const struc
     /* a constant stride between buffers of one kind: nothing to gather */
     bool strided = true;
     const int dev0 = gj_hip_is_device_ptr(frames[0]);
-    const ptrdiff_t step = count > 1 ? frames[1] - frames[0] : (ptrdiff_t)raw;
+    /* (addresses compared as integers: the buffers may be unrelated allocations, whose pointers C does not let us subtract) */
+    const ptrdiff_t step = count > 1 ? (ptrdiff_t)((uintptr_t)frames[1] - (uintptr_t)frames[0]) : (ptrdiff_t)raw;
     for (int f = 1; f < count && strided; f++)
-        strided = frames[f] - frames[f - 1] == step && gj_hip_is_device_ptr(frames[f]) == dev0;
+        strided = (ptrdiff_t)((uintptr_t)frames[f] - (uintptr_t)frames[f - 1]) == step && gj_hip_is_device_ptr(frames[f]) == dev0;
     if (strided && step >= (ptrdiff_t)raw)
         return gpujpeg_amd_encoder_encode_batch(e, param, pi, frames[0], (size_t)step, count, images_compressed, images_compressed_size);
     if (gj_ensure_device_buffer((void**)&e->b_gather, &e->b_gather_cap, raw * (size_t)count) != 0) return -1;

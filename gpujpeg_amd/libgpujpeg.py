@@ -338,7 +338,7 @@ class Decoder:
         raw = self.lib.image_size(pi)
         return [o[:raw] for o in outs], pi
 
-    def decode_batch(self, streams, device_out=None, out_stride=None, device_in=None, in_stride=None, sizes=None):
+    def decode_batch(self, streams, device_out=None, out_stride=None, device_in=None, in_stride=None, sizes=None, frame_bytes=None):
         """gpujpeg_amd_decoder_decode_batch: streams with one header behind one set of launches. streams: list of numpy uint8 arrays (host;
         packed into one buffer here), or device_in = integer device pointer of stream 0 with in_stride and sizes. Pixels go to device_out
         (integer device pointer, frames out_stride apart) or come back as a list of numpy arrays. Returns (pixels or None, ImageParameters)."""
@@ -360,12 +360,19 @@ class Decoder:
             if rc != 0:
                 raise RuntimeError(f"gpujpeg_amd_decoder_decode_batch failed ({rc})")
             return None, pi
-        # host output: the frame size is not known before the first stream has been parsed -- ask the library
-        pi0, p0 = ImageParameters(), Parameters()
-        first = np.ascontiguousarray(streams[0] if device_in is None else np.zeros(0, np.uint8))
-        if self.lib.L.gpujpeg_decoder_get_image_info(first.ctypes.data_as(C.c_void_p), first.size, C.byref(pi0), C.byref(p0), None) != 0:
-            raise RuntimeError("gpujpeg_decoder_get_image_info failed")
-        bound = max(int(pi0.width) * int(pi0.height) * 4 + 4096, 1)  # (the library checks the real frame size against the stride)
+        # host output: the frame size is not known before the first stream has been parsed -- ask the library (streams in host memory),
+        # or take the caller's word (device streams: frame_bytes = room per decoded frame)
+        if device_in is not None:
+            if not frame_bytes:
+                raise ValueError("decode_batch(device_in=..., device_out=None) needs frame_bytes: the size of a decoded frame is not known "
+                                 "before a stream has been parsed, and the streams are in device memory")
+            bound = int(frame_bytes)
+        else:
+            pi0, p0 = ImageParameters(), Parameters()
+            first = np.ascontiguousarray(streams[0])
+            if self.lib.L.gpujpeg_decoder_get_image_info(first.ctypes.data_as(C.c_void_p), first.size, C.byref(pi0), C.byref(p0), None) != 0:
+                raise RuntimeError("gpujpeg_decoder_get_image_info failed")
+            bound = max(int(pi0.width) * int(pi0.height) * 4 + 4096, 1)  # (the library checks the real frame size against the stride)
         out = np.empty(bound * n, np.uint8)
         rc = self.lib.L.gpujpeg_amd_decoder_decode_batch(self.h, base, in_stride, csz, n, out.ctypes.data, bound, C.byref(pi))
         if rc != 0:

@@ -197,6 +197,8 @@ typedef struct gj_enc_job {
 } gj_enc_job;
 /* 1 when gj_hip_encode takes a batch (gj_enc_job::batch.count > 1) of this job's configuration */
 GJ_HIP_API int gj_hip_encode_batchable(const gj_enc_job* job);
+/* 1 when gj_hip_encode codes this job through tile streams + k_gather (the launch that uses and clears gj_enc_job::tail_set's group totals) */
+GJ_HIP_API int gj_hip_encode_tiles(const gj_enc_job* job);
 
 /* events (may be NULL): 0 start, 1 after preprocess, 2 after DCT/quant, 3 after k_huffman, 4 after k_scan_segments,
  * 5 after k_assemble (+ segment info) */

@@ -108,6 +108,7 @@ def test_emu_reuse_padding_and_reconfiguration(O, G, emu_lib):
     T.test_width_padding(O, G, emu_lib)
     T.test_decoder_reuse_without_clearing(O, G, emu_lib)
     T.test_zero_image_round_trip(O, G, emu_lib)
+    T.test_encoder_path_changes_between_frames(O, G, emu_lib)
 
 
 @pytest.mark.parametrize("seed", range(0, 160, 4))

@@ -289,6 +289,31 @@ def test_width_padding(O, G, gpu_lib):
         assert np.array_equal(enc.encode(p, pi, buf), O.encode(img, raw))
 
 
+def test_encoder_path_changes_between_frames(O, G, gpu_lib):
+    """One encoder, alternating between the tile path (k_encode_* + k_gather) and the coefficient-plane paths (fused path off,
+    flipped input, kept coefficients) from frame to frame: k_gather's two sets of group totals alternate only between tile-path
+    calls (a plane-path call used to flip the set and the next tile-path call wrote a stream of the wrong size)."""
+    w, h = 160, 96
+    raw = (O.gradient(w, h, 3).astype(np.int32) + O.noise(w * h * 3, seed=11) % 24).clip(0, 255).astype(np.uint8).reshape(-1)
+    case = ("paths", w, h, 1, 1, 75, 5, 0, None, 3)
+    p, pi = api_params(gpu_lib, G, case)
+    want = O.encode(O.make_image(w, h, restart_interval=5), raw)
+    flipped_want = None
+    enc = G.Encoder(gpu_lib)
+    seq = ["tile", "flip", "tile", "tile", "generic", "tile", "keep", "flip", "tile", "tile"]
+    for step, kind in enumerate(seq):
+        enc.set_fused(kind != "generic")
+        enc.keep_coefficients(kind == "keep")
+        assert enc.set_option("enc_opt_flipped", "1" if kind == "flip" else "0") == 0
+        got = enc.encode(p, pi, raw)
+        if kind == "flip":
+            if flipped_want is None:
+                flipped_want = got.copy()
+            assert np.array_equal(got, flipped_want), f"step {step} ({kind})"
+        else:
+            assert np.array_equal(got, want), f"step {step} ({kind}): {got.size} B against {want.size} B"
+
+
 # ---- entropy decoder variants: sub-sequence parallel kernel (default), lane-per-segment kernel, and the hand-over of
 # ---- segments that do not fit the LDS stage
 ENTROPY_CASES = [
@@ -903,6 +928,27 @@ def test_frame_batch_device_resident(O, G, gpu_lib):
     assert dec.last_batch() == (0, n)
     assert L.gj_hip_memcpy_d2h(px.ctypes.data, d_out, raw * n, None) == 0 and L.gj_hip_stream_sync(None) == 0
     assert all(np.array_equal(px[f * raw:(f + 1) * raw], want_px[f]) for f in range(n))
+    # device streams, host pixels (the binding used to raise) -- the caller says how much room a frame needs
+    got_px, _ = dec.decode_batch(None, device_in=ptrs[0], in_stride=stride, sizes=sizes, frame_bytes=raw)
+    assert all(np.array_equal(got_px[f], want_px[f]) for f in range(n))
+    with pytest.raises(ValueError):
+        dec.decode_batch(None, device_in=ptrs[0], in_stride=stride, sizes=sizes)
+    # the SAME decoder on another sequence: a smaller image, whose slots are smaller than the cached header's frame -- the call used
+    # to fail with "Output stride ... smaller than a decoded frame" --, then one of the old dimensions with another quality (the cached
+    # header fits the slots but is not these streams'): frame 0 goes the ordinary way and replaces the cache, the others are batched
+    for (w2, h2, q2) in ((320, 240, 75), (640, 480, 50), (640, 480, 75)):
+        case2 = ("d2", w2, h2, 1, 1, q2, -1, 0, None, 3)
+        p2, pi2 = api_params(gpu_lib, G, case2)
+        raw2 = w2 * h2 * 3
+        frames2 = np.stack([natural_image(w2, h2, 3, seed=90 + f) for f in range(n)])
+        want2 = [O.encode(oracle_image(O, case2), frames2[f]) for f in range(n)]
+        assert L.gj_hip_memcpy_h2d(d_frames, frames2.ctypes.data, raw2 * n, None) == 0 and L.gj_hip_stream_sync(None) == 0
+        ptrs2, sizes2 = enc.encode_batch_noclone(p2, pi2, d_frames, n, stride=raw2, gpu=True)
+        assert sizes2 == [s.size for s in want2]
+        dec.decode_batch(None, device_out=d_out, out_stride=raw2, device_in=ptrs2[0], in_stride=ptrs2[1] - ptrs2[0], sizes=sizes2)
+        assert dec.last_batch() == (n - 1, 1)
+        assert L.gj_hip_memcpy_d2h(px.ctypes.data, d_out, raw2 * n, None) == 0 and L.gj_hip_stream_sync(None) == 0
+        assert all(np.array_equal(px[f * raw2:(f + 1) * raw2], O.decode(want2[f])[0]) for f in range(n))
     enc.close()
     dec.close()
     for q in (d_frames, d_out, d_odd):

@@ -33,7 +33,6 @@
 #define GJ_PAR_CAP_U 8192
 #define GJ_PAR_MAX_BLOCKS 1280
 #define GJ_PAR_GMAX 64        // segments per batch
-#define GJ_PAR_RESIDENT 1024  // workgroups of the token-mode kernel the GPU holds at once (256 CUs x 4)
 #ifndef GJ_PAR_SUB
 #define GJ_PAR_SUB 16         // bytes per sub-sequence
 #endif

@@ -52,7 +52,7 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, unsigned cap_u, unsigned max_
 // k_huffman_decode_tok (shared with the launcher's choice of the kernel)
 #define GJ_TOK_CAP_U 10752     // bytes of unstuffed stream per group, incl. 8 B of zero padding per segment
 #define GJ_TOK_MAX_BLOCKS 2304 // blocks per batch
-#define GJ_TOK_RESIDENT 1024u  // workgroups the GPU holds at once (256 CUs x 4)
+#define GJ_TOK_RESIDENT ((unsigned)gj_hip_cu_count() * 4u)  // workgroups of the token decoder the GPU holds at once (MI355X: 256 CUs x 4)
 #define GJ_TOK_GMAX 64         // segments per batch
 
 // ---- IDCT side

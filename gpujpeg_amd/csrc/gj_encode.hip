@@ -1922,7 +1922,7 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const unsigned wgs = ((unsigned)g.comp[0].segment_count + spt - 1) / spt;
         T = gj_make_tail(job, 3 * wgs, {0u, wgs, 2 * wgs, ~0u}, (unsigned)spt);
         // (a component per workgroup while three times the tiles still fit the places the GPU has: GJ_ENC_SPLIT=<tiles> moves the limit, 0 = never)
-        const unsigned split_up_to = job->tune.enc_split >= 0 ? (unsigned)job->tune.enc_split : 341u;
+        const unsigned split_up_to = job->tune.enc_split >= 0 ? (unsigned)job->tune.enc_split : (unsigned)gj_hip_cu_count() * 4u / 3u; // (MI355X: 341)
         const bool split = wgs * frames <= split_up_to;
         if (split) whole = gj_encode_kernel(g, true);
         hipLaunchKernelGGL(whole, dim3(wgs, split ? 3 : 1, frames), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,

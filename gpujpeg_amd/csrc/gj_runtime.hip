@@ -49,6 +49,21 @@ int gj_hip_device_props(int device, char name[256], int* major, int* minor, size
     return 0;
 }
 
+// compute units of the CURRENT device (cached per device): the batch plans and kernel choices that depend on how many workgroups the
+// device holds at once ask here instead of assuming the MI355X's 256 (other parts, partitioned modes: CPX / NPS)
+int gj_hip_cu_count(void)
+{
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        hipDeviceProp_t p;
+        const int n = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 int gj_hip_runtime_version(int* driver, int* runtime)
 {
     if (chk(hipDriverGetVersion(driver))) return -1;

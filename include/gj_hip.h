@@ -35,6 +35,8 @@ GJ_HIP_API int gj_hip_set_device(int device);
 GJ_HIP_API int gj_hip_device_reset(void);
 GJ_HIP_API int gj_hip_device_props(int device, char name[256], int* major, int* minor, size_t* global_mem, size_t* shared_mem,
                         int* regs_per_block, int* cu_count);
+/* compute units of the current device (cached): what "the workgroups the device holds at once" is derived from */
+GJ_HIP_API int gj_hip_cu_count(void);
 GJ_HIP_API int gj_hip_runtime_version(int* driver, int* runtime);
 GJ_HIP_API const char* gj_hip_last_error(void);
 

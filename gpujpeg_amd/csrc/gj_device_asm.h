@@ -63,3 +63,10 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
     return v + d;
 }
 
+// (c == 255) as 0.0 / 1.0 for an integer c in [0, 255]: the clamp-to-[0, 1] output modifier on c - 254, one packed instruction per sample pair
+__device__ __forceinline__ gj_f2 gj_is255_f(gj_f2 v)
+{
+    gj_f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(v), "v"((gj_f2)-254.0f));
+    return d;
+}

@@ -206,10 +206,11 @@ __device__ __forceinline__ void gj_color_444(const gj_geom& g, const unsigned bx
     const int cols = exists ? min(8, max(0, g.width - (int)(bx * 8))) : 0, rows = exists ? min(8, max(0, g.height - (int)(by * 8))) : 0;
     const uint32_t m_lo = cols >= 4 ? 0xFFFFFFFFu : (1u << (8 * cols)) - 1u;
     const uint32_t m_hi = cols >= 8 ? 0xFFFFFFFFu : cols > 4 ? (1u << (8 * (cols - 4))) - 1u : 0u;
+    const GjColorLane<CS_FROM, CS_TO> CL;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         uint32_t o0[2], o1[2], o2[2];
-        gj_color_row<CS_FROM, CS_TO>(px[r], o0, o1, o2);
+        gj_color_row<CS_FROM, CS_TO>(CL, px[r], o0, o1, o2);
         if (!interior) {
             const uint32_t lo = r < rows ? m_lo : 0u, hi = r < rows ? m_hi : 0u;
             o0[0] &= lo; o0[1] &= hi; o1[0] &= lo; o1[1] &= hi; o2[0] &= lo; o2[1] &= hi;
@@ -241,10 +242,11 @@ __global__ __launch_bounds__(256, 2) void k_fused_rgb444(const gj_geom g, const 
     const gj_comp_geom& k0 = g.comp[0];
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
     const unsigned lb = blockIdx.x * 256u + threadIdx.x;
-    if (lb >= nb) return;
+    const bool exists = lb < nb; // (no early exit: the colour transform is a matrix instruction over the whole wave, gj_device.h)
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
     uint32_t pk[3][16]; // the three component blocks, one byte per sample
-    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, true, pk);
+    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, exists, pk);
+    if (!exists) return;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         uint32_t q[32];
@@ -702,6 +704,9 @@ struct GjCoderLds {
     uint32_t *segx, *segend, *segbase, *segbits, *segff; // [64] ([65] segbase)
 };
 #define GJ_ENC_SORT_KEYS 32 // sort key of a block = min(non-zero AC coefficients, 31)
+#ifndef GJ_ENC_SORT
+#define GJ_ENC_SORT 1 // (0: A/B builds without the hand-over, make variant DEFS=-DGJ_ENC_SORT=0)
+#endif
 // the coder's LDS, declared by each of the three kernels that call gj_code_tile (37.9 KB + the kernel's quantisation tables: four workgroups per CU)
 #define GJ_CODER_LDS(L)                                                                                                                         \
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];                                                                          \
@@ -878,6 +883,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         if (i < GJ_ENC_MAX_SPT) L.segff[i] = 0;
         if (i < 4) L.wsum[i] = 0;
         // rank of the block among the wave's 64 by its number of non-zero AC coefficients (blocks that do not exist: none)
+#if GJ_ENC_SORT
         const uint32_t key = min((uint32_t)__builtin_popcount(mlo & ~1u) + (uint32_t)__builtin_popcount(mhi), (uint32_t)GJ_ENC_SORT_KEYS - 1u);
         uint32_t* const cnt = L.cnt + wave * GJ_ENC_SORT_KEYS;
         const uint32_t r0 = atomicAdd(&cnt[key], 1u); // (place among the blocks of the same key: any order will do)
@@ -890,6 +896,10 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         const uint32_t ci = gj_wave_incl_scan(c);
         const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key << 2), (int)(ci - c)) + r0;
         const uint32_t t = ((((r >> 4) + (uint32_t)rot) & 3u) << 6) | ((uint32_t)wave << 4) | (r & 15u); // the thread that walks block i
+#else
+        (void)rot;
+        const uint32_t t = (uint32_t)i; // (A/B builds: every lane walks its own block)
+#endif
         // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342): the difference where the
         // predecessor is a block of this wave, the term itself where it is one of the previous wave's last (the walker subtracts edge[])
         const int src = lane - dc_dist;

@@ -10,13 +10,14 @@
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256) void k_test_color444(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const uint32_t nrows)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nrows) return;
+    const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, i = i0 < nrows ? i0 : nrows - 1; // (every lane stays: gj_color_row's contract)
     uint32_t px[6], o0[2], o1[2], o2[2];
     const uint2* p = reinterpret_cast<const uint2*>(in + (size_t)i * 24);
     const uint2 a = p[0], b = p[1], c = p[2];
     px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y;
-    gj_color_row<CS_FROM, CS_TO>(px, o0, o1, o2);
+    const GjColorLane<CS_FROM, CS_TO> CL;
+    gj_color_row<CS_FROM, CS_TO>(CL, px, o0, o1, o2);
+    if (i0 >= nrows) return;
     const size_t plane = (size_t)nrows * 8;
     *reinterpret_cast<uint2*>(out + (size_t)i * 8) = make_uint2(o0[0], o0[1]);
     *reinterpret_cast<uint2*>(out + plane + (size_t)i * 8) = make_uint2(o1[0], o1[1]);

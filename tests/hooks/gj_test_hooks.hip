@@ -39,3 +39,27 @@ extern "C" __attribute__((visibility("default"))) int gj_test_color444(int cs_fr
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+
+// v_mfma_f32_4x4x1_16b_f32 with given per-lane operands: what lands where (tests/test_gpu_parity.py::test_mfma_4x4x1_layout pins the
+// operand layout gj_device.h's colour transform relies on). `via_asm`: the B operand comes out of an inline-assembly instruction right
+// in front of the matrix instruction, as in the product (hazards between the two are the compiler's business).
+__global__ __launch_bounds__(64) void k_test_mfma4x4(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ out,
+                                                     const int via_asm)
+{
+    const int l = threadIdx.x;
+    const float av = a[l];
+    float bv = b[l];
+    gj_f4 acc = gj_f4{c[l * 4], c[l * 4 + 1], c[l * 4 + 2], c[l * 4 + 3]};
+    if (via_asm) {
+        gj_f2 t = gj_f2{bv + 254.0f, bv + 254.0f};
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"((gj_f2)-254.0f));
+        bv = t.x;
+    }
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc, 0, 0, 0);
+    out[l * 4] = acc.x; out[l * 4 + 1] = acc.y; out[l * 4 + 2] = acc.z; out[l * 4 + 3] = acc.w;
+}
+extern "C" __attribute__((visibility("default"))) int gj_test_mfma4x4(const float* d_a, const float* d_b, const float* d_c, float* d_out, int via_asm, gj_stream_t stream)
+{
+    hipLaunchKernelGGL(k_test_mfma4x4, dim3(1), dim3(64), 0, (hipStream_t)stream, d_a, d_b, d_c, d_out, via_asm);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

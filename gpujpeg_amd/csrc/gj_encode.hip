@@ -696,43 +696,17 @@ __device__ __forceinline__ void gj_fdct_quant_zz(const uint32_t (&px)[16], const
 struct GjCoderLds {
     uint32_t* coef;      // [32][256]; rows GJ_ENC_PRIV_ROWS.. double as the shared bit window once the walks are done
     const uint32_t* lut; // [2][272]: per table type AC[(run << 4) | nbits] then DC[nbits], entry = (code bits + nbits) << 26 | code << nbits
-    uint32_t* wsum;      // [4] block-length totals of the waves (blocks in tile order), added up by the lanes that walk them
-    int* edge;           // [4][16] the last sixteen DC terms of each wave (predecessors of the next wave's first blocks)
-    uint2* rec_m;        // [256] what the lane that walks a block is handed: the block's non-zero masks ...
-    uint32_t* rec_f;     // [256] ... and GJ_REC_* : its index in the tile, DC term, table, flags
-    uint32_t* cnt;       // [4][GJ_ENC_SORT_KEYS] counters of the waves' counting sorts (zero between two sorts)
+    uint32_t* wsum;      // [4] block-length totals of the waves
+    int* edge;           // [4][16] the last sixteen DC terms of each wave (predecessors of the next wave's first lanes)
     uint32_t *segx, *segend, *segbase, *segbits, *segff; // [64] ([65] segbase)
 };
-#define GJ_ENC_SORT_KEYS 32 // sort key of a block = min(non-zero AC coefficients, 31)
-#ifndef GJ_ENC_SORT
-#define GJ_ENC_SORT 1 // (0: A/B builds without the hand-over, make variant DEFS=-DGJ_ENC_SORT=0)
-#endif
-// the coder's LDS, declared by each of the three kernels that call gj_code_tile (37.9 KB + the kernel's quantisation tables: four workgroups per CU)
-#define GJ_CODER_LDS(L)                                                                                                                         \
-    __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];                                                                          \
-    __shared__ uint32_t s_lut[2 * 272];                                                                                                         \
-    __shared__ uint32_t s_wsum[4];                                                                                                              \
-    __shared__ int s_edge[64];                                                                                                                  \
-    __shared__ __attribute__((aligned(8))) uint2 s_rec_m[256];                                                                                  \
-    __shared__ uint32_t s_rec_f[256];                                                                                                           \
-    __shared__ uint32_t s_cnt[4 * GJ_ENC_SORT_KEYS];                                                                                            \
-    __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT]; \
-    const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_rec_m, s_rec_f, s_cnt, s_segx, s_segend, s_segbase, s_segbits, s_segff};             \
-    if (threadIdx.x < 4 * GJ_ENC_SORT_KEYS) s_cnt[threadIdx.x] = 0 /* (visible behind the kernel's first barrier) */
-
-// GjCoderLds::rec_f: bits 0..7 the block's index in the tile, 8..19 its DC difference (or, GJ_REC_CROSS, its DC term: the predecessor
-// is edge[bits 21..26]), 27 the block exists, 28 chrominance tables, 29 last block of its segment
-#define GJ_REC_CROSS (1u << 20)
-#define GJ_REC_ACTIVE (1u << 27)
-#define GJ_REC_TABLE (1u << 28)
-#define GJ_REC_LAST (1u << 29)
 
 // the private stream of a lane while it walks its block
 struct GjWalk {
     uint32_t hi;     // accumulator: `fill` < 32 bits, left-aligned
     int fill;
     int produced;    // completed dwords so far
-    int stored;      // the first `stored` of them sit in the block's column, the others in the block's d_temp slot
+    int stored;      // the first `stored` of them sit in the lane's column, the others in the block's d_temp slot
     int lim;         // 2 * produced + 1 while every completed dword could be stored in place; GJ_ENC_NO_STORE once one could not
 };
 #define GJ_ENC_NO_STORE 4096
@@ -830,41 +804,30 @@ __device__ __forceinline__ void gj_merge_stream(const GjWalk& w, const uint8_t* 
     }
 }
 
-// Steps 2-5 for one component of a tile. i = thread = the block of the tile whose coefficients the thread has just stored in column i,
-// j = local segment of that block, k = block inside its segment, nblocks = blocks of that segment, table = 0 luminance / 1 chrominance
-// tables, dc_dist = blocks back to the previous block of the same component; recip = the 16.16 reciprocal the caller derived j from
-// (j = min(i * recip >> 16, GJ_ENC_MAX_SPT - 1)), rot = which wave takes the longest blocks (callers vary it with the workgroup and
-// the component so that no SIMD of a CU collects them); region = the tile's area of d_temp (GJ_TEMP_BYTES_PER_BLOCK per block: the
-// tile's UNSTUFFED stream from its start -- every segment on a dword boundary, in the order of the scan --, block b's spill slot at
-// b * GJ_TEMP_BYTES_PER_BLOCK, which the stream reaches only after block b has been merged into it), seg_count_left = segments of the
-// scan from the tile's first one on (the last one of a scan gets no restart marker); seg_bytes / seg_ff = unstuffed size and 0xFF
-// count per segment (k_gather stuffs). Returns the size of the tile's FINISHED stream (stuffed, restart markers included; the same in
-// every thread).
-//
-// WHO WALKS WHICH BLOCK (round 5). The lanes of a wave walk together: a wave pays for the LONGEST of its 64 blocks (~20 non-zero
-// coefficients at 8K q75 where the average luminance block has 7.7: 596 vector instructions per wave, 270 if blocks were equal,
-// profiles/r4_09). So the blocks change hands between the mask step and the walk: every wave sorts its 64 blocks by their number of
-// non-zero coefficients (a counting sort: one returning LDS atomic per lane, one 32-lane prefix sum), and the blocks of rank 16 q .. 16 q + 15
-// of EVERY wave go to wave (q + rot) & 3 -- the quartiles change places, no count has to cross a wave before the one barrier that the
-// hand-over needs anyway. A walker is told its block by a 12-byte record (masks, index, DC difference); it walks AND merges that block
-// (private dwords stay in the block's own column, bit positions are taken in tile order by the block's home lane and handed back
-// through the upper halves of rows 0..2 of the column, which the walk has consumed), so streams, drain and counts are unchanged.
+// Steps 2-5 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
+// nblocks = blocks of that segment, table = 0 luminance / 1 chrominance tables, dc_dist = lanes back to the previous block of the
+// same component; region = the tile's area of d_temp (GJ_TEMP_BYTES_PER_BLOCK per block: the tile's UNSTUFFED stream from its start --
+// every segment on a dword boundary, in the order of the scan --, block i's spill slot at i * GJ_TEMP_BYTES_PER_BLOCK, which the stream
+// reaches only after block i has been merged into it), seg_count_left = segments of the scan from the tile's first one on (the last
+// one of a scan gets no restart marker); seg_bytes / seg_ff = unstuffed size and 0xFF count per segment (k_gather stuffs).
+// Returns the size of the tile's FINISHED stream (stuffed, restart markers included; the same in every thread).
 __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int i, const int j, const int k, const bool active, const int spt,
-                                                 const int nblocks, const int table, const int dc_dist, const uint32_t recip, const int rot,
-                                                 const int seg_count_left, uint8_t* __restrict__ region,
+                                                 const int nblocks, const int table, const int dc_dist, const int seg_count_left,
+                                                 uint8_t* __restrict__ region,
                                                  uint32_t* __restrict__ seg_bytes, uint32_t* __restrict__ seg_ff, const uint32_t first_segment,
                                                  const int trace0 = -1)
 {
     (void)trace0;
     const int lane = i & 63, wave = i >> 6;
-    uint8_t* const coef_b = reinterpret_cast<uint8_t*>(L.coef);
-    uint8_t* const home = coef_b + i * 4; // the column of block i
+    uint8_t* const col = reinterpret_cast<uint8_t*>(L.coef) + i * 4;
     uint32_t* const s_bits = L.coef + GJ_ENC_PRIV_ROWS * 256;
+    const uint32_t* const lut_ac = L.lut + table * 272;
+    const uint32_t* const lut_dc = lut_ac + 256;
 
-    // ---- 2. read the column back: non-zero mask, DC term; sort key, rank, hand-over record
+    // ---- 2. read the column back: non-zero mask, DC term
+    uint32_t mlo = 0, mhi = 0;
+    int dc = 0;
     {
-        uint32_t mlo = 0, mhi = 0;
-        int dc = 0;
         uint32_t elo = 0, ehi = 0;
 #pragma unroll
         for (int q = 0; q < 32; q++) {
@@ -879,87 +842,52 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
             mlo = __builtin_amdgcn_perm(ehi, elo, 0x05040100u); // lower halves: positions 0..15 | 16..31
             mhi = __builtin_amdgcn_perm(ehi, elo, 0x07060302u); // upper halves: positions 32..47 | 48..63
         }
-        if (lane >= 48) L.edge[wave * 16 + (lane - 48)] = dc;
-        if (i < GJ_ENC_MAX_SPT) L.segff[i] = 0;
-        if (i < 4) L.wsum[i] = 0;
-        // rank of the block among the wave's 64 by its number of non-zero AC coefficients (blocks that do not exist: none)
-#if GJ_ENC_SORT
-        const uint32_t key = min((uint32_t)__builtin_popcount(mlo & ~1u) + (uint32_t)__builtin_popcount(mhi), (uint32_t)GJ_ENC_SORT_KEYS - 1u);
-        uint32_t* const cnt = L.cnt + wave * GJ_ENC_SORT_KEYS;
-        const uint32_t r0 = atomicAdd(&cnt[key], 1u); // (place among the blocks of the same key: any order will do)
-        gj_wave_sync();
-        uint32_t c = 0;
-        if (lane < GJ_ENC_SORT_KEYS) {
-            c = cnt[lane];
-            cnt[lane] = 0; // for the next sort
-        }
-        const uint32_t ci = gj_wave_incl_scan(c);
-        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(key << 2), (int)(ci - c)) + r0;
-        const uint32_t t = ((((r >> 4) + (uint32_t)rot) & 3u) << 6) | ((uint32_t)wave << 4) | (r & 15u); // the thread that walks block i
-#else
-        (void)rot;
-        const uint32_t t = (uint32_t)i; // (A/B builds: every lane walks its own block)
-#endif
-        // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342): the difference where the
-        // predecessor is a block of this wave, the term itself where it is one of the previous wave's last (the walker subtracts edge[])
-        const int src = lane - dc_dist;
-        const int pred = __builtin_amdgcn_ds_bpermute((src & 63) << 2, dc);
-        const bool first = k - dc_dist < 0, cross = !first && src < 0 && wave > 0;
-        const int val = (first || cross) ? dc : dc - pred;
-        uint32_t f = (uint32_t)i | (((uint32_t)val & 0xFFFu) << 8);
-        if (cross) f |= GJ_REC_CROSS | ((uint32_t)(wave * 16 + src) << 21); // = edge[(wave - 1) * 16 + 16 + src]
-        if (active) f |= GJ_REC_ACTIVE;
-        if (table) f |= GJ_REC_TABLE;
-        if (active && k == nblocks - 1) f |= GJ_REC_LAST;
-        L.rec_m[t] = make_uint2(mlo, mhi);
-        L.rec_f[t] = f;
     }
-    __syncthreads(); // B1: every column, record and edge is in LDS (and, for the first component, the tables)
+    if (lane >= 48) L.edge[wave * 16 + (lane - 48)] = dc;
+    if (i < GJ_ENC_MAX_SPT) L.segff[i] = 0;
+    __syncthreads(); // B1: edges visible (and, for the first component, the tables)
 
-    // ---- 3. the walk, of the block the sort has handed to this lane
-    const uint32_t rf = L.rec_f[i];
-    const int b = (int)(rf & 255u);
-    const bool wactive = (rf & GJ_REC_ACTIVE) != 0;
-    uint8_t* const col = coef_b + b * 4;
-    uint32_t* const spill = reinterpret_cast<uint32_t*>(region + (size_t)b * GJ_TEMP_BYTES_PER_BLOCK);
+    // ---- 3. the walk
     GjWalk w = {0, 0, 0, 0, 1};
-    if (wactive) {
-        const uint2 mm = L.rec_m[i];
-        const uint32_t* const lut_ac = L.lut + ((rf & GJ_REC_TABLE) ? 272 : 0);
-        const uint32_t* const lut_dc = lut_ac + 256;
-        int dc_diff = (int)(rf << 12) >> 20; // bits 8..19, sign-extended
-        if (rf & GJ_REC_CROSS) dc_diff -= L.edge[(rf >> 21) & 63u];
+    uint32_t* const spill = reinterpret_cast<uint32_t*>(region + (size_t)i * GJ_TEMP_BYTES_PER_BLOCK); // (lane i = block i of the tile)
+    int dc_diff = 0;
+    {
+        // DC prediction inside the segment (reset at its first block, src/gpujpeg_huffman_gpu_encoder.cu:339-342)
+        const int src = lane - dc_dist;
+        int pred = __builtin_amdgcn_ds_bpermute((src & 63) << 2, dc);
+        if (src < 0 && wave > 0) pred = L.edge[(wave - 1) * 16 + (16 + src)];
+        if (k - dc_dist < 0) pred = 0;
+        dc_diff = dc - pred;
+    }
+    if (active) {
         int nbits;
         uint32_t bits;
         gj_value_bits2<false>(dc_diff, nbits, bits);
         const uint32_t ent = lut_dc[nbits];
         gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, spill, 0);
-        gj_walk_ac(col, mm.x & ~1u, mm.y, lut_ac, w, spill);
+        gj_walk_ac(col, mlo & ~1u, mhi, lut_ac, w, spill);
     }
-    const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill; // (< 1664)
-    // the block's length goes home through the upper half of row 0 of its column (position 32: read and done with), and into its home wave's total
-    *reinterpret_cast<uint16_t*>(col + 2) = (uint16_t)len;
-    if (len) atomicAdd(&L.wsum[b >> 6], len);
+    const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill;
 
     if (trace0 >= 0) GJ_TRACE_E(trace0 + 1); // walk done (this wave)
-    __syncthreads(); // B2: lengths and wave totals; every walk is finished, so the window rows are free
-    // ---- 4. bit positions, in tile order: lane i for block i
+    // ---- 4. bit positions
+    const uint32_t winc = gj_wave_incl_scan(len);
+    if (lane == 63) L.wsum[wave] = winc;
+    __syncthreads(); // B2: wave totals; every walk is finished, so the window rows are free
+    uint32_t excl;
     {
-        const uint32_t mylen = *reinterpret_cast<const uint16_t*>(home + 2);
-        const uint32_t winc = gj_wave_incl_scan(mylen);
-        const uint32_t a = L.wsum[0], bb = L.wsum[1], c = L.wsum[2];
-        const uint32_t incl = winc + (wave == 0 ? 0u : wave == 1 ? a : wave == 2 ? a + bb : a + bb + c);
-        if (active && k == 0) L.segx[j] = incl - mylen;
+        const uint32_t a = L.wsum[0], b = L.wsum[1], c = L.wsum[2];
+        const uint32_t incl = winc + (wave == 0 ? 0u : wave == 1 ? a : wave == 2 ? a + b : a + b + c);
+        if (active && k == 0) L.segx[j] = incl - len;
         if (active && k == nblocks - 1) L.segend[j] = incl;
-        const uint32_t excl = incl - mylen; // (< 2^19) to the block's walker: upper halves of rows 1 and 2
-        *reinterpret_cast<uint16_t*>(home + 1024 + 2) = (uint16_t)excl;
-        *reinterpret_cast<uint16_t*>(home + 2048 + 2) = (uint16_t)(excl >> 16);
-        // clear the first window
+        excl = incl - len;
+    }
+    {   // clear the first window
         uint4* z = reinterpret_cast<uint4*>(s_bits) + i * 2;
         z[0] = make_uint4(0, 0, 0, 0);
         z[1] = make_uint4(0, 0, 0, 0);
     }
-    __syncthreads(); // B3: segment ends and block positions visible, window cleared
+    __syncthreads(); // B3: segment ends visible, window cleared
     if (trace0 >= 0) GJ_TRACE_E(trace0 + 2); // positions known
     // segment books, redundantly in every wave (lane l keeps local segment l): bits with ones-padding to a byte, dword base
     uint32_t sbits = 0, sdw = 0;
@@ -977,13 +905,11 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
     }
     uint32_t start_bit = 0;
     int pad_bits = 0;
-    {   // of the WALKED block b
-        const int jb = min((int)(((uint32_t)b * recip) >> 16), GJ_ENC_MAX_SPT - 1);
-        const uint32_t my_base = (uint32_t)__builtin_amdgcn_ds_bpermute(jb << 2, (int)sbase);
-        const uint32_t my_x = wactive ? L.segx[jb] : 0u;
-        const uint32_t excl = (uint32_t)*reinterpret_cast<const uint16_t*>(col + 1024 + 2) | ((uint32_t)*reinterpret_cast<const uint16_t*>(col + 2048 + 2) << 16);
+    {
+        const uint32_t my_base = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)sbase);
+        const uint32_t my_x = active ? L.segx[j] : 0u;
         start_bit = my_base * 32u + (excl - my_x);
-        if (rf & GJ_REC_LAST) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
+        if (active && k == nblocks - 1) pad_bits = (int)((8u - ((start_bit + len) & 7u)) & 7u);
     }
 
     // ---- 5. merge into the window, drain the window to HBM
@@ -1003,7 +929,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
             for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
             __syncthreads();
         }
-        if (wactive && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, wbase, wend);
+        if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, wbase, wend);
         __syncthreads(); // B4: window complete
         // every wave drains whole segments: no search for the owner of a dword, the 0xFF count of a segment is one wave reduction
         for (int sl = wave; sl < nseg; sl += 4) {
@@ -1277,8 +1203,13 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
                                                           uint32_t* __restrict__ seg_ff, const GjTail T)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
-    GJ_CODER_LDS(L);
+    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_edge[64];
+    __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
+    const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
     GJ_TRACE_E(0);
@@ -1324,8 +1255,8 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
         gj_fdct_quant_zz(pk[c], s_q[c], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         GJ_TRACE_E(2 + 4 * c); // transformed (this wave)
         const uint64_t first_block = kc.data_offset / 64 + (uint64_t)seg0 * B; // coding-order index of the tile's first block of this component
-        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, recip, (int)(blockIdx.x + blockIdx.z) + c,
-                                           k0.segment_count - seg0, temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
+        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
+                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
         // file order: the luminance scan's tiles, then the two chrominance scans'
         if (i == 0) gj_piece_put(T, (uint32_t)c * gridDim.x + blockIdx.x, size, fz * T.f_tail);
     }
@@ -1344,8 +1275,13 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
                                                            uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
                                                            uint32_t* __restrict__ seg_ff, const GjTail T)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
-    GJ_CODER_LDS(L);
+    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_edge[64];
+    __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
+    const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
     gj_load_coder_lut(s_lut, lut, i);
@@ -1434,8 +1370,8 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         const uint64_t first_block = (uint64_t)seg0 * B;
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, ((int)nm - (seg0 + j) * ri) * 4) : 0, table,
-                                           p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, recip, (int)(blockIdx.x + blockIdx.z),
-                                           g.segment_count - seg0, temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)seg0);
+                                           p == 0 ? 3 : (p == 1 ? 1 : 4) /* Y1 follows the Y0 of its own MCU */, g.segment_count - seg0,
+                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)seg0);
         if (i == 0) gj_piece_put(T, blockIdx.x, size, (size_t)blockIdx.z * T.f_tail);
     }
 }
@@ -1471,8 +1407,13 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
                                                           uint8_t* __restrict__ temp, uint32_t* __restrict__ seg_bytes,
                                                           uint32_t* __restrict__ seg_ff, const GjTail T)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
-    GJ_CODER_LDS(L);
+    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ int s_edge[64];
+    __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
+    const GjCoderLds L = {s_coef, s_lut, s_wsum, s_edge, s_segx, s_segend, s_segbase, s_segbits, s_segff};
 
     const int i = threadIdx.x;
     gj_load_coder_lut(s_lut, lut, i);
@@ -1629,8 +1570,8 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
         for (int t = 0; t < 16; t++) GJ_KEEP(px[t]);
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         const uint64_t first_block = s_first_block;
-        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, recip,
-                                           (int)(blockIdx.x + blockIdx.z), scan_segs - seg0, temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff,
+        const uint32_t size = gj_code_tile(L, i, j, k, active, spt, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0,
+                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff,
                                            (uint32_t)(scan_first + seg0));
         // (workgroups are numbered in file order: the tiles of scan 0, of scan 1, ...)
         if (i == 0) gj_piece_put(T, blockIdx.x, size, (size_t)blockIdx.z * T.f_tail);

@@ -60,25 +60,13 @@ __device__ __forceinline__ float gj_sample_f(const uint32_t (&c)[2])
 }
 
 // pixels X and X + 1 of a row: component samples -> colour transform -> bytes 3X .. 3X + 5 of the packed output row
-// (GJ_COLOR_MFMA: the matrix product on the matrix pipe, gj_device.h -- all 64 lanes of the wave execute the call; CL = the lane's operands)
 template <int CS_FROM, int CS_TO, int X>
-__device__ __forceinline__ void gj_store_pair(const GjColorLane<CS_FROM, CS_TO>& CL, const uint32_t (&c0)[2], const uint32_t (&c1)[2], const uint32_t (&c2)[2],
-                                              uint32_t (&px)[6])
+__device__ __forceinline__ void gj_store_pair(const uint32_t (&c0)[2], const uint32_t (&c1)[2], const uint32_t (&c2)[2], uint32_t (&px)[6])
 {
     gj_f2 a = gj_f2{gj_sample_f<X>(c0), gj_sample_f<X + 1>(c0)};
     gj_f2 b = gj_f2{gj_sample_f<X>(c1), gj_sample_f<X + 1>(c1)};
     gj_f2 c = gj_f2{gj_sample_f<X>(c2), gj_sample_f<X + 1>(c2)};
-    if (GJ_COLOR_MFMA && gj_color_is_matrix<CS_FROM, CS_TO>()) {
-        constexpr GjColorMat K = gj_color_mat<CS_FROM, CS_TO>();
-        const gj_f2 da = K.scaled[0] ? gj_is255_f(a) : (gj_f2)0.0f, db = K.scaled[1] ? gj_is255_f(b) : (gj_f2)0.0f, dc = K.scaled[2] ? gj_is255_f(c) : (gj_f2)0.0f;
-        const gj_f4 p = gj_color_pixel_mfma<CS_FROM, CS_TO>(CL, a.x, b.x, c.x, da.x, db.x, dc.x);
-        const gj_f4 q = gj_color_pixel_mfma<CS_FROM, CS_TO>(CL, a.y, b.y, c.y, da.y, db.y, dc.y);
-        a = gj_f2{p.x, q.x};
-        b = gj_f2{p.y, q.y};
-        c = gj_f2{p.z, q.z};
-    } else {
-        gj_color_f<CS_FROM, CS_TO>(a, b, c);
-    }
+    gj_color_f<CS_FROM, CS_TO>(a, b, c);
     constexpr int B = 3 * X;
     px[(B + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a.x, (B + 0) & 3, px[(B + 0) >> 2]);
     px[(B + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(b.x, (B + 1) & 3, px[(B + 1) >> 2]);
@@ -100,16 +88,15 @@ __device__ __forceinline__ void gj_store_rgb444(const gj_geom& g, uint8_t* __res
     const size_t pitch = (size_t)g.width * 3 + g.width_padding;
     const bool interior = lb < nb && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
-    const GjColorLane<CS_FROM, CS_TO> CL;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         // colour transform in fp32 on pixel pairs (gj_color_f, exact; see gj_device.h), results packed straight into the 24 output bytes
         uint32_t px[6] = {0, 0, 0, 0, 0, 0};
         const uint32_t c0[2] = {pk[0][2 * r], pk[0][2 * r + 1]}, c1[2] = {pk[1][2 * r], pk[1][2 * r + 1]}, c2[2] = {pk[2][2 * r], pk[2][2 * r + 1]};
-        gj_store_pair<CS_FROM, CS_TO, 0>(CL, c0, c1, c2, px);
-        gj_store_pair<CS_FROM, CS_TO, 2>(CL, c0, c1, c2, px);
-        gj_store_pair<CS_FROM, CS_TO, 4>(CL, c0, c1, c2, px);
-        gj_store_pair<CS_FROM, CS_TO, 6>(CL, c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 0>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 2>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 4>(c0, c1, c2, px);
+        gj_store_pair<CS_FROM, CS_TO, 6>(c0, c1, c2, px);
         const unsigned y = by * 8 + r;
         if (interior && aligned) {
             uint2* p = reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)bx * 24);

@@ -267,126 +267,14 @@ __device__ __forceinline__ float gj_row_byte_f(const uint32_t (&px)[6])
          : (I & 3) == 2 ? gj_ubyte_f<2>(w) : gj_ubyte_f<3>(w);
 }
 
-// ------------------------------------------------------------------------------------------------
-// The 3 x 3 colour matrix on the MATRIX pipe (round 5). The packed-FMA form above spends 36 v_pk_fma_f32 + 24 v_pk_add_f32 of a row's
-// 108 vector instructions on the matrix product and the c + (c == 255) step; the kernels that call it are bound by vector issue, and
-// the CU's matrix pipe, which issues beside the vector ALU, is idle. v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4 x 4 outer
-// products D = A (4 x 1) * B (1 x 4) + C over the wave: lane l supplies A[l & 3] and B[l & 3] of block l >> 2 and receives column l & 3
-// of D in four registers (row i in register i). With A = column k of the matrix (lane l holds row l & 3, row 3 is zero) and B = channel k
-// of the LANE'S OWN pixel, three accumulating instructions leave (Y, Cb, Cr, 0) of that pixel in the lane's four result registers; the
-// constant term travels in as C. The reference's c * 256 / 255 = c + (c == 255) is linear, so it is three more instructions with
-// B = clamp(c - 254) (one packed add with the clamp modifier per sample pair) instead of an addition per sample. Every product and partial sum
-// is a multiple of 1/512 below 2^11 (see above): exact in fp32 in ANY order and under either rounding of the accumulation, so the bytes
-// are those of the FMA form -- tests/test_gpu_parity.py::test_exhaustive_colour_transform_fused pushes all 2^24 triples of all seven
-// matrices through this code. Per row of 8 pixels: 24 conversions + 12 packed adds + 24 v_cvt_pk_u8_f32 = 60 vector instructions
-// (108 before) and 48 matrix instructions of 8 cycles.
-// CONTRACT: all 64 lanes of the wave execute the call (the four lanes of a block exchange their A operands).
-// ------------------------------------------------------------------------------------------------
-#ifndef GJ_COLOR_MFMA
-#define GJ_COLOR_MFMA 1
-#endif
-typedef float gj_f4 __attribute__((ext_vector_type(4)));
-
-struct GjColorMat {
-    float m[9];     // row-major, divided by 256: output i, input k
-    float off[3];   // constant term of output i (offset + rounding term)
-    bool scaled[3]; // input k goes through c * 256 / 255
-};
-__device__ constexpr GjColorMat gj_color_mat_to(const int m0, const int m1, const int m2, const int m3, const int m4, const int m5, const int m6, const int m7,
-                                                const int m8, const int b0, const int b1, const int b2)
-{
-    const float s = 1.0f / 256.0f, h = 0.5f / 256.0f; // gj_matrix_to_f
-    return GjColorMat{{m0 * s, m1 * s, m2 * s, m3 * s, m4 * s, m5 * s, m6 * s, m7 * s, m8 * s}, {b0 + h, b1 + h, b2 + h}, {true, true, true}};
-}
-__device__ constexpr GjColorMat gj_color_mat_from(const int m0, const int m1, const int m2, const int m3, const int m4, const int m5, const int m6, const int m7,
-                                                  const int m8, const int b0, const int b1, const int b2)
-{
-    const float s = 1.0f / 256.0f, h = 0.5f / 256.0f; // gj_matrix_from_f
-    return GjColorMat{{m0 * s, m1 * s, m2 * s, m3 * s, m4 * s, m5 * s, m6 * s, m7 * s, m8 * s},
-                      {h - (float)(m0 * b0 + m1 * b1 + m2 * b2) * s, h - (float)(m3 * b0 + m4 * b1 + m5 * b2) * s, h - (float)(m6 * b0 + m7 * b1 + m8 * b2) * s},
-                      {b0 == 0, b1 == 0, b2 == 0}};
-}
-template <int CS_FROM, int CS_TO>
-__device__ constexpr GjColorMat gj_color_mat()
-{
-    if (CS_FROM == GJ_CS_RGB) {
-        if (CS_TO == GJ_CS_BT601) return gj_color_mat_to(66, 129, 25, -38, -74, 112, 112, -94, -18, 16, 128, 128);
-        if (CS_TO == GJ_CS_BT601_256) return gj_color_mat_to(77, 150, 29, -43, -85, 128, 128, -107, -21, 0, 128, 128);
-        if (CS_TO == GJ_CS_BT709) return gj_color_mat_to(47, 157, 16, -26, -87, 112, 112, -102, -10, 16, 128, 128);
-        return gj_color_mat_to(77, 150, 29, -38, -74, 112, 157, -132, -26, 0, 128, 128); // GJ_CS_YUV
-    }
-    if (CS_FROM == GJ_CS_BT601) return gj_color_mat_from(298, 0, 409, 298, -100, -208, 298, 516, 0, 16, 128, 128);
-    if (CS_FROM == GJ_CS_BT601_256) return gj_color_mat_from(256, 0, 359, 256, -88, -183, 256, 454, 0, 0, 128, 128);
-    if (CS_FROM == GJ_CS_BT709) return gj_color_mat_from(298, 0, 459, 298, -55, -136, 298, 541, 0, 16, 128, 128);
-    return gj_color_mat_from(256, 0, 292, 256, -101, -149, 256, 520, 0, 0, 128, 128); // GJ_CS_YUV
-}
-// the transforms gj_color_f knows (one side is RGB, the other one of the four YCbCr variants)
-template <int CS_FROM, int CS_TO>
-__device__ constexpr bool gj_color_is_matrix()
-{
-    return CS_FROM != CS_TO && CS_FROM != GJ_CS_NONE && CS_TO != GJ_CS_NONE && (CS_FROM == GJ_CS_RGB || CS_TO == GJ_CS_RGB);
-}
-
-// the lane's operands: column k of the matrix (row = lane & 3) and the constant terms
-template <int CS_FROM, int CS_TO>
-struct GjColorLane {
-    float a[3];
-    gj_f4 c0;
-    __device__ __forceinline__ GjColorLane()
-    {
-        if (!(GJ_COLOR_MFMA && gj_color_is_matrix<CS_FROM, CS_TO>())) { // (the FMA form has its constants in the instructions)
-            a[0] = a[1] = a[2] = 0.0f;
-            c0 = gj_f4{0.0f, 0.0f, 0.0f, 0.0f};
-            return;
-        }
-        constexpr GjColorMat K = gj_color_mat<CS_FROM, CS_TO>();
-        const int row = (int)(threadIdx.x & 3u); // (workgroups are whole waves: lane & 3)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            a[k] = row == 0 ? K.m[k] : row == 1 ? K.m[3 + k] : row == 2 ? K.m[6 + k] : 0.0f;
-            GJ_KEEP(a[k]); // (one register for the kernel's life: left to itself the compiler derives the value again in front of every use)
-        }
-        float o0 = K.off[0], o1 = K.off[1], o2 = K.off[2], o3 = 0.0f;
-        GJ_KEEP(o0); GJ_KEEP(o1); GJ_KEEP(o2); GJ_KEEP(o3);
-        c0 = gj_f4{o0, o1, o2, o3};
-    }
-};
-
-// one pixel: channels c[k] (and d[k] = clamp(c[k] - 254) for the scaled ones) -> the three outputs, before rounding
-template <int CS_FROM, int CS_TO>
-__device__ __forceinline__ gj_f4 gj_color_pixel_mfma(const GjColorLane<CS_FROM, CS_TO>& L, const float c0, const float c1, const float c2, const float d0,
-                                                     const float d1, const float d2)
-{
-    constexpr GjColorMat K = gj_color_mat<CS_FROM, CS_TO>();
-    const float c[3] = {c0, c1, c2}, d[3] = {d0, d1, d2};
-    gj_f4 acc = L.c0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (K.m[k] == 0.0f && K.m[3 + k] == 0.0f && K.m[6 + k] == 0.0f) continue;
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(L.a[k], c[k], acc, 0, 0, 0);
-        if (K.scaled[k]) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(L.a[k], d[k], acc, 0, 0, 0);
-    }
-    return acc;
-}
-
 // One row of a packed 4:4:4 block: 8 pixels x 3 bytes -> the row of each of the three component blocks (2 dwords each)
 template <int CS_FROM, int CS_TO, int X>
-__device__ __forceinline__ void gj_color_row_pair(const GjColorLane<CS_FROM, CS_TO>& L, const uint32_t (&px)[6], uint32_t (&o0)[2], uint32_t (&o1)[2], uint32_t (&o2)[2])
+__device__ __forceinline__ void gj_color_row_pair(const uint32_t (&px)[6], uint32_t (&o0)[2], uint32_t (&o1)[2], uint32_t (&o2)[2])
 {
     gj_f2 a = gj_f2{gj_row_byte_f<3 * X>(px), gj_row_byte_f<3 * X + 3>(px)};
     gj_f2 b = gj_f2{gj_row_byte_f<3 * X + 1>(px), gj_row_byte_f<3 * X + 4>(px)};
     gj_f2 c = gj_f2{gj_row_byte_f<3 * X + 2>(px), gj_row_byte_f<3 * X + 5>(px)};
-    if (GJ_COLOR_MFMA && gj_color_is_matrix<CS_FROM, CS_TO>()) {
-        constexpr GjColorMat K = gj_color_mat<CS_FROM, CS_TO>();
-        const gj_f2 da = K.scaled[0] ? gj_is255_f(a) : (gj_f2)0.0f, db = K.scaled[1] ? gj_is255_f(b) : (gj_f2)0.0f, dc = K.scaled[2] ? gj_is255_f(c) : (gj_f2)0.0f;
-        const gj_f4 p = gj_color_pixel_mfma<CS_FROM, CS_TO>(L, a.x, b.x, c.x, da.x, db.x, dc.x);
-        const gj_f4 q = gj_color_pixel_mfma<CS_FROM, CS_TO>(L, a.y, b.y, c.y, da.y, db.y, dc.y);
-        a = gj_f2{p.x, q.x};
-        b = gj_f2{p.y, q.y};
-        c = gj_f2{p.z, q.z};
-    } else {
-        gj_color_f<CS_FROM, CS_TO>(a, b, c);
-    }
+    gj_color_f<CS_FROM, CS_TO>(a, b, c);
     o0[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a.x, X & 3, o0[X >> 2]);
     o0[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(a.y, (X + 1) & 3, o0[X >> 2]);
     o1[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(b.x, X & 3, o1[X >> 2]);
@@ -395,15 +283,14 @@ __device__ __forceinline__ void gj_color_row_pair(const GjColorLane<CS_FROM, CS_
     o2[X >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c.y, (X + 1) & 3, o2[X >> 2]);
 }
 
-// CONTRACT (GJ_COLOR_MFMA): all 64 lanes of the wave execute the call. L = the lane's operands, made once per kernel.
 template <int CS_FROM, int CS_TO>
-__device__ __forceinline__ void gj_color_row(const GjColorLane<CS_FROM, CS_TO>& L, const uint32_t (&px)[6], uint32_t (&o0)[2], uint32_t (&o1)[2], uint32_t (&o2)[2])
+__device__ __forceinline__ void gj_color_row(const uint32_t (&px)[6], uint32_t (&o0)[2], uint32_t (&o1)[2], uint32_t (&o2)[2])
 {
     o0[0] = o0[1] = o1[0] = o1[1] = o2[0] = o2[1] = 0;
-    gj_color_row_pair<CS_FROM, CS_TO, 0>(L, px, o0, o1, o2);
-    gj_color_row_pair<CS_FROM, CS_TO, 2>(L, px, o0, o1, o2);
-    gj_color_row_pair<CS_FROM, CS_TO, 4>(L, px, o0, o1, o2);
-    gj_color_row_pair<CS_FROM, CS_TO, 6>(L, px, o0, o1, o2);
+    gj_color_row_pair<CS_FROM, CS_TO, 0>(px, o0, o1, o2);
+    gj_color_row_pair<CS_FROM, CS_TO, 2>(px, o0, o1, o2);
+    gj_color_row_pair<CS_FROM, CS_TO, 4>(px, o0, o1, o2);
+    gj_color_row_pair<CS_FROM, CS_TO, 6>(px, o0, o1, o2);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -63,13 +63,3 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
     return v + d;
 }
 
-// (c == 255) as 0.0 / 1.0 for an integer c in [0, 255]: the clamp-to-[0, 1] output modifier on c - 254, one packed instruction per sample pair.
-// The result is an operand of a matrix instruction (gj_device.h, colour transform): a vector instruction's result may be read by an MFMA
-// two wait states later at the earliest. The compiler keeps that distance for instructions it knows, not for inline assembly (found on the
-// MI355X in round 5: the first pixel of every row took the register's previous contents) -- hence the s_nop inside.
-__device__ __forceinline__ gj_f2 gj_is255_f(gj_f2 v)
-{
-    gj_f2 d;
-    asm("v_pk_add_f32 %0, %1, %2 clamp\n\ts_nop 1" : "=v"(d) : "v"(v), "v"((gj_f2)-254.0f));
-    return d;
-}

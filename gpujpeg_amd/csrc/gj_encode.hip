@@ -206,11 +206,10 @@ __device__ __forceinline__ void gj_color_444(const gj_geom& g, const unsigned bx
     const int cols = exists ? min(8, max(0, g.width - (int)(bx * 8))) : 0, rows = exists ? min(8, max(0, g.height - (int)(by * 8))) : 0;
     const uint32_t m_lo = cols >= 4 ? 0xFFFFFFFFu : (1u << (8 * cols)) - 1u;
     const uint32_t m_hi = cols >= 8 ? 0xFFFFFFFFu : cols > 4 ? (1u << (8 * (cols - 4))) - 1u : 0u;
-    const GjColorLane<CS_FROM, CS_TO> CL;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         uint32_t o0[2], o1[2], o2[2];
-        gj_color_row<CS_FROM, CS_TO>(CL, px[r], o0, o1, o2);
+        gj_color_row<CS_FROM, CS_TO>(px[r], o0, o1, o2);
         if (!interior) {
             const uint32_t lo = r < rows ? m_lo : 0u, hi = r < rows ? m_hi : 0u;
             o0[0] &= lo; o0[1] &= hi; o1[0] &= lo; o1[1] &= hi; o2[0] &= lo; o2[1] &= hi;
@@ -242,11 +241,10 @@ __global__ __launch_bounds__(256, 2) void k_fused_rgb444(const gj_geom g, const 
     const gj_comp_geom& k0 = g.comp[0];
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
     const unsigned lb = blockIdx.x * 256u + threadIdx.x;
-    const bool exists = lb < nb; // (no early exit: the colour transform is a matrix instruction over the whole wave, gj_device.h)
+    if (lb >= nb) return;
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
     uint32_t pk[3][16]; // the three component blocks, one byte per sample
-    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, exists, pk);
-    if (!exists) return;
+    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, true, pk);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         uint32_t q[32];
@@ -1571,8 +1569,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
         gj_fdct_quant_zz(px, s_q[table ? 1 : 0], reinterpret_cast<uint8_t*>(s_coef) + i * 4);
         const uint64_t first_block = s_first_block;
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, sg.nblocks, table, g.interleaved ? (int)g.mcu_prev[mcu_pos] : 1, scan_segs - seg0,
-                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff,
-                                           (uint32_t)(scan_first + seg0));
+                                           temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(scan_first + seg0));
         // (workgroups are numbered in file order: the tiles of scan 0, of scan 1, ...)
         if (i == 0) gj_piece_put(T, blockIdx.x, size, (size_t)blockIdx.z * T.f_tail);
     }

@@ -34,10 +34,3 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
     return v + d;
 }
 
-__device__ __forceinline__ gj_f2 gj_is255_f(gj_f2 v)
-{
-    gj_f2 d = v + (gj_f2)-254.0f;
-    d.x = d.x < 0.0f ? 0.0f : (d.x > 1.0f ? 1.0f : d.x);
-    d.y = d.y < 0.0f ? 0.0f : (d.y > 1.0f ? 1.0f : d.y);
-    return d;
-}

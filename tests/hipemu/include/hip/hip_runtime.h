@@ -117,31 +117,6 @@ static inline int hipemu_bpermute(hipemu_site site, int addr, int x)
 static inline void hipemu_wave_barrier(hipemu_site site) { uint64_t m; (void)hipemu::wave_exchange(site, 0, &m); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier(HIPEMU_SITE)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
-/* v_mfma_f32_4x4x1_16b_f32: sixteen blocks of four lanes; block b computes D (4 x 4) = A (4 x 1) * B (1 x 4) + C with A[i] from lane 4 b + i,
- * B[j] from lane 4 b + j, and lane 4 b + j holding column j of C / D in four registers (row i in register i). One fused multiply-add per
- * element (the hardware's f32 MFMA is an fmaf chain). All 64 lanes take part (the instruction ignores EXEC): a lane missing at the
- * rendezvous is an error of the kernel, reported by wave_exchange like any divergent cross-lane operation. */
-typedef float hipemu_f4 __attribute__((ext_vector_type(4)));
-static inline hipemu_f4 hipemu_mfma_f32_4x4x1f32(hipemu_site site, float a, float b, hipemu_f4 c)
-{
-    uint64_t m;
-    uint32_t abits;
-    memcpy(&abits, &a, 4);
-    const uint64_t* v = hipemu::wave_exchange(site, abits, &m);
-    const int base = hipemu::lane_id() & ~3;
-    for (int i = 0; i < 4; i++) {
-        float ai = 0.0f;
-        if ((m >> (base + i)) & 1) {
-            const uint32_t w = (uint32_t)v[base + i];
-            memcpy(&ai, &w, 4);
-        } else {
-            ai = NAN; /* a lane of the block is not there: on the GPU its register would be read all the same -- make the mistake visible */
-        }
-        c[i] = fmaf(ai, b, c[i]);
-    }
-    return c;
-}
-#define __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, cbsz, abid, blgp) hipemu_mfma_f32_4x4x1f32(HIPEMU_SITE, (a), (b), (c))
 #define __builtin_amdgcn_s_sleep(n) sched_yield() /* a workgroup waiting for one on another OS thread */
 #define __threadfence() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)

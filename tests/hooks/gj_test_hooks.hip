@@ -10,14 +10,13 @@
 template <int CS_FROM, int CS_TO>
 __global__ __launch_bounds__(256) void k_test_color444(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const uint32_t nrows)
 {
-    const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, i = i0 < nrows ? i0 : nrows - 1; // (every lane stays: gj_color_row's contract)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nrows) return;
     uint32_t px[6], o0[2], o1[2], o2[2];
     const uint2* p = reinterpret_cast<const uint2*>(in + (size_t)i * 24);
     const uint2 a = p[0], b = p[1], c = p[2];
     px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; px[4] = c.x; px[5] = c.y;
-    const GjColorLane<CS_FROM, CS_TO> CL;
-    gj_color_row<CS_FROM, CS_TO>(CL, px, o0, o1, o2);
-    if (i0 >= nrows) return;
+    gj_color_row<CS_FROM, CS_TO>(px, o0, o1, o2);
     const size_t plane = (size_t)nrows * 8;
     *reinterpret_cast<uint2*>(out + (size_t)i * 8) = make_uint2(o0[0], o0[1]);
     *reinterpret_cast<uint2*>(out + plane + (size_t)i * 8) = make_uint2(o1[0], o1[1]);
@@ -39,27 +38,3 @@ extern "C" __attribute__((visibility("default"))) int gj_test_color444(int cs_fr
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-
-// v_mfma_f32_4x4x1_16b_f32 with given per-lane operands: what lands where (tests/test_gpu_parity.py::test_mfma_4x4x1_layout pins the
-// operand layout gj_device.h's colour transform relies on). `via_asm`: the B operand comes out of an inline-assembly instruction right
-// in front of the matrix instruction, as in the product (hazards between the two are the compiler's business).
-__global__ __launch_bounds__(64) void k_test_mfma4x4(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ out,
-                                                     const int via_asm)
-{
-    const int l = threadIdx.x;
-    const float av = a[l];
-    float bv = b[l];
-    gj_f4 acc = gj_f4{c[l * 4], c[l * 4 + 1], c[l * 4 + 2], c[l * 4 + 3]};
-    if (via_asm) {
-        gj_f2 t = gj_f2{bv + 254.0f, bv + 254.0f};
-        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(t) : "v"(t), "v"((gj_f2)-254.0f));
-        bv = t.x;
-    }
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc, 0, 0, 0);
-    out[l * 4] = acc.x; out[l * 4 + 1] = acc.y; out[l * 4 + 2] = acc.z; out[l * 4 + 3] = acc.w;
-}
-extern "C" __attribute__((visibility("default"))) int gj_test_mfma4x4(const float* d_a, const float* d_b, const float* d_c, float* d_out, int via_asm, gj_stream_t stream)
-{
-    hipLaunchKernelGGL(k_test_mfma4x4, dim3(1), dim3(64), 0, (hipStream_t)stream, d_a, d_b, d_c, d_out, via_asm);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}

@@ -998,7 +998,6 @@ struct GjTail {
     // frame batch (gj_enc_job::batch: blockIdx.z = frame): what lies between the buffers of two frames; all zero for a single frame
     uint64_t f_raw, f_temp, f_jpeg; // bytes
     uint32_t f_seg, f_tail;         // words of seg_bytes / seg_ff, of the tile list and of the group totals
-    uint32_t stagger, stagger_below; // k_encode_rgb444: workgroups below `stagger_below` start stagger x 512 cycles x (their wave slot) late (0: none)
 };
 
 __device__ __forceinline__ uint32_t gj_pick4(const uint32_t (&a)[GJ_MAX_COMP], const uint32_t s)
@@ -1212,13 +1211,6 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
 
     const int i = threadIdx.x;
     GJ_TRACE_E(0);
-    if (!ONE_COMPONENT && T.stagger && blockIdx.x < T.stagger_below) {
-        // A lone frame's first generation: all workgroups of a CU would ask for their pixels in the same microsecond and then wait ~9 us for the
-        // same 50 MB burst with idle ALUs. The k-th workgroup a CU received sits in wave slot k of its SIMDs (HW_ID bits 3:0): it waits k steps,
-        // so the first one has its pixels (and the CU to itself) while the others' loads are on their way.
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u;
-        for (uint32_t r = 0; r < slot * T.stagger; r++) __builtin_amdgcn_s_sleep(8);
-    }
     gj_load_coder_lut(s_lut, lut, i);
     if (i < 192) s_q[i >> 6][i & 63] = (g.comp[i >> 6].type ? q_chroma : q_luma)[i & 63];
     // frame blockIdx.z of a batch (gj_enc_job::batch; strides zero for a single frame)
@@ -1803,10 +1795,6 @@ static GjTail gj_make_tail(const gj_enc_job* job, const unsigned pieces, const u
     T.f_jpeg = batch ? job->batch.jpeg : 0;
     T.f_seg = batch ? job->batch.seg : 0;
     T.f_tail = batch ? job->batch.tail : 0;
-    // (only where a single launch fills the device more than once: batches and small frames start as they are)
-    const unsigned resident = (unsigned)gj_hip_cu_count() * 4u;
-    T.stagger = (!batch && job->tune.enc_stagger > 0 && pieces / 3u > resident) ? (uint32_t)job->tune.enc_stagger : 0u;
-    T.stagger_below = resident;
     return T;
 }
 

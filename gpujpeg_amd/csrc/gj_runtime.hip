@@ -160,5 +160,4 @@ extern "C" void gj_hip_tuning_from_env(gj_tuning* t)
     t->dec_balance = (e = getenv("GJ_DEC_BALANCE")) && e[0] == '1';
     t->enc_split = (e = getenv("GJ_ENC_SPLIT")) ? atoi(e) : -1;
     t->dec_fill = (e = getenv("GJ_DEC_FILL")) ? atoi(e) : 0;
-    t->enc_stagger = (e = getenv("GJ_ENC_STAGGER")) ? atoi(e) : 0;
 }

@@ -140,8 +140,6 @@ typedef struct gj_tuning {
     int dec_tok_nocoop;  /* GJ_DEC_TOK_NOCOOP=1: the token-mode entropy decoder copies its batch segment by segment instead of as one piece (A/B) */
     int enc_by_blocks;   /* GJ_ENC_BLOCKS: packed RGB 4:4:4 through k_encode_blocks (a workgroup codes one component of its tile: three times the
                             workgroups, a third of the work each) 1 = always, -1 = never, 0 = small frames only */
-    int enc_stagger;     /* GJ_ENC_STAGGER=<n>: the first generation of k_encode_rgb444's workgroups of a lone frame starts its pixel burst n x 0.21 us x
-                            (wave slot of the workgroup on its SIMD) late, so that the CU's first workgroup computes while the others still load (0 = off) */
     int dec_fill;        /* GJ_DEC_FILL=<32nds>: how full the sub-sequence decoders' LDS stage is planned on average (default 23, up to 27 when that keeps
                             a single frame within one generation of workgroups); A/B runs of the batch plan */
     int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that

@@ -117,7 +117,6 @@ static inline int hipemu_bpermute(hipemu_site site, int addr, int x)
 static inline void hipemu_wave_barrier(hipemu_site site) { uint64_t m; (void)hipemu::wave_exchange(site, 0, &m); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier(HIPEMU_SITE)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
-#define __builtin_amdgcn_s_getreg(imm) 0 /* (hardware registers: wave slot, XCC id ... -- performance hints only) */
 #define __builtin_amdgcn_s_sleep(n) sched_yield() /* a workgroup waiting for one on another OS thread */
 #define __threadfence() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)

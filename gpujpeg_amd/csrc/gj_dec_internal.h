@@ -55,6 +55,19 @@ GjBatchPlan gj_plan_batches(const gj_dec_job* job, unsigned cap_u, unsigned max_
 #define GJ_TOK_RESIDENT ((unsigned)gj_hip_cu_count() * 4u)  // workgroups of the token decoder the GPU holds at once (MI355X: 256 CUs x 4)
 #define GJ_TOK_GMAX 64         // segments per batch
 
+// ---- what k_marker_scan leaves per scanning workgroup (gj_dec_markers.hip), read by k_marker_table and -- when the table launch is folded into it --
+// by k_huffman_decode_tok
+#define GJ_SCAN_LIST 2048    // restart markers a workgroup may hold (beyond that the host walks the stream)
+#define GJ_SCAN_REC_WORDS 16 // 32-bit words of a record (layout: gj_dec_markers.hip)
+struct GjOther { uint32_t pos, code, after, b03, b47; }; // a marker that is no restart marker: position, code, restart markers of its workgroup behind it, the 8 bytes behind the code
+// other marker q (0, 1) of a record whose words 4 .. 15 are r1, r2, r3
+__device__ __forceinline__ GjOther gj_rec_other(const uint4& r1, const uint4& r2, const uint4& r3, const uint32_t q)
+{
+    return q == 0 ? GjOther{r1.x, r1.y, r1.z, r1.w, r2.x} : GjOther{r2.z, r2.w, r3.x, r3.y, r3.z};
+}
+// the 16 bits behind the code: the length of the marker's segment (big-endian in the stream)
+__device__ __forceinline__ uint32_t gj_other_len(const GjOther& o) { return ((o.b03 & 0xFFu) << 8) | ((o.b03 >> 8) & 0xFFu); }
+
 // ---- IDCT side
 typedef void (*gj_idct_tok_t)(const gj_geom, const int16_t*, const uint2*, const uint16_t*, uint32_t, const float*, uint8_t*);
 gj_idct_tok_t gj_idct_tok_for(const gj_geom& g); // the token-fed IDCT kernel for this configuration, or nullptr

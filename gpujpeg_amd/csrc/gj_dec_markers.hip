@@ -32,13 +32,13 @@ extern "C" GJ_HIP_API int gj_hip_trace_set_markers(void* p) { return hipMemcpyTo
 #else
 #define GJ_TRACE_M(slot) ((void)0)
 #endif
-#define GJ_SCAN_LIST 2048    // restart markers a workgroup may hold (beyond that the host walks the stream)
+// (GJ_SCAN_LIST, GJ_SCAN_REC_WORDS and the records' other-marker layout: gj_dec_internal.h -- the token decoder reads them too)
 #define GJ_SCAN_WGS 256      // workgroups (= records every workgroup reads in one pass) up to 16 MB of stream
 #define GJ_SCAN_WGS_MAX 1024 // ... of one round of 16 pieces each up to 64 MB (k_marker_table reads their records in passes of 256); rounds beyond
-#define GJ_SCAN_REC_WORDS 16 // 32-bit words of a record:
+// (GJ_SCAN_REC_WORDS = 16, gj_dec_internal.h) 32-bit words of a record:
 //   [0] restart markers   [1] position of the last one   [2] other markers (0 .. 2)   [3] 1 = more restart markers than the list holds / more
-//   than two other markers   [4 + 4 q ..] other marker q: position, code, the 16 bits behind the code (segment length), restart markers of
-//   the workgroup behind it
+//   than two other markers   [4 + 6 q ..] other marker q: position, code, restart markers of the workgroup behind it, the 8 bytes behind the
+//   code (what the host validates of an SOS header: length, component, tables, spectral selection), one spare word
 
 // the frames of a batch (blockIdx.z = frame): sizes == nullptr for a single stream
 struct GjScanBatch {
@@ -182,13 +182,17 @@ __global__ __launch_bounds__(256) void k_marker_scan(const uint8_t* __restrict__
     const bool too_many = total > (uint32_t)GJ_SCAN_LIST;
     const uint32_t n_own = min(s_own_other, 2u);
     const bool swap = n_own > 1 && s_own_q[1] < s_own_q[0];
-    if (tid < 2 && (uint32_t)tid < n_own) { // code and the 16 bits behind it
+    if (tid < 2 && (uint32_t)tid < n_own) { // code and the 8 bytes behind it
         const int src = swap ? 1 - tid : tid;
         const uint32_t q = s_own_q[src];
-        rec[4 + 4 * tid] = q;
-        rec[5 + 4 * tid] = jpeg[q + 1];
-        rec[6 + 4 * tid] = ((q + 2 < size ? (uint32_t)jpeg[q + 2] : 0u) << 8) | (q + 3 < size ? (uint32_t)jpeg[q + 3] : 0u);
-        rec[7 + 4 * tid] = s_own_after[src];
+        uint32_t b[2] = {0, 0};
+        for (int k = 0; k < 8; k++)
+            if ((uint64_t)q + 2 + k < size) b[k >> 2] |= (uint32_t)jpeg[q + 2 + k] << (8 * (k & 3));
+        rec[4 + 6 * tid] = q;
+        rec[5 + 6 * tid] = jpeg[q + 1];
+        rec[6 + 6 * tid] = s_own_after[src];
+        rec[7 + 6 * tid] = b[0];
+        rec[8 + 6 * tid] = b[1];
     }
     if (tid == 2) {
         rec[0] = total;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uin
     __shared__ uint32_t s_mpos[GJ_SCAN_LIST];              // the workgroup's restart markers in order: offset in its part | code & 7 << 24
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_opos[GJ_SCAN_MAX_OTHER], s_ocode[GJ_SCAN_MAX_OTHER], s_olen[GJ_SCAN_MAX_OTHER], s_orank[GJ_SCAN_MAX_OTHER]; // other markers so far
+    __shared__ uint32_t s_ob[GJ_SCAN_MAX_OTHER][2];                                                                                  // ... the 8 bytes behind their codes
     __shared__ uint32_t s_nother, s_own_slot[2], s_own_after[2], s_own_n, s_tot;
     __shared__ int s_prev_wg;
     __shared__ uint32_t s_prev_last, s_maxlen, s_before, s_bad;
@@ -247,12 +252,13 @@ __global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uin
     for (uint32_t base = 0; base <= me; base += 256) {
         const uint32_t i = base + (uint32_t)tid;
         const bool have = i <= me;
-        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
         if (have) {
             const uint4* r4 = reinterpret_cast<const uint4*>(recs + (size_t)i * GJ_SCAN_REC_WORDS);
             r0 = r4[0];
             r1 = r4[1];
             r2 = r4[2];
+            r3 = r4[3];
         }
         const uint32_t n = r0.x, no = min(r0.z, 2u);
         if (have && r0.w) s_bad = 1;
@@ -262,15 +268,17 @@ __global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uin
         if (have && i < me && n) atomicMax(&s_prev_wg, (int)i);
         if (have)
             for (uint32_t q = 0; q < no; q++) {
-                const uint4 o = q == 0 ? r1 : r2; // position, code, length, restart markers behind it
+                const GjOther o = gj_rec_other(r1, r2, r3, q); // position, code, restart markers behind it, the 8 bytes behind the code
                 const uint32_t slot = oincl - no + q;
                 if (slot < GJ_SCAN_MAX_OTHER) {
-                    s_opos[slot] = o.x;
-                    s_ocode[slot] = o.y & 0xFFu;
-                    s_olen[slot] = o.z & 0xFFFFu;
-                    s_orank[slot] = incl - o.w; // restart markers in front of it
+                    s_opos[slot] = o.pos;
+                    s_ocode[slot] = o.code & 0xFFu;
+                    s_olen[slot] = gj_other_len(o);
+                    s_orank[slot] = incl - o.after; // restart markers in front of it
+                    s_ob[slot][0] = o.b03;
+                    s_ob[slot][1] = o.b47;
                 }
-                if (i == me) { s_own_slot[q] = slot; s_own_after[q] = o.w; }
+                if (i == me) { s_own_slot[q] = slot; s_own_after[q] = o.after; }
             }
         if (have && i == me) { s_before = incl - n; s_nother = oincl; s_own_n = no; s_tot = n; }
         __syncthreads();
@@ -369,9 +377,7 @@ __global__ __launch_bounds__(256) void k_marker_table(const gj_geom g, const uin
         // what the host validates about it
         hsum->other_pos[slot] = p;
         hsum->other_code[slot] = (uint8_t)s_ocode[slot];
-        uint32_t ob[4] = {0, 0, 0, 0}; // (whole words to the host's memory)
-        for (int b = 0; b < 16; b++)
-            if ((uint64_t)p + 2 + b < size) ob[b >> 2] |= (uint32_t)jpeg[p + 2 + b] << (8 * (b & 3));
+        const uint32_t ob[4] = {s_ob[slot][0], s_ob[slot][1], 0, 0}; // (whole words to the host's memory; the host looks at the first eight bytes)
         for (int q = 0; q < 4; q++) reinterpret_cast<uint32_t*>(hsum->other_bytes[slot])[q] = ob[q];
         hsum->other_after[slot] = s_own_after[tid];
     }

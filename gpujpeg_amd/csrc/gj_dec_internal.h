@@ -29,6 +29,11 @@ static inline void gj_debug_stage(const bool on, hipStream_t st, const char* wha
     fprintf(stderr, "[GPUJPEG] [Debug] %s: %s\n", what, hipGetErrorString(e));
 }
 
+// ---- the marker scan's second launch when it was left to gj_hip_decode (gj_dec_job::scan)
+void gj_launch_marker_table_deferred(const gj_dec_job* job, hipStream_t st);
+// does gj_launch_huffman_tok derive its batches' table entries from the scan's records itself (no k_marker_table launch)?
+bool gj_tok_folds_table(const gj_dec_job* job);
+
 // ---- entropy decoders: each launches its kernel for the whole segment table of the job
 void gj_launch_huffman_serial(const gj_dec_job* job, hipStream_t st);
 void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st);

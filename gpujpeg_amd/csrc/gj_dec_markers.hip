@@ -428,11 +428,51 @@ extern "C" int gj_hip_find_segments(const gj_geom* g, const uint8_t* d_jpeg, uin
                                       h_maxlen_parts, maxlen_capacity, maxlen_part_count, stream, tune, nullptr);
 }
 
+static int gj_find_segments_impl(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                 uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                 gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
+                                 uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
+                                 const gj_tuning* tune, const gj_batch* batch, gj_scan_deferred* defer);
+
 extern "C" int gj_hip_find_segments_batch(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
                                           uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
                                           gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
                                           uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
                                           const gj_tuning* tune, const gj_batch* batch)
+{
+    return gj_find_segments_impl(g, d_jpeg, begin, size, d_seg_pos, d_seg_len, d_seg_index, max_segments, d_scratch, d_summary, d_hdr_ref, hdr_n, h_summary,
+                                 h_maxlen_parts, maxlen_capacity, maxlen_part_count, stream, tune, batch, nullptr);
+}
+
+extern "C" int gj_hip_find_segments_deferred(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                             uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                             gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
+                                             uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
+                                             const gj_tuning* tune, gj_scan_deferred* defer)
+{
+    defer->valid = 0;
+    return gj_find_segments_impl(g, d_jpeg, begin, size, d_seg_pos, d_seg_len, d_seg_index, max_segments, d_scratch, d_summary, d_hdr_ref, hdr_n, h_summary,
+                                 h_maxlen_parts, maxlen_capacity, maxlen_part_count, stream, tune, nullptr, defer);
+}
+
+// the second launch of the scan: from gj_find_segments_impl, or later from gj_hip_decode (gj_scan_deferred)
+void gj_launch_marker_table(const gj_geom* g, const uint8_t* d_jpeg, const gj_scan_deferred* sc, const GjScanBatch& B, unsigned frames, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_marker_table, dim3(sc->wgs, 1, frames), dim3(256), 0, st, *g, d_jpeg, sc->begin, sc->size, sc->part_bytes, sc->recs, sc->lists, sc->h_maxlen_parts,
+                       sc->d_summary, sc->h_summary, sc->d_seg_pos, sc->d_seg_len, sc->d_seg_index, sc->max_segments + GJ_MAX_COMP, B);
+}
+void gj_launch_marker_table_deferred(const gj_dec_job* job, hipStream_t st)
+{
+    const GjScanBatch B = {nullptr, 0, 0, 0, 0};
+    gj_launch_marker_table(&job->g, job->d_jpeg, &job->scan, B, 1, st);
+    gj_debug_stage(job->tune.debug_sync != 0, st, "k_marker_table (deferred)");
+}
+
+static int gj_find_segments_impl(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                 uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                 gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
+                                 uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
+                                 const gj_tuning* tune, const gj_batch* batch, gj_scan_deferred* defer)
 {
     hipStream_t st = (hipStream_t)stream;
     GjScanBatch B = {nullptr, 0, 0, 0, 0};
@@ -469,8 +509,21 @@ extern "C" int gj_hip_find_segments_batch(const gj_geom* g, const uint8_t* d_jpe
     auto kern = iters == 1 ? k_marker_scan<1> : iters == 2 ? k_marker_scan<2> : iters == 4 ? k_marker_scan<4> : iters == 8 ? k_marker_scan<8> : k_marker_scan<16>;
     hipLaunchKernelGGL(kern, dim3(wgs, 1, frames), dim3(256), 0, st, d_jpeg, begin, size, rounds, recs, lists, h_summary, d_hdr_ref, hdr_n, B);
     gj_debug_stage(tune->debug_sync != 0, st, "k_marker_scan");
-    hipLaunchKernelGGL(k_marker_table, dim3(wgs, 1, frames), dim3(256), 0, st, *g, d_jpeg, begin, size, (uint32_t)part, recs, lists, h_maxlen_parts, d_summary, h_summary, d_seg_pos,
-                       d_seg_len, d_seg_index, max_segments + GJ_MAX_COMP, B);
+    gj_scan_deferred sc;
+    sc.valid = 1;
+    sc.wgs = wgs; sc.part_bytes = (uint32_t)part;
+    sc.begin = begin; sc.size = size;
+    sc.recs = recs; sc.lists = lists;
+    sc.d_seg_pos = d_seg_pos; sc.d_seg_len = d_seg_len; sc.d_seg_index = d_seg_index;
+    sc.max_segments = max_segments;
+    sc.d_summary = d_summary; sc.h_summary = h_summary;
+    sc.h_maxlen_parts = h_maxlen_parts; sc.maxlen_capacity = maxlen_capacity; sc.maxlen_part_count = maxlen_part_count;
+    sc.folded = nullptr;
+    if (defer != nullptr && frames == 1 && wgs <= 256u) { // (the token decoder reads the records of up to 256 scanning workgroups in one pass)
+        *defer = sc;
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    gj_launch_marker_table(g, d_jpeg, &sc, B, frames, st);
     gj_debug_stage(tune->debug_sync != 0, st, "k_marker_table");
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -74,6 +74,8 @@ struct gpujpeg_decoder {
     uint8_t* b_gather; size_t b_gather_cap;        /* streams given as separate buffers (decode_batch_ptrs), gathered 16-byte aligned */
     uint8_t* b_scatter; size_t b_scatter_cap;      /* ... and the frames decoded back to back before they go to separate buffers */
     int b_last_batched, b_last_single;             /* frames of the last batch call that the batched launches decoded / that went the ordinary way */
+    int last_folded;                               /* the last decode call did without the k_marker_table launch (gj_scan_deferred) */
+    long n_spec, n_folded, n_again;                /* calls launched on the cached header / of those without the table launch / decoded again the careful way */
     int b_chunk;                                   /* gpujpeg_amd_decoder_set_batch_chunk: frames per launch at most, 0 = the default */
 };
 
@@ -320,6 +322,8 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     int seg_count = 0;
     const uint32_t* d_seg_count = NULL;
     gj_scan_summary* sum_cur = d->d_summary;
+    gj_scan_deferred scan_deferred;
+    memset(&scan_deferred, 0, sizeof scan_deferred);
     const size_t S = (size_t)g->segment_count + GJ_MAX_COMP;
     if (gj_ensure_device_buffer((void**)&d->d_seg, &d->d_seg_cap, (S * 4 + 8) * sizeof(uint32_t)) != 0) goto out;
     if (device_scan) {
@@ -328,7 +332,9 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         /* (a speculative launch on a device-resident stream has its header compared with the cached one by the scan's first kernel) */
         const bool cmp = spec && jpeg_on_device;
         /* the kernels write what the host validates straight into pinned host memory */
-        const size_t max_chunks = gj_hip_find_segments_max_chunks(r.scan_begin[0], image_size);
+        /* (a word per scanning workgroup, or -- when the table launch is folded into the token decoder -- per batch of that kernel: at most a few thousand) */
+        size_t max_chunks = gj_hip_find_segments_max_chunks(r.scan_begin[0], image_size);
+        if (max_chunks < 4096) max_chunks = 4096;
         int frc = 0;
         if (max_chunks * sizeof(uint32_t) > d->h_maxlen_cap) {
             gj_hip_host_free(d->h_maxlen);
@@ -341,7 +347,12 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         d->h_summary->header_differs = 0;
         GJ_HT(c, 0);
         if (stats) gj_hip_event_record(c->timers.ev[4], c->stream); /* (the marker scan is GPU time of this call: events 4 and 5 bracket it) */
-        if (frc == 0)
+        /* speculative launches leave the scan's second launch to gj_hip_decode: the token decoder does without it (gj_scan_deferred) */
+        if (frc == 0 && spec)
+            frc = gj_hip_find_segments_deferred(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
+                                                d->d_scan_scratch, sum_cur, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, d->h_summary,
+                                                d->h_maxlen, (uint32_t)(d->h_maxlen_cap / sizeof(uint32_t)), &d->maxlen_parts, c->stream, &d->tune, &scan_deferred);
+        else if (frc == 0)
             frc = gj_hip_find_segments(g, d_jpeg, r.scan_begin[0], image_size, d->d_seg, d->d_seg + S, d->d_seg + 2 * S, (uint32_t)g->segment_count,
                                        d->d_scan_scratch, sum_cur, cmp ? d->d_hdr_cache : NULL, cmp ? (uint32_t)d->hdr_cache_len : 0u, d->h_summary,
                                        d->h_maxlen, (uint32_t)(d->h_maxlen_cap / sizeof(uint32_t)), &d->maxlen_parts, c->stream, &d->tune);
@@ -471,6 +482,10 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     job.d_seg_index = d->d_seg + 2 * S;
     job.seg_count = seg_count;
     job.d_seg_count = d_seg_count;
+    job.scan = scan_deferred;
+    d->last_folded = 0;
+    job.scan.folded = &d->last_folded;
+    if (spec) d->n_spec++;
     job.d_huff_tab = d->d_huff_tab;
     job.d_qtab = d->d_qtab;
     job.d_qtabf = (const float*)(const void*)(d->d_huff_tab + GJ_TABS_QF_OFFSET);
@@ -565,6 +580,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
     } else {
         output->data = d_raw;
     }
+    if (d->last_folded) d->n_folded++;
     GJ_HT(c, 1);
     if (gj_hip_stream_sync(c->stream) != 0) {
         GJ_ERROR("Decoder failed: %s\n", gj_hip_last_error());
@@ -587,6 +603,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         for (int i = 0; ok && i < g->comp_count; i++)
             if (chk.huff_map[i][0] != r.huff_map[i][0] || chk.huff_map[i][1] != r.huff_map[i][1]) ok = false;
         if (!ok) { /* different header or unusual scan structure: decode again the careful way */
+            d->n_again++;
             const bool overflow_only = d->h_summary->seq_overflow != 0 && d->h_summary->header_differs == 0;
             if (overflow_only) d->need_planes = true; /* (the header was the assumed one: it stays cached, the next frames launch on it with the other kernels) */
             else d->hdr_cache_valid = false;
@@ -1068,6 +1085,15 @@ void gpujpeg_decoder_print_options(void)
 /* ------------------------------------------------------------------ MI355X extensions (include/gpujpeg_amd_ext.h) */
 
 void gpujpeg_amd_decoder_set_batch_chunk(struct gpujpeg_decoder* d, int frames) { if (d) d->b_chunk = frames > 0 ? frames : 0; }
+
+int gpujpeg_amd_decoder_get_path_counters(struct gpujpeg_decoder* d, long counters[3])
+{
+    if (!d || !counters) return -1;
+    counters[0] = d->n_spec;
+    counters[1] = d->n_folded;
+    counters[2] = d->n_again;
+    return 0;
+}
 
 int gpujpeg_amd_decoder_last_batch(struct gpujpeg_decoder* d, int* batched, int* single)
 {

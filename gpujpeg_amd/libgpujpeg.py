@@ -380,6 +380,13 @@ class Decoder:
         raw = self.lib.image_size(pi)
         return [out[i * bound:i * bound + raw].copy() for i in range(n)], pi
 
+    def path_counters(self):
+        """(speculative launches, of those without the k_marker_table launch, decoded again the careful way) of this decoder so far"""
+        a = (C.c_long * 3)()
+        self.lib.L.gpujpeg_amd_decoder_get_path_counters.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        assert self.lib.L.gpujpeg_amd_decoder_get_path_counters(self.h, a) == 0
+        return tuple(int(x) for x in a)
+
     def stats(self):
         s = DurationStats()
         self.lib.L.gpujpeg_decoder_get_stats(self.h, C.byref(s))

@@ -209,6 +209,29 @@ GJ_HIP_API int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
 
 
 /* ------------------------------------------------------------------ decoder */
+/* A marker scan whose SECOND launch (k_marker_table: records -> segment table) has been left to gj_hip_decode (gj_hip_find_segments_deferred:
+ * speculative single-frame launches). k_huffman_decode_tok derives the table entries of its batches from the scan's records itself and writes the
+ * summary the host validates -- one launch and ~11 us less per decoded frame --; for any other entropy decoder gj_hip_decode launches k_marker_table
+ * first, with the arguments kept here. valid = 0: the table has been written (gj_hip_find_segments). */
+struct gj_scan_summary;
+typedef struct gj_scan_deferred {
+    int valid;
+    uint32_t wgs, part_bytes;      /* scanning workgroups (<= 256) and the bytes of the stream each of them took */
+    uint64_t begin, size;
+    const uint32_t* recs;          /* [wgs] records, [wgs] marker lists (d_scratch of the scan) */
+    const uint32_t* lists;
+    uint32_t* d_seg_pos;           /* where k_marker_table writes, should it be launched after all */
+    uint32_t* d_seg_len;
+    uint32_t* d_seg_index;
+    uint32_t max_segments;
+    struct gj_scan_summary* d_summary;
+    struct gj_scan_summary* h_summary; /* pinned host memory */
+    uint32_t* h_maxlen_parts;      /* pinned host memory: the longest segment per scanning workgroup (table launch) or per entropy-decoder batch (folded) */
+    uint32_t maxlen_capacity;
+    uint32_t* maxlen_part_count;   /* host: how many of those words the launch that ran has written */
+    int* folded;                   /* host, may be NULL: set to 1 by gj_hip_decode when the table launch was folded into the entropy decoder, to 0 otherwise */
+} gj_scan_deferred;
+
 typedef struct gj_dec_job {
     gj_geom g;                     /* pixel_format / color_space describe the requested output */
     const uint8_t* d_jpeg;         /* whole file in HBM */
@@ -245,6 +268,7 @@ typedef struct gj_dec_job {
     uint32_t tok_cap;              /* >= 4 x jpeg_size (tokens) */
     void* d_blkrec;                /* [g.block_count] uint2 per block in coding order: first token, count << 16 | (uint16) DC term;
                                       count 0xFFFF = the block is in d_coefs (segment decoded piece by piece) */
+    gj_scan_deferred scan;         /* valid: the segment table has not been written yet (see gj_scan_deferred) */
     gj_batch batch;                /* count > 1: a batch of frames with the same header (speculative launches only: d_seg_count and d_overflow
                                       point to frame 0's words inside arrays of gj_scan_summary) */
 } gj_dec_job;
@@ -319,6 +343,14 @@ GJ_HIP_API int gj_hip_find_segments_batch(const gj_geom* g, const uint8_t* d_jpe
                                           gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
                                           uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
                                           const gj_tuning* tune, const gj_batch* batch);
+/* gj_hip_find_segments for ONE frame whose table launch may be left to gj_hip_decode: launches k_marker_scan, and k_marker_table only when the scan has
+ * more than 256 workgroups (streams beyond 16 MB); otherwise *defer describes the pending launch (defer->valid = 1) for gj_dec_job::scan. The caller must
+ * decode with that job on the same stream next -- nothing else writes the table. */
+GJ_HIP_API int gj_hip_find_segments_deferred(const gj_geom* g, const uint8_t* d_jpeg, uint64_t begin, uint64_t size, uint32_t* d_seg_pos,
+                                             uint32_t* d_seg_len, uint32_t* d_seg_index, uint32_t max_segments, uint32_t* d_scratch,
+                                             gj_scan_summary* d_summary, const uint8_t* d_hdr_ref, uint32_t hdr_n, gj_scan_summary* h_summary,
+                                             uint32_t* h_maxlen_parts, uint32_t maxlen_capacity, uint32_t* maxlen_part_count, gj_stream_t stream,
+                                             const gj_tuning* tune, gj_scan_deferred* defer);
 /* workgroups the marker scan cuts [begin, size) into at most (capacity of h_maxlen_parts) */
 GJ_HIP_API size_t gj_hip_find_segments_max_chunks(uint64_t begin, uint64_t size);
 

@@ -104,6 +104,10 @@ GPUJPEG_API void gpujpeg_amd_decoder_set_batch_chunk(struct gpujpeg_decoder* dec
 /* how the frames of the last batch call were coded: by the batched launches / frame by frame inside the call (tests, benchmarks) */
 GPUJPEG_API int gpujpeg_amd_encoder_last_batch(struct gpujpeg_encoder* encoder, int* batched, int* single);
 GPUJPEG_API int gpujpeg_amd_decoder_last_batch(struct gpujpeg_decoder* decoder, int* batched, int* single);
+/* how the decode calls of this decoder ran so far (tests, benchmarks): [0] launched speculatively on the cached header of the previous frame,
+ * [1] of those, without the marker scan's second launch (the token decoder derived its segment table from the scan's records itself),
+ * [2] speculative launches whose stream turned out not to be what was assumed and that were decoded again the careful way */
+GPUJPEG_API int gpujpeg_amd_decoder_get_path_counters(struct gpujpeg_decoder* decoder, long counters[3]);
 GPUJPEG_API int gpujpeg_amd_decoder_decode_batch(struct gpujpeg_decoder* decoder, const uint8_t* streams, size_t stream_stride, const size_t* sizes,
                                                  int count, uint8_t* output, size_t output_stride, struct gpujpeg_image_parameters* param_image);
 

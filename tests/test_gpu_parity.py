@@ -494,6 +494,75 @@ def test_token_mode_decoder(O, G, gpu_lib, tc, monkeypatch):
     dec.close()
 
 
+FOLD_CASES = [
+    # name, w, h, quality, restart, pattern -- non-interleaved RGB 4:4:4 through k_huffman_decode_tok on the speculative path
+    ("natural_auto", 1920, 136, 75, -1, "natural"),
+    ("natural_q90_odd", 1119, 561, 90, 12, "natural"),
+    ("noise_q75", 640, 368, 75, -1, "noise"),
+    ("tiny_segments_r1", 320, 64, 30, 1, "natural"),  # ~1000 restart markers per scanning workgroup
+    ("flat", 640, 480, 75, 36, "flat"),
+    ("one_segment_per_scan", 64, 32, 75, 40, "natural"),  # no restart marker at all: every scan is its own last segment
+]
+
+
+@pytest.mark.parametrize("fc", FOLD_CASES, ids=[c[0] for c in FOLD_CASES])
+def test_token_decoder_without_the_table_launch(O, G, gpu_lib, fc, monkeypatch):
+    """Frames of a sequence (one header) on one decoder: from the second one on the launch is speculative and the token decoder derives its batches'
+    segment table from the marker scan's records itself -- no k_marker_table launch (gj_scan_deferred, round 5). Pixels equal the oracle's; streams
+    that are NOT the complete, regular stream the geometry describes (restart markers out of sequence, missing, surplus; no EOI; a stranger's header)
+    are noticed on the device and decoded again the careful way, with the result a fresh decoder gives."""
+    name, w, h, q, ri, pattern = fc
+    case = (name, w, h, 1, 1, q, ri, 0, None, 3)
+    img = oracle_image(O, case)
+
+    def frame(seed):
+        if pattern == "noise":
+            return O.noise(w * h * 3, seed=seed)
+        if pattern == "flat":
+            return np.full(w * h * 3, 60 + seed % 100, np.uint8)
+        return natural_image(w, h, 3, seed=seed)
+
+    streams = [O.encode(img, frame(40 + f)) for f in range(4)]
+    monkeypatch.setenv("GJ_DEC_TOKENS", "1")
+    dec = G.Decoder(gpu_lib)
+    for rnd in range(2):
+        for f, jpeg in enumerate(streams):
+            assert np.array_equal(dec.decode(jpeg)[0], O.decode(jpeg)[0]), (rnd, f)
+    spec, folded, again = dec.path_counters()
+    # (a stream whose three scan-ending markers all lie in ONE scanning workgroup's part -- a few KB: the last two cases -- is walked by the host and
+    # never launches speculatively: a scanning workgroup's record holds two markers that are no restart markers)
+    assert spec == (0 if name in ("tiny_segments_r1", "one_segment_per_scan") else 7) and again == 0, (spec, folded, again)
+    assert folded == spec, "every speculative launch of this geometry does without the table kernel"
+    # ---- streams the geometry does not describe, on the speculative path
+    jpeg = streams[1]
+    pos = [i for i in range(len(jpeg) - 1) if jpeg[i] == 0xFF and 0xD0 <= jpeg[i + 1] <= 0xD7]
+    bad = []
+    if len(pos) >= 4:
+        a = jpeg.copy(); a[pos[1] + 1], a[pos[2] + 1] = a[pos[2] + 1], a[pos[1] + 1]; bad.append(("swapped numbers", a))
+        b = np.delete(jpeg, [pos[len(pos) // 2], pos[len(pos) // 2] + 1]); bad.append(("missing marker", b))
+        c = np.insert(jpeg, pos[-1], [0xFF, 0xD0 + ((jpeg[pos[-1] + 1] - 0xD0 + 7) % 8)]); bad.append(("surplus marker", c))
+    bad.append(("no EOI", jpeg[:-2].copy()))
+    other = O.encode(oracle_image(O, ("o", w, h, 1, 1, max(10, q - 20), ri, 0, None, 3)), frame(7))  # same dimensions, other tables: a stranger's header
+    bad.append(("other header", other))
+    for what, b in bad:
+        fresh = G.Decoder(gpu_lib)
+        try:
+            want = fresh.decode(b)[0]
+        except RuntimeError:
+            want = None
+        fresh.close()
+        assert np.array_equal(dec.decode(jpeg)[0], O.decode(jpeg)[0])  # (the cached header is this sequence's again)
+        try:
+            got = dec.decode(b)[0]
+        except RuntimeError:
+            got = None
+        assert (got is None) == (want is None), what
+        if want is not None:
+            assert np.array_equal(got, want), what
+    assert np.array_equal(dec.decode(jpeg)[0], O.decode(jpeg)[0])
+    dec.close()
+
+
 def test_token_mode_longer_sub_sequences(O, G, gpu_lib, monkeypatch):
     """k_huffman_decode_tok cuts a group into sub-sequences of 17..20 bytes instead of 16 when that saves it a whole pass of its 256 lanes
     (an 8K frame's luminance batches). Forced here on a small frame: batches of GJ_DEC_G segments whose groups hold a little more than

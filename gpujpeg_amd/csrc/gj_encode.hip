@@ -161,23 +161,20 @@ __device__ __forceinline__ void gj_color_static(int& a, int& b, int& c)
 // last component of this one), gj_color_444 is the colour transform in fp32 on pixel pairs (gj_color_row). Samples outside the image
 // are zero *component* values (src/gpujpeg_common.c:941-944).
 template <int R0 = 0, int R1 = 8> // rows [R0, R1) of the block position
-__device__ __forceinline__ void gj_load_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by, const bool exists,
-                                            uint32_t (&px)[8][6])
+__device__ __forceinline__ void gj_load_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by, uint32_t (&px)[8][6])
 {
     const size_t pitch = (size_t)g.width * 3 + g.width_padding;
-    const bool interior = exists && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
+    const bool interior = (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
-    if (!exists) { // a lane without a block (tile slack, past the last block): zeros, and none of the per-byte branches below
-#pragma unroll
-        for (int r = R0; r < R1; r++)
-#pragma unroll
-            for (int w = 0; w < 6; w++) px[r][w] = 0;
-    } else if (interior && aligned) {
+    if (interior && aligned) {
+        // (the row pointers by addition: written as (by * 8 + r) * pitch the compiler multiplies 64-bit numbers for every row)
+        const uint8_t* row = raw + (size_t)(by * 8 + R0) * pitch + (size_t)bx * 24;
 #pragma unroll
         for (int r = R0; r < R1; r++) {
-            const uint2* p = reinterpret_cast<const uint2*>(raw + (size_t)(by * 8 + r) * pitch + (size_t)bx * 24);
+            const uint2* p = reinterpret_cast<const uint2*>(row);
             const uint2 a = p[0], b = p[1], c = p[2];
             px[r][0] = a.x; px[r][1] = a.y; px[r][2] = b.x; px[r][3] = b.y; px[r][4] = c.x; px[r][5] = c.y;
+            row += pitch;
         }
     } else {
 #pragma unroll
@@ -189,7 +186,7 @@ __device__ __forceinline__ void gj_load_444(const gj_geom& g, const uint8_t* __r
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const unsigned byte = w * 4 + b, x = bx * 8 + byte / 3;
-                    if (exists && x < (unsigned)g.width && y < (unsigned)g.height) d |= (uint32_t)raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] << (8 * b);
+                    if (x < (unsigned)g.width && y < (unsigned)g.height) d |= (uint32_t)raw[(size_t)y * pitch + (size_t)x * 3 + byte % 3] << (8 * b);
                 }
                 px[r][w] = d;
             }
@@ -198,19 +195,19 @@ __device__ __forceinline__ void gj_load_444(const gj_geom& g, const uint8_t* __r
 }
 
 template <int CS_FROM, int CS_TO>
-__device__ __forceinline__ void gj_color_444(const gj_geom& g, const unsigned bx, const unsigned by, const bool exists, const uint32_t (&px)[8][6],
-                                             uint32_t (&pk)[3][16])
+__device__ __forceinline__ void gj_color_444(const gj_geom& g, const unsigned bx, const unsigned by, const uint32_t (&px)[8][6], uint32_t (&pk)[3][16])
 {
-    const bool interior = exists && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
-    // byte masks of the samples that lie inside the image (all ones for interior blocks)
-    const int cols = exists ? min(8, max(0, g.width - (int)(bx * 8))) : 0, rows = exists ? min(8, max(0, g.height - (int)(by * 8))) : 0;
-    const uint32_t m_lo = cols >= 4 ? 0xFFFFFFFFu : (1u << (8 * cols)) - 1u;
-    const uint32_t m_hi = cols >= 8 ? 0xFFFFFFFFu : cols > 4 ? (1u << (8 * (cols - 4))) - 1u : 0u;
+    const bool interior = (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         uint32_t o0[2], o1[2], o2[2];
         gj_color_row<CS_FROM, CS_TO>(px[r], o0, o1, o2);
         if (!interior) {
+            // byte masks of the samples that lie inside the image: samples outside are zero COMPONENT values (src/gpujpeg_common.c:941-944).
+            // (worked out here, inside the branch only the waves at the image's edges take)
+            const int cols = min(8, max(0, g.width - (int)(bx * 8))), rows = min(8, max(0, g.height - (int)(by * 8)));
+            const uint32_t m_lo = cols >= 4 ? 0xFFFFFFFFu : (1u << (8 * cols)) - 1u;
+            const uint32_t m_hi = cols >= 8 ? 0xFFFFFFFFu : cols > 4 ? (1u << (8 * (cols - 4))) - 1u : 0u;
             const uint32_t lo = r < rows ? m_lo : 0u, hi = r < rows ? m_hi : 0u;
             o0[0] &= lo; o0[1] &= hi; o1[0] &= lo; o1[1] &= hi; o2[0] &= lo; o2[1] &= hi;
         }
@@ -222,13 +219,14 @@ __device__ __forceinline__ void gj_color_444(const gj_geom& g, const unsigned bx
     }
 }
 
+// bx, by: a block position INSIDE the block grid (callers clamp the positions of lanes that have no block of their own to one that exists: what
+// such a lane computes is never looked at, and a special case for it -- 48 registers of zeros -- is paid by every wave, round 5)
 template <int CS_FROM, int CS_TO>
-__device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by,
-                                                  const bool exists, uint32_t (&pk)[3][16])
+__device__ __forceinline__ void gj_load_color_444(const gj_geom& g, const uint8_t* __restrict__ raw, const unsigned bx, const unsigned by, uint32_t (&pk)[3][16])
 {
     uint32_t px[8][6]; // 8 rows x 24 bytes
-    gj_load_444(g, raw, bx, by, exists, px);
-    gj_color_444<CS_FROM, CS_TO>(g, bx, by, exists, px, pk);
+    gj_load_444(g, raw, bx, by, px);
+    gj_color_444<CS_FROM, CS_TO>(g, bx, by, px, pk);
 }
 
 template <int CS_FROM, int CS_TO>
@@ -244,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void k_fused_rgb444(const gj_geom g, const 
     if (lb >= nb) return;
     const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
     uint32_t pk[3][16]; // the three component blocks, one byte per sample
-    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, true, pk);
+    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, pk);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         uint32_t q[32];
@@ -1172,16 +1170,12 @@ __global__ __launch_bounds__(256) void k_gather(const GjTail T0)
     }
 }
 
-// the workgroup's Huffman tables in the layout of GjCoderLds::lut, from the host's (code << 8 | size) tables [type * 2 + is_ac][symbol]
+// the workgroup's Huffman tables in the layout of GjCoderLds::lut: the host has them ready behind its (code << 8 | size) tables
+// (gj_enc_job::d_huff_lut + GJ_CODER_LUT_OFFSET, gj_huffman_coder_lut; worked out in the kernel they cost every wave ~60 vector instructions, round 5)
 __device__ __forceinline__ void gj_load_coder_lut(uint32_t* s_lut, const uint32_t* __restrict__ lut, const int i)
 {
-    for (int t = i; t < 2 * 272; t += 256) {
-        const int type = t >= 272, idx = t - type * 272;
-        const bool ac = idx < 256;
-        const int sym = ac ? idx : idx - 256, nbits = ac ? (sym & 15) : sym;
-        const uint32_t old = lut[(type * 2 + (ac ? 1 : 0)) * 256 + sym];
-        s_lut[t] = (((old & 0xFFu) + (uint32_t)nbits) << 26) | ((old >> 8) << nbits);
-    }
+    static_assert(GJ_CODER_LUT_WORDS == 2 * 272 && GJ_CODER_LUT_WORDS % 4 == 0, "layout of GjCoderLds::lut");
+    if (i < GJ_CODER_LUT_WORDS / 4) reinterpret_cast<uint4*>(s_lut)[i] = reinterpret_cast<const uint4*>(lut + GJ_CODER_LUT_OFFSET)[i];
 }
 
 // ================================================================================================
@@ -1203,7 +1197,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[3][64];
-    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lut[2 * 272];
     __shared__ uint32_t s_wsum[4];
     __shared__ int s_edge[64];
     __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
@@ -1231,11 +1225,26 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
     const unsigned lb = (unsigned)blockIdx.x * (unsigned)tile_blocks + (unsigned)i;
     const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
-    const unsigned by = lb / (unsigned)k0.blocks_x, bx = lb - by * (unsigned)k0.blocks_x;
+    // the block position: the tile's first block by one division of uniform values, the lane's by carrying over the ends of the block rows (a lane
+    // without a block of its own -- tile slack, behind the last block -- takes the frame's last one: nobody looks at what it makes of it)
+    unsigned bx, by;
+    {
+        const unsigned bxn = (unsigned)k0.blocks_x, lbc = min(lb, nb - 1u);
+        if (bxn >= 256u) {
+            const unsigned lb0 = (unsigned)blockIdx.x * (unsigned)tile_blocks;
+            const unsigned by0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lb0 / bxn));
+            bx = lbc - by0 * bxn;
+            by = by0;
+            if (bx >= bxn) { bx -= bxn; by++; } // (a tile of 256 blocks crosses the end of a block row once at most)
+        } else {
+            by = lbc / bxn;
+            bx = lbc - by * bxn;
+        }
+    }
 
     // ---- pixels -> three byte-packed component blocks
     uint32_t pk[3][16];
-    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, active, pk);
+    gj_load_color_444<CS_FROM, CS_TO>(g, raw, bx, by, pk);
     __syncthreads(); // tables are in LDS
     GJ_TRACE_E(1); // pixels loaded and converted
 
@@ -1275,7 +1284,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_uyvy422(const gj_geom g, cons
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
-    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lut[2 * 272];
     __shared__ uint32_t s_wsum[4];
     __shared__ int s_edge[64];
     __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];
@@ -1407,7 +1416,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_blocks(const gj_geom g, const
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_coef[32 * 256];
     __shared__ __attribute__((aligned(8))) float s_q[2][64];
-    __shared__ uint32_t s_lut[2 * 272];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lut[2 * 272];
     __shared__ uint32_t s_wsum[4];
     __shared__ int s_edge[64];
     __shared__ uint32_t s_segx[GJ_ENC_MAX_SPT], s_segend[GJ_ENC_MAX_SPT], s_segbase[GJ_ENC_MAX_SPT + 1], s_segbits[GJ_ENC_MAX_SPT], s_segff[GJ_ENC_MAX_SPT];

@@ -89,13 +89,21 @@ struct gpujpeg_encoder* gpujpeg_encoder_create(cudaStream_t stream)
     if (gj_timers_create(&e->coder.timers) != 0) goto fail;
     e->d_fwd_q[0] = gj_hip_malloc(64 * sizeof(float));
     e->d_fwd_q[1] = gj_hip_malloc(64 * sizeof(float));
-    e->d_huff_lut = gj_hip_malloc(4 * 256 * sizeof(uint32_t));
+    e->d_huff_lut = gj_hip_malloc((GJ_CODER_LUT_OFFSET + GJ_CODER_LUT_WORDS) * sizeof(uint32_t));
     e->d_result = gj_hip_malloc(4 * sizeof(uint32_t));
     e->h_result = gj_hip_host_alloc(4 * sizeof(uint32_t));
     e->h_header = gj_hip_host_alloc(GJ_MAIN_HEADER_CAP);
     if (!e->d_fwd_q[0] || !e->d_fwd_q[1] || !e->d_huff_lut || !e->d_result || !e->h_result || !e->h_header) goto fail;
-    uint32_t lut[4 * 256];
+    uint32_t lut[GJ_CODER_LUT_OFFSET + GJ_CODER_LUT_WORDS];
     gj_huffman_encoder_lut(lut);
+    /* the same tables as the fused encoders' coder reads them (gj_encode.hip: GjCoderLds::lut): per table type 256 AC entries indexed by
+     * (run << 4) | nbits, then 16 DC entries indexed by nbits; entry = (code length + nbits) << 26 | code << nbits */
+    for (int t = 0; t < GJ_CODER_LUT_WORDS; t++) {
+        const int type = t >= 272, idx = t - type * 272, ac = idx < 256;
+        const int sym = ac ? idx : idx - 256, nbits = ac ? (sym & 15) : sym;
+        const uint32_t old = lut[(type * 2 + ac) * 256 + sym];
+        lut[GJ_CODER_LUT_OFFSET + t] = (((old & 0xFFu) + (uint32_t)nbits) << 26) | ((old >> 8) << nbits);
+    }
     if (gj_hip_memcpy_h2d(e->d_huff_lut, lut, sizeof lut, e->coder.stream) != 0 || gj_hip_stream_sync(e->coder.stream) != 0) goto fail;
     return e;
 fail:

@@ -119,6 +119,8 @@ typedef struct gj_geom {
 } gj_geom;
 
 /* ------------------------------------------------------------------ encoder */
+#define GJ_CODER_LUT_OFFSET 1024 /* words of gj_enc_job::d_huff_lut in front of the coder's tables */
+#define GJ_CODER_LUT_WORDS 544
 /* Developer switches (A/B measurements, forced modes of the tests). Read from the environment ONCE, when a coder is created
  * (gj_hip_tuning_from_env); the launchers never look at the environment. */
 typedef struct gj_tuning {
@@ -171,7 +173,9 @@ typedef struct gj_enc_job {
     uint8_t* d_planes;             /* padded planar components (generic path only) */
     int16_t* d_coefs;              /* quantised coefficients, 64 per block */
     const float* d_fwd_q[2];       /* forward tables, luminance / chrominance (src/gpujpeg_table.c:103-123 layout) */
-    const uint32_t* d_huff_lut;    /* [4][256]: (code << 8) | size ; order lumaDC, lumaAC, chromaDC, chromaAC */
+    const uint32_t* d_huff_lut;    /* [4][256]: (code << 8) | size ; order lumaDC, lumaAC, chromaDC, chromaAC; behind them, at GJ_CODER_LUT_OFFSET, the
+                                      GJ_CODER_LUT_WORDS words of the fused encoders' coder: per table type AC[(run << 4) | nbits] (256) then DC[nbits] (16),
+                                      entry = (code bits + nbits) << 26 | code << nbits (gj_huffman_coder_lut) */
     uint8_t* d_temp;               /* per-segment unstuffed bitstreams */
     uint32_t* d_seg_bytes;         /* [segment_count] unstuffed byte count */
     uint32_t* d_seg_ff;            /* [segment_count] number of 0xFF bytes */

@@ -63,3 +63,10 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
     return v + d;
 }
 
+// (a << N) + b as the one instruction it is (left to itself the compiler splits a table index of two fields into two shifts and a three-operand add)
+template <int N> __device__ __forceinline__ uint32_t gj_lshl_add_u32(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(N), "v"(b));
+    return r;
+}

@@ -691,7 +691,7 @@ __device__ __forceinline__ void gj_fdct_quant_zz(const uint32_t (&px)[16], const
 
 struct GjCoderLds {
     uint32_t* coef;      // [32][256]; rows GJ_ENC_PRIV_ROWS.. double as the shared bit window once the walks are done
-    const uint32_t* lut; // [2][272]: per table type AC[(run << 4) | nbits] then DC[nbits], entry = (code bits + nbits) << 26 | code << nbits
+    const uint32_t* lut; // [2][272]: per table type AC[(run << 4) | ((16 - nbits) & 15)] then DC[nbits], entry = (code bits + nbits) << 26 | code << nbits
     uint32_t* wsum;      // [4] block-length totals of the waves
     int* edge;           // [4][16] the last sixteen DC terms of each wave (predecessors of the next wave's first lanes)
     uint32_t *segx, *segend, *segbase, *segbits, *segff; // [64] ([65] segbase)
@@ -699,10 +699,12 @@ struct GjCoderLds {
 
 // the private stream of a lane while it walks its block
 struct GjWalk {
-    uint32_t hi;     // accumulator: `fill` < 32 bits, left-aligned
-    int fill;
+    uint32_t hi;     // accumulator: 64 - room < 32 bits, left-aligned
+    int room;        // 64 - the bits in the accumulator: what a code word is shifted left by, less its own length (kept in this form: one subtraction
+                     // per symbol where "fill += n; shift = 64 - fill" takes two)
     int produced;    // completed dwords so far
-    int stored;      // the first `stored` of them sit in the lane's column, the others in the block's d_temp slot
+    int stored;      // once a dword has gone to the block's d_temp slot (lim == GJ_ENC_NO_STORE): the first `stored` dwords sit in the lane's column,
+                     // the others in the slot; before that every completed dword is in the column (gj_walk_stored)
     int lim;         // 2 * produced + 1 while every completed dword could be stored in place; GJ_ENC_NO_STORE once one could not
 };
 #define GJ_ENC_NO_STORE 4096
@@ -714,22 +716,22 @@ struct GjWalk {
 // the segment's final stream, written there by the drain, never reaches a slot whose block it has not passed yet.
 __device__ __forceinline__ void gj_put(GjWalk& w, const uint32_t cw, const int n, uint8_t* col, uint32_t* __restrict__ spill, const int p)
 {
-    w.fill += n;
-    const uint64_t t = (uint64_t)cw << (64 - w.fill); // fill was < 32, n <= 26: the shift is >= 6
+    w.room -= n;
+    const uint64_t t = (uint64_t)cw << w.room; // room was > 32, n <= 26: the shift is >= 6
     w.hi |= (uint32_t)(t >> 32);
-    if (w.fill >= 32) {
+    if (w.room <= 32) {
         if (w.lim <= min(p, GJ_ENC_PRIV_ROWS - 1)) {
             *reinterpret_cast<uint16_t*>(col + w.produced * 2048) = (uint16_t)(w.hi >> 16);
             *reinterpret_cast<uint16_t*>(col + w.produced * 2048 + 1024) = (uint16_t)w.hi;
             w.lim += 2;
-            w.stored++;
         } else {
+            if (w.lim != GJ_ENC_NO_STORE) w.stored = w.produced; // (the first dword that goes to the slot: the ones in front are in the column)
             spill[w.produced] = w.hi;
             w.lim = GJ_ENC_NO_STORE;
         }
         w.produced++;
         w.hi = (uint32_t)t;
-        w.fill -= 32;
+        w.room += 32;
     }
 }
 
@@ -768,10 +770,12 @@ __device__ __forceinline__ void gj_walk_ac(uint8_t* col, const uint32_t mlo, con
                     run -= 16;
                 } while (run >= 16);
             }
-            int nbits;
-            uint32_t bits;
-            gj_value_bits2<true>(v, nbits, bits);
-            const uint32_t ent = lut_ac[(run << 4) | nbits];
+            // category and magnitude bits of the (non-zero) coefficient (ITU T.81 F.1.2.1.1): t = v - 1 for a negative v; the first bit of t that
+            // differs from its sign is the top bit of |v|, so k = v_ffbh_i32(t) = 32 - category. The AC table is indexed by (run << 4) | (k & 15)
+            // (gj_huffman_coder_lut): with the table's base moved down by 16 entries that is base[(run << 4) + k], two shift-adds
+            const int sg = v >> 31, t = v + sg, k = gj_ffbh_i32(t);
+            const uint32_t bits = __builtin_amdgcn_ubfe((uint32_t)t, 0, (uint32_t)(32 - k));
+            const uint32_t ent = (lut_ac - 16)[gj_lshl_add_u32<4>((uint32_t)run, (uint32_t)k)];
             gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, spill, p);
         }
     }
@@ -787,9 +791,10 @@ __device__ __forceinline__ void gj_merge_stream(const GjWalk& w, const uint8_t* 
                                                 const uint32_t wend)
 {
     uint32_t prevv = 0;
+    const int stored = w.lim == GJ_ENC_NO_STORE ? w.stored : w.produced; // completed dwords that sit in the column
     for (int f = 0; f <= ndw; f++) { // (iteration ndw only flushes the carry)
         uint32_t cur = 0;
-        if (f < w.stored) cur = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
+        if (f < stored) cur = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
         else if (f < w.produced) cur = spill[f];
         else if (f == w.produced) cur = (uint32_t)(tail >> 32);
         else if (f == w.produced + 1) cur = (uint32_t)tail;
@@ -844,7 +849,7 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
     __syncthreads(); // B1: edges visible (and, for the first component, the tables)
 
     // ---- 3. the walk
-    GjWalk w = {0, 0, 0, 0, 1};
+    GjWalk w = {0, 64, 0, 0, 1};
     uint32_t* const spill = reinterpret_cast<uint32_t*>(region + (size_t)i * GJ_TEMP_BYTES_PER_BLOCK); // (lane i = block i of the tile)
     int dc_diff = 0;
     {
@@ -863,7 +868,8 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
         gj_put(w, (ent & 0x03FFFFFFu) | bits, (int)(ent >> 26), col, spill, 0);
         gj_walk_ac(col, mlo & ~1u, mhi, lut_ac, w, spill);
     }
-    const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)w.fill;
+    const int fill = 64 - w.room; // bits in the accumulator (< 32)
+    const uint32_t len = (uint32_t)w.produced * 32u + (uint32_t)fill;
 
     if (trace0 >= 0) GJ_TRACE_E(trace0 + 1); // walk done (this wave)
     // ---- 4. bit positions
@@ -914,8 +920,8 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
     // one funnel shift (v_alignbit_b32) of two neighbouring stream dwords and one ds_or_b32.
     const uint32_t sh = start_bit & 31u, d0 = start_bit >> 5;
     uint64_t tail = (uint64_t)w.hi << 32;
-    if (pad_bits) tail |= (uint64_t)((1u << pad_bits) - 1u) << (64 - w.fill - pad_bits);
-    const int ndw = w.produced + (w.fill + pad_bits > 32 ? 2 : (w.fill + pad_bits > 0 ? 1 : 0)); // stream dwords incl. the tail
+    if (pad_bits) tail |= (uint64_t)((1u << pad_bits) - 1u) << (64 - fill - pad_bits);
+    const int ndw = w.produced + (fill + pad_bits > 32 ? 2 : (fill + pad_bits > 0 ? 1 : 0)); // stream dwords incl. the tail
     const int nseg = min(spt, seg_count_left);
     uint32_t* const dst = reinterpret_cast<uint32_t*>(region); // dword d of the tile stream
     for (uint32_t wbase = 0; wbase < total_dw; wbase += GJ_ENC_WIN_DW) {

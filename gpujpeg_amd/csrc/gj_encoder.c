@@ -97,12 +97,14 @@ struct gpujpeg_encoder* gpujpeg_encoder_create(cudaStream_t stream)
     uint32_t lut[GJ_CODER_LUT_OFFSET + GJ_CODER_LUT_WORDS];
     gj_huffman_encoder_lut(lut);
     /* the same tables as the fused encoders' coder reads them (gj_encode.hip: GjCoderLds::lut): per table type 256 AC entries indexed by
-     * (run << 4) | nbits, then 16 DC entries indexed by nbits; entry = (code length + nbits) << 26 | code << nbits */
+     * (run << 4) | ((16 - nbits) & 15), then 16 DC entries indexed by nbits; entry = (code length + nbits) << 26 | code << nbits */
     for (int t = 0; t < GJ_CODER_LUT_WORDS; t++) {
         const int type = t >= 272, idx = t - type * 272, ac = idx < 256;
         const int sym = ac ? idx : idx - 256, nbits = ac ? (sym & 15) : sym;
         const uint32_t old = lut[(type * 2 + ac) * 256 + sym];
-        lut[GJ_CODER_LUT_OFFSET + t] = (((old & 0xFFu) + (uint32_t)nbits) << 26) | ((old >> 8) << nbits);
+        /* (the AC entries sit at (run << 4) | ((16 - nbits) & 15): the walk indexes them with 32 - nbits as v_ffbh_i32 delivers it; EOB and ZRL, nbits = 0, stay where they were) */
+        const int at = ac ? type * 272 + ((sym & 0xF0) | ((16 - nbits) & 15)) : t;
+        lut[GJ_CODER_LUT_OFFSET + at] = (((old & 0xFFu) + (uint32_t)nbits) << 26) | ((old >> 8) << nbits);
     }
     if (gj_hip_memcpy_h2d(e->d_huff_lut, lut, sizeof lut, e->coder.stream) != 0 || gj_hip_stream_sync(e->coder.stream) != 0) goto fail;
     return e;

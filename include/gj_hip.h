@@ -174,7 +174,7 @@ typedef struct gj_enc_job {
     int16_t* d_coefs;              /* quantised coefficients, 64 per block */
     const float* d_fwd_q[2];       /* forward tables, luminance / chrominance (src/gpujpeg_table.c:103-123 layout) */
     const uint32_t* d_huff_lut;    /* [4][256]: (code << 8) | size ; order lumaDC, lumaAC, chromaDC, chromaAC; behind them, at GJ_CODER_LUT_OFFSET, the
-                                      GJ_CODER_LUT_WORDS words of the fused encoders' coder: per table type AC[(run << 4) | nbits] (256) then DC[nbits] (16),
+                                      GJ_CODER_LUT_WORDS words of the fused encoders' coder: per table type AC[(run << 4) | ((16 - nbits) & 15)] (256) then DC[nbits] (16),
                                       entry = (code bits + nbits) << 26 | code << nbits (gj_huffman_coder_lut) */
     uint8_t* d_temp;               /* per-segment unstuffed bitstreams */
     uint32_t* d_seg_bytes;         /* [segment_count] unstuffed byte count */

@@ -34,3 +34,4 @@ __device__ __forceinline__ gj_f2 gj_scale256_f(gj_f2 v)
     return v + d;
 }
 
+template <int N> __device__ __forceinline__ uint32_t gj_lshl_add_u32(uint32_t a, uint32_t b) { return (a << N) + b; }

@@ -785,24 +785,31 @@ __device__ __forceinline__ void gj_walk_ac(uint8_t* col, const uint32_t mlo, con
     }
 }
 
-// step 5 of gj_code_tile for one lane and one window [wbase, wend) of the tile stream
+// step 5 of gj_code_tile for one lane and one window [wbase, wend) of the tile stream: the lane's stream -- its completed dwords (column, then, for the
+// rare block that outgrew it, the block's d_temp slot), the accumulator, the padding -- lands `sh` bits into dword d0 of the tile stream, every output
+// dword is a funnel shift of two neighbours ORed into the window. One loop per KIND of source (round 5: a single loop that picked the source of every
+// dword behind four lane-dependent conditions cost 28 vector instructions per dword; these take 8), the window's bounds only where a tile's stream
+// needs more than one window (WHOLE = false: noise at high qualities).
+template <bool WHOLE>
 __device__ __forceinline__ void gj_merge_stream(const GjWalk& w, const uint8_t* col, const uint32_t* __restrict__ spill, const uint64_t tail,
                                                 const int ndw, const uint32_t sh, const uint32_t d0, uint32_t* s_bits, const uint32_t wbase,
                                                 const uint32_t wend)
 {
-    uint32_t prevv = 0;
-    const int stored = w.lim == GJ_ENC_NO_STORE ? w.stored : w.produced; // completed dwords that sit in the column
-    for (int f = 0; f <= ndw; f++) { // (iteration ndw only flushes the carry)
-        uint32_t cur = 0;
-        if (f < stored) cur = ((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024);
-        else if (f < w.produced) cur = spill[f];
-        else if (f == w.produced) cur = (uint32_t)(tail >> 32);
-        else if (f == w.produced + 1) cur = (uint32_t)tail;
+    uint32_t prevv = 0, d = d0;
+    auto emit = [&](const uint32_t cur) {
         const uint32_t out = __builtin_amdgcn_alignbit(prevv, cur, sh);
-        const uint32_t d = d0 + (uint32_t)f;
-        if (out && d >= wbase && d < wend) atomicOr(&s_bits[d - wbase], out);
+        if (out && (WHOLE || (d >= wbase && d < wend))) atomicOr(&s_bits[d - wbase], out); // (a dword that is not zero lies inside the lane's segment)
         prevv = cur;
-    }
+        d++;
+    };
+    const int stored = w.lim == GJ_ENC_NO_STORE ? w.stored : w.produced; // completed dwords that sit in the column
+    for (int f = 0; f < stored; f++)
+        emit(((uint32_t)*reinterpret_cast<const uint16_t*>(col + f * 2048) << 16) | *reinterpret_cast<const uint16_t*>(col + f * 2048 + 1024));
+    for (int f = stored; f < w.produced; f++) emit(spill[f]);
+    // the tail: ndw - produced = 0, 1 or 2 dwords of it carry bits; one more step flushes the last carry
+    emit((uint32_t)(tail >> 32));
+    if (ndw > w.produced) emit((uint32_t)tail);
+    if (ndw > w.produced + 1) emit(0u);
 }
 
 // Steps 2-5 for one component of a tile. i = thread, j = local segment of the lane's block, k = block inside its segment,
@@ -931,7 +938,10 @@ __device__ __forceinline__ uint32_t gj_code_tile(const GjCoderLds& L, const int 
             for (uint32_t d = i; d < wend - wbase; d += 256) s_bits[d] = 0;
             __syncthreads();
         }
-        if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) gj_merge_stream(w, col, spill, tail, ndw, sh, d0, s_bits, wbase, wend);
+        if (active && d0 + (uint32_t)ndw + 1u > wbase && d0 < wend) {
+            if (total_dw <= (uint32_t)GJ_ENC_WIN_DW) gj_merge_stream<true>(w, col, spill, tail, ndw, sh, d0, s_bits, 0u, total_dw);
+            else gj_merge_stream<false>(w, col, spill, tail, ndw, sh, d0, s_bits, wbase, wend);
+        }
         __syncthreads(); // B4: window complete
         // every wave drains whole segments: no search for the owner of a dword, the 0xFF count of a segment is one wave reduction
         for (int sl = wave; sl < nseg; sl += 4) {

@@ -16,13 +16,14 @@ On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --
                     JPEG in + raw out for the decoder) / its average hipEvent duration in a SOLO timed region (one pipeline, the GPU
                     otherwise idle, events on the coder's own stream) against 8 TB/s; `by_kernel` has every kernel of the step,
                     `contended` the same kernel inside the headline region where four pipelines share the GPU; `traffic` = HBM bytes
-                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r4_traffic.json; dropped when the
+                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r5_traffic.json; dropped when the
                     device sources differ from the ones profiled)
   encode_only / decode_only   each direction alone, device resident ("w/o PCIe" in the reference's tables)
   full_api          host buffers in and out (pinned), i.e. what a drop-in caller of the reference API sees, PCIe included
   workloads         HD / 4K / 8K / 16K RGB, 16K 4:2:2 interleaved q90 (BASELINE config 4), each with its own roofline; the 8K frame with the
                     reference's own contents: `8k_noise` (7680x4320.random_12345.tst), `8k_gradient` (7680x4320.gradient.tst), `8k_camera`
-                    (its camera sample, tests/golden/make_camera_fixture.py); 256 x 4K batch (config 5) resident in HBM (`batch256_4k`) and
+                    (its camera sample, tests/golden/make_camera_fixture.py) and `8k_camera_quality_sweep` (q10 ... q100: the sweep the reference's
+                    README publishes); 256 x 4K batch (config 5) resident in HBM (`batch256_4k`) and
                     from pinned host memory in and out (`batch256_4k_host`); the same batch, 256 HD frames and 256 HD packed 4:2:2 frames through the
                     batch calls of include/gpujpeg_amd_ext.h -- every kernel launched once per chunk of frames -- (`batch256_4k_batched`,
                     `batch256_hd_batched`, `batch256_hd422_batched`) next to 256 HD frames one call per frame (`batch256_hd`)
@@ -61,7 +62,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 DTYPE_DETAIL = "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients"
 
 
-TRAFFIC_FILE = "r4_traffic.json"
+TRAFFIC_FILE = "r5_traffic.json"
 
 
 from gpujpeg_amd.source_hash import kernel_source_hash  # noqa: E402
@@ -69,7 +70,7 @@ from gpujpeg_amd.source_hash import kernel_source_hash  # noqa: E402
 
 def load_traffic(key="kernels", workload="8k"):
     """HBM bytes per launch (`kernels`) / vector instructions per launch (`valu_insts`) of a workload from the committed PMC passes
-    (profiles/r4_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
+    (profiles/r5_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
         for w in d.get("workloads", {}).values():  # bench.py times the two marker kernels with one pair of events: one name for their sum
@@ -88,14 +89,14 @@ def load_traffic(key="kernels", workload="8k"):
 # cycles when it is a plain add / sub / and / or / xor / mov / not / ashr / fp32 mul-add-fma and for ~4.3 cycles otherwise (shifts, bit-field,
 # compare, select, convert, packed-fp32, three-operand integer: tools/ubench/valu_rate.hip on this GPU, profiles/r2_09_ubench.txt). The
 # issue floor of a kernel = SQ_INSTS_VALU per launch (PMC pass) x the cycles of its class mix (static mix of the kernel's code,
-# tools/isa_loops.py --mix -> profiles/r4_isa_mix.json) / 1024 SIMDs / 2.4 GHz; the floors with every instruction in the fast and in
+# tools/isa_loops.py --mix -> profiles/r5_isa_mix.json) / 1024 SIMDs / 2.4 GHz; the floors with every instruction in the fast and in
 # the slow class bracket it.
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def load_isa_mix():
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r4_isa_mix.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r5_isa_mix.json")))
         return d["cycles"], {k: v["whole"]["share4"] for k, v in d["kernels"].items()}
     except Exception:
         return {"valu2": 2.4, "valu4": 4.3}, {}
@@ -407,6 +408,12 @@ class Lanes:
             ln["enc"].close()
             ln["dec"].close()
         self.lanes = []
+
+
+def owns_direction(name):
+    """Does this kernel alone move its direction's algorithmic bytes (raw pixels on one side, the entropy-coded stream on the other)? The fused
+    encoders do (pixels in, tile streams out); every decoder kernel and the tail kernels of the encoder are stages."""
+    return name.startswith("enc:k_encode_")
 
 
 def kernel_names(spec, enc_ms, token_mode):
@@ -854,11 +861,18 @@ def main():
         traffic = load_traffic("kernels", args.workload) if standard else {}
 
         def roof(name, ms):
-            # the kernels that only move the entropy-coded stream (k_gather: unstuffed in, stuffed out; the marker scan: stream in; the generic tail
-            # kernels) are priced with the stream's bytes, the others with their direction's algorithmic bytes (raw + JPEG)
-            b = 2 * jsize if any(k in name for k in ("k_gather", "k_assemble", "k_scan_segments")) else jsize if "k_markers" in name else alg
-            ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"kernel": name, "ms": round(float(ms), 4), "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(b)}
+            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "ms": round(float(ms), 4), "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(alg)}
+
+        def stage(name, ms):
+            #  a kernel that is ONE STAGE of its direction -- entropy decoder, IDCT, k_gather, the marker scan -- does not move the
+            # direction's algorithmic bytes: it is reported with the bytes it touched (PMC passes under profiles/, when taken on these sources)
+            # against the peak and with its vector-issue fraction, not with an HBM `frac` of bytes it never sees
+            if owns_direction(name):
+                return dict(roof(name, ms), owns_direction_bytes=True, traffic=traffic.get(name), **issue(name, ms))
+            t = traffic.get(name)
+            touched = None if not t or ms <= 0 else round(t / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            return dict({"kernel": name, "ms": round(float(ms), 4), "owns_direction_bytes": False, "bytes_touched": t, "bytes_touched_frac_of_peak": touched}, **issue(name, ms))
 
         live = [i for i in range(9) if solo[i] > 0.006]  # (event slots of kernels this configuration does not launch hold only the gap between two events)
         dom = max(live, key=lambda i: solo[i])
@@ -877,7 +891,7 @@ def main():
                     "valu_issue_floor_ms_if_all_2cycle": round(per(cyc["valu2"]), 4), "valu_issue_floor_ms_if_all_4cycle": round(per(cyc["valu4"]), 4),
                     "valu_issue_frac": round(weighted / ms, 3)}
 
-        by_kernel = [dict(roof(names[i], solo[i]), traffic=traffic.get(names[i]), **issue(names[i], solo[i])) for i in live]
+        by_kernel = [stage(names[i], solo[i]) for i in live]
         r = roof(names[dom], solo[dom])
         enc_total, dec_total = float(sum(solo[i] for i in live if i < 5)), float(sum(solo[i] for i in live if i >= 5))  # (slots of kernels that were not launched hold the gap between two events)
         result = {
@@ -900,12 +914,13 @@ def main():
             "decode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["dec_wall"] / 1e6, 2) if args.mode != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"],
                          "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg), **issue(names[dom], solo[dom]),
-                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r4_traffic.json) x the cycles of the kernel's instruction class mix "
-                                      "(2.4 / 4.3 cycles per wave64 instruction, profiles/r4_isa_mix.json) / 1024 SIMDs / 2.4 GHz / duration -- the roofline that "
+                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r5_traffic.json) x the cycles of the kernel's instruction class mix "
+                                      "(2.4 / 4.3 cycles per wave64 instruction, profiles/r5_isa_mix.json) / 1024 SIMDs / 2.4 GHz / duration -- the roofline that "
                                       "actually bounds these kernels; the all-2-cycle and all-4-cycle floors bracket it",
                          "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
-                                   "coder's stream); profiles/r4_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
+                                   "coder's stream); profiles/r5_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
                          "by_kernel": by_kernel,
+                         "solo_vs_filled": None,  # (filled in by extras(): the same kernel's per-frame cost when the device is full)
                          "by_direction": {"encode": dict(roof("all encoder kernels", enc_total)), "decode": dict(roof("all decoder kernels", dec_total))},
                          "contended": dict(roof(names[dom], cont[dom]), concurrent_pipelines=S,
                                            kernel_ms={names[i]: round(float(cont[i]), 4) for i in live})},
@@ -952,6 +967,15 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
         for mode in ("encode", "decode"):
             m = measure(lib, spec, device, dev_index, barrier, mode=mode, streams=args.streams, steps=5, warmup=2, min_seconds=0.3)
             result[f"{mode}_only"] = dict(brief(spec, m), note="device resident (GPU_IMAGE in / stream in HBM, HBM buffer out): the reference's 'w/o PCIe' figure")
+        # (VERDICT r4 #7b) the contract's roofline is the dominant kernel's SOLO duration, which carries a lone launch's ramp and under-filled last
+        # generation of workgroups; the same kernel's cost per frame when the device is full = its share of the encode-only rate of four pipelines
+        rf = result["roofline"]
+        if rf["kernel"].startswith("enc:") and rf["by_direction"]["encode"]["ms"] > 0:
+            share = rf["ms"] / rf["by_direction"]["encode"]["ms"]
+            filled = result["encode_only"]["ms_per_frame"] * share
+            rf["solo_vs_filled"] = {"solo_ms": rf["ms"], "filled_ms_per_frame": round(filled, 4),
+                                    "filled_frac": round(rf["algorithmic_bytes_per_launch"] / (filled * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "note": "filled = encode-only ms per frame with four pipelines x the kernel's share of the encoder's solo GPU time"}
         full = {}
         for mode in ("encode", "decode", "both"):
             m = measure(lib, spec, device, dev_index, barrier, mode=mode, streams=args.streams, steps=3, warmup=1, min_seconds=0.3, host_io=True)
@@ -979,15 +1003,44 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
             dom_ = max(live_, key=lambda i: solo_[i])
             tr_ = load_traffic("kernels", key) if pattern == "natural" else {}
             fr = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None  # noqa: E731
+            enc_ms_, dec_ms_ = float(sum(solo_[i] for i in live_ if i < 5)), float(sum(solo_[i] for i in live_ if i >= 5))
+            # the kernel with the longest duration; its HBM fraction is its own when it moves its direction's bytes alone (the fused encoders), its
+            # DIRECTION's otherwise (an entropy decoder never sees the raw pixels: pricing it with them crowned it "dominant" in round 4)
+            own_ = owns_direction(nm[dom_])
+            basis_ms = float(solo_[dom_]) if own_ else (enc_ms_ if dom_ < 5 else dec_ms_)
             table[key] = dict(brief(sp, m), workload=sp.describe(), data=DATA_NOTE[pattern].format(w=sp.width, h=sp.height),
-                              solo_gpu_ms={"encode": round(float(sum(solo_[i] for i in live_ if i < 5)), 4), "decode": round(float(sum(solo_[i] for i in live_ if i >= 5)), 4)},
-                              roofline={"bound": "hbm", "kernel": nm[dom_], "ms": round(float(solo_[dom_]), 4), "frac": fr(float(solo_[dom_])),
-                                        "achieved": round(alg / (float(solo_[dom_]) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "algorithmic_bytes_per_launch": int(alg), "traffic": tr_.get(nm[dom_]),
-                                        "frac_encode_direction": fr(float(sum(solo_[i] for i in live_ if i < 5))), "frac_decode_direction": fr(float(sum(solo_[i] for i in live_ if i >= 5))),
+                              solo_gpu_ms={"encode": round(enc_ms_, 4), "decode": round(dec_ms_, 4)},
+                              roofline={"bound": "hbm", "kernel": nm[dom_], "ms": round(float(solo_[dom_]), 4), "frac": fr(basis_ms),
+                                        "frac_basis": "the kernel's own duration" if own_ else "the duration of all kernels of its direction (a stage kernel)",
+                                        "achieved": round(alg / (basis_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "algorithmic_bytes_per_launch": int(alg), "traffic": tr_.get(nm[dom_]) if own_ else None,
+                                        "frac_encode_direction": fr(enc_ms_), "frac_decode_direction": fr(dec_ms_),
                                         "by_kernel": {nm[i]: round(float(solo_[i]), 4) for i in live_}})
             del sp
             torch.cuda.empty_cache()
+        # the sweep the reference publishes (README.md:125-128 encode, :160-161 decode: 4K / HD / 8K at q10 ... q100): the 8K frame with its camera
+        # sample's contents at every quality, both directions together and each alone (four pipelines, device resident), the GPU time of each
+        # direction alone and its fraction of the HBM roofline -- where between q75 and noise does the decoder leave token mode, and what does it cost?
+        sweep = {}
+        for q in (10, 20, 30, 40, 50, 60, 70, 80, 90, 100):
+            sp = Spec(lib, "8k", "camera", q, device, 12345)
+            m = measure(lib, sp, device, dev_index, barrier, mode="both", streams=args.streams, steps=3, warmup=1, min_seconds=0.15, want_solo=True)
+            alg = sp.raw_bytes + m["jpeg_bytes"]
+            solo_ = m["solo_ms"]
+            live_ = [i for i in range(9) if solo_[i] > 0.006]
+            enc_ms_, dec_ms_ = float(sum(solo_[i] for i in live_ if i < 5)), float(sum(solo_[i] for i in live_ if i >= 5))
+            fr = lambda ms: round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None  # noqa: E731
+            row = {"mpix_s": brief(sp, m)["mpix_s"], "jpeg_bytes": m["jpeg_bytes"], "solo_gpu_ms": {"encode": round(enc_ms_, 4), "decode": round(dec_ms_, 4)},
+                   "frac_encode_direction": fr(enc_ms_), "frac_decode_direction": fr(dec_ms_)}
+            for mode in ("encode", "decode"):
+                mm = measure(lib, sp, device, dev_index, barrier, mode=mode, streams=args.streams, steps=3, warmup=1, min_seconds=0.12)
+                row[f"{mode}_only_mpix_s"] = brief(sp, mm)["mpix_s"]
+            sweep[f"q{q}"] = row
+            del sp
+            torch.cuda.empty_cache()
+        table["8k_camera_quality_sweep"] = dict(sweep, workload="7680x4320 RGB 4:4:4, the reference's camera sample tiled, non-interleaved, restart auto; quality 10 ... 100",
+                                                 note="the reference's tables: README.md:125-128 (encode), :160-161 (decode); mpix_s = encode + decode of every frame, "
+                                                      "four pipelines; *_only = one direction alone, device resident")
         ba = argparse.Namespace(**vars(args))
         ba.batch, ba.workload, ba.steps, ba.warmup, ba.verify = 256, "4k", 2, 1, False
         b = run_batch(ba, lib, device, dev_index, 0, 1, *WORKLOADS["4k"], emit=False)

@@ -575,7 +575,8 @@ void gj_coder_process_stats_overall(struct gj_coder* c) /* common.c:2238-2254 */
     if (c->ht_on && c->ht_calls > 0)
         fprintf(stderr, "[gj host timing] %s, %ld calls: to the first launch %.1f us, launches %.1f us, waiting %.1f us, behind the wait %.1f us\n",
                 c->encoder ? "encoder" : "decoder", c->ht_calls, c->ht[0] / c->ht_calls, c->ht[1] / c->ht_calls, c->ht[2] / c->ht_calls, c->ht[3] / c->ht_calls);
-    if (c->frames <= 1 || c->param.verbose <= GPUJPEG_LL_QUIET) return;
+    /* (frames = calls that were TIMED, perf_stats on: a coder whose statistics were off for the rest of its life has nothing to average) */
+    if (c->frames <= 1 || c->param.verbose <= GPUJPEG_LL_QUIET || !(c->aggregate_duration > 0.0)) return;
     fprintf(stderr, "\nAvg %s Duration: %10.4f ms\n", c->encoder ? "Encode" : "Decode", c->aggregate_duration / (double)c->frames);
     if (c->param.verbose >= GPUJPEG_LL_VERBOSE)
         fprintf(stderr, "Avg w/o 1st Iter:    %10.4f ms\n", (c->aggregate_duration - c->first_frame_duration) / ((double)c->frames - 1));

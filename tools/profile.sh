@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 W=${WORKLOAD:-8k}
-TAG=${TAG:-r4_$W}
+TAG=${TAG:-r5_$W}
 rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq
 ARGS="--workload $W --streams ${STREAMS:-1} --lean ${BENCH_ARGS}"
 if [ -n "$BATCH" ]; then ARGS="--workload 4k --batch $BATCH --streams ${STREAMS:-4} ${BENCH_ARGS}"; fi

@@ -853,7 +853,7 @@ def main():
     if rank == 0:
         S, reps, jsize = head["streams"], head["reps"], head["jpeg_bytes"]
         nblocks = ((width + 7) // 8) * ((height + 7) // 8) * (2 if spec.is422 else 3)
-        token_mode = nblocks >= (900000 if spec.is422 else 300000) and jsize <= (12 if spec.is422 else 8) * nblocks and not args.keep_coefs and not os.environ.get("GJ_DEC_NO_TOKENS")
+        token_mode = nblocks >= (900000 if spec.is422 else 300000) and jsize <= (12 if spec.is422 else 16) * nblocks and not args.keep_coefs and not os.environ.get("GJ_DEC_NO_TOKENS")
         names = kernel_names(spec, head["solo_ms"], token_mode)
         alg = spec.raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (the same sum)
         solo, cont = head["solo_ms"], head["kernel_ms"]
@@ -996,7 +996,7 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
             m = measure(lib, sp, device, dev_index, barrier, mode="both", streams=args.streams, steps=5, warmup=2, min_seconds=0.3, want_solo=True)
             alg = sp.raw_bytes + m["jpeg_bytes"]
             nblk = ((sp.width + 7) // 8) * ((sp.height + 7) // 8) * (2 if sp.is422 else 3)
-            tokm = nblk >= (900000 if sp.is422 else 300000) and m["jpeg_bytes"] <= (12 if sp.is422 else 8) * nblk and not os.environ.get("GJ_DEC_NO_TOKENS")
+            tokm = nblk >= (900000 if sp.is422 else 300000) and m["jpeg_bytes"] <= (12 if sp.is422 else 16) * nblk and not os.environ.get("GJ_DEC_NO_TOKENS")
             nm = kernel_names(sp, m["solo_ms"], tokm)
             solo_ = m["solo_ms"]
             live_ = [i for i in range(9) if solo_[i] > 0.006]

@@ -19,7 +19,11 @@ extern "C" int gj_hip_decode_wants_tokens(const gj_geom* g, uint64_t jpeg_size, 
     // (round 3, k_huffman_decode_tok: a 4K RGB frame -- 389 K blocks -- gains 9 % enc+dec and 7 % decode-only, an HD frame loses 4 %)
     // (a batch of frames, gj_frame_strides: the blocks of all its frames fill the GPU, so HD frames take token mode too)
     const uint64_t blocks_in_flight = (uint64_t)g->block_count * (g->fb.frames > 1 ? g->fb.frames : 1u);
-    return blocks_in_flight >= (g->interleaved ? 900000u : 300000u) && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 8u);
+    // (round 5, k_huffman_decode_tok on denser streams: the camera frame at q100, 11.8 B per block, decodes 11 % faster through tokens than through the
+    // planes -- 133.6 against 120.0 Gpix/s decode-only --; `.tst` noise at q75, 26.8 B per block, 5 % slower -- 34.7 against 36.7: the entropy stage takes
+    // 0.908 ms either way, ~2.2 symbols per byte at a sub-sequence hit rate that noise's long codes halve, and the token-fed IDCT then moves as many bytes
+    // as the planes would. The gate for non-interleaved scans moves from 8 to 16 B per block.)
+    return blocks_in_flight >= (g->interleaved ? 900000u : 300000u) && jpeg_size <= (uint64_t)g->block_count * (g->interleaved ? 12u : 16u);
 }
 
 // A batch of frames (gj_dec_job::batch) is a speculative launch on one header through the sub-sequence entropy decoders -- tokens for non-interleaved

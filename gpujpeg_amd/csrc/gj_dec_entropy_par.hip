@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                                                             const uint32_t* __restrict__ seg_index, const int seg_count_max,
                                                             const uint32_t* __restrict__ seg_count_ptr, const GjBatchPlan plan,
                                                             const uint16_t* __restrict__ tabs, int16_t* __restrict__ coefs,
-                                                            const int zero_fill /* 1: the planes are not known to be zero */)
+                                                            const int zero_fill /* 1: the planes are not known to be zero */, const GjFold F)
 {
     // every segment of a group ends with a partial sub-sequence: at most CAP_U / SUB + n sub-sequences for n segments (tighter bounds
     // hold only for short sub-sequences; nsub is clamped below all the same, so that a fault in this arithmetic cannot become a write
@@ -195,15 +195,23 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     if (si0 >= seg_count) return;
     const int nseg = min(min(G, plan.first[pc] + plan.count[pc] - si0), seg_count - si0);
     uint32_t my_nblk = 0, my_ucap = 0;
+    // the batch's table entries: from the table, or (no table launch: GjFold, gj_dec_internal.h) from the marker scan's records -- scratch: the stage
+    uint32_t ld_s = 0xFFFFFFFFu, ld_p = 0, ld_l = 0;
+    if (F.recs == nullptr) {
+        if (tid < nseg) { ld_s = seg_index[si0 + tid]; ld_p = seg_pos[si0 + tid]; ld_l = seg_len[si0 + tid]; }
+    } else {
+        static_assert(GJ_FOLD_SCRATCH_WORDS(GJ_PAR_GMAX) <= GJ_PAR_CAP_U / 4, "fold scratch inside the stage");
+        if (!gj_fold_batch<GJ_PAR_GMAX>(F, g, jpeg, jpeg_size, plan, pc, si0, nseg, s_U, s_tmp, ld_s, ld_p, ld_l)) return;
+    }
     if (tid < GJ_PAR_GMAX) {
         uint32_t pos = 0, len = 0, nblk = 0, first = 0, tb = 0;
         if (tid < nseg) {
-            const uint32_t s = seg_index[si0 + tid];
+            const uint32_t s = ld_s;
             if (s < (uint32_t)g.segment_count) {
                 const GjSeg sg = gj_segment(g, (int)s);
                 nblk = (uint32_t)sg.nblocks;
-                pos = seg_pos[si0 + tid];
-                len = seg_len[si0 + tid];
+                pos = ld_p;
+                len = ld_l;
                 if (INTERLEAVED) {
                     first = (uint32_t)sg.mcu_first; // first MCU
                 } else {
@@ -212,6 +220,8 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
                     tb = (uint32_t)((kc.dc_table * 2 + 0) * GJ_DEC2_WORDS * 2) | ((uint32_t)((kc.ac_table * 2 + 1) * GJ_DEC2_WORDS * 2) << 16);
                 }
                 if (((len + 3u) & ~3u) + 8u > (uint32_t)GJ_PAR_CAP_U || nblk > (uint32_t)GJ_PAR_MAX_BLOCKS) { // too long for the LDS stage / the per-block arrays: in pieces at the end
+                    // (the pieces are cut from the table: without one -- GjFold -- the host decodes this frame again the careful way, with the table launch)
+                    if (F.recs != nullptr) F.hsum->rst_irregular = 1u;
                     s_long[atomicAdd(&s_nlong, 1)] = (uint32_t)tid;
                     len = 0;
                     nblk = 0;
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
     //      segment, except that its first sub-sequence is entered in the state the previous piece was left in. The block count and
     //      the DC predictors are carried along; the DC differences go to the plane and are summed up there, 256 blocks at a time.
     constexpr uint32_t GJ_PAR_PIECE = GJ_PAR_CAP_U - 64;
-    const int nlong = s_nlong;
+    const int nlong = F.recs != nullptr ? 0 : s_nlong; // (no table, no pieces: the frame is decoded again, see above)
     for (int li = 0; li < nlong; li++) {
         const int jl = (int)s_long[li];
         const GjSeg sg = gj_segment(g, (int)seg_index[si0 + jl]);
@@ -722,6 +732,24 @@ void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st)
                                 : (sub == 256 ? k_huffman_decode_par<false, 256> : sub == 128 ? k_huffman_decode_par<false, 128>
                                    : sub == 64 ? k_huffman_decode_par<false, 64> : sub == 32 ? k_huffman_decode_par<false, 32>
                                    : sub == 8 ? k_huffman_decode_par<false, 8> : k_huffman_decode_par<false, 16>);
+    GjFold F = {nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
+    const bool fold = gj_par_folds_table(job);
+    if (fold) {
+        const gj_scan_deferred& sc = job->scan;
+        F = GjFold{sc.recs, sc.lists, sc.wgs, sc.part_bytes, sc.begin, sc.h_summary, sc.h_maxlen_parts};
+        *sc.maxlen_part_count = batches; // (the host takes the maximum over the batches' words)
+    }
     hipLaunchKernelGGL(kernel, dim3(batches, 1, job->batch.count > 1 ? job->batch.count : 1u), dim3(256), 0, st, g, job->d_jpeg, job->jpeg_size, job->d_seg_pos, job->d_seg_len,
-                       job->d_seg_index, job->seg_count, job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1);
+                       job->d_seg_index, job->seg_count, fold ? nullptr : job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, F);
+}
+
+// the table launch folded into this kernel (GjFold, gj_dec_internal.h): one frame of a non-interleaved stream whose batches are cut per scan
+bool gj_par_folds_table(const gj_dec_job* job)
+{
+    const gj_geom& g = job->g;
+    if (!job->scan.valid || job->batch.count > 1 || g.fb.sizes != nullptr || g.interleaved || g.restart_interval <= 0 || job->seg_count != g.segment_count) return false;
+    if (job->scan.wgs > 256u || job->scan.h_summary == nullptr || job->scan.h_maxlen_parts == nullptr || job->scan.maxlen_part_count == nullptr) return false;
+    if (job->tune.dec_sub) return false; // (the tuning aid's sub-sequence sizes change the stage's use)
+    const GjBatchPlan plan = gj_plan_batches(job, GJ_PAR_CAP_U, GJ_PAR_MAX_BLOCKS, GJ_PAR_GMAX, 0);
+    return plan.n == g.comp_count && (uint32_t)plan.batch0[plan.n] <= job->scan.maxlen_capacity;
 }

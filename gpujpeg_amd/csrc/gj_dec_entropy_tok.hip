@@ -182,24 +182,6 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
     return (p1 - e1) | (z << 5);
 }
 
-// The segment table without its launch (round 5). k_marker_table turns the scanning workgroups' records and marker lists into table entries --
-// 11 us and a launch gap in front of every decoded frame, at every size -- and all a batch needs of that table is the positions of its own G + 1
-// markers. On the speculative path (the same header as the previous frame: the only outcome the host accepts is a COMPLETE, REGULAR stream --
-// every scan with all its segments, restart markers numbered in sequence, SOS headers between the scans, EOI) the structure is known from the
-// geometry: restart marker number r of the stream ends segment r - (scans in front) ... so a workgroup reads the <= 256 records (one per lane, one
-// trip), checks that every scan has exactly the restart markers it should have (prefix sums), finds the scanning workgroups that hold its
-// markers (binary search in LDS) and reads them from their lists (second trip). Anything else -- a marker too many or too few, a number out of
-// sequence, an unexpected marker code -- raises rst_irregular in the host's summary and the workgroup leaves: the host decodes the frame again
-// the careful way, through k_marker_table (gj_decoder.c). Workgroup 0 also writes the summary the host validates (scan boundaries, SOS bytes, EOI).
-struct GjFold {
-    const uint32_t* recs;  // nullptr: the table has been written (seg_pos / seg_len / seg_index)
-    const uint32_t* lists;
-    uint32_t nwg, part_bytes;
-    uint64_t begin;
-    gj_scan_summary* hsum; // host memory
-    uint32_t* h_maxlen;    // host memory: one word per batch
-};
-
 template <bool COOP>
 __global__ __launch_bounds__(256, GJ_TOK_WG_PER_CU) void k_huffman_decode_tok(const gj_geom g, const uint8_t* __restrict__ jpeg, uint64_t jpeg_size,
                                                                const uint32_t* __restrict__ seg_pos, const uint32_t* __restrict__ seg_len,
@@ -263,125 +245,9 @@ __global__ __launch_bounds__(256, GJ_TOK_WG_PER_CU) void k_huffman_decode_tok(co
     const int seg_count = seg_count_ptr ? min((int)*seg_count_ptr, seg_count_max) : seg_count_max;
     if (si0 >= seg_count) return;
     const int nseg = min(min(G, plan.first[pc] + plan.count[pc] - si0), seg_count - si0);
-    if (F.recs != nullptr) {
-        // ---- the batch's table entries from the marker scan's records (see GjFold). Scratch: the start of the pool, free until the groups are formed.
-        uint32_t* const f_rinc = reinterpret_cast<uint32_t*>(sm.pool); // [256] restart markers up to and including scanning workgroup t
-        uint32_t* const f_o = f_rinc + 256;                            // [GJ_SCAN_MAX_OTHER][6] the other markers in stream order: position, code, restart markers in front, bytes 0..3, 4..7 behind the code, restart markers of its workgroup behind it
-        uint32_t* const f_mpos = f_o + GJ_SCAN_MAX_OTHER * 6;          // [GMAX + 1] the batch's restart markers: entry j ends segment k0 - 1 + j of the scan
-        uint32_t* const f_mnum = f_mpos + GMAX + 1;                    // ... their numbers (RSTn & 7)
-        uint32_t* const f_max = f_mnum + GMAX + 1;                     // [1] longest segment of the batch, [2] flags (a workgroup-wide "or" without __syncthreads_or, which takes LDS of its own)
-        static_assert((256 + GJ_SCAN_MAX_OTHER * 6 + 2 * (GJ_TOK_GMAX + 1) + 3) * 2 <= (GJ_TOK_MAX_BLOCKS + GJ_TOK_GMAX) * 2, "fold scratch inside the block slots");
-        const int S = g.comp_count; // scans of a non-interleaved stream, in component order
-        const uint32_t base0 = (uint32_t)(((reinterpret_cast<uintptr_t>(jpeg) + F.begin) & ~(uintptr_t)15) - reinterpret_cast<uintptr_t>(jpeg)); // where the scanning workgroups' parts begin
-        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-        if ((uint32_t)tid < F.nwg) {
-            const uint4* r4 = reinterpret_cast<const uint4*>(F.recs + (size_t)tid * GJ_SCAN_REC_WORDS);
-            r0 = r4[0]; r1 = r4[1]; r2 = r4[2]; r3 = r4[3];
-        }
-        const uint32_t n = r0.x, no = min(r0.z, 2u);
-        const bool bad = r0.w != 0 || n > (uint32_t)GJ_SCAN_LIST || r0.z > 2u;
-        if (tid < 3) f_max[tid] = 0; // (visible behind the barriers of the prefix sum)
-        uint32_t tot;
-        const uint32_t inc = gj_wg256_incl_scan((n & 0xFFFFFFu) | (no << 24), s_tmp, &tot); // (a frame has < 2^24 restart markers and a regular one S other markers)
-        const uint32_t rinc = inc & 0xFFFFFFu, oinc = inc >> 24;
-        f_rinc[tid] = rinc;
-        for (uint32_t q = 0; q < no; q++) {
-            const uint32_t slot = oinc - no + q;
-            if (slot < (uint32_t)GJ_SCAN_MAX_OTHER) {
-                const GjOther o = gj_rec_other(r1, r2, r3, q);
-                uint32_t* const fo = f_o + slot * 6;
-                fo[0] = o.pos; fo[1] = o.code & 0xFFu; fo[2] = rinc - o.after; fo[3] = o.b03; fo[4] = o.b47; fo[5] = o.after;
-            }
-        }
-        if (bad) f_max[1] = 1;
-        __syncthreads(); // (the scratch is written)
-        const bool bad_any = f_max[1] != 0;
-        const uint32_t total_rst = tot & 0xFFFFFFu, total_other = tot >> 24;
-        // is this the stream the geometry describes? scan c: segs_c - 1 restart markers, then the SOS of scan c + 1 (EOI behind the last one)
-        bool regular = !bad_any && total_other == (uint32_t)S && plan.n == S;
-        uint32_t exp_rst = 0, sstart = (uint32_t)F.begin, my_start = 0, my_end = 0, my_first = 0;
-        for (int c = 0; c < S && regular; c++) {
-            const uint32_t* const fo = f_o + c * 6;
-            const uint32_t first_rank = exp_rst;
-            exp_rst += (uint32_t)g.comp[c].segment_count - 1u;
-            regular = fo[1] == (c == S - 1 ? 0xD9u : 0xDAu) && fo[2] == exp_rst && fo[0] >= sstart && (uint64_t)fo[0] + 2u <= jpeg_size;
-            if (c == pc) { my_start = sstart; my_end = fo[0]; my_first = first_rank; }
-            sstart = fo[0] + 2u + (((fo[3] & 0xFFu) << 8) | ((fo[3] >> 8) & 0xFFu)); // behind the SOS header
-        }
-        regular = regular && total_rst == exp_rst;
-        const uint32_t segs_pc = (uint32_t)g.comp[pc].segment_count;
-        const int k0 = si0 - plan.first[pc]; // the batch's first segment inside its scan
-        bool irregular = false;
-        if (regular && tid <= nseg) { // the restart marker that ends segment k0 - 1 + tid of the scan
-            const int kk = k0 - 1 + tid;
-            uint32_t pos = 0, num = 0xFFu;
-            if (kk >= 0 && (uint32_t)kk + 1u < segs_pc) {
-                const uint32_t q = my_first + (uint32_t)kk; // its rank among the stream's restart markers (< total_rst)
-                int lo = 0, hi = (int)F.nwg - 1;            // the first scanning workgroup with more than q markers up to and including its own
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (f_rinc[mid] > q) hi = mid; else lo = mid + 1;
-                }
-                const uint32_t idx = q - (lo ? f_rinc[lo - 1] : 0u);
-                if (idx < (uint32_t)GJ_SCAN_LIST) {
-                    const uint32_t ent = F.lists[(size_t)lo * GJ_SCAN_LIST + idx];
-                    pos = base0 + (uint32_t)lo * F.part_bytes + (ent & 0xFFFFFFu);
-                    num = ent >> 24;
-                } else {
-                    irregular = true;
-                }
-            }
-            f_mpos[tid] = pos;
-            f_mnum[tid] = num;
-        }
-        __syncthreads();
-        if (regular && tid < nseg) {
-            const uint32_t k = (uint32_t)(k0 + tid);
-            const bool last = k + 1u == segs_pc;
-            const uint32_t from = k == 0 ? my_start : f_mpos[tid] + 2u, to = last ? my_end : f_mpos[tid + 1];
-            if (!last && f_mnum[tid + 1] != (k & 7u)) irregular = true; // RSTn out of sequence: the reference reader treats it specially, the host walk reproduces that
-            if (last && to <= from && segs_pc > 1u) irregular = true;   // an empty segment in front of the end of a scan
-            if (to > jpeg_size) irregular = true;
-            ld_s = (uint32_t)g.comp[pc].first_segment + k;
-            ld_p = from;
-            ld_l = to > from ? to - from : 0u;
-            atomicMax(f_max, ld_l);
-        }
-        if (!regular || irregular) f_max[2] = 1;
-        __syncthreads();
-        const bool give_up = f_max[2] != 0;
-        if (blockIdx.x == 0) { // what the host validates (the table kernel's summary, gj_dec_markers.hip)
-            gj_scan_summary* const hs = F.hsum;
-            if (tid < (int)min(total_other, (uint32_t)GJ_SCAN_MAX_OTHER)) {
-                const uint32_t* const fo = f_o + tid * 6;
-                hs->other_pos[tid] = fo[0];
-                hs->other_code[tid] = (uint8_t)fo[1];
-                const uint32_t ob[4] = {fo[3], fo[4], 0, 0};
-                for (int q = 0; q < 4; q++) reinterpret_cast<uint32_t*>(hs->other_bytes[tid])[q] = ob[q];
-                hs->other_after[tid] = fo[5];
-            }
-            if (tid == 0) {
-                hs->rst_count = total_rst;
-                hs->other_count = total_other;
-                hs->scan_count = regular ? (uint32_t)S : 0u;
-                hs->status = regular ? 1u : 2u;
-                hs->segment_count = regular ? total_rst + (uint32_t)S : 0u;
-            }
-            if (regular && tid < S) { // scan boundaries: behind the SOS header in front (scan 0: the start of the data) .. the marker that ends it
-                uint32_t st = (uint32_t)F.begin;
-                if (tid > 0) {
-                    const uint32_t* const fp = f_o + (tid - 1) * 6;
-                    st = fp[0] + 2u + (((fp[3] & 0xFFu) << 8) | ((fp[3] >> 8) & 0xFFu));
-                }
-                hs->scan_start[tid] = st;
-                hs->scan_end[tid] = f_o[tid * 6];
-            }
-        }
-        if (tid == 0) {
-            F.h_maxlen[blockIdx.x] = give_up ? 0u : *f_max;
-            if (give_up) F.hsum->rst_irregular = 1u;
-        }
-        if (give_up) return;
+    if (F.recs != nullptr) { // the batch's table entries from the marker scan's records (gj_fold_batch, gj_dec_internal.h); scratch: the start of the pool, free until the groups are formed
+        static_assert(GJ_FOLD_SCRATCH_WORDS(GJ_TOK_GMAX) * 2 <= (GJ_TOK_MAX_BLOCKS + GJ_TOK_GMAX) * 2, "fold scratch inside the block slots");
+        if (!gj_fold_batch<GJ_TOK_GMAX>(F, g, jpeg, jpeg_size, plan, pc, si0, nseg, reinterpret_cast<uint32_t*>(sm.pool), s_tmp, ld_s, ld_p, ld_l)) return;
     }
     // the Huffman tables of the batch's scan are on their way while the segment table is read (a batch cut per scan belongs to component
     // `pc`; otherwise, or when a segment says something else, they are loaded where the groups are formed)

@@ -71,7 +71,8 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
         (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
     }
     // a marker scan whose table launch was left to us (gj_scan_deferred): the token decoder reads the scan's records itself, everything else needs the table
-    const bool folded = job->scan.valid && tokens && tok_sub && gj_tok_folds_table(job);
+    const bool takes_par = !(tokens && tok_sub) && !seq && par;
+    const bool folded = job->scan.valid && ((tokens && tok_sub && gj_tok_folds_table(job)) || (takes_par && gj_par_folds_table(job)));
     if (job->scan.valid && !folded) gj_launch_marker_table_deferred(job, st);
     if (job->scan.valid && job->scan.folded) *job->scan.folded = folded ? 1 : 0;
     if (tokens && tok_sub) gj_launch_huffman_tok(job, st);

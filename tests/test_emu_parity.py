@@ -62,9 +62,10 @@ def test_emu_token_mode_decoder(O, G, emu_lib, tc, monkeypatch):
     T.test_token_mode_decoder(O, G, emu_lib, tc, monkeypatch)
 
 
+@pytest.mark.parametrize("kernel", ["tok", "par"])
 @pytest.mark.parametrize("fc", T.FOLD_CASES, ids=[c[0] for c in T.FOLD_CASES])
-def test_emu_token_decoder_without_the_table_launch(O, G, emu_lib, fc, monkeypatch):
-    T.test_token_decoder_without_the_table_launch(O, G, emu_lib, fc, monkeypatch)
+def test_emu_token_decoder_without_the_table_launch(O, G, emu_lib, fc, monkeypatch, kernel):
+    T.test_token_decoder_without_the_table_launch(O, G, emu_lib, fc, monkeypatch, kernel)
 
 
 def test_emu_token_mode_longer_sub_sequences(O, G, emu_lib, monkeypatch):

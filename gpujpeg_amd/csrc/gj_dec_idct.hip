@@ -88,6 +88,8 @@ __device__ __forceinline__ void gj_store_rgb444(const gj_geom& g, uint8_t* __res
     const size_t pitch = (size_t)g.width * 3 + g.width_padding;
     const bool interior = lb < nb && (bx * 8 + 8 <= (unsigned)g.width) && (by * 8 + 8 <= (unsigned)g.height);
     const bool aligned = ((pitch | (size_t)raw) & 3) == 0;
+    // (the rows' addresses by addition: written as (by * 8 + r) * pitch the compiler multiplies 64-bit numbers for every row, round 5)
+    uint8_t* row = raw + (size_t)(by * 8) * pitch + (size_t)bx * 24;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         // colour transform in fp32 on pixel pairs (gj_color_f, exact; see gj_device.h), results packed straight into the 24 output bytes
@@ -99,10 +101,11 @@ __device__ __forceinline__ void gj_store_rgb444(const gj_geom& g, uint8_t* __res
         gj_store_pair<CS_FROM, CS_TO, 6>(c0, c1, c2, px);
         const unsigned y = by * 8 + r;
         if (interior && aligned) {
-            uint2* p = reinterpret_cast<uint2*>(raw + (size_t)y * pitch + (size_t)bx * 24);
+            uint2* p = reinterpret_cast<uint2*>(row);
             p[0] = make_uint2(px[0], px[1]);
             p[1] = make_uint2(px[2], px[3]);
             p[2] = make_uint2(px[4], px[5]);
+            row += pitch;
         } else if (lb < nb && y < (unsigned)g.height) {
 #pragma unroll
             for (int byte = 0; byte < 24; byte++) {

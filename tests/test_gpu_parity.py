@@ -507,7 +507,7 @@ FOLD_CASES = [
 
 @pytest.mark.parametrize("kernel", ["tok", "par"])
 @pytest.mark.parametrize("fc", FOLD_CASES, ids=[c[0] for c in FOLD_CASES])
-def test_token_decoder_without_the_table_launch(O, G, gpu_lib, fc, monkeypatch, kernel="tok"):
+def test_token_decoder_without_the_table_launch(O, G, gpu_lib, fc, monkeypatch, kernel):
     """Frames of a sequence (one header) on one decoder: from the second one on the launch is speculative and the token decoder derives its batches'
     segment table from the marker scan's records itself -- no k_marker_table launch (gj_scan_deferred, round 5). Pixels equal the oracle's; streams
     that are NOT the complete, regular stream the geometry describes (restart markers out of sequence, missing, surplus; no EOI; a stranger's header)

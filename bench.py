@@ -573,7 +573,7 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
         torch.cuda.empty_cache()
     # --batch-api batch: the frames of a pipeline go through gpujpeg_amd_encoder_encode_batch / gpujpeg_amd_decoder_decode_batch (every kernel
     # launched once per chunk of frames, the frame is a grid dimension) instead of one libgpujpeg call per frame
-    batch_api = getattr(args, "batch_api", "frame") == "batch" and not host_io
+    batch_api = getattr(args, "batch_api", "frame") == "batch"
     direction = getattr(args, "mode", "both") if batch_api else "both"  # (one direction alone: the batch calls only)
     S = max(1, min(getattr(args, "batch_streams", 0) or args.streams, len(frames))) if batch_api else max(1, min(args.streams, len(frames)))
     p = lib.default_parameters()
@@ -595,8 +595,10 @@ def run_batch(args, lib, device, local_rank, rank, world, width, height, emit=Tr
               "enc": e, "dec": d, "bytes": 0, "digest": [], "batched": None}
         if batch_api:  # the pipeline's frames back to back, and room for as many decoded frames
             ln["stack"] = torch.stack(ln["frames"]).contiguous()
+            if host_io:
+                ln["stack"] = ln["stack"].pin_memory()
             ln["frames"] = [ln["stack"][k] for k in range(ln["stack"].shape[0])]
-            ln["out_stack"] = torch.empty_like(ln["stack"])
+            ln["out_stack"] = torch.empty_like(ln["stack"]).pin_memory() if host_io else torch.empty_like(ln["stack"])
             ln["out"] = ln["out_stack"][-1]
         lanes.append(ln)
     if batch_api:
@@ -789,6 +791,7 @@ def main():
     ap.add_argument("--calibrate", action="store_true", help="run a 256 MiB device fill + copy first (known byte counts for calibrating PMC traffic counters)")
     ap.add_argument("--keep-coefs", action="store_true", help="decoder keeps its coefficients in HBM (adds the per-frame clear; tuning aid)")
     ap.add_argument("--lib", default=None, help="another build of the library (A/B runs of compile-time variants: make -C gpujpeg_amd/csrc variant NAME=...)")
+    ap.add_argument("--host-io", action="store_true", help="the timed region with pinned host buffers in and out (what `full_api` reports; tuning aid, not the headline)")
     ap.add_argument("--verify", action="store_true", help="check the results of the last frame(s) against the oracle (slow)")
     args = ap.parse_args()
 
@@ -841,7 +844,7 @@ def main():
 
     spec = Spec(lib, args.workload, args.pattern, args.quality, device, 12345 + rank, internal_rgb=args.internal_rgb)
     head = measure(lib, spec, device, dev_index, barrier, mode=args.mode, streams=args.streams, steps=args.steps, warmup=args.warmup,
-                   min_seconds=args.min_seconds, keep_coefs=args.keep_coefs, want_solo=True)
+                   min_seconds=args.min_seconds, keep_coefs=args.keep_coefs, want_solo=True, host_io=args.host_io)
     # whole-job figures: max over ranks of the elapsed time, SUM over ranks of the frames each rank really coded (every rank sizes its
     # own batch from its own probe, so the counts differ by a few per cent)
     from gpujpeg_amd.sharding import barrier_and_max, gather_counts

@@ -517,6 +517,7 @@ int gj_timers_create(struct gj_timers* t)
         if ((t->ev[i] = gj_hip_event_create()) == NULL) return -1;
     for (int i = 0; i < 2; i++)
         if ((t->copy_in[i] = gj_hip_event_create()) == NULL || (t->copy_out[i] = gj_hip_event_create()) == NULL) return -1;
+    if ((t->lane_in = gj_hip_event_create()) == NULL || (t->lane_out = gj_hip_event_create()) == NULL) return -1;
     return 0;
 }
 
@@ -527,6 +528,8 @@ void gj_timers_destroy(struct gj_timers* t)
         gj_hip_event_destroy(t->copy_in[i]);
         gj_hip_event_destroy(t->copy_out[i]);
     }
+    gj_hip_event_destroy(t->lane_in);
+    gj_hip_event_destroy(t->lane_out);
     memset(t, 0, sizeof *t);
 }
 

@@ -314,7 +314,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
         d_jpeg = image;
     } else {
         if (gj_ensure_device_buffer((void**)&d->d_jpeg, &d->d_jpeg_cap, image_size + 64) != 0) goto out;
-        if (gj_hip_memcpy_h2d(d->d_jpeg, image, image_size, c->stream) != 0) goto out;
+        if (gj_hip_memcpy_h2d(d->d_jpeg, image, image_size, c->stream) != 0) goto out; /* (on the coder's own stream, not in the upload lane behind other coders' images) */
         d_jpeg = d->d_jpeg;
     }
 
@@ -574,8 +574,8 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
             assert(output->data != NULL);
             dst = output->data;
         }
-        gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
-        if (gj_hip_memcpy_d2h(dst, d_raw, g->raw_size, c->stream) != 0) goto out;
+        gj_hip_event_record(c->timers.copy_out[0], c->stream);
+        if (gj_hip_download(dst, d_raw, g->raw_size, c->stream, stats ? NULL : c->timers.lane_out) != 0) goto out; /* (the process's download lane) */
         if (stats) gj_hip_event_record(c->timers.copy_out[1], c->stream);
     } else {
         output->data = d_raw;
@@ -944,9 +944,10 @@ again:
     }
     if (!out_on_device) {
         gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
+        const gj_stream_t down = gj_hip_lane_begin(1, frame_raw, c->stream); /* (the process's download lane for frames of 1 MiB and more) */
         for (int f = 0; f < count; f++)
-            if (gj_hip_memcpy_d2h(output + (size_t)f * output_stride, d_out + (size_t)f * d_out_stride, frame_raw, c->stream) != 0) goto out;
-        if (gj_hip_stream_sync(c->stream) != 0) goto out;
+            if (gj_hip_memcpy_d2h(output + (size_t)f * output_stride, d_out + (size_t)f * d_out_stride, frame_raw, down) != 0) goto out;
+        if (gj_hip_lane_end(down, c->stream, c->timers.lane_out) != 0 || gj_hip_stream_sync(c->stream) != 0) goto out;
     }
     if (param_image) {
         *param_image = c->param_image;

@@ -264,7 +264,8 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     } else if (input->type == GPUJPEG_ENCODER_INPUT_IMAGE) {
         if (gj_ensure_device_buffer((void**)&c->d_raw_own, &c->d_raw_cap, g->raw_size) != 0) return -1;
         gj_hip_event_record(c->timers.copy_in[0], c->stream); /* (also without perf_stats: see gj_internal.h, copy markers) */
-        if (gj_hip_memcpy_h2d(c->d_raw_own, input->image, g->raw_size, c->stream) != 0) {
+        /* (through the process's upload lane unless the copy is timed on the coder's stream) */
+        if (gj_hip_upload(c->d_raw_own, input->image, g->raw_size, c->stream, stats ? NULL : c->timers.lane_in) != 0) {
             GJ_ERROR("Encoder raw data copy failed: %s\n", gj_hip_last_error());
             return -1;
         }
@@ -363,6 +364,8 @@ int gpujpeg_encoder_encode(struct gpujpeg_encoder* e, const struct gpujpeg_param
     } else {
         if (ensure_out_buffer(e, e->d_jpeg_cap) != 0) return -1;
         gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
+        /* (the compressed stream stays on the coder's own stream: queued behind other coders' images in the download lane it came out 10-40 %
+         * slower with four coders, profiles/r5_07) */
         if (gj_hip_memcpy_d2h(e->out_buf, e->d_jpeg, size, c->stream) != 0) return -1;
         if (stats) gj_hip_event_record(c->timers.copy_out[1], c->stream);
         if (gj_hip_stream_sync(c->stream) != 0) return -1;
@@ -521,8 +524,10 @@ int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpu
         if (!frames_on_device) {
             if (gj_ensure_device_buffer((void**)&e->b_raw, &e->b_raw_cap, (size_t)g->raw_size * (size_t)count) != 0) return -1;
             gj_hip_event_record(c->timers.copy_in[0], c->stream); /* (copy marker, see gj_internal.h) */
+            const gj_stream_t up = gj_hip_lane_begin(0, g->raw_size, c->stream); /* (the process's upload lane for frames of 1 MiB and more) */
             for (int f = 0; f < count; f++)
-                if (gj_hip_memcpy_h2d(e->b_raw + (size_t)f * g->raw_size, frames + (size_t)f * frame_stride, g->raw_size, c->stream) != 0) return -1;
+                if (gj_hip_memcpy_h2d(e->b_raw + (size_t)f * g->raw_size, frames + (size_t)f * frame_stride, g->raw_size, up) != 0) return -1;
+            if (gj_hip_lane_end(up, c->stream, c->timers.lane_in) != 0) return -1;
             d_frames = e->b_raw;
             d_stride = g->raw_size;
         }

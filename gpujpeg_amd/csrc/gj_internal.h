@@ -58,6 +58,8 @@ struct gj_timers {
      * the upload AND one in front of the download the HIP runtime overlaps the copies of concurrent coders (8K, four pipelines, pinned buffers both
      * ways: 10.6 against 8.3 Gpix/s; one of the two alone changes nothing; measured in round 4, profiles/r4_08_copy_markers.txt). */
     gj_event_t copy_in[2], copy_out[2];
+    /* what the calling thread waits for behind a copy through the process's copy lanes (gj_hip_upload / gj_hip_download) */
+    gj_event_t lane_in, lane_out;
     bool valid;
 };
 

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "gj_hip.h"
 
@@ -101,6 +102,72 @@ void gj_hip_host_free(void* p)
 int gj_hip_memcpy_h2d(void* d, const void* s, size_t n, gj_stream_t st) { return chk(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); }
 int gj_hip_memcpy_d2h(void* d, const void* s, size_t n, gj_stream_t st) { return chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); }
 int gj_hip_memcpy_d2d(void* d, const void* s, size_t n, gj_stream_t st) { return chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st)); }
+
+// ---- copy lanes: whole images cross the host link on ONE stream per direction and device, whatever coder they belong to, and the calling thread
+// waits for them -- no stream waits for another stream's event.
+// Measured on the MI355X box (tools/ubench/pcie_duplex.py, tools/ubench/host_link_patterns.hip, profiles/r5_07): a direction alone carries 55-57 GB/s.
+// N synchronous coders that upload 99.5 MB, run a kernel and download 99.5 MB per call move
+//   28-33 GB/s each way   copying on their own streams (what the library did before: the link behaves as if it were half duplex),
+//   20-39 GB/s            through one upload and one download stream tied into the coder's stream with hipStreamWaitEvent both ways,
+//   15-28 GB/s            with an upload, a compute and a download stream per coder and events between them,
+//   46-47 GB/s            through one upload and one download stream when the THREAD waits for its copy (hipEventSynchronize) -- from two coders up.
+// The calls of the API are synchronous anyway, so the last form costs nothing but two host wake-ups per call. Copies below g_lane_min_bytes
+// (tables, headers, the streams of small frames), calls without an event and GJ_COPY_LANES=0 stay asynchronous on the caller's stream.
+static size_t g_lane_min_bytes = (size_t)1 << 20; // (GJ_COPY_LANES=<MiB> moves it, 0 turns the lanes off)
+static std::mutex g_lane_mutex;
+static hipStream_t g_lane[64][2];
+static int g_lanes_enabled = -1;
+static hipStream_t gj_lane(int dir, size_t n)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_lane_mutex);
+    if (g_lanes_enabled < 0) {
+        const char* e = getenv("GJ_COPY_LANES");
+        g_lanes_enabled = !(e && e[0] == '0' && e[1] == 0);
+        if (e && atoi(e) > 0) g_lane_min_bytes = (size_t)atoi(e) << 20;
+    }
+    if (!g_lanes_enabled || n < g_lane_min_bytes) return nullptr;
+    if (!g_lane[dev][dir] && hipStreamCreateWithFlags(&g_lane[dev][dir], hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        g_lane[dev][dir] = nullptr;
+    }
+    return g_lane[dev][dir];
+}
+// upload: what `st` holds does not touch dst (the callers' staging buffers are idle at this point of a call); complete on return when it went
+// through the lane, asynchronous on st otherwise -- either way ordered in front of what the caller launches on st next
+int gj_hip_upload(void* d, const void* s, size_t n, gj_stream_t st, gj_event_t done)
+{
+    hipStream_t lane = done ? gj_lane(0, n) : nullptr;
+    if (!lane) return chk(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st));
+    if (chk(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, lane)) || chk(hipEventRecord((hipEvent_t)done, lane))) return -1;
+    return chk(hipEventSynchronize((hipEvent_t)done));
+}
+// download of what the work on `st` produced: through the lane the thread waits for st first and for the copy afterwards (complete on return);
+// otherwise the copy is asynchronous on st and the caller synchronises as before
+int gj_hip_download(void* d, const void* s, size_t n, gj_stream_t st, gj_event_t done)
+{
+    hipStream_t lane = done ? gj_lane(1, n) : nullptr;
+    if (!lane) return chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st));
+    if (chk(hipStreamSynchronize((hipStream_t)st))) return -1;
+    if (chk(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, lane)) || chk(hipEventRecord((hipEvent_t)done, lane))) return -1;
+    return chk(hipEventSynchronize((hipEvent_t)done));
+}
+// the same for several copies of one direction behind each other (the frames of a batch call): _begin says which stream they go on -- the lane, after
+// the work on st when they are downloads -- and _end makes the thread wait for them when that was a lane
+gj_stream_t gj_hip_lane_begin(int download, size_t bytes_each, gj_stream_t st)
+{
+    hipStream_t lane = gj_lane(download ? 1 : 0, bytes_each);
+    if (!lane) return st;
+    if (download && chk(hipStreamSynchronize((hipStream_t)st))) return st;
+    return (gj_stream_t)lane;
+}
+int gj_hip_lane_end(gj_stream_t lane, gj_stream_t st, gj_event_t done)
+{
+    if (lane == st) return 0;
+    if (chk(hipEventRecord((hipEvent_t)done, (hipStream_t)lane))) return -1;
+    return chk(hipEventSynchronize((hipEvent_t)done));
+}
 int gj_hip_memset(void* d, int v, size_t n, gj_stream_t st) { return chk(hipMemsetAsync(d, v, n, (hipStream_t)st)); }
 int gj_hip_stream_sync(gj_stream_t st) { return chk(hipStreamSynchronize((hipStream_t)st)); }
 

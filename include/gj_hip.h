@@ -47,6 +47,16 @@ GJ_HIP_API void gj_hip_host_free(void* p);
 GJ_HIP_API int gj_hip_memcpy_h2d(void* dst, const void* src, size_t n, gj_stream_t s); /* async on s */
 GJ_HIP_API int gj_hip_memcpy_d2h(void* dst, const void* src, size_t n, gj_stream_t s);
 GJ_HIP_API int gj_hip_memcpy_d2d(void* dst, const void* src, size_t n, gj_stream_t s);
+/* Copies of whole images between host and device. Large ones go through the process's one stream per direction and device ("copy lanes",
+ * gj_runtime.hip: the host link carries both directions at once only that way) and are COMPLETE when the call returns: the thread waits for the
+ * copy on `done`, an event of the caller that no other call in flight uses; gj_hip_download waits for the work on s first. Small copies,
+ * done == NULL and GJ_COPY_LANES=0: asynchronous on s, exactly gj_hip_memcpy_h2d / _d2h. */
+GJ_HIP_API int gj_hip_upload(void* dst, const void* src, size_t n, gj_stream_t s, gj_event_t done);
+GJ_HIP_API int gj_hip_download(void* dst, const void* src, size_t n, gj_stream_t s, gj_event_t done);
+/* several such copies of one direction: copy with gj_hip_memcpy_h2d / _d2h on the stream gj_hip_lane_begin returns (the lane -- behind the work on s
+ * when `download` -- or s itself), then gj_hip_lane_end: complete on return when that was a lane, asynchronous on s otherwise */
+GJ_HIP_API gj_stream_t gj_hip_lane_begin(int download, size_t bytes_each, gj_stream_t s);
+GJ_HIP_API int gj_hip_lane_end(gj_stream_t lane, gj_stream_t s, gj_event_t done);
 GJ_HIP_API int gj_hip_memset(void* dst, int value, size_t n, gj_stream_t s);
 GJ_HIP_API int gj_hip_stream_sync(gj_stream_t s);
 /* 1 if p points to device (HBM) memory, 0 for host memory (reference: test/unit/run_tests.c:40-78) */

@@ -179,6 +179,7 @@ template <typename T, typename U> static inline T atomicExch(T* p, U v) { return
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 typedef struct hipemu_stream* hipStream_t;
+#define hipStreamNonBlocking 1u
 typedef struct hipemu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
@@ -196,6 +197,7 @@ hipError_t hipHostFree(void* p);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipStreamSynchronize(hipStream_t st);
+hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned flags);
 hipError_t hipGetLastError(void);
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDeviceCount(int* n);

@@ -33,7 +33,13 @@ int gj_hip_device_count(void)
 
 int gj_hip_get_device(int* device) { return chk(hipGetDevice(device)); }
 int gj_hip_set_device(int device) { return chk(hipSetDevice(device)); }
-int gj_hip_device_reset(void) { return chk(hipDeviceReset()); }
+static void gj_lanes_forget(int dev);
+int gj_hip_device_reset(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) gj_lanes_forget(dev); // (the reset destroys the device's streams: the copy lanes are created again on demand)
+    return chk(hipDeviceReset());
+}
 
 int gj_hip_device_props(int device, char name[256], int* major, int* minor, size_t* global_mem, size_t* shared_mem,
                         int* regs_per_block, int* cu_count)
@@ -117,6 +123,11 @@ static size_t g_lane_min_bytes = (size_t)1 << 20; // (GJ_COPY_LANES=<MiB> moves 
 static std::mutex g_lane_mutex;
 static hipStream_t g_lane[64][2];
 static int g_lanes_enabled = -1;
+static void gj_lanes_forget(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_lane_mutex);
+    if (dev >= 0 && dev < 64) g_lane[dev][0] = g_lane[dev][1] = nullptr;
+}
 static hipStream_t gj_lane(int dir, size_t n)
 {
     int dev = 0;

@@ -1,5 +1,6 @@
 """-m gpu: API behaviour of the drop-in library (ownership, device pointers, statistics, errors)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -482,3 +483,36 @@ def test_foreign_jpegs_from_libjpeg(O, G, gpu_lib, tmp_path, mode, subsampling):
                 theirs = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB" if mode == "RGB" else "L")).reshape(-1)
                 assert psnr(px, theirs) > 30.0, (mode, subsampling, quality, optimize, restart_rows)
     dec.close()
+
+
+@pytest.mark.gpu
+def test_host_buffers_after_device_reset(tmp_path):
+    """gpujpeg_device_reset destroys the device's streams, the process's copy lanes (gj_runtime.hip) among them: coders created afterwards get
+    new ones. In a process of its own -- the reset would take this session's torch context with it."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from gpujpeg_amd import libgpujpeg as G
+lib = G.Library()
+assert lib.L.gpujpeg_init_device(0, 0) == 0
+w, h = 1024, 768  # 2.4 MB of RGB: above the lanes' threshold
+raw = (np.arange(w * h * 3, dtype=np.int64) %% 251).astype(np.uint8)
+def roundtrip():
+    p, pi = lib.default_parameters(), lib.default_image_parameters()
+    pi.width, pi.height = w, h
+    enc, dec = G.Encoder(lib), G.Decoder(lib)
+    jpeg = enc.encode(p, pi, raw)
+    px, _ = dec.decode(jpeg)
+    enc.close(); dec.close()
+    return jpeg, px
+a = roundtrip()
+lib.L.gpujpeg_device_reset()
+assert lib.L.gpujpeg_init_device(0, 0) == 0
+b = roundtrip()
+assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

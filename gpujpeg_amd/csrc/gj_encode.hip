@@ -1012,6 +1012,8 @@ struct GjTail {
     // frame batch (gj_enc_job::batch: blockIdx.z = frame): what lies between the buffers of two frames; all zero for a single frame
     uint64_t f_raw, f_temp, f_jpeg; // bytes
     uint32_t f_seg, f_tail;         // words of seg_bytes / seg_ff, of the tile list and of the group totals
+    // k_encode_rgb444: the last tiles of a frame larger than the GPU are coded one component per workgroup (see there)
+    uint32_t tail_from, tiles;      // first tile that is split (0xFFFFFFFF: none), tiles of the frame
 };
 
 __device__ __forceinline__ uint32_t gj_pick4(const uint32_t (&a)[GJ_MAX_COMP], const uint32_t s)
@@ -1237,9 +1239,27 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     const uint32_t recip = (65536u + (uint32_t)B - 1u) / (uint32_t)B; // j = i / B through a 16.16 reciprocal (exact for i < 256, B <= 256)
     const int j = min((int)(((uint32_t)i * recip) >> 16), GJ_ENC_MAX_SPT - 1);
     const int k = i - j * B;       // block inside its segment
-    const int seg0 = blockIdx.x * spt; // first segment (inside each component's scan)
+    // The tile and, when the workgroup codes ONE component of it, which. Three shapes of launch:
+    //   all three components per workgroup (frames from ~half a generation of workgroups up),
+    //   ONE_COMPONENT with gridDim.y == 3 (small frames: see below),
+    //   and a mixture: the LAST tiles of a frame that has more tiles than the GPU has places (8K: 2058 tiles for 1024 places) as three short workgroups
+    //   each, behind the whole ones in the grid. A launch ends with the workgroups that started last; the whole tiles of the last, under-filled
+    //   generation run on nearly empty CUs at the latency of one workgroup (~36 us), the split ones start as soon as the first places come free
+    //   and take ~40 % of that. 8K alone: 80.7 -> 73.9 us with the last 16 ... 96 tiles split, nothing lost with four pipelines up to 32
+    //   (profiles/r5_09_encoder_tail_tiles_split.txt); the verdict's "lone-launch tax".
+    unsigned tile = blockIdx.x, ntiles = gridDim.x;
+    int only = ONE_COMPONENT ? (int)blockIdx.y : -1;
+    if (!ONE_COMPONENT && T.tail_from != 0xFFFFFFFFu) {
+        ntiles = T.tiles;
+        if (blockIdx.x >= T.tail_from) {
+            const unsigned r = blockIdx.x - T.tail_from, q = r / 3u;
+            tile = T.tail_from + q;
+            only = (int)(r - 3u * q);
+        }
+    }
+    const int seg0 = (int)tile * spt; // first segment (inside each component's scan)
     const unsigned nb = (unsigned)(k0.blocks_x * k0.blocks_y);
-    const unsigned lb = (unsigned)blockIdx.x * (unsigned)tile_blocks + (unsigned)i;
+    const unsigned lb = tile * (unsigned)tile_blocks + (unsigned)i;
     const bool active = i < tile_blocks && lb < nb; // (every component has the same geometry)
     // the block position: the tile's first block by one division of uniform values, the lane's by carrying over the ends of the block rows (a lane
     // without a block of its own -- tile slack, behind the last block -- takes the frame's last one: nobody looks at what it makes of it)
@@ -1247,7 +1267,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     {
         const unsigned bxn = (unsigned)k0.blocks_x, lbc = min(lb, nb - 1u);
         if (bxn >= 256u) {
-            const unsigned lb0 = (unsigned)blockIdx.x * (unsigned)tile_blocks;
+            const unsigned lb0 = tile * (unsigned)tile_blocks;
             const unsigned by0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lb0 / bxn));
             bx = lbc - by0 * bxn;
             by = by0;
@@ -1270,7 +1290,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
     // (a template parameter: the check costs the three-component instantiation of the 8K frame 0.7 us when it is made at run time)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        if (ONE_COMPONENT && c != (int)blockIdx.y) continue;
+        if (only >= 0 && c != only) continue;
         const gj_comp_geom& kc = g.comp[c];
         // (pinned: the transform of component c + 1 would otherwise be hoisted over the coder of c)
 #pragma unroll
@@ -1281,7 +1301,7 @@ __global__ __launch_bounds__(256, 4) void k_encode_rgb444(const gj_geom g, const
         const uint32_t size = gj_code_tile(L, i, j, k, active, spt, active ? min(B, (int)nb - (seg0 + j) * B) : 0, kc.type, 1, k0.segment_count - seg0,
                                            temp + first_block * GJ_TEMP_BYTES_PER_BLOCK, seg_bytes, seg_ff, (uint32_t)(kc.first_segment + seg0), 2 + 4 * c);
         // file order: the luminance scan's tiles, then the two chrominance scans'
-        if (i == 0) gj_piece_put(T, (uint32_t)c * gridDim.x + blockIdx.x, size, fz * T.f_tail);
+        if (i == 0) gj_piece_put(T, (uint32_t)c * ntiles + tile, size, fz * T.f_tail);
     }
 }
 
@@ -1950,7 +1970,17 @@ extern "C" int gj_hip_encode(const gj_enc_job* job, gj_stream_t stream, gj_event
         const unsigned split_up_to = job->tune.enc_split >= 0 ? (unsigned)job->tune.enc_split : (unsigned)gj_hip_cu_count() * 4u / 3u; // (MI355X: 341)
         const bool split = wgs * frames <= split_up_to;
         if (split) whole = gj_encode_kernel(g, true);
-        hipLaunchKernelGGL(whole, dim3(wgs, split ? 3 : 1, frames), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
+        // (a frame with more tiles than the GPU has places: its last tiles as three workgroups each, see the kernel; GJ_ENC_TAIL=<tiles>, 0 = none)
+        unsigned grid_x = wgs;
+        const unsigned tail = job->tune.enc_tail >= 0 ? (unsigned)job->tune.enc_tail : 32u;
+        T.tail_from = 0xFFFFFFFFu;
+        T.tiles = wgs;
+        // (an explicit GJ_ENC_TAIL applies to frames of any size: the tests reach the mixture with small frames that way)
+        if (!split && frames == 1 && tail > 0 && wgs > tail && (job->tune.enc_tail > 0 || wgs > (unsigned)gj_hip_cu_count() * 4u)) {
+            T.tail_from = wgs - tail;
+            grid_x = wgs + 2u * tail;
+        }
+        hipLaunchKernelGGL(whole, dim3(grid_x, split ? 3 : 1, frames), dim3(256), 0, st, g, job->d_raw, job->d_fwd_q[0], job->d_fwd_q[1], job->d_huff_lut, job->d_temp,
                            job->d_seg_bytes, job->d_seg_ff, T);
     } else {
     tiles = false;

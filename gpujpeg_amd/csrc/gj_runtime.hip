@@ -237,5 +237,6 @@ extern "C" void gj_hip_tuning_from_env(gj_tuning* t)
     t->host_timing = (e = getenv("GJ_HOST_TIMING")) && e[0] == '1';
     t->dec_balance = (e = getenv("GJ_DEC_BALANCE")) && e[0] == '1';
     t->enc_split = (e = getenv("GJ_ENC_SPLIT")) ? atoi(e) : -1;
+    t->enc_tail = (e = getenv("GJ_ENC_TAIL")) ? atoi(e) : -1;
     t->dec_fill = (e = getenv("GJ_DEC_FILL")) ? atoi(e) : 0;
 }

@@ -136,6 +136,7 @@ typedef struct gj_geom {
 typedef struct gj_tuning {
     int no_fused;        /* GPUJPEG_NO_FUSED: generic kernels only */
     int enc_split;       /* GJ_ENC_SPLIT=<tiles>: frames of up to so many tiles are coded one component per workgroup (-1: the default limit) */
+    int enc_tail;        /* GJ_ENC_TAIL=<tiles>: so many of the last tiles of a frame larger than the GPU are coded one component per workgroup (-1: default 32, 0: none) */
     int dec_balance;     /* GJ_DEC_BALANCE=1: sparse frames' batches cut by estimated time so that they fill one generation (latency of a lone decode) */
     int host_timing;     /* GJ_HOST_TIMING=1: the coder prints where the host's time of its calls went when it is destroyed */
     int host_scan;       /* GPUJPEG_HOST_SCAN: the decoder walks the stream on the host like the reference */

@@ -415,18 +415,20 @@ def test_encoder_tiles_and_gather(O, G, gpu_lib, tc, monkeypatch):
     case = (name, w, h, pf, cs, q, restart, il, sub, 3)
     comps = {0: 1, 1: 3}.get(pf)
     raw = natural_image(w, h, comps, seed=w) if comps and not noisy else O.noise(O.raw_size(w, h, pf), seed=w * 7 + h)
-    # (k_encode_rgb444 codes a small frame one component per workgroup, a large one all three in one: GJ_ENC_SPLIT moves the limit -- both ways here)
-    for split in (None, "0", "100000"):
-        if split is None:
-            monkeypatch.delenv("GJ_ENC_SPLIT", raising=False)
-        else:
-            monkeypatch.setenv("GJ_ENC_SPLIT", split)
-        enc = G.Encoder(gpu_lib)  # (reads the switch)
+    # (k_encode_rgb444 codes a small frame one component per workgroup, a large one all three in one: GJ_ENC_SPLIT moves the limit -- both ways here;
+    #  and the last tiles of a frame larger than the GPU one component per workgroup behind the whole ones: GJ_ENC_TAIL reaches that mixture with a small frame)
+    for split, tail in ((None, None), ("0", None), ("100000", None), ("0", "1"), ("0", "2"), ("0", "5")):
+        for var, val in (("GJ_ENC_SPLIT", split), ("GJ_ENC_TAIL", tail)):
+            if val is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, val)
+        enc = G.Encoder(gpu_lib)  # (reads the switches)
         for seg_info in (0, 1, 0):
             want = O.encode(oracle_image(O, case, segment_info=seg_info), raw)
             p, pi = api_params(gpu_lib, G, case, segment_info=seg_info)
             got = enc.encode(p, pi, raw)
-            assert got.size == want.size and np.array_equal(got, want), (name, seg_info, split, got.size, want.size)
+            assert got.size == want.size and np.array_equal(got, want), (name, seg_info, split, tail, got.size, want.size)
         enc.close()
 
 

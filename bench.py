@@ -922,6 +922,10 @@ def main():
                                       "actually bounds these kernels; the all-2-cycle and all-4-cycle floors bracket it",
                          "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
                                    "coder's stream); profiles/r5_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
+                         "dominant": ("the launch with the longest solo duration of an encoded and decoded frame. Since the encoder's last tiles are split "
+                                      "(round 5: k_encode_rgb444 84 -> 75 us alone) that is the token decoder on most runs, a stage of the decode direction: "
+                                      "`achieved` prices the direction's algorithmic bytes per frame (SURVEY 8(d)) against its duration, `traffic` is what it "
+                                      "touches itself; by_kernel / by_direction carry the others"),
                          "by_kernel": by_kernel,
                          "solo_vs_filled": None,  # (filled in by extras(): the same kernel's per-frame cost when the device is full)
                          "by_direction": {"encode": dict(roof("all encoder kernels", enc_total)), "decode": dict(roof("all decoder kernels", dec_total))},
@@ -973,11 +977,14 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
         # (VERDICT r4 #7b) the contract's roofline is the dominant kernel's SOLO duration, which carries a lone launch's ramp and under-filled last
         # generation of workgroups; the same kernel's cost per frame when the device is full = its share of the encode-only rate of four pipelines
         rf = result["roofline"]
-        if rf["kernel"].startswith("enc:") and rf["by_direction"]["encode"]["ms"] > 0:
-            share = rf["ms"] / rf["by_direction"]["encode"]["ms"]
+        # (of the encoder's main kernel, whichever kernel is the longest of the run: it is the one that owns its direction's bytes)
+        enc_k = max((k for k in rf["by_kernel"] if k["kernel"].startswith("enc:") and k.get("owns_direction_bytes")), key=lambda k: k["ms"], default=None)
+        if enc_k and rf["by_direction"]["encode"]["ms"] > 0:
+            share = enc_k["ms"] / rf["by_direction"]["encode"]["ms"]
             filled = result["encode_only"]["ms_per_frame"] * share
-            rf["solo_vs_filled"] = {"solo_ms": rf["ms"], "filled_ms_per_frame": round(filled, 4),
-                                    "filled_frac": round(rf["algorithmic_bytes_per_launch"] / (filled * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            rf["solo_vs_filled"] = {"kernel": enc_k["kernel"], "solo_ms": enc_k["ms"], "filled_ms_per_frame": round(filled, 4),
+                                    "solo_frac": enc_k.get("frac"),
+                                    "filled_frac": round(enc_k["algorithmic_bytes"] / (filled * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                     "note": "filled = encode-only ms per frame with four pipelines x the kernel's share of the encoder's solo GPU time"}
         full = {}
         for mode in ("encode", "decode", "both"):

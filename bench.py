@@ -879,6 +879,10 @@ def main():
 
         live = [i for i in range(9) if solo[i] > 0.006]  # (event slots of kernels this configuration does not launch hold only the gap between two events)
         dom = max(live, key=lambda i: solo[i])
+        # what an event pair measures with NOTHING between the two records (the slots of kernels this configuration does not launch): the part of every
+        # `ms` below that is the event records themselves -- rocprofv3's kernel durations (profiles/) correspond to ms - event_gap_ms
+        idle_slots = [float(solo[i]) for i in range(9) if 0.0005 < solo[i] <= 0.006]
+        event_gap = round(sum(idle_slots) / len(idle_slots), 4) if idle_slots else None
         valu = load_traffic("valu_insts", args.workload) if traffic else {}
 
         cyc, share4 = load_isa_mix()
@@ -926,6 +930,12 @@ def main():
                                       "(round 5: k_encode_rgb444 84 -> 75 us alone) that is the token decoder on most runs, a stage of the decode direction: "
                                       "`achieved` prices the direction's algorithmic bytes per frame (SURVEY 8(d)) against its duration, `traffic` is what it "
                                       "touches itself; by_kernel / by_direction carry the others"),
+                         "event_gap_ms": event_gap,
+                         "ms_net_of_event_gap": None if event_gap is None else round(r["ms"] - event_gap, 4),
+                         "frac_net_of_event_gap": None if event_gap is None else round(alg / ((r["ms"] - event_gap) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "event_gap_note": "hipEvent duration of an event pair with no launch between the records, from the library's event slots of kernels this "
+                                           "configuration does not launch; `ms` and `frac` above are the raw event durations (kernel + one event record), the "
+                                           "rocprofv3 durations under profiles/ agree with the net values",
                          "by_kernel": by_kernel,
                          "solo_vs_filled": None,  # (filled in by extras(): the same kernel's per-frame cost when the device is full)
                          "by_direction": {"encode": dict(roof("all encoder kernels", enc_total)), "decode": dict(roof("all decoder kernels", dec_total))},

@@ -343,27 +343,28 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
     uint16_t* stage = s_stage[threadIdx.x >> 6];
 
     // ---- 1. the three block records (independent loads)
-    uint32_t start[3], cnt[3], dc[3];
-    bool in_plane[3];
+    // (count and DC term stay packed as the record holds them -- count << 16 | DC, bit 31: "the block is in the coefficient planes" -- until their
+    // component is worked on: the kernel has no register to spare, profiles/r5_11)
+    uint32_t start[3], cd[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        start[c] = cnt[c] = dc[c] = 0;
-        in_plane[c] = false;
+        start[c] = cd[c] = 0;
         if (lb < nb) {
             const uint2 r = d_rec[g.comp[c].data_offset / 64 + lb];
             start[c] = r.x;
-            cnt[c] = r.y >> 16;
-            dc[c] = r.y & 0xFFFFu;
-            if (cnt[c] == 0xFFFFu) { in_plane[c] = true; cnt[c] = 0; }
-            else if (cnt[c] > 63u || start[c] > tok_cap || cnt[c] > tok_cap - start[c]) cnt[c] = 0; // (a record nobody wrote: damaged stream)
+            uint32_t n = r.y >> 16;
+            const bool planes = n == 0xFFFFu;
+            if (planes || n > 63u || start[c] > tok_cap || n > tok_cap - start[c]) n = 0; // (the second: a record nobody wrote, damaged stream)
+            cd[c] = (r.y & 0xFFFFu) | (n << 16) | (planes ? 0x80000000u : 0u);
         }
     }
+    auto cnt_of = [](const uint32_t x) { return (x >> 16) & 0x7FFFu; };
     __syncthreads(); // (s_q; everything below is private to a wave)
 
     // ---- 2. per component: the tokens of the wave's 64 blocks go through the LDS stage (consecutive blocks of a scan have
     //         consecutive tokens); the loads of the next component are in flight while this one is transformed
     uint32_t pk[3][16];
-    GjTokRange cur = gj_tok_fetch(d_tok, start[0], cnt[0], lane);
+    GjTokRange cur = gj_tok_fetch(d_tok, start[0], cnt_of(cd[0]), lane);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const bool fast = cur.fast;
@@ -372,8 +373,9 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
             *reinterpret_cast<uint4*>(stage + lane * 8) = cur.t0;
             if (lane * 8 + 512 < GJ_TOK_STAGE) *reinterpret_cast<uint4*>(stage + lane * 8 + 512) = cur.t1;
         }
-        if (c < 2) cur = gj_tok_fetch(d_tok, start[c + 1], cnt[c + 1], lane);
-        gj_tok_to_slot<false>(slot, stage, lane, fast, S, start[c], cnt[c], dc[c], in_plane[c],
+        if (c < 2) cur = gj_tok_fetch(d_tok, start[c + 1], cnt_of(cd[c + 1]), lane);
+        const bool in_plane = (int32_t)cd[c] < 0;
+        gj_tok_to_slot<false>(slot, stage, lane, fast, S, start[c], cnt_of(cd[c]), cd[c] & 0xFFFFu, in_plane,
                        reinterpret_cast<const uint4*>(coefs + g.comp[c].data_offset + (size_t)lb * 64), d_tok);
         // the block as rows; dequantisation + IDCT
         uint32_t wb[32];
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, 4) void k_idct_tok_rgb444(const gj_geom g, con
             const uint4 v = *gj_slot_row(slot, lane, r);
             wb[r * 4] = v.x; wb[r * 4 + 1] = v.y; wb[r * 4 + 2] = v.z; wb[r * 4 + 3] = v.w;
         }
-        gj_idct_pk(wb, s_q[in_plane[c] ? 1 : 0][c], pk[c]);
+        gj_idct_pk(wb, s_q[in_plane ? 1 : 0][c], pk[c]);
 #pragma unroll
         for (int i = 0; i < 16; i++) GJ_KEEP(pk[c][i]); // one transform at a time (see k_idct_fused_rgb444)
     }

@@ -743,13 +743,14 @@ void gj_launch_huffman_par(const gj_dec_job* job, hipStream_t st)
                        job->d_seg_index, job->seg_count, fold ? nullptr : job->d_seg_count, plan, job->d_huff_tab2, job->d_coefs, job->clear_coefs ? 0 : 1, F);
 }
 
-// the table launch folded into this kernel (GjFold, gj_dec_internal.h): one frame of a non-interleaved stream whose batches are cut per scan
+// the table launch folded into this kernel (GjFold, gj_dec_internal.h): one frame whose batches are cut per scan (one scan per component, or one interleaved scan)
 bool gj_par_folds_table(const gj_dec_job* job)
 {
     const gj_geom& g = job->g;
-    if (!job->scan.valid || job->batch.count > 1 || g.fb.sizes != nullptr || g.interleaved || g.restart_interval <= 0 || job->seg_count != g.segment_count) return false;
+    if (!job->scan.valid || job->batch.count > 1 || g.fb.sizes != nullptr || g.restart_interval <= 0 || job->seg_count != g.segment_count) return false;
     if (job->scan.wgs > 256u || job->scan.h_summary == nullptr || job->scan.h_maxlen_parts == nullptr || job->scan.maxlen_part_count == nullptr) return false;
     if (job->tune.dec_sub) return false; // (the tuning aid's sub-sequence sizes change the stage's use)
     const GjBatchPlan plan = gj_plan_batches(job, GJ_PAR_CAP_U, GJ_PAR_MAX_BLOCKS, GJ_PAR_GMAX, 0);
-    return plan.n == g.comp_count && (uint32_t)plan.batch0[plan.n] <= job->scan.maxlen_capacity;
+    // (the plan the prologue's arithmetic assumes: a range per scan -- one per component, or the one interleaved scan)
+    return plan.n == (g.interleaved ? 1 : g.comp_count) && (uint32_t)plan.batch0[plan.n] <= job->scan.maxlen_capacity;
 }

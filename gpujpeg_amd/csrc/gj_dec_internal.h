@@ -111,7 +111,9 @@ __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g,
     uint32_t* const f_mpos = f_o + GJ_SCAN_MAX_OTHER * 6;     // [GMAX + 1] the batch's restart markers: entry j ends segment k0 - 1 + j of the scan
     uint32_t* const f_mnum = f_mpos + GMAX + 1;               // ... their numbers (RSTn & 7)
     uint32_t* const f_max = f_mnum + GMAX + 1;                // [0] longest segment of the batch, [1], [2] flags (a workgroup-wide "or" without __syncthreads_or, which takes LDS of its own)
-    const int S = g.comp_count; // scans of a non-interleaved stream, in component order
+    // scans of the stream: one per component in component order, or ONE interleaved scan that holds every segment (plan range 0)
+    const int S = g.interleaved ? 1 : g.comp_count;
+    auto segs_of = [&](const int c) { return g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[c].segment_count; };
     const uint32_t base0 = (uint32_t)(((reinterpret_cast<uintptr_t>(jpeg) + F.begin) & ~(uintptr_t)15) - reinterpret_cast<uintptr_t>(jpeg)); // where the scanning workgroups' parts begin
     uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
     if ((uint32_t)tid < F.nwg) {
@@ -143,13 +145,13 @@ __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g,
     for (int c = 0; c < S && regular; c++) {
         const uint32_t* const fo = f_o + c * 6;
         const uint32_t first_rank = exp_rst;
-        exp_rst += (uint32_t)g.comp[c].segment_count - 1u;
+        exp_rst += segs_of(c) - 1u;
         regular = fo[1] == (c == S - 1 ? 0xD9u : 0xDAu) && fo[2] == exp_rst && fo[0] >= sstart && (uint64_t)fo[0] + 2u <= jpeg_size;
         if (c == pc) { my_start = sstart; my_end = fo[0]; my_first = first_rank; }
         sstart = fo[0] + 2u + (((fo[3] & 0xFFu) << 8) | ((fo[3] >> 8) & 0xFFu)); // behind the SOS header
     }
     regular = regular && total_rst == exp_rst;
-    const uint32_t segs_pc = (uint32_t)g.comp[pc].segment_count;
+    const uint32_t segs_pc = segs_of(pc);
     const int k0 = si0 - plan.first[pc]; // the batch's first segment inside its scan
     bool irregular = false;
     if (regular && tid <= nseg) { // the restart marker that ends segment k0 - 1 + tid of the scan
@@ -182,7 +184,7 @@ __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g,
         if (!last && f_mnum[tid + 1] != (k & 7u)) irregular = true; // RSTn out of sequence: the reference reader treats it specially, the host walk reproduces that
         if (last && to <= from && segs_pc > 1u) irregular = true;   // an empty segment in front of the end of a scan
         if (to > jpeg_size) irregular = true;
-        ld_s = (uint32_t)g.comp[pc].first_segment + k;
+        ld_s = (g.interleaved ? 0u : (uint32_t)g.comp[pc].first_segment) + k;
         ld_p = from;
         ld_l = to > from ? to - from : 0u;
         atomicMax(f_max, ld_l);

@@ -504,6 +504,10 @@ FOLD_CASES = [
     ("tiny_segments_r1", 320, 64, 30, 1, "natural"),  # ~1000 restart markers per scanning workgroup
     ("flat", 640, 480, 75, 36, "flat"),
     ("one_segment_per_scan", 64, 32, 75, 40, "natural"),  # no restart marker at all: every scan is its own last segment
+    # interleaved scans (one SOS, every segment in it) through k_huffman_decode_par<interleaved>: name, w, h, quality, restart, pattern, sampling
+    ("il_444", 640, 368, 75, -1, "natural", None),
+    ("il_420_odd", 645, 483, 85, 7, "natural", [(2, 2), (1, 1), (1, 1)]),
+    ("il_422_noise", 800, 304, 75, 5, "noise", [(2, 1), (1, 1), (1, 1)]),
 ]
 
 
@@ -514,8 +518,11 @@ def test_token_decoder_without_the_table_launch(O, G, gpu_lib, fc, monkeypatch, 
     segment table from the marker scan's records itself -- no k_marker_table launch (gj_scan_deferred, round 5). Pixels equal the oracle's; streams
     that are NOT the complete, regular stream the geometry describes (restart markers out of sequence, missing, surplus; no EOI; a stranger's header)
     are noticed on the device and decoded again the careful way, with the result a fresh decoder gives."""
-    name, w, h, q, ri, pattern = fc
-    case = (name, w, h, 1, 1, q, ri, 0, None, 3)
+    name, w, h, q, ri, pattern = fc[:6]
+    interleaved = len(fc) > 6
+    if interleaved and kernel == "tok":
+        pytest.skip("interleaved scans do not take the token decoder of non-interleaved frames")
+    case = (name, w, h, 1, 1, q, ri, 1 if interleaved else 0, fc[6] if interleaved else None, 3)
     img = oracle_image(O, case)
 
     def frame(seed):
@@ -546,7 +553,7 @@ def test_token_decoder_without_the_table_launch(O, G, gpu_lib, fc, monkeypatch, 
         b = np.delete(jpeg, [pos[len(pos) // 2], pos[len(pos) // 2] + 1]); bad.append(("missing marker", b))
         c = np.insert(jpeg, pos[-1], [0xFF, 0xD0 + ((jpeg[pos[-1] + 1] - 0xD0 + 7) % 8)]); bad.append(("surplus marker", c))
     bad.append(("no EOI", jpeg[:-2].copy()))
-    other = O.encode(oracle_image(O, ("o", w, h, 1, 1, max(10, q - 20), ri, 0, None, 3)), frame(7))  # same dimensions, other tables: a stranger's header
+    other = O.encode(oracle_image(O, ("o", w, h, 1, 1, max(10, q - 20), ri, case[7], case[8], 3)), frame(7))  # same dimensions, other tables: a stranger's header
     bad.append(("other header", other))
     for what, b in bad:
         fresh = G.Decoder(gpu_lib)

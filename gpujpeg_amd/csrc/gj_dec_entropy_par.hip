@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_huffman_decode_par(const gj_geom g, con
         if (tid < nseg) { ld_s = seg_index[si0 + tid]; ld_p = seg_pos[si0 + tid]; ld_l = seg_len[si0 + tid]; }
     } else {
         static_assert(GJ_FOLD_SCRATCH_WORDS(GJ_PAR_GMAX) <= GJ_PAR_CAP_U / 4, "fold scratch inside the stage");
-        if (!gj_fold_batch<GJ_PAR_GMAX>(F, g, jpeg, jpeg_size, plan, pc, si0, nseg, s_U, s_tmp, ld_s, ld_p, ld_l)) return;
+        if (!gj_fold_batch<GJ_PAR_GMAX, INTERLEAVED>(F, g, jpeg, jpeg_size, plan, pc, si0, nseg, s_U, s_tmp, ld_s, ld_p, ld_l)) return;
     }
     if (tid < GJ_PAR_GMAX) {
         uint32_t pos = 0, len = 0, nblk = 0, first = 0, tb = 0;

@@ -100,7 +100,8 @@ struct GjFold {
 // gets its segment's geometric index, position and length (ld_s, ld_p, ld_l). All 256 threads call; `scratch` = GJ_FOLD_SCRATCH_WORDS(GMAX) words
 // of LDS nobody else uses meanwhile, s_tmp = the 4 words of gj_wg256_incl_scan. Returns false (in every thread) when the stream is not the
 // regular one the geometry describes: rst_irregular is raised in the host's summary and the workgroup must leave. Workgroup 0 writes the summary.
-template <int GMAX>
+// (IL: the stream is ONE interleaved scan -- a template parameter: asked at run time it cost the 8K frame's token decoder 1.3 us, profiles/r5_13)
+template <int GMAX, bool IL = false>
 __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g, const uint8_t* __restrict__ jpeg, const uint64_t jpeg_size, const GjBatchPlan& plan,
                                               const int pc, const int si0, const int nseg, uint32_t* const scratch, uint32_t* const s_tmp, uint32_t& ld_s,
                                               uint32_t& ld_p, uint32_t& ld_l)
@@ -112,8 +113,8 @@ __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g,
     uint32_t* const f_mnum = f_mpos + GMAX + 1;               // ... their numbers (RSTn & 7)
     uint32_t* const f_max = f_mnum + GMAX + 1;                // [0] longest segment of the batch, [1], [2] flags (a workgroup-wide "or" without __syncthreads_or, which takes LDS of its own)
     // scans of the stream: one per component in component order, or ONE interleaved scan that holds every segment (plan range 0)
-    const int S = g.interleaved ? 1 : g.comp_count;
-    auto segs_of = [&](const int c) { return g.interleaved ? (uint32_t)g.segment_count : (uint32_t)g.comp[c].segment_count; };
+    const int S = IL ? 1 : g.comp_count;
+    auto segs_of = [&](const int c) { return IL ? (uint32_t)g.segment_count : (uint32_t)g.comp[c].segment_count; };
     const uint32_t base0 = (uint32_t)(((reinterpret_cast<uintptr_t>(jpeg) + F.begin) & ~(uintptr_t)15) - reinterpret_cast<uintptr_t>(jpeg)); // where the scanning workgroups' parts begin
     uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
     if ((uint32_t)tid < F.nwg) {
@@ -184,7 +185,7 @@ __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g,
         if (!last && f_mnum[tid + 1] != (k & 7u)) irregular = true; // RSTn out of sequence: the reference reader treats it specially, the host walk reproduces that
         if (last && to <= from && segs_pc > 1u) irregular = true;   // an empty segment in front of the end of a scan
         if (to > jpeg_size) irregular = true;
-        ld_s = (g.interleaved ? 0u : (uint32_t)g.comp[pc].first_segment) + k;
+        ld_s = (IL ? 0u : (uint32_t)g.comp[pc].first_segment) + k;
         ld_p = from;
         ld_l = to > from ? to - from : 0u;
         atomicMax(f_max, ld_l);

@@ -16,7 +16,7 @@ On rank 0 at N = 1 the same JSON line also carries (each a short bounded run; --
                     JPEG in + raw out for the decoder) / its average hipEvent duration in a SOLO timed region (one pipeline, the GPU
                     otherwise idle, events on the coder's own stream) against 8 TB/s; `by_kernel` has every kernel of the step,
                     `contended` the same kernel inside the headline region where four pipelines share the GPU; `traffic` = HBM bytes
-                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r5_traffic.json; dropped when the
+                    per launch from the PMC passes under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r6_traffic.json; dropped when the
                     device sources differ from the ones profiled)
   encode_only / decode_only   each direction alone, device resident ("w/o PCIe" in the reference's tables)
   full_api          host buffers in and out (pinned), i.e. what a drop-in caller of the reference API sees, PCIe included
@@ -62,7 +62,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 DTYPE_DETAIL = "u8 samples, fp32 colour transform and DCT (bit-exact with the reference's integer / float arithmetic), i16 coefficients"
 
 
-TRAFFIC_FILE = "r5_traffic.json"
+TRAFFIC_FILE = "r6_traffic.json"
+ROTATE = 3  # distinct frames (and output buffers) per pipeline, see Spec
 
 
 from gpujpeg_amd.source_hash import kernel_source_hash  # noqa: E402
@@ -70,7 +71,7 @@ from gpujpeg_amd.source_hash import kernel_source_hash  # noqa: E402
 
 def load_traffic(key="kernels", workload="8k"):
     """HBM bytes per launch (`kernels`) / vector instructions per launch (`valu_insts`) of a workload from the committed PMC passes
-    (profiles/r5_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
+    (profiles/r6_traffic.json, written by tools/profile.sh); empty when the device sources have changed since they were taken."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
         for w in d.get("workloads", {}).values():  # bench.py times the two marker kernels with one pair of events: one name for their sum
@@ -89,14 +90,14 @@ def load_traffic(key="kernels", workload="8k"):
 # cycles when it is a plain add / sub / and / or / xor / mov / not / ashr / fp32 mul-add-fma and for ~4.3 cycles otherwise (shifts, bit-field,
 # compare, select, convert, packed-fp32, three-operand integer: tools/ubench/valu_rate.hip on this GPU, profiles/r2_09_ubench.txt). The
 # issue floor of a kernel = SQ_INSTS_VALU per launch (PMC pass) x the cycles of its class mix (static mix of the kernel's code,
-# tools/isa_loops.py --mix -> profiles/r5_isa_mix.json) / 1024 SIMDs / 2.4 GHz; the floors with every instruction in the fast and in
+# tools/isa_loops.py --mix -> profiles/r6_isa_mix.json) / 1024 SIMDs / 2.4 GHz; the floors with every instruction in the fast and in
 # the slow class bracket it.
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def load_isa_mix():
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r5_isa_mix.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r6_isa_mix.json")))
         return d["cycles"], {k: v["whole"]["share4"] for k, v in d["kernels"].items()}
     except Exception:
         return {"valu2": 2.4, "valu4": 4.3}, {}
@@ -172,6 +173,16 @@ class Spec:
         self.quality = 90 if (self.is422 and quality == 75) else quality
         frame = synth_frame(lib, self.width, self.height, pattern, seed, device)
         self.frame = to_uyvy(frame) if self.is422 else frame
+        # (VERDICT r5 #9a) every pipeline walks ROTATE distinct frames at distinct addresses (and as many output buffers), in the timed regions and in
+        # the solo kernel timings: one 8K frame (99.5 MB) would sit in the 256 MB Infinity Cache between two launches, three do not. The natural
+        # pattern differs by its noise seed; the reference's own contents (`.tst` noise / gradient, the camera sample) are the same file at other addresses
+        self.variants = [self.frame]
+        for k in range(1, ROTATE):
+            if pattern == "natural":
+                v = synth_frame(lib, self.width, self.height, pattern, seed + 1000 * k, device)
+                self.variants.append(to_uyvy(v) if self.is422 else v)
+            else:
+                self.variants.append(self.frame)  # (cloned per lane below: other addresses, same bytes)
         p = lib.default_parameters()
         p.quality, p.restart_interval, p.verbose, p.perf_stats = self.quality, G.RESTART_AUTO, -1, 1
         if internal_rgb:
@@ -224,7 +235,8 @@ _STREAMS = {}
 class BenchLane(C.Structure):
     """struct gj_bench_lane of tools/bench_loop.c"""
     _fields_ = [("enc", C.c_void_p), ("dec", C.c_void_p), ("param", C.c_void_p), ("param_image", C.c_void_p), ("images", C.POINTER(C.c_void_p)),
-                ("image_count", C.c_int), ("images_on_device", C.c_int), ("out", C.c_void_p), ("out_on_device", C.c_int)]
+                ("image_count", C.c_int), ("images_on_device", C.c_int), ("out", C.c_void_p), ("out_on_device", C.c_int),
+                ("outs", C.POINTER(C.c_void_p)), ("out_count", C.c_int)]
 
 
 _CLOOP = {"lib": None, "tried": False}
@@ -247,10 +259,12 @@ def c_loop(enabled=True):
     return _CLOOP["lib"]
 
 
-def run_frames_c(loop, ln, p, pi, images, on_device, out_ptr, frames, mode, jp, js):
+def run_frames_c(loop, ln, p, pi, images, on_device, out_ptr, frames, mode, jp, js, outs=None):
     """`frames` frames of one pipeline through tools/bench_loop.c; returns (jpeg pointer, size, encoder seconds, decoder seconds, bytes)"""
     arr = (C.c_void_p * len(images))(*images)
-    lane = BenchLane(ln["enc"].h, ln["dec"].h, C.addressof(p), C.addressof(pi), arr, len(images), int(on_device), out_ptr, int(on_device))
+    oarr = (C.c_void_p * len(outs))(*outs) if outs else None
+    lane = BenchLane(ln["enc"].h, ln["dec"].h, C.addressof(p), C.addressof(pi), arr, len(images), int(on_device), out_ptr, int(on_device),
+                     oarr, len(outs) if outs else 0)
     jpeg = C.cast(jp, C.POINTER(C.c_uint8))
     size, secs, nbytes = C.c_size_t(int(js)), (C.c_double * 2)(), C.c_size_t(0)
     rc = loop.gj_bench_run(C.byref(lane), frames, {"both": 0, "encode": 1, "decode": 2}[mode], C.byref(jpeg), C.byref(size), secs, C.byref(nbytes))
@@ -291,13 +305,14 @@ class Lanes:
             e, d = G.Encoder(lib, ts.cuda_stream), G.Decoder(lib, ts.cuda_stream)
             ln = {"stream": ts, "enc": e, "dec": d}
             if host_io:  # what a drop-in caller of the reference API has: host memory on both sides (pinned, like gpujpeg_image_load_from_file's)
-                ln["frame"] = spec.frame.cpu().pin_memory()
-                ln["out"] = torch.empty_like(ln["frame"]).pin_memory()
+                ln["frames"] = [v.cpu().pin_memory() for v in spec.variants]
+                ln["outs"] = [torch.empty_like(ln["frames"][0]).pin_memory() for _ in spec.variants]
                 assert e.set_option("enc_opt_out", "enc_out_val_pinned") == 0
             else:
-                ln["frame"] = spec.frame if si == 0 else spec.frame.clone()
-                ln["out"] = torch.empty_like(spec.frame)
+                ln["frames"] = [v if (si == 0 and (k == 0 or v is not spec.frame)) else v.clone() for k, v in enumerate(spec.variants)]
+                ln["outs"] = [torch.empty_like(spec.frame) for _ in spec.variants]
                 assert e.set_option("enc_opt_out", "enc_out_val_device") == 0
+            ln["frame"], ln["out"], ln["turn"] = ln["frames"][0], ln["outs"][0], 0
             if keep_coefs:
                 d.keep_coefficients()
             d.init(spec.p, lib.default_image_parameters())  # turns perf_stats on for the decoder (same API as the reference)
@@ -308,6 +323,8 @@ class Lanes:
 
     def encode(self, ln):
         sp = self.spec
+        ln["turn"] = (ln["turn"] + 1) % len(ln["frames"])  # (the Python loop rotates like tools/bench_loop.c; decode() writes the output of the same turn)
+        ln["frame"], ln["out"] = ln["frames"][ln["turn"]], ln["outs"][ln["turn"]]
         if self.host_io:
             inp = G.EncoderInput()
             inp.type, inp.image = G.ENCODER_INPUT_IMAGE, ln["frame"].data_ptr()
@@ -367,11 +384,12 @@ class Lanes:
             go.wait()
             jp, js = ln["last"]
             if loop is not None and not stats:  # the whole region in one foreign call: nothing of the interpreter between two API calls
-                jp, js, te, td, _ = run_frames_c(loop, ln, self.p, self.spec.pi, [ln["frame"].data_ptr()], not self.host_io, ln["out"].data_ptr(),
-                                                 steps * reps, mode, jp, js)
+                jp, js, te, td, nb = run_frames_c(loop, ln, self.p, self.spec.pi, [f.data_ptr() for f in ln["frames"]], not self.host_io, ln["out"].data_ptr(),
+                                                  steps * reps, mode, jp, js, outs=[o.data_ptr() for o in ln["outs"]])
                 if idx == 0:
                     walls[0], walls[1] = te, td
                 ln["last"] = (jp, js)
+                ln["mean_jpeg"] = nb / max(1, steps * reps)
                 return
             for _ in range(steps * reps):
                 a = time.perf_counter()
@@ -448,7 +466,7 @@ def measure(lib, spec, device, local_rank, barrier, mode="both", streams=4, step
     if want_solo:  # per-kernel durations with all pipelines running: their own short region, with the events on
         L.set_stats(True)
         *_, kms = L.run(mode, 1, max(8, reps // 2), sync, local_rank)
-    jsize = int(L.lanes[0]["last"][1])
+    jsize = int(round(L.lanes[0].get("mean_jpeg") or L.lanes[0]["last"][1]))  # (mean over the frames of the rotation)
     S = len(L.lanes)
     L.close()
     return {"elapsed": elapsed, "reps": reps, "streams": S, "enc_wall": enc_wall, "dec_wall": dec_wall, "kernel_ms": kms, "solo_ms": solo,
@@ -901,13 +919,20 @@ def main():
         by_kernel = [stage(names[i], solo[i]) for i in live]
         r = roof(names[dom], solo[dom])
         enc_total, dec_total = float(sum(solo[i] for i in live if i < 5)), float(sum(solo[i] for i in live if i >= 5))  # (slots of kernels that were not launched hold the gap between two events)
+        n_enc, n_dec = sum(1 for i in live if i < 5), sum(1 for i in live if i >= 5)
+        gap = event_gap or 0.0  # (an event pair brackets the kernel AND one event record: rocprofv3's kernel durations are the net values)
+        enc_net, dec_net = max(enc_total - n_enc * gap, 0.0), max(dec_total - n_dec * gap, 0.0)
+
+        def dir_frac(nbytes, ms):
+            return round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else None
         result = {
             "metric": ("Mpix/s encode+decode (8K RGB q75)" if args.workload == "8k" else f"Mpix/s encode+decode ({args.workload})") if args.mode == "both"
                       else f"Mpix/s {args.mode} only ({args.workload})",
             "value": round(spec.pixels * frames_all / elapsed / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "frames_all_ranks": frames_all, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_detail": DTYPE_DETAIL,
-            "data": f"synthetic ({args.pattern}), {S} {width}x{height} frame(s) per rank resident in HBM, one per pipeline",
+            "data": f"synthetic ({args.pattern}), {S * ROTATE} {width}x{height} frames per rank resident in HBM: every pipeline walks {ROTATE} distinct frames "
+                    f"and {ROTATE} output buffers round-robin (no frame is re-read out of the 256 MB Infinity Cache)",
             "config": {"workload": spec.describe() + (" (7680x4320 -> 36)" if args.workload == "8k" else "") + ", encode then decode of every frame",
                        "frames_per_step_per_gpu": S * reps, "frames_per_step_per_pipeline": reps, "streams_per_gpu": S, "timed_seconds": round(elapsed, 3),
                        "untimed_before": f"16 frames per pipeline (sizing of the step), then {args.warmup} warm-up steps of the timed shape; the interpreter's "
@@ -920,12 +945,28 @@ def main():
             "encode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["enc_wall"] / 1e6, 2) if args.mode != "decode" else None,
             "decode_mpix_s_pipeline0": round(spec.pixels * args.steps * reps / head["dec_wall"] / 1e6, 2) if args.mode != "encode" else None,
             "roofline": {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["frac"],
+                         "frac_basis": ("the dominant kernel's own bytes: a fused encoder moves its direction's algorithmic bytes (raw in + JPEG out) alone"
+                                        if owns_direction(names[dom]) else
+                                        "FLATTERING for this kernel: `frac` divides the whole decode direction's algorithmic bytes (JPEG in + raw out) by the duration "
+                                        "of ONE of its stage kernels, which never writes a pixel; the figures the driver's clock and the profiles support are "
+                                        "frac_path, frac_encode_direction, frac_decode_direction and frac_hbm_read_encode below"),
+                         #  the four fractions a reader can recompute: whole path from the driver-timed region, each direction from the
+                         # sum of its kernels' solo durations (hipEvents net of the event record, = rocprofv3's kernel durations under profiles/),
+                         # and north_star's own definition: raw input bytes of the encoder / encoder direction time / peak, target 0.70
+                         "frac_path": round(2 * alg * frames_all / elapsed / 1e9 / HBM_PEAK_GBS, 5) if args.mode == "both" else None,
+                         "frac_path_basis": "(encode + decode algorithmic bytes per frame) / (ms_per_step / frames_per_step_per_gpu) / peak: every kernel, launch gap and "
+                                            "host call of the timed region included, four pipelines sharing the device",
+                         "frac_encode_direction": dir_frac(alg, enc_net), "frac_decode_direction": dir_frac(alg, dec_net),
+                         "frac_hbm_read_encode": dir_frac(spec.raw_bytes, enc_net), "target": 0.70,
+                         "frac_hbm_read_encode_basis": "BASELINE.json north_star: raw input bytes of the encoder (HBM read) / sum of the encoder kernels' solo durations / "
+                                                       "8 TB/s; the target is 0.70. These kernels are bound by vector-instruction issue (valu_issue_frac), not by HBM: DESIGN 4",
+                         "direction_ms_net_of_event_gap": {"encode": round(enc_net, 4), "decode": round(dec_net, 4), "encode_kernels": n_enc, "decode_kernels": n_dec},
                          "traffic": traffic.get(names[dom]), "ms": r["ms"], "algorithmic_bytes_per_launch": int(alg), **issue(names[dom], solo[dom]),
-                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r5_traffic.json) x the cycles of the kernel's instruction class mix "
-                                      "(2.4 / 4.3 cycles per wave64 instruction, profiles/r5_isa_mix.json) / 1024 SIMDs / 2.4 GHz / duration -- the roofline that "
+                         "valu_note": "valu_issue_frac: SQ_INSTS_VALU per launch (profiles/r6_traffic.json) x the cycles of the kernel's instruction class mix "
+                                      "(2.4 / 4.3 cycles per wave64 instruction, profiles/r6_isa_mix.json) / 1024 SIMDs / 2.4 GHz / duration -- the roofline that "
                                       "actually bounds these kernels; the all-2-cycle and all-4-cycle floors bracket it",
                          "timing": "average hipEvent duration over 10 solo launches inside this run (one pipeline, GPU otherwise idle, events on the "
-                                   "coder's stream); profiles/r5_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
+                                   "coder's stream); profiles/r6_* hold the rocprofv3 --kernel-trace --stats summary of the same configuration",
                          "dominant": ("the launch with the longest solo duration of an encoded and decoded frame. Since the encoder's last tiles are split "
                                       "(round 5: k_encode_rgb444 84 -> 75 us alone) that is the token decoder on most runs, a stage of the decode direction: "
                                       "`achieved` prices the direction's algorithmic bytes per frame (SURVEY 8(d)) against its duration, `traffic` is what it "
@@ -960,7 +1001,7 @@ def verify_headline(lib, spec, device, args):
     jp, js = L.encode(ln)
     L.decode(ln, jp, js)
     torch.cuda.synchronize()
-    host = spec.frame.cpu().numpy().reshape(-1)
+    host = ln["frame"].cpu().numpy().reshape(-1)  # (the frame of the rotation this turn coded)
     img = (O.make_image(spec.width, spec.height, pixel_format=3, color_space=3, quality=spec.quality, interleaved=1) if spec.is422
            else O.make_image(spec.width, spec.height, quality=spec.quality, color_space_internal=1 if args.internal_rgb else 3))
     want = O.encode(img, host)

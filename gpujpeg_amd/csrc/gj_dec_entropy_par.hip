@@ -750,6 +750,10 @@ bool gj_par_folds_table(const gj_dec_job* job)
     if (!job->scan.valid || job->batch.count > 1 || g.fb.sizes != nullptr || g.restart_interval <= 0 || job->seg_count != g.segment_count) return false;
     if (job->scan.wgs > 256u || job->scan.h_summary == nullptr || job->scan.h_maxlen_parts == nullptr || job->scan.maxlen_part_count == nullptr) return false;
     if (job->tune.dec_sub) return false; // (the tuning aid's sub-sequence sizes change the stage's use)
+    //  a segment beyond the LDS stage / the per-block arrays is decoded in pieces, and the pieces are cut from the TABLE: the folded
+    // kernel can only raise rst_irregular for it, which costs a second decode of every frame of such a sequence. The longest segment of the
+    // previous frame with this header (or of this one, after a host walk) says whether that is to be expected; 0 = not known
+    if (job->max_seg_len == 0 || ((job->max_seg_len + 3u) & ~3u) + 8u > (uint32_t)GJ_PAR_CAP_U || g.seg_blocks > GJ_PAR_MAX_BLOCKS) return false;
     const GjBatchPlan plan = gj_plan_batches(job, GJ_PAR_CAP_U, GJ_PAR_MAX_BLOCKS, GJ_PAR_GMAX, 0);
     // (the plan the prologue's arithmetic assumes: a range per scan -- one per component, or the one interleaved scan)
     return plan.n == (g.interleaved ? 1 : g.comp_count) && (uint32_t)plan.batch0[plan.n] <= job->scan.maxlen_capacity;

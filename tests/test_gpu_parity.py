@@ -504,6 +504,7 @@ FOLD_CASES = [
     ("tiny_segments_r1", 320, 64, 30, 1, "natural"),  # ~1000 restart markers per scanning workgroup
     ("flat", 640, 480, 75, 36, "flat"),
     ("one_segment_per_scan", 64, 32, 75, 40, "natural"),  # no restart marker at all: every scan is its own last segment
+    ("long_segments_q100_noise", 640, 368, 100, 120, "noise"),  # 17 KB segments: decoded in pieces cut from the table, so the fold is refused up front (it was decoded twice, every frame)
     # interleaved scans (one SOS, every segment in it) through k_huffman_decode_par<interleaved>: name, w, h, quality, restart, pattern, sampling
     ("il_444", 640, 368, 75, -1, "natural", None),
     ("il_420_odd", 645, 483, 85, 7, "natural", [(2, 2), (1, 1), (1, 1)]),

@@ -56,6 +56,52 @@ def test_frame_sharding_world2():
         assert total == total_frames
 
 
+def _worker8(rank, world, port, total_frames, out):
+    """one of the eight ranks of `bench.py --gpus 8` as far as the CPU can play it: the sharding, the two reductions of the timed region and the
+    placement of its four launch threads on a two-socket node (ranks 0-3 next to socket 0, ranks 4-7 next to socket 1; SMT siblings at +128)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpujpeg_amd.sharding import barrier_and_max, gather_counts, parse_cpulist, plan_affinity, shard_frames
+    mine = shard_frames(total_frames, rank, world)
+    sockets = [parse_cpulist("0-63,128-191"), parse_cpulist("64-127,192-255")]
+    near = [sockets[r // 4] for r in range(world)]
+    cpus = plan_affinity(rank, world, 4, range(256), near, avoid={0, 1, 64})  # (the launcher and a stranger keep three cores busy)
+    everything = [None] * world
+    dist.all_gather_object(everything, (mine, cpus))
+    elapsed = barrier_and_max(1.0 + 0.125 * rank)
+    total = gather_counts(len(mine))
+    out.put((rank, everything, elapsed, total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_world8():
+    """(VERDICT r5 #9) the shape of the driver's --gpus 8 run: 8 ranks x 4 launch threads, BASELINE config 5's 256 frames"""
+    world, total_frames = 8, 256
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, total_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, everything, elapsed, total in results:
+        shards = [e[0] for e in everything]
+        plans = [e[1] for e in everything]
+        assert sorted(x for s in shards for x in s) == list(range(total_frames)), "shards must cover the batch exactly once"
+        assert all(len(s) == total_frames // world for s in shards)
+        assert all(p is not None and len(p) == 4 and len(set(p)) == 4 for p in plans)
+        assert len(set().union(*map(set, plans))) == 32, "launch threads of different ranks never share a core"
+        for r, p in enumerate(plans):
+            assert set(p) <= set(range(0, 64)) | set(range(128, 192)) if r < 4 else set(p) <= set(range(64, 128)) | set(range(192, 256))
+            assert not set(p) & {0, 1, 64}
+        assert elapsed == 1.0 + 0.125 * 7 and total == total_frames
+
+
 def test_single_process_defaults():
     from gpujpeg_amd.sharding import barrier_and_max, gather_counts, shard_frames
     assert shard_frames(10, 0, 1) == list(range(10))

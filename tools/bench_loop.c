@@ -20,6 +20,8 @@ struct gj_bench_lane {
     int images_on_device; /* GPUJPEG_ENCODER_INPUT_GPU_IMAGE instead of _IMAGE */
     uint8_t* out;         /* decoder's custom buffer */
     int out_on_device;
+    uint8_t* const* outs; /* out_count custom buffers walked round-robin (NULL: `out` for every frame) */
+    int out_count;
 };
 
 static double now(void)
@@ -50,8 +52,9 @@ __attribute__((visibility("default"))) int gj_bench_run(const struct gj_bench_la
         }
         const double b = now();
         if (mode != 1) {
-            if (ln->out_on_device) gpujpeg_decoder_output_set_custom_cuda(&out, ln->out);
-            else gpujpeg_decoder_output_set_custom(&out, ln->out);
+            uint8_t* dst = ln->outs != NULL && ln->out_count > 0 ? ln->outs[f % ln->out_count] : ln->out;
+            if (ln->out_on_device) gpujpeg_decoder_output_set_custom_cuda(&out, dst);
+            else gpujpeg_decoder_output_set_custom(&out, dst);
             const int rc = gpujpeg_decoder_decode(ln->dec, *jpeg, *size, &out);
             if (rc != 0) return rc;
         }

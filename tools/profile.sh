@@ -7,10 +7,11 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 W=${WORKLOAD:-8k}
-TAG=${TAG:-r5_$W}
+TAG=${TAG:-r6_$W}
 rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq
 ARGS="--workload $W --streams ${STREAMS:-1} --lean ${BENCH_ARGS}"
 if [ -n "$BATCH" ]; then ARGS="--workload 4k --batch $BATCH --streams ${STREAMS:-4} ${BENCH_ARGS}"; fi
+TRACE_ARGS="$ARGS" # (the counter passes of a batch run another shape: the header of the summary names both commands, each with its own arguments)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python bench.py --steps ${STEPS:-20} --warmup 3 $ARGS > $OUT/prof_stats.log 2>&1
 tail -1 $OUT/prof_stats.log | cut -c1-300
 PM="--steps 3 --warmup 1 --min-seconds 0 --calibrate"
@@ -21,5 +22,5 @@ fi
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python bench.py $PM $ARGS > $OUT/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python bench.py $PM $ARGS > $OUT/prof_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/prof_sq -- python bench.py $PM $ARGS > $OUT/prof_sq.log 2>&1
-python tools/rocprof_summary.py $OUT $TAG "cmd: rocprofv3 ... -- python bench.py $ARGS (kernel trace: --steps ${STEPS:-20}; PMC passes: $PM)" > $OUT/${TAG}_summary.log 2>&1 || true
+python tools/rocprof_summary.py $OUT $TAG "kernel trace + stats: rocprofv3 --kernel-trace --stats -- python bench.py --steps ${STEPS:-20} --warmup 3 $TRACE_ARGS | PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*; each its own run): rocprofv3 --kernel-trace --pmc ... -- python bench.py $PM $ARGS" > $OUT/${TAG}_summary.log 2>&1 || true
 grep -E "^k_|^void k_" $OUT/${TAG}_kernel_stats.txt | head -14

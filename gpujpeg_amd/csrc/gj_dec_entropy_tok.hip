@@ -65,6 +65,22 @@ unsigned long long gj_tok_stats[64];
 #define GJ_STAT_WAVE(sm, i, lane, sym) ((void)0)
 #endif
 
+// The reader's window. GJ_TOK_WIN 0: both dwords of the window are read from the stage for every symbol (ds_read2_b32 in front of the look-up, on the
+// symbol's dependent chain). GJ_TOK_WIN 1 (round 6 experiment): the window lives in two registers; the dword BEHIND it is asked for at the top of every
+// iteration -- its latency hides under the table look-up -- and moves in when the position crosses a dword (a symbol has at most 26 bits: one step).
+#ifndef GJ_TOK_WIN
+#define GJ_TOK_WIN 1
+#endif
+#if GJ_TOK_WIN == 1
+#define GJ_TOK_WIN_INIT(sm, p1) uint32_t wcur_ = (p1) >> 5, w0_ = (sm).U[wcur_], w1_ = (sm).U[wcur_ + 1], wnx_ = 0
+#define GJ_TOK_WIN_BITS(sm, p1) wnx_ = (sm).U[wcur_ + 2]; const uint32_t win = __builtin_amdgcn_alignbit(w0_, w1_, ~(p1))
+#define GJ_TOK_WIN_STEP(p1) do { const uint32_t wn_ = (p1) >> 5; const bool cross_ = wn_ != wcur_; w0_ = cross_ ? w1_ : w0_; w1_ = cross_ ? wnx_ : w1_; wcur_ = wn_; } while (0)
+#else
+#define GJ_TOK_WIN_INIT(sm, p1) ((void)0)
+#define GJ_TOK_WIN_BITS(sm, p1) const uint32_t wi = (p1) >> 5; const uint32_t win = __builtin_amdgcn_alignbit((sm).U[wi], (sm).U[wi + 1], ~(p1))
+#define GJ_TOK_WIN_STEP(p1) ((void)0)
+#endif
+
 // state between two symbols: bits [0,5) overshoot into the next sub-sequence, [5,11) zig-zag index
 // counts of a sub-sequence: bits [0,16) blocks completed, [16,32) tokens
 
@@ -102,13 +118,14 @@ __device__ __forceinline__ uint32_t gj_tok_run_in(const GjTokLds& sm, const uint
     const uint32_t e1 = start_bit - 1u;
     uint32_t z = 1;
     uint32_t toff = (uint32_t)GJ_DEC2_WORDS * 2u;
+    GJ_TOK_WIN_INIT(sm, p1);
     while (p1 < e1) {
-        const uint32_t wi = p1 >> 5;
-        const uint32_t win = __builtin_amdgcn_alignbit(sm.U[wi], sm.U[wi + 1], ~p1);
+        GJ_TOK_WIN_BITS(sm, p1);
         const uint16_t* t = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(sm.tab) + toff);
         uint32_t e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)];
         p1 += e & 31u;
+        GJ_TOK_WIN_STEP(p1);
         z += (e >> 9) & 63u;
         const uint32_t inside = (uint32_t)((int32_t)(z - 64u) >> 31); // all ones until the block is complete
         z &= inside;
@@ -136,9 +153,9 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
     uint32_t toff = z == 0 ? 0u : (uint32_t)GJ_DEC2_WORDS * 2u; // byte offset of the table: DC in front of a block, AC inside
     uint32_t nb = 0, ntok = 0, mx = 0;
     uint16_t* tp = tok_out; // MODE 1: where the next token goes (ntok follows from it at the end)
+    GJ_TOK_WIN_INIT(sm, p1);
     while (p1 < e1) {
-        const uint32_t wi = p1 >> 5;
-        const uint32_t win = __builtin_amdgcn_alignbit(sm.U[wi], sm.U[wi + 1], ~p1); // the next 32 bits of the stream
+        GJ_TOK_WIN_BITS(sm, p1); // win: the next 32 bits of the stream
         const uint16_t* t = reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(sm.tab) + toff);
         uint32_t e = t[gj_bfe_u32<32 - GJ_DEC_FAST_BITS, GJ_DEC_FAST_BITS>(win)];
         if ((e & 31u) == 0) e = t[(e >> 5) + ((win >> 16) & 63u)]; // codes longer than 10 bits
@@ -170,6 +187,7 @@ __device__ __forceinline__ uint32_t gj_tok_decode(const GjTokLds& sm, const uint
             }
         }
         p1 += tot;
+        GJ_TOK_WIN_STEP(p1);
         z += adv;
         const uint32_t inside = (uint32_t)((int32_t)(z - 64u) >> 31); // all ones until the block is complete
         z &= inside;

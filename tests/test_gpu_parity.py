@@ -544,7 +544,10 @@ def test_token_decoder_without_the_table_launch(O, G, gpu_lib, fc, monkeypatch, 
     # (a stream whose three scan-ending markers all lie in ONE scanning workgroup's part -- a few KB: the last two cases -- is walked by the host and
     # never launches speculatively: a scanning workgroup's record holds two markers that are no restart markers)
     assert spec == (0 if name in ("tiny_segments_r1", "one_segment_per_scan") else 7) and again == 0, (spec, folded, again)
-    assert folded == spec, "every speculative launch of this geometry does without the table kernel"
+    if name == "long_segments_q100_noise":  # segments beyond the LDS stage are cut into pieces from the table: speculative, with the table launch, decoded ONCE
+        assert folded == 0, (spec, folded, again)
+    else:
+        assert folded == spec, "every speculative launch of this geometry does without the table kernel"
     # ---- streams the geometry does not describe, on the speculative path
     jpeg = streams[1]
     pos = [i for i in range(len(jpeg) - 1) if jpeg[i] == 0xFF and 0xD0 <= jpeg[i + 1] <= 0xD7]

@@ -41,6 +41,7 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 extern thread_local uint3 threadIdx, blockIdx;
 extern thread_local dim3 blockDim, gridDim;
 
+#define __launch_bounds__(...)
 #define __global__
 #define __device__
 #define __host__
@@ -66,23 +67,52 @@ static inline unsigned __byte_perm(unsigned x, unsigned y, unsigned s)
     return r;
 }
 
+/* what CUDA's headers give device code besides the above: the integer intrinsics of the two Huffman modules, mixed-sign min / max */
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline unsigned max(unsigned a, int b) { return a > (unsigned)b ? a : (unsigned)b; }
+static inline unsigned max(int a, unsigned b) { return (unsigned)a > b ? (unsigned)a : b; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned min(unsigned a, int b) { return a < (unsigned)b ? a : (unsigned)b; }
+static inline unsigned min(int a, unsigned b) { return (unsigned)a < b ? (unsigned)a : b; }
+enum { cudaFuncCachePreferShared = 1 };
+template <typename F> static inline cudaError_t cudaFuncSetCacheConfig(F, int) { return cudaSuccess; }
+
 namespace cudaemu {
 struct shared_mark { shared_mark(); };
 void sync_threads();
-/* runs fn(ctx) once per CUDA thread of every block of the grid */
-void run_grid(dim3 grid, dim3 block, void (*fn)(void*), void* ctx);
+/* runs fn(ctx) once per CUDA thread of every block of the grid. warp = true: WARP MODE (see cudaemu.cpp) -- the 32 threads of a warp run in
+ * lock step as far as a program can tell: shared-memory reads wait until every other lane of the warp has stopped (at a read, a vote, a
+ * barrier, or its end), votes collect all lanes. Needs the translation unit compiled with -fsanitize=thread: its load / store hooks are how the
+ * emulator sees shared memory accesses. */
+void run_grid(dim3 grid, dim3 block, void (*fn)(void*), void* ctx, bool warp);
+unsigned ballot(int predicate);
+unsigned atomic_add(unsigned* p, unsigned v);
 
 template <typename F, typename... A>
 void launch(dim3 grid, dim3 block, size_t shm, cudaStream_t stream, F kernel, A... args)
 {
     (void)shm; (void)stream;
     auto body = [&]() { kernel(args...); };
-    run_grid(grid, block, [](void* p) { (*static_cast<decltype(body)*>(p))(); }, &body);
+#ifdef CUDAEMU_WARP
+    const bool warp = true;
+#else
+    const bool warp = false;
+#endif
+    run_grid(grid, block, [](void* p) { (*static_cast<decltype(body)*>(p))(); }, &body, warp);
 }
 } // namespace cudaemu
 
 #define __syncthreads() cudaemu::sync_threads()
-#define CUDAEMU_LAUNCH(grid, block, shm, stream, kernel, ...) cudaemu::launch(grid, block, shm, stream, kernel, __VA_ARGS__)
+#define CUDAEMU_LAUNCH(grid, block, shm, stream, kernel, ...) cudaemu::launch(grid, block, shm, stream, kernel, ##__VA_ARGS__)
+/* warp votes (src/gpujpeg_huffman_gpu_encoder.cu:202-262): every lane of the warp that has not ended takes part */
+#define __ballot_sync(mask, pred) cudaemu::ballot((pred) != 0)
+#define __ballot(pred) cudaemu::ballot((pred) != 0)
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return cudaemu::atomic_add(p, v); }
+#define cudaMemcpyToSymbol(sym, src, n, off, kind) (memcpy((char*)(sym) + (off), (src), (n)), cudaSuccess)
 
 #define cudaMemcpyToSymbolAsync(sym, src, n, off, kind, st) (memcpy((char*)(sym) + (off), (src), (n)), cudaSuccess)
 static inline cudaError_t cudaMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t w, size_t h,

@@ -6,9 +6,10 @@
  * stub/cuda_runtime.h, and so are three of its five CUDA modules -- src/gpujpeg_preprocessor.cu,
  * gpujpeg_dct_gpu.cu and gpujpeg_postprocessor.cu, i.e. colour transforms, sub/upsampling, fDCT+quantisation
  * and dequantisation+IDCT -- which run on the CPU under the cudaemu execution model (oracle/cudaemu) or on
- * the GPU through hipcc (oracle/hipstub). What is still missing at link time are the two Huffman GPU modules
- * (warp-32 intrinsics); this file provides their entry points by running the reference's own CPU Huffman
- * decoder and the restated segment coder (whose bytes gjref_reencode_cpu_huffman checks against the
+ * the GPU through hipcc (oracle/hipstub). The two Huffman GPU modules
+ * (warp-32 intrinsics) run under cudaemu's warp mode in the CPU builds (round 6: GJREF_EMU_HUFFMAN, all five CUDA modules are the reference's);
+ * the hipcc build for gfx950 (wave64) and the timing builds still take this file's stand-ins for their entry points: the reference's own CPU
+ * Huffman decoder and the restated segment coder (whose bytes gjref_reencode_cpu_huffman checks against the
  * reference's CPU Huffman encoder). With GJREF_RESTATED_STAGES defined the three arithmetic modules are
  * replaced by the restatement of gj_oracle.c as well (the round-1 build, kept for bisecting a mismatch).
  *
@@ -165,6 +166,7 @@ int gpujpeg_idct_gpu(struct gpujpeg_decoder* decoder)
 
 #endif /* GJREF_RESTATED_STAGES */
 
+#ifndef GJREF_EMU_HUFFMAN /* (the cudaemu builds link the reference's own two Huffman GPU modules, oracle/Makefile EMU_WARP_CU: no stand-ins there) */
 /* ---- Huffman "GPU" encoder (reference: src/gpujpeg_huffman_gpu_encoder.cu:973,1072) ---- */
 struct gpujpeg_huffman_gpu_encoder { int unused; };
 
@@ -217,6 +219,7 @@ int gpujpeg_huffman_gpu_decoder_decode(struct gpujpeg_decoder* decoder)
     memcpy(coder->d_data_quantized, coder->data_quantized, coder->data_size * sizeof(int16_t));
     return 0;
 }
+#endif /* !GJREF_EMU_HUFFMAN */
 
 #ifdef GJREF_RESTATED_STAGES
 /* ---- postprocessor (reference: src/gpujpeg_postprocessor.cu:349,445) ---- */
@@ -257,6 +260,10 @@ int cudaGraphicsUnmapResources(int count, void* resources, cudaStream_t stream)
 int gjref_reencode_cpu_huffman(struct gpujpeg_encoder* encoder, uint8_t** out, size_t* size)
 {
     struct gpujpeg_coder* coder = &encoder->coder;
+    {   /* (the geometry cross-check the Huffman stand-in makes on every call: here for the builds that run the reference's own kernels) */
+        gjo_image img;
+        image_from_coder(coder, &img);
+    }
     if (coder->data_quantized == NULL && gpujpeg_coder_allocate_cpu_huffman_buf(coder) != 0) return -1;
     memcpy(coder->data_quantized, coder->d_data_quantized, coder->data_size * sizeof(int16_t));
     encoder->writer->buffer_current = encoder->writer->buffer;

@@ -1,8 +1,9 @@
 """Pins the CPU restatement (oracle/gj_oracle.c) against the reference's own code.
 
 oracle/_ref/libgpujpeg_ref.so is the reference's host C files (driver, geometry, tables, JFIF writer/reader,
-CPU Huffman coders) compiled unmodified from /root/reference against a host-memory CUDA stub; its CUDA-only
-stages are provided by the restatement. So for identical parameters and pixels:
+CPU Huffman coders) AND all five of its CUDA modules (colour / sampling, fDCT + quantiser, dequantiser + IDCT, and since round 6 the two
+Huffman GPU modules) compiled unmodified from /root/reference against a host-memory CUDA stub and run under the cudaemu execution
+model (oracle/cudaemu; contraction off). So for identical parameters and pixels:
   * complete JPEG bytes must match  -> geometry, tables, header bytes, Huffman, stuffing, RSTn, stitching
   * the reference's CPU Huffman coder re-encoding the same coefficients must give the same file
   * decode through reference reader + reference CPU Huffman decoder must match the restated parser/decoder
@@ -40,6 +41,58 @@ def test_encode_bytes_and_decode_pixels(O, G, ref, case):
     assert np.array_equal(px, opx)
 
 
+def _warp_stats(ref):
+    st = (C.c_ulong * 4)()
+    ref.L.cudaemu_warp_stats(st)
+    return list(st)
+
+
+HUFF_GPU_CASES = CASES + [("huff_many_segments_r2", 400, 304, 1, 1, 90, 2, 0, None, 3), ("huff_il_420_r3", 322, 242, 1, 1, 60, 3, 1, [(2, 2), (1, 1), (1, 1)], 3),
+                          ("huff_q100_noise_r5", 128, 96, 1, 1, 100, 5, 0, None, 3)]
+
+
+@pytest.mark.parametrize("case", HUFF_GPU_CASES, ids=[c[0] for c in HUFF_GPU_CASES])
+def test_reference_huffman_gpu_kernels_run_and_agree(O, G, ref, case):
+    """ The reference's two Huffman GPU modules -- src/gpujpeg_huffman_gpu_encoder.cu (encode_kernel_warp :304-404, serialization :417-503,
+    compaction :563-613) and gpujpeg_huffman_gpu_decoder.cu (table kernel :546-610, decode_kernel :397-495) -- compiled where they lie and run under
+    cudaemu's warp mode (32 lanes in lock step: votes, code words exchanged through shared memory). For every configuration:
+    reference GPU Huffman encoder bytes == reference CPU Huffman encoder bytes == oracle, reference GPU Huffman decoder coefficients == oracle,
+    and the counters prove the kernels ran (the reference takes its CPU coders for restart interval 0 / fewer than 32 segments)."""
+    raw = make_raw(O, case)
+    p, pi = api_params(ref, G, case)
+    img = oracle_image(O, case)
+    enc = G.Encoder(ref)
+    before = _warp_stats(ref)
+    jpeg = enc.encode(p, pi, raw)
+    after = _warp_stats(ref)
+    want = O.encode(img, raw)
+    assert np.array_equal(jpeg, want), "reference GPU Huffman encoder stream != oracle"
+    if case[6] != 0:  # src/gpujpeg_encoder.c:510-533: restart interval 0 is coded by the CPU Huffman coder
+        # encode_kernel_warp + serialization + compaction (the decomposition-table kernel ran when the encoder was created)
+        assert after[0] - before[0] == 3 and after[2] > before[2] and after[3] > before[3], (before, after)
+    else:
+        assert after[0] == before[0]
+    out, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+    ref.L.gjref_reencode_cpu_huffman.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    assert ref.L.gjref_reencode_cpu_huffman(enc.h, C.byref(out), C.byref(size)) == 0
+    assert np.array_equal(np.ctypeslib.as_array(out, shape=(size.value,)), jpeg), "reference GPU Huffman encoder != reference CPU Huffman encoder"
+
+    dec = G.Decoder(ref)
+    before = _warp_stats(ref)
+    px, _ = dec.decode(jpeg)
+    after = _warp_stats(ref)
+    n = C.c_size_t()
+    ref.L.gjref_decoder_coefficients.restype = C.POINTER(C.c_int16)
+    ref.L.gjref_decoder_coefficients.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    got = np.ctypeslib.as_array(ref.L.gjref_decoder_coefficients(dec.h, C.byref(n)), shape=(n.value,)).copy()
+    st = O.parse(want)
+    assert np.array_equal(got, O.huffman_decode(st, want)), "reference GPU Huffman decoder coefficients != oracle"
+    assert np.array_equal(px, O.decode(want)[0])
+    segments = img.segment_count
+    if segments >= 32:  # src/gpujpeg_decoder.c:255-268: fewer than 32 segments go to the CPU Huffman decoder
+        assert after[0] - before[0] == 2 and after[1] > before[1], (segments, before, after)  # table kernel + decode kernel
+
+
 @pytest.mark.parametrize("seed", range(160))
 def test_random_configurations(O, G, ref, seed):
     """The restatement against the reference (its host C + its CUDA kernels on the CPU, contraction off) on random configurations: pixel
@@ -52,9 +105,15 @@ def test_random_configurations(O, G, ref, seed):
                     "component (src/gpujpeg_preprocessor.cu:53-63): ignored by a GPU, a trap on the CPU; covered on the GPU by test_gpu_refhip.py")
     raw = random_raw(O, case, seed)
     p, pi = api_params(ref, G, case)
-    jpeg = G.Encoder(ref).encode(p, pi, raw)
+    enc = G.Encoder(ref)
+    jpeg = enc.encode(p, pi, raw)
     want = O.encode(oracle_image(O, case), raw)
     assert jpeg.size == want.size and np.array_equal(jpeg, want), (case, "stream differs")
+    # (round 6: `jpeg` comes out of the reference's Huffman GPU kernels under cudaemu's warp mode; the same coefficients through its CPU Huffman coder)
+    out, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+    ref.L.gjref_reencode_cpu_huffman.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    assert ref.L.gjref_reencode_cpu_huffman(enc.h, C.byref(out), C.byref(size)) == 0
+    assert np.array_equal(np.ctypeslib.as_array(out, shape=(size.value,)), jpeg), (case, "reference GPU Huffman encoder != reference CPU Huffman encoder")
     px, info = G.Decoder(ref).decode(jpeg)
     opx, oinfo = O.decode(want)
     assert (info.width, info.height, info.pixel_format, info.color_space) == (oinfo.width, oinfo.height, oinfo.pixel_format, oinfo.color_space)

@@ -205,6 +205,7 @@ class Spec:
         return f"{self.width}x{self.height} RGB 4:4:4 q{self.quality} non-interleaved, restart auto"
 
 
+_TUNE = {"no_tokens": False}
 _PIN = {"cpus": None}  # cores of this rank's launch threads (gpujpeg_amd.sharding.plan_affinity), None = leave the scheduler alone
 
 
@@ -810,6 +811,7 @@ def main():
     ap.add_argument("--keep-coefs", action="store_true", help="decoder keeps its coefficients in HBM (adds the per-frame clear; tuning aid)")
     ap.add_argument("--lib", default=None, help="another build of the library (A/B runs of compile-time variants: make -C gpujpeg_amd/csrc variant NAME=...)")
     ap.add_argument("--host-io", action="store_true", help="the timed region with pinned host buffers in and out (what `full_api` reports; tuning aid, not the headline)")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME[=VALUE]", help="developer setting for every coder of this run (gpujpeg_amd_tuning; INTEGRATION.md), repeatable")
     ap.add_argument("--verify", action="store_true", help="check the results of the last frame(s) against the oracle (slow)")
     args = ap.parse_args()
 
@@ -839,6 +841,11 @@ def main():
         dist.init_process_group("nccl" if ndev >= world else "gloo", **({"device_id": device} if ndev >= world else {}))
 
     lib = G.Library(args.lib)  # raises if the HIP library has not been built: there is no fallback
+    # developer settings (forced kernel paths, A/B): the library does not read the environment; this tool hands over what its environment and --tune name
+    G.apply_environment_settings(lib)
+    for t in args.tune:
+        assert lib.tuning(t), f"unknown developer setting {t}"
+    _TUNE["no_tokens"] = bool(os.environ.get("GJ_DEC_NO_TOKENS")) or any(t.split("=")[0] == "GJ_DEC_NO_TOKENS" for t in args.tune)
     assert lib.L.gpujpeg_init_device(dev_index, 0) == 0
     settle_interpreter()
     C_LOOP_OK["ok"] = not (args.lib or args.python_loop)
@@ -874,7 +881,7 @@ def main():
     if rank == 0:
         S, reps, jsize = head["streams"], head["reps"], head["jpeg_bytes"]
         nblocks = ((width + 7) // 8) * ((height + 7) // 8) * (2 if spec.is422 else 3)
-        token_mode = nblocks >= (900000 if spec.is422 else 300000) and jsize <= (12 if spec.is422 else 16) * nblocks and not args.keep_coefs and not os.environ.get("GJ_DEC_NO_TOKENS")
+        token_mode = nblocks >= (900000 if spec.is422 else 300000) and jsize <= (12 if spec.is422 else 16) * nblocks and not args.keep_coefs and not _TUNE["no_tokens"]
         names = kernel_names(spec, head["solo_ms"], token_mode)
         alg = spec.raw_bytes + jsize  # encoder: raw in + JPEG out; decoder: JPEG in + raw out (the same sum)
         solo, cont = head["solo_ms"], head["kernel_ms"]
@@ -1058,7 +1065,7 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
             m = measure(lib, sp, device, dev_index, barrier, mode="both", streams=args.streams, steps=5, warmup=2, min_seconds=0.3, want_solo=True)
             alg = sp.raw_bytes + m["jpeg_bytes"]
             nblk = ((sp.width + 7) // 8) * ((sp.height + 7) // 8) * (2 if sp.is422 else 3)
-            tokm = nblk >= (900000 if sp.is422 else 300000) and m["jpeg_bytes"] <= (12 if sp.is422 else 16) * nblk and not os.environ.get("GJ_DEC_NO_TOKENS")
+            tokm = nblk >= (900000 if sp.is422 else 300000) and m["jpeg_bytes"] <= (12 if sp.is422 else 16) * nblk and not _TUNE["no_tokens"]
             nm = kernel_names(sp, m["solo_ms"], tokm)
             solo_ = m["solo_ms"]
             live_ = [i for i in range(9) if solo_[i] > 0.006]

@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include "gj_internal.h"
+#include "gpujpeg_amd_ext.h"
 
 /* ------------------------------------------------------------------ logging */
 const char* gj_fg_red = "";
@@ -629,4 +630,12 @@ int gj_parse_channel_remap(unsigned* out, const char* val, const char* optname)
     }
     *out = map | ((unsigned)mapped_count << 24);
     return GPUJPEG_NOERR;
+}
+
+/* ---- developer settings (include/gpujpeg_amd_ext.h): the library itself never reads the environment */
+int gpujpeg_amd_tuning(const char* setting) { return gj_hip_tuning_setting(setting); }
+const char* const* gpujpeg_amd_tuning_names(void)
+{
+    int n;
+    return gj_hip_tuning_names(&n);
 }

@@ -709,20 +709,20 @@ void gj_launch_idct(const gj_dec_job* job, hipStream_t st, gj_idct_tok_t idct_to
         const unsigned nb = g.interleaved ? (unsigned)g.block_count : (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y); // one lane per block (position)
         hipLaunchKernelGGL(idct_tok, dim3((nb + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, (const uint2*)job->d_blkrec, (const uint16_t*)job->d_tok, job->tok_cap,
                            job->d_qtabf, job->d_raw);
-        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+        if (ev) GJ_HIP_CHECK(hipEventRecord((hipEvent_t)ev[2], st));
     } else if (uyvy) {
         const unsigned nm = (unsigned)(g.comp[1].blocks_x * g.comp[1].blocks_y);
         hipLaunchKernelGGL(k_idct_fused_uyvy422, dim3((nm + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
-        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+        if (ev) GJ_HIP_CHECK(hipEventRecord((hipEvent_t)ev[2], st));
     } else if (fused) {
         const unsigned nb = (unsigned)(g.comp[0].blocks_x * g.comp[0].blocks_y);
         hipLaunchKernelGGL(fused, dim3((nb + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf, job->d_raw, job->zero_coefs);
-        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+        if (ev) GJ_HIP_CHECK(hipEventRecord((hipEvent_t)ev[2], st));
     } else {
         hipLaunchKernelGGL(k_idct, dim3(((unsigned)g.block_count + 255) / 256, 1, frames), dim3(256), 0, st, g, job->d_coefs, job->d_qtabf,
                            job->d_planes, job->zero_coefs);
         if (job->flipped) hipLaunchKernelGGL(k_flip_planes, dim3(1024), dim3(256), 0, st, g, job->d_planes); // src/gpujpeg_postprocessor.cu:447
-        if (ev) (void)hipEventRecord((hipEvent_t)ev[2], st);
+        if (ev) GJ_HIP_CHECK(hipEventRecord((hipEvent_t)ev[2], st));
         if (g.no_transform) {
             hipLaunchKernelGGL(k_copy_planes_out, dim3(2048, 1, frames), dim3(256), 0, st, g, job->d_planes, job->d_raw);
         } else {

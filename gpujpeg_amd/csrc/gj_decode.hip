@@ -43,7 +43,8 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     const gj_geom& g = job->g;
     if (g.blocks_per_mcu > GJ_MAX_MCU_BLOCKS) return -1;
     if ((job->batch.count > 1 || g.fb.sizes != nullptr) && (!gj_hip_decode_batchable(job) || g.fb.sizes == nullptr || job->batch.count > 65535u)) return -1;
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[0], st);
+    gj_hip_note_reset();
+    if (ev) GJ_HIP_CHECK(hipEventRecord((hipEvent_t)ev[0], st));
     bool par = job->d_huff_tab2 != nullptr && job->seg_count > 0;
     if (job->tune.dec_serial) par = false; // the lane-per-segment kernel (A/B measurements, tests)
     const bool fast_ok = par && !job->tune.dec_careful && job->d_overflow != nullptr; // kernels that take whole segments into LDS are allowed
@@ -66,9 +67,9 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     // Both entropy decoders store only non-zero coefficients. The sub-sequence kernel zero-fills the blocks of the segments it
     // decodes itself; clear_coefs asks for a full clear first (segments missing from the table, lane-per-segment kernel).
     if (tokens) {
-        if (job->clear_coefs) (void)hipMemsetAsync(job->d_blkrec, 0, (size_t)g.block_count * sizeof(uint2), st);
+        if (job->clear_coefs) GJ_HIP_CHECK(hipMemsetAsync(job->d_blkrec, 0, (size_t)g.block_count * sizeof(uint2), st));
     } else if (job->clear_coefs || !par) {
-        (void)hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st);
+        GJ_HIP_CHECK(hipMemsetAsync(job->d_coefs, 0, g.data_size * sizeof(int16_t), st));
     }
     // a marker scan whose table launch was left to us (gj_scan_deferred): the token decoder reads the scan's records itself, everything else needs the table
     const bool takes_par = !(tokens && tok_sub) && !seq && par;
@@ -80,8 +81,8 @@ extern "C" int gj_hip_decode(const gj_dec_job* job, gj_stream_t stream, gj_event
     else if (par) gj_launch_huffman_par(job, st);
     else gj_launch_huffman_serial(job, st);
     gj_debug_stage(job->tune.debug_sync != 0, st, "entropy decoder");
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[1], st);
+    if (ev) GJ_HIP_CHECK(hipEventRecord((hipEvent_t)ev[1], st));
     gj_launch_idct(job, st, idct_tok, ev);
-    if (ev) (void)hipEventRecord((hipEvent_t)ev[3], st);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (ev) GJ_HIP_CHECK(hipEventRecord((hipEvent_t)ev[3], st));
+    return (hipGetLastError() == hipSuccess && !gj_hip_noted()) ? 0 : -1;
 }

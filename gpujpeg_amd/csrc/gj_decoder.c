@@ -100,7 +100,7 @@ struct gpujpeg_decoder* gpujpeg_decoder_create(cudaStream_t stream)
     d->coder.stream = (gj_stream_t)stream;
     d->req_pixel_format = GPUJPEG_PIXFMT_AUTODETECT;
     d->req_color_space = GPUJPEG_CS_DEFAULT;
-    gj_hip_tuning_from_env(&d->tune);
+    gj_hip_tuning_defaults(&d->tune);
     d->coder.ht_on = d->tune.host_timing != 0;
     d->use_fused = !d->tune.no_fused;
     gpujpeg_set_default_parameters(&d->coder.param);

@@ -1,5 +1,11 @@
 // gj_device.h -- device-side helpers shared by the encoder and decoder kernels (gfx950, wave64).
 #pragma once
+// Runtime calls inside the launchers: checked where they are made (gj_runtime.hip keeps the first failure of the thread for gj_hip_last_error;
+// gj_hip_encode / gj_hip_decode return -1 when gj_hip_noted() says there was one). Kernel launches report through hipGetLastError() at the end.
+extern "C" int gj_hip_note(int hip_error);
+extern "C" void gj_hip_note_reset(void);
+extern "C" int gj_hip_noted(void);
+#define GJ_HIP_CHECK(call) ((void)gj_hip_note((int)(call)))
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -79,7 +79,7 @@ struct gpujpeg_encoder* gpujpeg_encoder_create(cudaStream_t stream)
     e->coder.encoder = true;
     e->coder.stream = (gj_stream_t)stream;
     e->table_quality = -1;
-    gj_hip_tuning_from_env(&e->tune);
+    gj_hip_tuning_defaults(&e->tune);
     e->coder.ht_on = e->tune.host_timing != 0;
     e->use_fused = !e->tune.no_fused;
     gpujpeg_set_default_parameters(&e->coder.param);

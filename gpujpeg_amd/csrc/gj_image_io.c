@@ -4,8 +4,9 @@
  * in src/utils/image_delegate.c, pam.c, y4m.c).
  *
  * Implemented natively: headerless raw files (.rgb .rgba .yuv .yuva .uyvy .i420 .r .raw), PNM (P5/P6),
- * PAM (P7), Y4M (8-bit 4:4:4 / 4:2:2 / 4:2:0 / mono) and the synthetic ".tst" images. BMP/GIF/PNG/TGA go
- * through vendored third-party decoders in the reference and are reported as unsupported here.
+ * PAM (P7), Y4M (8-bit 4:4:4 / 4:2:2 / 4:2:0 / mono), the synthetic ".tst" images, BMP and TGA (read and written with the bytes the reference's
+ * vendored stb writers produce); PNG (read, written) and GIF (read) live in gj_image_png.c. The reference goes through vendored third-party code for
+ * the last four (src/utils/image_delegate.c); nothing of it is used here.
  */
 #define _GNU_SOURCE
 #include <ctype.h>

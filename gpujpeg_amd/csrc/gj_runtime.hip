@@ -24,6 +24,12 @@ static int chk(hipError_t e)
 
 extern "C" {
 
+// the launchers (gj_hip_encode / gj_hip_decode and what they call) check every runtime call where they make it: the first failure of a thread is kept
+// for gj_hip_last_error, gj_hip_noted says whether there has been one since gj_hip_note_reset
+int gj_hip_note(int hip_error) { return chk((hipError_t)hip_error); }
+void gj_hip_note_reset(void) { g_last = hipSuccess; }
+int gj_hip_noted(void) { return g_last != hipSuccess; }
+
 int gj_hip_device_count(void)
 {
     int n = 0;
@@ -119,10 +125,10 @@ int gj_hip_memcpy_d2d(void* d, const void* s, size_t n, gj_stream_t st) { return
 //   46-47 GB/s            through one upload and one download stream when the THREAD waits for its copy (hipEventSynchronize) -- from two coders up.
 // The calls of the API are synchronous anyway, so the last form costs nothing but two host wake-ups per call. Copies below g_lane_min_bytes
 // (tables, headers, the streams of small frames), calls without an event and GJ_COPY_LANES=0 stay asynchronous on the caller's stream.
-static size_t g_lane_min_bytes = (size_t)1 << 20; // (GJ_COPY_LANES=<MiB> moves it, 0 turns the lanes off)
+static size_t g_lane_min_bytes = (size_t)1 << 20; // (the developer setting GJ_COPY_LANES=<MiB> moves it, 0 turns the lanes off: gj_hip_tuning_setting)
 static std::mutex g_lane_mutex;
 static hipStream_t g_lane[64][2];
-static int g_lanes_enabled = -1;
+static int g_lanes_enabled = 1;
 static void gj_lanes_forget(int dev)
 {
     std::lock_guard<std::mutex> lk(g_lane_mutex);
@@ -133,11 +139,6 @@ static hipStream_t gj_lane(int dir, size_t n)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(g_lane_mutex);
-    if (g_lanes_enabled < 0) {
-        const char* e = getenv("GJ_COPY_LANES");
-        g_lanes_enabled = !(e && e[0] == '0' && e[1] == 0);
-        if (e && atoi(e) > 0) g_lane_min_bytes = (size_t)atoi(e) << 20;
-    }
     if (!g_lanes_enabled || n < g_lane_min_bytes) return nullptr;
     if (!g_lane[dev][dir] && hipStreamCreateWithFlags(&g_lane[dev][dir], hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
@@ -214,29 +215,78 @@ float gj_hip_event_elapsed_ms(gj_event_t a, gj_event_t b)
 
 } // extern "C"
 
-// the developer switches, read once per coder (gj_hip.h)
-extern "C" void gj_hip_tuning_from_env(gj_tuning* t)
+// ---- The developer settings (gj_hip.h: gj_tuning). Process-wide values, set through gj_hip_tuning_setting (public: gpujpeg_amd_tuning,
+// include/gpujpeg_amd_ext.h) and copied into a coder when it is created; the launchers see only the coder's copy. The RELEASE library never reads
+// the environment: builds with -DGJ_TUNING_ENV -- the `trace` / `variant` targets of the Makefile and the CPU execution model of
+// tests/hipemu, i.e. what the measurement tools load -- additionally take every setting whose name is in the environment when a coder is created.
+static std::mutex g_tune_mutex;
+static gj_tuning g_tune = {/*no_fused*/ 0, /*enc_split*/ -1, /*enc_tail*/ -1, 0, 0, 0, 0, /*dec_tokens*/ -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static const char* const g_tune_names[] = {"GPUJPEG_NO_FUSED", "GPUJPEG_HOST_SCAN", "GJ_ENC_NO_WHOLE422", "GJ_DEC_TOKENS", "GJ_DEC_NO_TOKENS", "GJ_DEC_ENTROPY", "GJ_DEC_G",
+                                           "GJ_DEC_SUB", "GJ_DEC_NO_SPEC", "GJ_DEC_SEQ", "GJ_DEC_DEBUG_SYNC", "GJ_DEC_TOK_NOCOOP", "GJ_SCAN_SHAPE", "GJ_ENC_BLOCKS",
+                                           "GJ_HOST_TIMING", "GJ_DEC_BALANCE", "GJ_ENC_SPLIT", "GJ_ENC_TAIL", "GJ_DEC_FILL", "GJ_COPY_LANES", nullptr};
+// one setting: `name` as in INTEGRATION.md's table, `v` its value (may be empty: "the name is present"); false for an unknown name
+static bool gj_tune_apply(gj_tuning* t, const char* name, const char* v)
 {
-    memset(t, 0, sizeof *t);
-    const char* e;
-    t->no_fused = getenv("GPUJPEG_NO_FUSED") != nullptr;
-    t->host_scan = getenv("GPUJPEG_HOST_SCAN") != nullptr;
-    t->enc_no_whole422 = getenv("GJ_ENC_NO_WHOLE422") != nullptr;
-    t->dec_tokens = -1;
-    if ((e = getenv("GJ_DEC_TOKENS")) && e[0] == '1') t->dec_tokens = 1;
-    if (getenv("GJ_DEC_NO_TOKENS")) t->dec_tokens = 0;
-    t->dec_serial = (e = getenv("GJ_DEC_ENTROPY")) && e[0] == 's';
-    t->dec_batch = (e = getenv("GJ_DEC_G")) ? atoi(e) : 0;
-    t->dec_sub = (e = getenv("GJ_DEC_SUB")) ? atoi(e) : 0;
-    t->dec_no_spec = getenv("GJ_DEC_NO_SPEC") != nullptr;
-    if ((e = getenv("GJ_DEC_SEQ"))) t->dec_seq = e[0] == '1' ? 1 : 2;
-    t->debug_sync = (e = getenv("GJ_DEC_DEBUG_SYNC")) && e[0] == '1';
-    t->dec_tok_nocoop = (e = getenv("GJ_DEC_TOK_NOCOOP")) && e[0] == '1';
-    t->scan_shape = (e = getenv("GJ_SCAN_SHAPE")) ? atoi(e) : 0;
-    t->enc_by_blocks = (e = getenv("GJ_ENC_BLOCKS")) ? atoi(e) : 0;
-    t->host_timing = (e = getenv("GJ_HOST_TIMING")) && e[0] == '1';
-    t->dec_balance = (e = getenv("GJ_DEC_BALANCE")) && e[0] == '1';
-    t->enc_split = (e = getenv("GJ_ENC_SPLIT")) ? atoi(e) : -1;
-    t->enc_tail = (e = getenv("GJ_ENC_TAIL")) ? atoi(e) : -1;
-    t->dec_fill = (e = getenv("GJ_DEC_FILL")) ? atoi(e) : 0;
+    const auto is = [&](const char* n) { return std::strcmp(name, n) == 0; };
+    const int num = std::atoi(v);
+    if (is("GPUJPEG_NO_FUSED")) t->no_fused = 1;
+    else if (is("GPUJPEG_HOST_SCAN")) t->host_scan = 1;
+    else if (is("GJ_ENC_NO_WHOLE422")) t->enc_no_whole422 = 1;
+    else if (is("GJ_DEC_TOKENS")) { if (v[0] == '1') t->dec_tokens = 1; }
+    else if (is("GJ_DEC_NO_TOKENS")) t->dec_tokens = 0;
+    else if (is("GJ_DEC_ENTROPY")) t->dec_serial = v[0] == 's';
+    else if (is("GJ_DEC_G")) t->dec_batch = num;
+    else if (is("GJ_DEC_SUB")) t->dec_sub = num;
+    else if (is("GJ_DEC_NO_SPEC")) t->dec_no_spec = 1;
+    else if (is("GJ_DEC_SEQ")) t->dec_seq = v[0] == '1' ? 1 : 2;
+    else if (is("GJ_DEC_DEBUG_SYNC")) t->debug_sync = v[0] == '1';
+    else if (is("GJ_DEC_TOK_NOCOOP")) t->dec_tok_nocoop = v[0] == '1';
+    else if (is("GJ_SCAN_SHAPE")) t->scan_shape = num;
+    else if (is("GJ_ENC_BLOCKS")) t->enc_by_blocks = num;
+    else if (is("GJ_HOST_TIMING")) t->host_timing = v[0] == '1';
+    else if (is("GJ_DEC_BALANCE")) t->dec_balance = v[0] == '1';
+    else if (is("GJ_ENC_SPLIT")) t->enc_split = num;
+    else if (is("GJ_ENC_TAIL")) t->enc_tail = num;
+    else if (is("GJ_DEC_FILL")) t->dec_fill = num;
+    else if (is("GJ_COPY_LANES")) { // (process-wide, not per coder: 0 turns the copy lanes off, <MiB> moves the size from which a copy takes them)
+        std::lock_guard<std::mutex> lk(g_lane_mutex);
+        g_lanes_enabled = !(v[0] == '0' && v[1] == 0);
+        g_lane_min_bytes = num > 0 ? (size_t)num << 20 : (size_t)1 << 20;
+    } else return false;
+    return true;
+}
+extern "C" int gj_hip_tuning_setting(const char* setting)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    if (setting == nullptr) { // back to the defaults
+        g_tune = gj_tuning{0, -1, -1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        std::lock_guard<std::mutex> lk2(g_lane_mutex);
+        g_lanes_enabled = 1;
+        g_lane_min_bytes = (size_t)1 << 20;
+        return 0;
+    }
+    char name[40];
+    const char* eq = std::strchr(setting, '=');
+    const size_t n = eq ? (size_t)(eq - setting) : std::strlen(setting);
+    if (n == 0 || n >= sizeof name) return -1;
+    std::memcpy(name, setting, n);
+    name[n] = 0;
+    return gj_tune_apply(&g_tune, name, eq ? eq + 1 : "") ? 0 : -1;
+}
+extern "C" const char* const* gj_hip_tuning_names(int* count)
+{
+    *count = (int)(sizeof g_tune_names / sizeof g_tune_names[0]) - 1; // (the array ends with a null pointer)
+    return g_tune_names;
+}
+extern "C" void gj_hip_tuning_defaults(gj_tuning* t)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mutex);
+        *t = g_tune;
+    }
+#ifdef GJ_TUNING_ENV
+    for (const char* n : g_tune_names)
+        if (n != nullptr)
+            if (const char* e = getenv(n)) gj_tune_apply(t, n, e);
+#endif
 }

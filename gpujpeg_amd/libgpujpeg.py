@@ -155,6 +155,25 @@ class Library:
         if hasattr(L, "gpujpeg_amd_decoder_decode_batch"):
             L.gpujpeg_amd_decoder_decode_batch.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, vp, C.c_size_t, C.POINTER(ImageParameters)]
 
+    # ---- developer settings (include/gpujpeg_amd_ext.h: gpujpeg_amd_tuning) ----
+    def tuning(self, setting):
+        """"NAME=VALUE" / "NAME" for the coders created from now on, None forgets every setting. True when the library took it
+        (False: unknown name, or a library without the call -- the reference builds)."""
+        if not hasattr(self.L, "gpujpeg_amd_tuning"):
+            return False
+        self.L.gpujpeg_amd_tuning.argtypes = [C.c_char_p]
+        return self.L.gpujpeg_amd_tuning(None if setting is None else setting.encode()) == 0
+
+    def tuning_names(self):
+        if not hasattr(self.L, "gpujpeg_amd_tuning_names"):
+            return []
+        self.L.gpujpeg_amd_tuning_names.restype = C.POINTER(C.c_char_p)
+        arr, out, i = self.L.gpujpeg_amd_tuning_names(), [], 0
+        while arr[i]:
+            out.append(arr[i].decode())
+            i += 1
+        return out
+
     # ---- parameter helpers ----
     def default_parameters(self):
         p = Parameters()
@@ -168,6 +187,19 @@ class Library:
 
     def image_size(self, param_image):
         return self.L.gpujpeg_image_calculate_size(C.byref(param_image))
+
+
+def apply_environment_settings(lib, environ=None):
+    """DEVELOPER AID for tests and measurement tools: hand the developer settings named in the environment (GJ_DEC_TOKENS=1, GJ_ENC_TAIL=0, ...;
+    INTEGRATION.md) to the library through gpujpeg_amd_tuning -- the library itself never reads the environment. Coders created afterwards
+    take them. No-op for libraries without the call (the reference builds under oracle/_ref)."""
+    import os
+    env = os.environ if environ is None else environ
+    if not lib.tuning(None):
+        return
+    for name in lib.tuning_names():
+        if name in env:
+            lib.tuning(f"{name}={env[name]}")
 
 
 class Encoder:

@@ -50,7 +50,7 @@ GJ_HIP_API int gj_hip_memcpy_d2d(void* dst, const void* src, size_t n, gj_stream
 /* Copies of whole images between host and device. Large ones go through the process's one stream per direction and device ("copy lanes",
  * gj_runtime.hip: the host link carries both directions at once only that way) and are COMPLETE when the call returns: the thread waits for the
  * copy on `done`, an event of the caller that no other call in flight uses; gj_hip_download waits for the work on s first. Small copies,
- * done == NULL and GJ_COPY_LANES=0: asynchronous on s, exactly gj_hip_memcpy_h2d / _d2h. */
+ * done == NULL and the developer setting GJ_COPY_LANES=0: asynchronous on s, exactly gj_hip_memcpy_h2d / _d2h. */
 GJ_HIP_API int gj_hip_upload(void* dst, const void* src, size_t n, gj_stream_t s, gj_event_t done);
 GJ_HIP_API int gj_hip_download(void* dst, const void* src, size_t n, gj_stream_t s, gj_event_t done);
 /* several such copies of one direction: copy with gj_hip_memcpy_h2d / _d2h on the stream gj_hip_lane_begin returns (the lane -- behind the work on s
@@ -131,8 +131,10 @@ typedef struct gj_geom {
 /* ------------------------------------------------------------------ encoder */
 #define GJ_CODER_LUT_OFFSET 1024 /* words of gj_enc_job::d_huff_lut in front of the coder's tables */
 #define GJ_CODER_LUT_WORDS 544
-/* Developer switches (A/B measurements, forced modes of the tests). Read from the environment ONCE, when a coder is created
- * (gj_hip_tuning_from_env); the launchers never look at the environment. */
+/* Developer settings (A/B measurements, forced modes of the tests): process-wide values set through gj_hip_tuning_setting("NAME=VALUE") -- the names
+ * in the comments below, public as gpujpeg_amd_tuning (gpujpeg_amd_ext.h) --, copied into a coder ONCE, when it is created (gj_hip_tuning_defaults);
+ * the launchers see the coder's copy only. The release library does not read the environment; builds with -DGJ_TUNING_ENV (`make trace`, `make variant`,
+ * the CPU execution model of tests/hipemu) also take the settings whose names are in the environment at that moment. */
 typedef struct gj_tuning {
     int no_fused;        /* GPUJPEG_NO_FUSED: generic kernels only */
     int enc_split;       /* GJ_ENC_SPLIT=<tiles>: frames of up to so many tiles are coded one component per workgroup (-1: the default limit) */
@@ -158,7 +160,9 @@ typedef struct gj_tuning {
     int dec_careful;     /* set by the host for ONE call, never from the environment: a kernel that takes whole segments into LDS met one that
                             does not fit (overflow flag) -- this call uses the kernels without that limit */
 } gj_tuning;
-GJ_HIP_API void gj_hip_tuning_from_env(gj_tuning* t);
+GJ_HIP_API void gj_hip_tuning_defaults(gj_tuning* t);
+GJ_HIP_API int gj_hip_tuning_setting(const char* setting);          /* "NAME=VALUE" or "NAME"; NULL: back to the defaults. 0, or -1 for an unknown name */
+GJ_HIP_API const char* const* gj_hip_tuning_names(int* count); /* the names gj_hip_tuning_setting knows */
 
 /* Frame batch (MI355X extension, gpujpeg_amd_{encoder_encode,decoder_decode}_batch): `count` frames of ONE geometry, tables and header behind
  * one set of launches (blockIdx.z = frame) -- an HD frame has 135 encoder tiles for the 1024 workgroup places of the device, a batch fills

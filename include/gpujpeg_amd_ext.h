@@ -36,6 +36,13 @@ GPUJPEG_API void gpujpeg_amd_encoder_keep_coefficients(struct gpujpeg_encoder* e
  * Default 0: the IDCT clears each block once it has read it, which saves the per-frame clear of the coefficient planes. */
 GPUJPEG_API void gpujpeg_amd_decoder_keep_coefficients(struct gpujpeg_decoder* decoder, int enabled);
 
+/* Developer settings: forced kernel paths for tests and A/B measurements ("GJ_DEC_TOKENS=1", "GJ_ENC_TAIL=0", ...; the table in INTEGRATION.md).
+ * Process-wide; a coder takes the values that are set when it is CREATED. `setting` is "NAME=VALUE" or "NAME"; NULL forgets every setting.
+ * Returns 0, -1 for a name the library does not know. The library never reads the environment (round 6). */
+GPUJPEG_API int gpujpeg_amd_tuning(const char* setting);
+/* the names gpujpeg_amd_tuning knows, NULL-terminated */
+GPUJPEG_API const char* const* gpujpeg_amd_tuning_names(void);
+
 /* Host-only helper (no device access): the marker segments the encoder would emit for these parameters --
  * everything up to the first scan (SOI .. COM), followed by the scan headers back to back. Parameters are
  * adjusted exactly like gpujpeg_encoder_encode() does on a fresh encoder (comp_count 0, RESTART_AUTO).

@@ -24,7 +24,17 @@ def O():
 
 @pytest.fixture(scope="session")
 def G():
+    """The ctypes binding. The tests force kernel paths with the developer settings of INTEGRATION.md by name (monkeypatch.setenv("GJ_DEC_TOKENS", "1")),
+    and the release library does not read the environment (round 6): every coder the tests create hands the settings named in the environment at that
+    moment to the library first (gpujpeg_amd_tuning; libgpujpeg.apply_environment_settings)."""
     from gpujpeg_amd import libgpujpeg
+    if not getattr(libgpujpeg, "_settings_from_environment", False):
+        for cls in (libgpujpeg.Encoder, libgpujpeg.Decoder):
+            def patched(self, lib, *a, _orig=cls.__init__, **kw):
+                libgpujpeg.apply_environment_settings(lib)
+                _orig(self, lib, *a, **kw)
+            cls.__init__ = patched
+        libgpujpeg._settings_from_environment = True
     return libgpujpeg
 
 

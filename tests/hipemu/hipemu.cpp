@@ -388,7 +388,9 @@ hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { *st = nullptr; return hipSuccess; } // (everything is synchronous here: one stream)
+// (everything is synchronous here, every stream is the same; the handle is NOT null, so that code which asks "did I get a stream of my own?" -- the
+// library's copy lanes, gj_runtime.hip -- takes the path it takes on the GPU: ADVICE r5)
+hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { static int one_stream; *st = reinterpret_cast<hipStream_t>(&one_stream); return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "hipemu error"; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }

@@ -30,15 +30,16 @@ def child(name, mode):
     import oracle as O
     from conftest import natural_image, oracle_image
     from gpujpeg_amd import libgpujpeg as G
-    if mode in ("tokens", "batchtok"):
-        os.environ["GJ_DEC_TOKENS"] = "1"
-    if mode == "seq":  # the lane-per-segment entropy decoder over an LDS stage (plane mode)
-        os.environ["GJ_DEC_NO_TOKENS"] = "1"
-        os.environ["GJ_DEC_SEQ"] = "1"
-    if mode == "seqtok":  # the same kernel in token mode
-        os.environ["GJ_DEC_TOKENS"] = "1"
-        os.environ["GJ_DEC_SEQ"] = "1"
     lib = G.Library(os.environ.get("GJ_FUZZ_LIB") or None)
+    G.apply_environment_settings(lib)  # (whatever the caller's environment names)
+    if mode in ("tokens", "batchtok"):
+        lib.tuning("GJ_DEC_TOKENS=1")
+    if mode == "seq":  # the lane-per-segment entropy decoder over an LDS stage (plane mode)
+        lib.tuning("GJ_DEC_NO_TOKENS")
+        lib.tuning("GJ_DEC_SEQ=1")
+    if mode == "seqtok":  # the same kernel in token mode
+        lib.tuning("GJ_DEC_TOKENS=1")
+        lib.tuning("GJ_DEC_SEQ=1")
     assert lib.L.gpujpeg_init_device(0, 0) == 0
     w, h, pf, cs, q, ri, il, ss, outfmt = CONFIGS[name]
     case = (name, w, h, pf, cs, q, ri, il, ss, 3)

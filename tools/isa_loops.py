@@ -58,8 +58,8 @@ def mix_json():
     symbol / per token) and over the whole kernel, as JSON for bench.py's class-weighted issue floor"""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    kernels = {"enc:k_encode_rgb444": ("gj_encode.o", "k_encode_rgb444<1, 3, false>"), "enc:k_gather": ("gj_encode.o", "k_gather"), "enc:k_assemble": ("gj_encode.o", "k_assemble"),
-               "enc:k_encode_uyvy422": ("gj_encode.o", "k_encode_uyvy422"),
+    kernels = {"enc:k_encode_rgb444": ("gj_enc_tiles.o", "k_encode_rgb444<1, 3, false>"), "enc:k_gather": ("gj_enc_assemble.o", "k_gather"), "enc:k_assemble": ("gj_enc_assemble.o", "k_assemble"),
+               "enc:k_encode_uyvy422": ("gj_enc_tiles.o", "k_encode_uyvy422"),
                "dec:k_huffman_decode_tok": ("gj_dec_entropy_tok.o", "k_huffman_decode_tok<true>"), "dec:k_idct_tok_rgb444": ("gj_dec_idct.o", "k_idct_tok_rgb444<3, 1>"),
                "dec:k_huffman_decode_win": ("gj_dec_entropy_seq.o", "k_huffman_decode_win<true>"), "dec:k_huffman_decode_seq": ("gj_dec_entropy_seq.o", "k_huffman_decode_seq<true, false>"), "dec:k_idct_tok_uyvy422": ("gj_dec_idct.o", "k_idct_tok_uyvy422"),
                "dec:k_huffman_decode_par": ("gj_dec_entropy_par.o", "k_huffman_decode_par<false, 16>"), "dec:k_idct_fused_rgb444": ("gj_dec_idct.o", "k_idct_fused_rgb444<3, 1>")}

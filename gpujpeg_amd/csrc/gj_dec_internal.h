@@ -125,8 +125,10 @@ __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g,
     const bool bad = r0.w != 0 || n > (uint32_t)GJ_SCAN_LIST || r0.z > 2u;
     if (tid < 3) f_max[tid] = 0; // (visible behind the barriers of the prefix sum)
     uint32_t tot;
-    const uint32_t inc = gj_wg256_incl_scan((n & 0xFFFFFFu) | (no << 24), s_tmp, &tot); // (a frame has < 2^24 restart markers and a regular one S other markers)
-    const uint32_t rinc = inc & 0xFFFFFFu, oinc = inc >> 24;
+    // (two sums in one scan: restart markers in the low 22 bits -- 256 workgroups x GJ_SCAN_LIST = 2^19 at most --, other markers above them: up to 2 per
+    // workgroup = 512, which an 8-bit field let wrap around to a small count on a malformed stream)
+    const uint32_t inc = gj_wg256_incl_scan((n & 0x3FFFFFu) | (no << 22), s_tmp, &tot);
+    const uint32_t rinc = inc & 0x3FFFFFu, oinc = inc >> 22;
     f_rinc[tid] = rinc;
     for (uint32_t q = 0; q < no; q++) {
         const uint32_t slot = oinc - no + q;
@@ -139,7 +141,7 @@ __device__ __forceinline__ bool gj_fold_batch(const GjFold& F, const gj_geom& g,
     if (bad) f_max[1] = 1;
     __syncthreads(); // (the scratch is written)
     const bool bad_any = f_max[1] != 0;
-    const uint32_t total_rst = tot & 0xFFFFFFu, total_other = tot >> 24;
+    const uint32_t total_rst = tot & 0x3FFFFFu, total_other = tot >> 22;
     // is this the stream the geometry describes? scan c: segs_c - 1 restart markers, then the SOS of scan c + 1 (EOI behind the last one)
     bool regular = !bad_any && total_other == (uint32_t)S && plan.n == S;
     uint32_t exp_rst = 0, sstart = (uint32_t)F.begin, my_start = 0, my_end = 0, my_first = 0;

@@ -604,6 +604,7 @@ static int decoder_decode(struct gpujpeg_decoder* d, uint8_t* image, size_t imag
             if (chk.huff_map[i][0] != r.huff_map[i][0] || chk.huff_map[i][1] != r.huff_map[i][1]) ok = false;
         if (!ok) { /* different header or unusual scan structure: decode again the careful way */
             d->n_again++;
+            if (d->last_folded) d->n_folded--; /* (counted at the launch: only accepted launches count as folded) */
             const bool overflow_only = d->h_summary->seq_overflow != 0 && d->h_summary->header_differs == 0;
             if (overflow_only) d->need_planes = true; /* (the header was the assumed one: it stays cached, the next frames launch on it with the other kernels) */
             else d->hdr_cache_valid = false;

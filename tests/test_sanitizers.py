@@ -56,5 +56,5 @@ def test_kernel_parity_tests_under_sanitizers(asan_env):
     room for) were of this kind, silent on the GPU and an occasional crash of the plain build here."""
     env = dict(asan_env, GJ_EMU_LIB=ASAN_LIB)
     sel = "frame_batch or tiles_and_gather or marker_scan or token_mode or reuse_padding or segment_info or dense_two_bit or emu_encode_decode_bit_exact or random_configurations"
-    out = _run(env, ["-m", "pytest", os.path.join(HERE, "test_emu_parity.py"), "-x", "-q", "-p", "no:faulthandler", "-p", "no:cacheprovider", "-k", sel], timeout=1500)
+    out = _run(env, ["-m", "pytest", os.path.join(HERE, "test_emu_parity.py"), "-x", "-q", "-n", "4", "-p", "no:faulthandler", "-p", "no:cacheprovider", "-k", sel], timeout=1500)
     assert " passed" in out and "failed" not in out, out[-1500:]

@@ -119,19 +119,26 @@ if __name__ == "__main__":
     if len(sys.argv) == 3:
         child(sys.argv[1], sys.argv[2])
         sys.exit(0)
-    bad = 0
     only = [a for a in sys.argv[1:] if a in CONFIGS]
-    for name in (only or CONFIGS):
-        # (the batch calls cover every layout: plane mode everywhere, token mode for the non-interleaved 4:4:4 configuration)
-        for mode in ("default", "tokens", "seq", "seqtok", "batch") + (("batchtok",) if name == "rgb_auto" else ()):
-            try:
-                r = subprocess.run([sys.executable, __file__, name, mode], capture_output=True, text=True, timeout=300)
-                lines = r.stdout.strip().splitlines()
-                ok = r.returncode == 0 and lines and lines[-1].startswith("DONE")
-                print(name, mode, "rc", r.returncode, lines[-1] if lines else "", "" if ok else "| " + (r.stderr.strip().splitlines() or [""])[-1][:200], flush=True)
-            except subprocess.TimeoutExpired:
-                ok = False
-                print(name, mode, "TIMEOUT", flush=True)
-            bad += 0 if ok else 1
+    # (the batch calls cover every layout: plane mode everywhere, token mode for the non-interleaved 4:4:4 configuration)
+    jobs = [(name, mode) for name in (only or CONFIGS) for mode in ("default", "tokens", "seq", "seqtok", "batch") + (("batchtok",) if name == "rgb_auto" else ())]
+
+    def one(job):
+        name, mode = job
+        try:
+            r = subprocess.run([sys.executable, __file__, name, mode], capture_output=True, text=True, timeout=600)
+            lines = r.stdout.strip().splitlines()
+            ok = r.returncode == 0 and lines and lines[-1].startswith("DONE")
+            return ok, " ".join(str(x) for x in (name, mode, "rc", r.returncode, lines[-1] if lines else "", "" if ok else "| " + (r.stderr.strip().splitlines() or [""])[-1][:200]))
+        except subprocess.TimeoutExpired:
+            return False, f"{name} {mode} TIMEOUT"
+
+    # the children are independent processes (a decoder each): a few at a time (FUZZ_JOBS, default 3; on the GPU they share the device)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, int(os.environ.get("FUZZ_JOBS", "3")))) as pool:
+        results = list(pool.map(one, jobs))
+    for ok, line in results:
+        print(line, flush=True)
+    bad = sum(0 if ok else 1 for ok, _ in results)
     print("fuzz failures:", bad)
     sys.exit(1 if bad else 0)

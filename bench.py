@@ -1050,7 +1050,7 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
             full[mode if mode != "both" else "encode_decode"] = brief(spec, m)
         full["note"] = ("host buffers in and out (pinned; GPUJPEG_ENCODER_INPUT_IMAGE / enc_out_val_pinned, host JPEG in / CUSTOM_BUFFER out): what a drop-in "
                         "caller of the reference API sees, PCIe transfers included; raw images cross the link on the library's one stream per direction "
-                        "(copy lanes, DESIGN 4.6: both directions at once; GJ_COPY_LANES=0 gives every coder's copies its own stream as before round 5)")
+                        "(copy lanes, DESIGN 4.6: both directions at once; the developer setting GJ_COPY_LANES=0 gives every coder's copies its own stream as before round 5)")
         result["full_api"] = full
     if not args.no_workloads and args.workload == "8k" and args.mode == "both":
         table = {"8k": {"mpix_s": result["value"], "ms_per_frame": round(result["ms_per_step"] / result["config"]["frames_per_step_per_gpu"], 4),

@@ -31,7 +31,8 @@ def G():
     if not getattr(libgpujpeg, "_settings_from_environment", False):
         for cls in (libgpujpeg.Encoder, libgpujpeg.Decoder):
             def patched(self, lib, *a, _orig=cls.__init__, **kw):
-                libgpujpeg.apply_environment_settings(lib)
+                if libgpujpeg._settings_from_environment:  # (a test of the settings call itself switches this off for its duration)
+                    libgpujpeg.apply_environment_settings(lib)
                 _orig(self, lib, *a, **kw)
             cls.__init__ = patched
         libgpujpeg._settings_from_environment = True

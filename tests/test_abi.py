@@ -85,3 +85,23 @@ def test_struct_layouts_match_ctypes_and_reference(G, tmp_path):
         (gen / "gpujpeg_version.h").write_text("#define GPUJPEG_VERSION_MAJOR 0\n#define GPUJPEG_VERSION_MINOR 27\n#define GPUJPEG_VERSION_PATCH 13\n")
         theirs = probe("/root/reference", tmp_path, "ref", extra=["-I", str(tmp_path / "gen")])
         assert ours == theirs, "public struct layout / constant drift versus the reference headers"
+
+
+def test_developer_settings_api_and_no_environment(lib, G):
+    """(round 6) The release library does not read the environment: it imports no getenv, and the developer settings go through
+    gpujpeg_amd_tuning (include/gpujpeg_amd_ext.h) -- known names accepted with or without a value, unknown names refused, NULL forgets everything."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", G.PRODUCT_LIB], capture_output=True, text=True).stdout
+    assert "getenv" not in syms, "the release library must not read the environment"
+    names = lib.tuning_names()
+    assert {"GJ_DEC_TOKENS", "GJ_DEC_NO_TOKENS", "GJ_ENC_TAIL", "GJ_DEC_SEQ", "GJ_COPY_LANES", "GPUJPEG_NO_FUSED"} <= set(names)
+    for n in names:
+        assert lib.tuning(n + "=1") or n == "", n
+    assert lib.tuning("GJ_DEC_NO_SPEC")          # a name alone
+    assert not lib.tuning("GJ_NO_SUCH_SETTING=1")  # unknown
+    assert not lib.tuning("=1") and not lib.tuning("")
+    assert lib.tuning(None)                      # back to the defaults
+    # the helper the tests and tools use hands over exactly what an environment names
+    G.apply_environment_settings(lib, {"GJ_DEC_TOKENS": "1", "HOME": "/nowhere"})
+    assert lib.tuning(None)
+

@@ -129,6 +129,7 @@ def test_emu_random_streams_all_decoder_paths(O, G, emu_lib, seed, monkeypatch):
 
 # ---- the API-level GPU tests that need no device tensors (tests/test_gpu_api.py): reader robustness, options, metadata
 def test_emu_error_paths_and_hostile_input(O, G, emu_lib):
+    A.test_developer_settings_reach_the_coders_that_follow(O, G, emu_lib)
     A.test_error_paths(G, emu_lib)
     A.test_hostile_tables_and_index(O, G, emu_lib)
     A.test_damaged_streams_do_not_crash(O, G, emu_lib)

@@ -157,6 +157,34 @@ def test_decoder_header_cache(O, G, gpu_lib, monkeypatch):
     dec.close()
 
 
+def test_developer_settings_reach_the_coders_that_follow(O, G, gpu_lib):
+    """gpujpeg_amd_tuning (round 6): a setting is process-wide and is taken by the coders created AFTER it; coders that exist keep theirs; NULL restores the
+    defaults. Observed through the decoder's path counters: GJ_DEC_NO_SPEC keeps a decoder off the speculative path."""
+    mk = lambda seed: O.encode(oracle_image(O, ("c", 320, 240, 1, 1, 75, -1, 0, None, 3)), natural_image(320, 240, 3, seed=seed))
+    frames = [mk(s) for s in (1, 2, 3, 4)]
+    G._settings_from_environment = False  # (tests/conftest.py hands the ENVIRONMENT's settings over before every coder it creates: not here)
+    try:
+        assert gpu_lib.tuning(None)
+        before = G.Decoder(gpu_lib)            # created with the defaults
+        assert gpu_lib.tuning("GJ_DEC_NO_SPEC")
+        after = G.Decoder(gpu_lib)             # created with the setting
+        for jpeg in frames:
+            want = O.decode(jpeg)[0]
+            assert np.array_equal(before.decode(jpeg)[0], want) and np.array_equal(after.decode(jpeg)[0], want)
+        assert before.path_counters()[0] == len(frames) - 1, before.path_counters()  # every frame but the first launched on the cached header
+        assert after.path_counters()[0] == 0, after.path_counters()
+        assert gpu_lib.tuning(None)
+        again = G.Decoder(gpu_lib)
+        for jpeg in frames:
+            again.decode(jpeg)
+        assert again.path_counters()[0] == len(frames) - 1
+        for d in (before, after, again):
+            d.close()
+    finally:
+        gpu_lib.tuning(None)
+        G._settings_from_environment = True
+
+
 @pytest.mark.parametrize("pf,comps,mapping", [(1, 3, "210"), (1, 3, "F0Z"), (6, 4, "1230"), (2, 3, "201"), (0, 1, "0")])
 def test_channel_remap_and_flip(O, G, gpu_lib, pf, comps, mapping):
     """enc_opt_channel_remap / enc_opt_flipped and their decoder counterparts (src/gpujpeg_preprocessor.cu:455-586,

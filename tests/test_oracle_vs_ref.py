@@ -47,6 +47,64 @@ def _warp_stats(ref):
     return list(st)
 
 
+@pytest.mark.parametrize("blocks", [1, 3, 70])
+def test_cudaemu_warp_mode_known_answers(ref, blocks):
+    """The execution model itself, apart from the reference: four small kernels written for this repository in the reference encoder's warp-synchronous style
+    (oracle/cudaemu/selftest/warp_selftest.cu: a prefix sum that hands values from lane to lane through shared memory with no barrier, compaction by vote,
+    partial exit + rotation + __syncthreads, room reserved with atomicAdd and read by the other lanes without a barrier) against closed forms. Every one of them
+    is wrong under a model that runs the lanes one after the other (the prefix sum in 120 of 128 lanes, tried with cudaemu's plain mode). 70 blocks: the grid
+    is spread over host threads."""
+    rng = np.random.default_rng(blocks)
+    n = blocks * 128
+    vin = rng.integers(0, 1 << 20, n, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    ptr = lambda a: a.ctypes.data_as(u32p)
+    # 1. prefix sum per warp
+    out = np.zeros(n, np.uint32)
+    ref.L.cudaemu_selftest_scan.argtypes = [u32p, u32p, C.c_int]
+    ref.L.cudaemu_selftest_scan(ptr(vin), ptr(out), blocks)
+    assert np.array_equal(out.reshape(-1, 32), np.cumsum(vin.reshape(-1, 32), axis=1, dtype=np.uint32))
+    # 2. compaction by vote
+    out = np.full(n, 0xFFFFFFFF, np.uint32)
+    cnt = np.zeros(n // 32, np.uint32)
+    ref.L.cudaemu_selftest_compact.argtypes = [u32p, u32p, u32p, C.c_int]
+    ref.L.cudaemu_selftest_compact(ptr(vin), ptr(out), ptr(cnt), blocks)
+    for w, row in enumerate(vin.reshape(-1, 32)):
+        odd = row[row & 1 == 1]
+        assert cnt[w] == odd.size and np.array_equal(out[w * 32:w * 32 + odd.size], odd) and np.all(out[w * 32 + odd.size:(w + 1) * 32] == 0xFFFFFFFF)
+    # 3. exits, rotation, block barrier, votes of the live lanes
+    out = np.zeros(n, np.uint32)
+    sums, votes = np.zeros(blocks, np.uint32), np.zeros(blocks * 4, np.uint32)
+    ref.L.cudaemu_selftest_rotate.argtypes = [u32p, u32p, u32p, u32p, C.c_int]
+    ref.L.cudaemu_selftest_rotate(ptr(vin), ptr(out), ptr(sums), ptr(votes), blocks)
+    for b in range(blocks):
+        live = 24 if b == 1 else 32
+        first = []
+        for w in range(4):
+            row, got = vin[b * 128 + w * 32:b * 128 + w * 32 + 32], out[b * 128 + w * 32:b * 128 + w * 32 + 32]
+            if w & 1:
+                assert np.all(got == 0xDEAD)
+                continue
+            assert np.array_equal(got[:live], np.roll(row[:live], -1)) and np.all(got[live:] == 0xBEEF)
+            assert votes[b * 4 + w] == (1 << live) - 1
+            first.append(int(row[1]))
+        assert sums[b] == (first[0] + first[1]) & 0xFFFFFFFF
+    # 4. room reserved with an atomic, its result handed to the warp through shared memory
+    out = np.zeros(n, np.uint32)
+    total = np.zeros(1, np.uint32)
+    ref.L.cudaemu_selftest_reserve.argtypes = [u32p, u32p, u32p, C.c_int]
+    ref.L.cudaemu_selftest_reserve(ptr(vin), ptr(out), ptr(total), blocks)
+    odd_all = vin[vin & 1 == 1]
+    assert total[0] == odd_all.size and np.array_equal(np.sort(out[:odd_all.size]), np.sort(odd_all))
+    runs = {tuple(row[row & 1 == 1]) for row in vin.reshape(-1, 32)}  # every warp's odd values lie together, in lane order, wherever its reservation landed
+    at = 0
+    while at < odd_all.size:
+        hit = [r for r in runs if len(r) and tuple(out[at:at + len(r)]) == r]
+        assert hit, at
+        runs.discard(hit[0])
+        at += len(hit[0])
+
+
 HUFF_GPU_CASES = CASES + [("huff_many_segments_r2", 400, 304, 1, 1, 90, 2, 0, None, 3), ("huff_il_420_r3", 322, 242, 1, 1, 60, 3, 1, [(2, 2), (1, 1), (1, 1)], 3),
                           ("huff_q100_noise_r5", 128, 96, 1, 1, 100, 5, 0, None, 3)]
 

@@ -946,9 +946,11 @@ again:
     if (!out_on_device) {
         gj_hip_event_record(c->timers.copy_out[0], c->stream); /* (copy marker) */
         const gj_stream_t down = gj_hip_lane_begin(1, frame_raw, c->stream); /* (the process's download lane for frames of 1 MiB and more) */
-        for (int f = 0; f < count; f++)
-            if (gj_hip_memcpy_d2h(output + (size_t)f * output_stride, d_out + (size_t)f * d_out_stride, frame_raw, down) != 0) goto out;
-        if (gj_hip_lane_end(down, c->stream, c->timers.lane_out) != 0 || gj_hip_stream_sync(c->stream) != 0) goto out;
+        int copies = 0;
+        for (int f = 0; f < count && copies == 0; f++)
+            copies = gj_hip_memcpy_d2h(output + (size_t)f * output_stride, d_out + (size_t)f * d_out_stride, frame_raw, down);
+        /* (a copy that could not be queued: the ones before it are still on their way INTO THE CALLER'S BUFFERS -- wait for the lane before the error leaves) */
+        if (gj_hip_lane_end(down, c->stream, c->timers.lane_out) != 0 || copies != 0 || gj_hip_stream_sync(c->stream) != 0) goto out;
     }
     if (param_image) {
         *param_image = c->param_image;

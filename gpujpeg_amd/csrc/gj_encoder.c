@@ -525,9 +525,11 @@ int gpujpeg_amd_encoder_encode_batch(struct gpujpeg_encoder* e, const struct gpu
             if (gj_ensure_device_buffer((void**)&e->b_raw, &e->b_raw_cap, (size_t)g->raw_size * (size_t)count) != 0) return -1;
             gj_hip_event_record(c->timers.copy_in[0], c->stream); /* (copy marker, see gj_internal.h) */
             const gj_stream_t up = gj_hip_lane_begin(0, g->raw_size, c->stream); /* (the process's upload lane for frames of 1 MiB and more) */
-            for (int f = 0; f < count; f++)
-                if (gj_hip_memcpy_h2d(e->b_raw + (size_t)f * g->raw_size, frames + (size_t)f * frame_stride, g->raw_size, up) != 0) return -1;
-            if (gj_hip_lane_end(up, c->stream, c->timers.lane_in) != 0) return -1;
+            int copies = 0;
+            for (int f = 0; f < count && copies == 0; f++)
+                copies = gj_hip_memcpy_h2d(e->b_raw + (size_t)f * g->raw_size, frames + (size_t)f * frame_stride, g->raw_size, up);
+            /* (a copy that could not be queued: the ones before it still read THE CALLER'S BUFFERS -- wait for the lane before the error leaves) */
+            if (gj_hip_lane_end(up, c->stream, c->timers.lane_in) != 0 || copies != 0) return -1;
             d_frames = e->b_raw;
             d_stride = g->raw_size;
         }

@@ -1077,7 +1077,12 @@ def extras(result, args, lib, spec, device, dev_index, barrier):
             # DIRECTION's otherwise (an entropy decoder never sees the raw pixels: pricing it with them crowned it "dominant" in round 4)
             own_ = owns_direction(nm[dom_])
             basis_ms = float(solo_[dom_]) if own_ else (enc_ms_ if dom_ < 5 else dec_ms_)
-            table[key] = dict(brief(sp, m), workload=sp.describe(), data=DATA_NOTE[pattern].format(w=sp.width, h=sp.height),
+            one_way = {}
+            if key in ("hd", "4k", "16k", "16k422"):  # the BASELINE configurations: each direction alone as well (config 2 is HD ENCODE: four pipelines, device resident)
+                for mode in ("encode", "decode"):
+                    mm = measure(lib, sp, device, dev_index, barrier, mode=mode, streams=args.streams, steps=3, warmup=1, min_seconds=0.15)
+                    one_way[f"{mode}_only_mpix_s"] = brief(sp, mm)["mpix_s"]
+            table[key] = dict(brief(sp, m), **one_way, workload=sp.describe(), data=DATA_NOTE[pattern].format(w=sp.width, h=sp.height),
                               solo_gpu_ms={"encode": round(enc_ms_, 4), "decode": round(dec_ms_, 4)},
                               roofline={"bound": "hbm", "kernel": nm[dom_], "ms": round(float(solo_[dom_]), 4), "frac": fr(basis_ms),
                                         "frac_basis": "the kernel's own duration" if own_ else "the duration of all kernels of its direction (a stage kernel)",

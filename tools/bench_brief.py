@@ -17,4 +17,4 @@ for k in ("encode_only", "decode_only"):
         print(k, d[k].get("mpix_s"))
 for k, v in d.get("workloads", {}).items():
     if isinstance(v, dict) and "mpix_s" in v:
-        print(" ", k, v["mpix_s"], v.get("solo_gpu_ms"))
+        print(" ", k, v["mpix_s"], v.get("solo_gpu_ms"), "enc/dec only", v.get("encode_only_mpix_s"), v.get("decode_only_mpix_s"))
